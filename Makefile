@@ -1,0 +1,47 @@
+# Build of the MI355X-native predicate evaluator.  Everything is built in-tree (the .so files
+# travel to the GPU box with the gpurun snapshot; they are git-ignored).
+#
+#   make            -> lib (HIP C-ABI library) + host (C++ host mirror) + oracle (test-only CPU restatement)
+#   make lib        -> kube_scheduler_rs_reference_amd/libksched_hip.so     hipcc, gfx950 only
+#   make host       -> kube_scheduler_rs_reference_amd/libksched_host.so    g++, links libksched_hip.so
+#   make oracle     -> oracle/liboracle.so                                  gcc, test infrastructure only
+HIPCC   ?= /opt/rocm/bin/hipcc
+CXX     ?= g++
+CC      ?= gcc
+ARCH    ?= gfx950
+PKG     := kube_scheduler_rs_reference_amd
+CSRC    := $(PKG)/csrc
+HOST    := $(PKG)/host
+
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed
+CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude
+CFLAGS   := -O2 -std=c11 -fPIC -Wall -Wextra -fopenmp
+
+LIB_HIP  := $(PKG)/libksched_hip.so
+LIB_HOST := $(PKG)/libksched_host.so
+LIB_ORA  := oracle/liboracle.so
+
+HOST_SRCS := $(wildcard $(HOST)/*.cpp)
+HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/ksched.h include/ksched_host.h
+
+.PHONY: all lib host oracle clean
+ifneq ($(HOST_SRCS),)
+all: lib host oracle
+else
+all: lib oracle
+endif
+
+lib: $(LIB_HIP)
+$(LIB_HIP): $(CSRC)/ksched_api.hip $(wildcard $(CSRC)/*.hpp) include/ksched.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ksched_api.hip
+
+host: $(LIB_HOST)
+$(LIB_HOST): $(HOST_SRCS) $(HOST_HDRS) $(LIB_HIP)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRCS) -L$(PKG) -lksched_hip -Wl,-rpath,'$$ORIGIN' -lpthread
+
+oracle: $(LIB_ORA)
+$(LIB_ORA): oracle/oracle.c oracle/oracle.h
+	$(CC) $(CFLAGS) -shared -o $@ oracle/oracle.c
+
+clean:
+	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA)

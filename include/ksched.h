@@ -1,0 +1,166 @@
+/*
+ * ksched.h -- C ABI of the MI355X-native batched pods x nodes predicate evaluator.
+ *
+ * This is the drop-in boundary for ONE path of acrlabs/kube-scheduler-rs-reference: the
+ * per-pod predicate filter-and-pick.  The reference has no FFI of its own (it is a pure Rust
+ * binary), so each entry point below names the reference code whose work it replaces.  All
+ * file:line citations are into the reference checkout.
+ *
+ *   reference                                            replaced by
+ *   ---------------------------------------------------  ------------------------------------------
+ *   node_store snapshot + per-evaluation LIST            ksched_set_nodes   (columns of `available`)
+ *     src/main.rs:56, src/predicates.rs:21-38
+ *   can_pod_fit            src/predicates.rs:20-43       KSCHED_FIT   bit of ksched_eval*
+ *   does_node_selector_match  src/predicates.rs:45-61    KSCHED_SEL   bit of ksched_eval*
+ *   check_node_validity    src/predicates.rs:63-77       feasible = fit AND sel (+ fit mask for the reason)
+ *   select_node_for_pod    src/main.rs:49-71             KSCHED_PICK_SAMPLED (injected sample indices)
+ *   (extension E1, BASELINE.json config 5)               KSCHED_PICK_BESTFIT
+ *   (extension E2, BASELINE.json config 5)               KSCHED_TAINT
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types; nothing ever unwinds across this boundary: every failure
+ *     is a negative return code (ksched_strerror gives the text).
+ *   - all quantities are exact signed 64-bit integers on the canonical domain: CPU in
+ *     milli-cores, memory in bytes.  `available` may be negative (src/predicates.rs:37).
+ *   - nodes are in canonical order (ascending node name); node index == column index.
+ *   - label columns are structure-of-arrays: label_val_ids[k*n + node] is the dictionary id of
+ *     the value of key k on that node, 0 = key absent.  Ids are exact (interned), never hashes.
+ *     sel_val_ids[k*p + pod]: 0 = pod does not constrain key k, KSCHED_SEL_NEVER = the pod asks
+ *     for a value no node carries, otherwise the required id.
+ *   - masks are pod-major: row `pod` has ksched_mask_words(n) uint64 words, bit (node % 64) of
+ *     word (node / 64); padding bits of the last word are always zero.
+ *   - the *_device entry points take device pointers (HBM resident, e.g. torch tensors'
+ *     data_ptr()) and a hipStream_t passed as void*; they enqueue and return without syncing.
+ *     The host-pointer entry points copy in, run, copy out and synchronise.
+ *   - a ksched_ctx is internally serialised by a mutex; use one ctx per device.
+ */
+#ifndef KSCHED_H
+#define KSCHED_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KSCHED_ABI_VERSION 1u
+
+/* at most this many label-key columns per batch */
+#define KSCHED_MAX_KEYS 32u
+/* reference: const ATTEMPTS: u32 = 5 (src/main.rs:49); the ABI accepts any value up to this */
+#define KSCHED_MAX_ATTEMPTS 64u
+/* selector id meaning "a value that no node carries" -> never matches */
+#define KSCHED_SEL_NEVER 0xFFFFFFFFu
+
+/* return codes */
+#define KSCHED_OK 0
+#define KSCHED_E_INVAL (-1)       /* bad argument (null pointer, inconsistent sizes, bad flags) */
+#define KSCHED_E_NODEVICE (-2)    /* no usable MI355X / HIP device; there is NO CPU fallback */
+#define KSCHED_E_HIP (-3)         /* a HIP runtime call failed; see ksched_last_error */
+#define KSCHED_E_NOMEM (-4)       /* host or device allocation failed */
+#define KSCHED_E_STATE (-5)       /* ksched_set_nodes has not been called */
+#define KSCHED_E_UNSUPPORTED (-6) /* request outside what this build supports */
+
+/* predicate / output selection flags for ksched_eval* */
+#define KSCHED_FIT 0x01u           /* resource fit: req <= available on cpu AND memory */
+#define KSCHED_SEL 0x02u           /* nodeSelector exact label match */
+#define KSCHED_TAINT 0x04u         /* (taints[n] & ~tolerations[p]) == 0   (extension E2) */
+#define KSCHED_PICK_SAMPLED 0x08u  /* first feasible of the injected samples, else -1 */
+#define KSCHED_PICK_BESTFIT 0x10u  /* lexicographic min (mem residual, cpu residual, node) (extension E1) */
+#define KSCHED_WANT_FIT_MASK 0x20u /* also write the fit-only mask (to rebuild InvalidNodeReason) */
+
+/* InvalidNodeReason, src/predicates.rs:14-18 (variant order kept); 0 = Ok(()) */
+#define KSCHED_REASON_OK 0
+#define KSCHED_REASON_NOT_ENOUGH_RESOURCES 1
+#define KSCHED_REASON_NODE_SELECTOR_MISMATCH 2
+#define KSCHED_REASON_TAINT_NOT_TOLERATED 3 /* extension E2 only; never produced without KSCHED_TAINT */
+
+/* kernel selection for ksched_set_option(ctx, KSCHED_OPT_KERNEL, v) */
+#define KSCHED_OPT_KERNEL 1
+#define KSCHED_KERNEL_AUTO 0
+#define KSCHED_KERNEL_DIRECT 1  /* lanes = nodes, compare-is-ballot */
+#define KSCHED_KERNEL_INDEXED 2 /* LDS-resident per-tile bitmap index, word-level */
+/* KSCHED_OPT_TIMING: 1 = bracket the mask kernel with hipEvents (adds two event records per call) */
+#define KSCHED_OPT_TIMING 2
+
+typedef struct ksched_ctx ksched_ctx;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+
+/* Create an evaluator bound to HIP device `device_id`.  Fails with KSCHED_E_NODEVICE when the
+ * process sees no GPU: the product path has no CPU backend by design. */
+int ksched_create(ksched_ctx **out, int device_id);
+void ksched_destroy(ksched_ctx *ctx);
+
+uint32_t ksched_abi_version(void);
+const char *ksched_strerror(int code);
+/* text of the last HIP failure on this ctx (empty string if none); valid until the next call */
+const char *ksched_last_error(const ksched_ctx *ctx);
+/* words per mask row for n nodes = ceil(n / 64) */
+uint32_t ksched_mask_words(uint32_t n_nodes);
+int ksched_set_option(ksched_ctx *ctx, int option, int64_t value);
+
+/* ---- node snapshot ----------------------------------------------------------------------
+ * Replaces, for a whole batch, what can_pod_fit recomputes per evaluation
+ * (src/predicates.rs:27-38): available[n] = allocatable[n] - sum(requests of pods bound to n).
+ * Host pointers; the library copies and builds its device-side columns and indexes.
+ *   avail_cpu_milli, avail_mem_bytes : [n] signed
+ *   label_val_ids : [n_keys][n] or NULL when n_keys == 0; ids must be < KSCHED_SEL_NEVER
+ *   taints        : [n] bit set of (interned) taints, or NULL = no taints
+ */
+int ksched_set_nodes(ksched_ctx *ctx, uint32_t n, const int64_t *avail_cpu_milli, const int64_t *avail_mem_bytes,
+                     const uint32_t *label_val_ids, uint32_t n_keys, const uint64_t *taints);
+
+/* number of nodes / keys of the current snapshot (0 before ksched_set_nodes) */
+uint32_t ksched_num_nodes(const ksched_ctx *ctx);
+uint32_t ksched_num_keys(const ksched_ctx *ctx);
+
+/* ---- evaluation, host buffers -------------------------------------------------------------
+ * One call = check_node_validity (src/predicates.rs:63-77) for every (pod, node) pair of the
+ * batch against the snapshot, plus optionally the pick of select_node_for_pod (src/main.rs:51-71).
+ *   req_cpu_milli, req_mem_bytes : [p]   total_pod_resources (src/util.rs:54-75), encoded
+ *   sel_val_ids   : [n_keys][p] or NULL (= no pod has a selector)
+ *   tolerations   : [p] or NULL (= tolerate nothing)        -- only read with KSCHED_TAINT
+ *   samples       : [p][attempts] node indices or NULL       -- only read with KSCHED_PICK_SAMPLED
+ *                   an index >= n is treated as an infeasible draw
+ *   out_feasible  : [p][W] or NULL
+ *   out_fit       : [p][W] or NULL; requires KSCHED_WANT_FIT_MASK
+ *   out_binding   : [p] or NULL; requires one of the KSCHED_PICK_* flags; -1 = no node
+ * Predicates not selected in `flags` are treated as true.
+ */
+int ksched_eval(ksched_ctx *ctx, uint32_t p, const int64_t *req_cpu_milli, const int64_t *req_mem_bytes,
+                const uint32_t *sel_val_ids, const uint64_t *tolerations, const uint32_t *samples,
+                uint32_t attempts, uint32_t flags, uint64_t *out_feasible, uint64_t *out_fit,
+                int32_t *out_binding);
+
+/* ---- evaluation, device buffers -----------------------------------------------------------
+ * Same contract with every array already resident in HBM.  out_feasible may be NULL only when
+ * no pick is requested and out_fit is given; when a pick is requested without out_feasible the
+ * library uses an internal scratch mask.  `hip_stream` is a hipStream_t (NULL = default stream).
+ */
+int ksched_eval_device(ksched_ctx *ctx, uint32_t p, const int64_t *req_cpu_milli, const int64_t *req_mem_bytes,
+                       const uint32_t *sel_val_ids, const uint64_t *tolerations, const uint32_t *samples,
+                       uint32_t attempts, uint32_t flags, uint64_t *out_feasible, uint64_t *out_fit,
+                       int32_t *out_binding, void *hip_stream);
+
+/* ---- reasons ------------------------------------------------------------------------------
+ * Host helper: rebuild check_node_validity's result for one pair from the two masks, in the
+ * reference's order (fit first: src/predicates.rs:68-70, then selector: :72-74).
+ * feasible_row / fit_row point at the pod's row of each mask.
+ */
+int ksched_reason(const uint64_t *feasible_row, const uint64_t *fit_row, uint32_t node, uint32_t flags);
+
+/* ---- measurement --------------------------------------------------------------------------
+ * With KSCHED_OPT_TIMING = 1 every ksched_eval* brackets its mask kernel with hipEvents on the
+ * launch stream.  ksched_kernel_time_ms synchronises those events and returns the accumulated
+ * kernel milliseconds and launch count since the last reset (both reset by the call).
+ */
+int ksched_kernel_time_ms(ksched_ctx *ctx, double *total_ms, uint64_t *launches);
+/* name of the mask kernel variant the last ksched_eval* used ("direct", "indexed", ...) */
+const char *ksched_last_kernel(const ksched_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSCHED_H */

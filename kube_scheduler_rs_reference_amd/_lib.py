@@ -1,0 +1,102 @@
+"""ctypes binding of libksched_hip.so (the C ABI declared in include/ksched.h).
+
+The product path has no CPU implementation: if the HIP library is missing this module raises at
+import time of the symbol table (`load()`), and `ksched_create` returns KSCHED_E_NODEVICE on a box
+without a GPU.  Nothing in this package imports `oracle/`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libksched_hip.so")
+
+# --- constants mirrored from include/ksched.h --------------------------------------------------
+ABI_VERSION = 1
+MAX_KEYS = 32
+MAX_ATTEMPTS = 64
+SEL_NEVER = 0xFFFFFFFF
+
+OK = 0
+E_INVAL = -1
+E_NODEVICE = -2
+E_HIP = -3
+E_NOMEM = -4
+E_STATE = -5
+E_UNSUPPORTED = -6
+
+FIT = 0x01
+SEL = 0x02
+TAINT = 0x04
+PICK_SAMPLED = 0x08
+PICK_BESTFIT = 0x10
+WANT_FIT_MASK = 0x20
+
+REASON_OK = 0
+REASON_NOT_ENOUGH_RESOURCES = 1
+REASON_NODE_SELECTOR_MISMATCH = 2
+REASON_TAINT_NOT_TOLERATED = 3
+REASON_NAMES = {0: "Ok", 1: "NotEnoughResources", 2: "NodeSelectorMismatch", 3: "TaintNotTolerated"}
+
+OPT_KERNEL = 1
+OPT_TIMING = 2
+KERNEL_AUTO = 0
+KERNEL_DIRECT = 1
+KERNEL_INDEXED = 2
+
+# every symbol include/ksched.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+_u32 = C.c_uint32
+SYMBOLS = {
+    "ksched_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "ksched_destroy": (None, [_vp]),
+    "ksched_abi_version": (_u32, []),
+    "ksched_strerror": (C.c_char_p, [C.c_int]),
+    "ksched_last_error": (C.c_char_p, [_vp]),
+    "ksched_mask_words": (_u32, [_u32]),
+    "ksched_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
+    "ksched_set_nodes": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _u32, _vp]),
+    "ksched_num_nodes": (_u32, [_vp]),
+    "ksched_num_keys": (_u32, [_vp]),
+    "ksched_eval": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "ksched_eval_device": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "ksched_reason": (C.c_int, [_vp, _vp, _u32, _u32]),
+    "ksched_kernel_time_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "ksched_last_kernel": (C.c_char_p, [_vp]),
+}
+
+_lib = None
+
+
+class KschedError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        msg = f"{where}: ksched error {code}"
+        try:
+            msg += f" ({load().ksched_strerror(code).decode()})"
+        except Exception:  # pragma: no cover
+            pass
+        if detail:
+            msg += f": {detail}"
+        super().__init__(msg)
+
+
+def load() -> C.CDLL:
+    """Load libksched_hip.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension has not been built (run `make lib` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ksched_abi_version() != ABI_VERSION:
+        raise ImportError(f"ABI mismatch: library {lib.ksched_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib

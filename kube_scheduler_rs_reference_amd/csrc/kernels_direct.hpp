@@ -1,0 +1,221 @@
+// kernels_direct.hpp -- "direct" mask kernel: lanes = nodes, the compare IS the ballot.
+//
+// Computes, for a batch of pods against the node snapshot, the feasibility bit of
+// check_node_validity (reference src/predicates.rs:63-77):
+//     fit  = req_cpu[p] <= avail_cpu[n] && req_mem[p] <= avail_mem[n]      (src/predicates.rs:42)
+//     sel  = for every key k: sel[k][p] == 0 || sel[k][p] == lab[k][n]     (src/predicates.rs:45-61)
+//     tnt  = (taints[n] & ~tol[p]) == 0                                    (extension E2)
+// and writes pod-major uint64 mask rows.
+//
+// Mapping (gfx950, wave64): one wave owns CW consecutive 64-node word columns, whose node
+// columns live in VGPRs for the whole kernel.  It walks pods 64 at a time; pod operands are
+// wave-uniform, so they come in through the scalar cache (s_load) and each v_cmp against them
+// yields the 64-node result word directly in an SGPR pair - no shuffle, no reduction.  The word
+// of pod j is parked in lane j (v_writelane), and after 64 pods every lane stores CW
+// consecutive words of "its" pod row.  The four waves of a block sit on adjacent columns, so a
+// block emits 16 consecutive words (128 B) per pod row.
+//
+// Cost model (measured numbers live in DESIGN.md): per (pod, 64 nodes) the VALU issues are
+// 2 x v_cmp_i64 (fit) + one v_cmp_u32 per *constrained* key (unconstrained keys are skipped by a
+// scalar branch) + 3 for taints + 2 x v_writelane.  That makes this kernel VALU-bound well below
+// the HBM write roofline; it is the general, always-applicable path.  The indexed kernel
+// (kernels_indexed.hpp) is the fast path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// clang (ROCm 7.2) exposes no __builtin_amdgcn_writelane; bind the LLVM intrinsic by name.
+// v_writelane_b32: lane `lane` of the result takes the wave-uniform `val`, the others keep `old`.
+extern "C" __device__ uint32_t ksched_writelane_u32(uint32_t val, uint32_t lane, uint32_t old) __asm(
+    "llvm.amdgcn.writelane.i32");
+
+namespace ksched {
+
+constexpr int kDirectCW = 4;      // word columns per wave
+constexpr int kDirectWaves = 4;   // waves per block  -> 16 words = 1024 nodes per block
+constexpr int kDirectKeys = 8;    // label keys handled per pass
+
+struct DirectArgs {
+    uint32_t n, p, W;
+    uint32_t key0, nkeys;          // this pass handles keys [key0, key0 + nkeys), nkeys <= kDirectKeys
+    uint32_t pod_tiles_per_block;  // 64-pod tiles walked by one block
+    uint32_t do_fit;               // KSCHED_FIT selected
+    uint32_t accumulate;           // AND into out_feas instead of overwriting (key passes after the first)
+};
+
+// Pointers are separate __restrict__ kernel parameters (not struct members) so that the
+// compiler can prove the pod columns are never clobbered by the mask stores and keeps the
+// wave-uniform pod loads on the scalar unit (s_load_*), leaving the VALU to the compares.
+template <bool SEL, bool TAINT, bool WANT_FIT>
+__global__ __launch_bounds__(64 * kDirectWaves) void k_eval_direct(
+    const int64_t *__restrict__ g_ncpu, const int64_t *__restrict__ g_nmem, const uint32_t *__restrict__ g_nlab,
+    const uint64_t *__restrict__ g_ntaint, const int64_t *__restrict__ g_pcpu, const int64_t *__restrict__ g_pmem,
+    const uint32_t *__restrict__ g_psel, const uint64_t *__restrict__ g_ptol, uint64_t *__restrict__ out_feas,
+    uint64_t *__restrict__ out_fit, const DirectArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t w0 = (blockIdx.x * kDirectWaves + wave) * kDirectCW;  // first word column of this wave
+    if (w0 >= a.W) return;
+
+    // ---- node columns of this wave -> registers -------------------------------------------
+    int64_t ncpu[kDirectCW], nmem[kDirectCW];
+    uint32_t nlab[kDirectKeys][kDirectCW];
+    uint64_t ntaint[kDirectCW];
+    uint64_t valid[kDirectCW];
+#pragma unroll
+    for (int c = 0; c < kDirectCW; ++c) {
+        const uint32_t node = (w0 + c) * 64u + lane;
+        const bool in = node < a.n;
+        valid[c] = __ballot(in);
+        ncpu[c] = in ? g_ncpu[node] : 0;
+        nmem[c] = in ? g_nmem[node] : 0;
+        if (SEL) {
+#pragma unroll
+            for (int k = 0; k < kDirectKeys; ++k)
+                nlab[k][c] = (in && (uint32_t)k < a.nkeys) ? g_nlab[(size_t)(a.key0 + k) * a.n + node] : 0u;
+        }
+        if (TAINT) ntaint[c] = (in && g_ntaint) ? g_ntaint[node] : 0ull;
+    }
+
+    const uint32_t tile0 = blockIdx.y * a.pod_tiles_per_block;
+    for (uint32_t t = 0; t < a.pod_tiles_per_block; ++t) {
+        const uint32_t p0 = (tile0 + t) * 64u;
+        if (p0 >= a.p) break;
+        const uint32_t jmax = min(64u, a.p - p0);
+
+        uint32_t flo[kDirectCW], fhi[kDirectCW];  // feasible word of pod (p0 + lane)
+        uint32_t rlo[kDirectCW], rhi[kDirectCW];  // fit-only word
+#pragma unroll
+        for (int c = 0; c < kDirectCW; ++c) { flo[c] = fhi[c] = rlo[c] = rhi[c] = 0u; }
+
+        for (uint32_t j = 0; j < jmax; ++j) {
+            const uint32_t p = p0 + j;  // wave-uniform -> scalar loads
+            uint64_t m[kDirectCW];
+#pragma unroll
+            for (int c = 0; c < kDirectCW; ++c) m[c] = valid[c];
+            if (a.do_fit) {
+                const int64_t rc = g_pcpu[p];
+                const int64_t rm = g_pmem[p];
+#pragma unroll
+                for (int c = 0; c < kDirectCW; ++c) m[c] &= __ballot(rc <= ncpu[c]) & __ballot(rm <= nmem[c]);
+            }
+            if (WANT_FIT) {
+#pragma unroll
+                for (int c = 0; c < kDirectCW; ++c) {
+                    rlo[c] = ksched_writelane_u32((uint32_t)m[c], j, rlo[c]);
+                    rhi[c] = ksched_writelane_u32((uint32_t)(m[c] >> 32), j, rhi[c]);
+                }
+            }
+            if (SEL) {
+#pragma unroll
+                for (int k = 0; k < kDirectKeys; ++k) {
+                    const uint32_t s = ((uint32_t)k < a.nkeys) ? g_psel[(size_t)(a.key0 + k) * a.p + p] : 0u;
+                    if (s != 0u) {  // wave-uniform branch: unconstrained keys cost no VALU work
+#pragma unroll
+                        for (int c = 0; c < kDirectCW; ++c) m[c] &= __ballot(s == nlab[k][c]);
+                    }
+                }
+            }
+            if (TAINT) {
+                const uint64_t ntol = g_ptol ? ~g_ptol[p] : ~0ull;
+#pragma unroll
+                for (int c = 0; c < kDirectCW; ++c) m[c] &= __ballot((ntaint[c] & ntol) == 0ull);
+            }
+#pragma unroll
+            for (int c = 0; c < kDirectCW; ++c) {
+                flo[c] = ksched_writelane_u32((uint32_t)m[c], j, flo[c]);
+                fhi[c] = ksched_writelane_u32((uint32_t)(m[c] >> 32), j, fhi[c]);
+            }
+        }
+
+        // ---- lane l stores CW consecutive words of pod row p0 + l --------------------------
+        if (lane < jmax) {
+            const size_t row = (size_t)(p0 + lane) * a.W;
+#pragma unroll
+            for (int c = 0; c < kDirectCW; ++c) {
+                if (w0 + c < a.W) {
+                    const uint64_t f = ((uint64_t)fhi[c] << 32) | flo[c];
+                    if (out_feas) {
+                        if (a.accumulate)
+                            out_feas[row + w0 + c] &= f;
+                        else
+                            out_feas[row + w0 + c] = f;
+                    }
+                    if (WANT_FIT && out_fit) out_fit[row + w0 + c] = ((uint64_t)rhi[c] << 32) | rlo[c];
+                }
+            }
+        }
+    }
+}
+
+// ---- picks ----------------------------------------------------------------------------------
+
+// select_node_for_pod (reference src/main.rs:51-71) with injected draws: the first of the
+// `attempts` sampled node indices whose feasible bit is set wins; none -> -1 (NoNodeFound,
+// src/main.rs:117).  One lane per pod.
+__global__ __launch_bounds__(256) void k_pick_sampled(const uint64_t *__restrict__ mask, const uint32_t *__restrict__ samples,
+                                                       int32_t *__restrict__ binding, uint32_t p, uint32_t n, uint32_t W,
+                                                       uint32_t attempts) {
+    const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pod >= p) return;
+    int32_t b = -1;
+    const uint64_t *row = mask + (size_t)pod * W;
+    for (uint32_t i = 0; i < attempts; ++i) {
+        const uint32_t s = samples[(size_t)pod * attempts + i];
+        if (s < n && ((row[s >> 6] >> (s & 63u)) & 1ull)) {
+            b = (int32_t)s;
+            break;
+        }
+    }
+    binding[pod] = b;
+}
+
+// Best fit (extension E1): argmin over feasible nodes of (avail_mem - req_mem, avail_cpu - req_cpu,
+// node index), lexicographic.  Both residuals are pod-independent shifts of the node's own
+// (avail_mem, avail_cpu), so the order of candidates is a property of the snapshot: bf_order
+// lists nodes in that order, bf_rank is its inverse, and the pick is the first feasible node
+// in bf_order.  One wave per pod: probe the head of bf_order 64 candidates at a time, and if the
+// first kProbe*64 candidates are all infeasible fall back to a coalesced scan of the row.
+constexpr int kBestfitProbe = 4;
+__global__ __launch_bounds__(256) void k_pick_bestfit(const uint64_t *__restrict__ mask, const uint32_t *__restrict__ bf_order,
+                                                       const uint32_t *__restrict__ bf_rank, int32_t *__restrict__ binding,
+                                                       uint32_t p, uint32_t n, uint32_t W) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pod = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pod >= p) return;
+    const uint64_t *row = mask + (size_t)pod * W;
+    for (int it = 0; it < kBestfitProbe; ++it) {
+        const uint32_t idx = (uint32_t)it * 64u + lane;
+        uint32_t node = 0;
+        bool bit = false;
+        if (idx < n) {
+            node = bf_order[idx];
+            bit = (row[node >> 6] >> (node & 63u)) & 1ull;
+        }
+        const uint64_t b = __ballot(bit);
+        if (b) {
+            const int first = __builtin_ctzll(b);
+            const uint32_t win = __shfl(node, first, 64);
+            if (lane == 0) binding[pod] = (int32_t)win;
+            return;
+        }
+        if ((uint32_t)(it + 1) * 64u >= n) {
+            if (lane == 0) binding[pod] = -1;
+            return;
+        }
+    }
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t w = lane; w < W; w += 64u) {
+        uint64_t word = row[w];
+        while (word) {
+            const uint32_t node = w * 64u + (uint32_t)__builtin_ctzll(word);
+            best = min(best, bf_rank[node]);
+            word &= word - 1ull;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off, 64));
+    if (lane == 0) binding[pod] = (best == 0xFFFFFFFFu) ? -1 : (int32_t)bf_order[best];
+}
+
+}  // namespace ksched

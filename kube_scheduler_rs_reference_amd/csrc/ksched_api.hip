@@ -1,0 +1,512 @@
+// ksched_api.hip -- implementation of include/ksched.h (C ABI) on HIP for gfx950.
+//
+// Host side of the evaluator: owns the device-resident node snapshot and its indexes, launches
+// the mask kernels and the pick kernels.  There is deliberately NO CPU implementation of the
+// predicates in this library: without a HIP device ksched_create fails with KSCHED_E_NODEVICE.
+#include "../../include/ksched.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "kernels_direct.hpp"
+#include "kernels_indexed.hpp"
+
+using namespace ksched;
+
+namespace {
+
+template <class T>
+struct DevBuf {
+    T *ptr = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc((void **)&ptr, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct ksched_ctx {
+    int device = 0;
+    std::mutex mu;
+    std::string last_error;
+    hipStream_t stream = nullptr;  // used by the host-pointer entry points
+
+    // node snapshot
+    bool have_nodes = false;
+    uint32_t n = 0, nkeys = 0, W = 0;
+    bool have_taints = false;
+    DevBuf<int64_t> ncpu, nmem;
+    DevBuf<uint32_t> nlab;
+    DevBuf<uint64_t> ntaint;
+    DevBuf<uint32_t> bf_order, bf_rank;
+    IndexedSnapshot idx;  // per-tile bitmap index (kernels_indexed.hpp)
+
+    // scratch for the host-pointer path
+    DevBuf<int64_t> pcpu, pmem;
+    DevBuf<uint32_t> psel, psamples;
+    DevBuf<uint64_t> ptol, feas, fit;
+    DevBuf<int32_t> binding;
+    // scratch mask when a pick is requested without an output mask
+    DevBuf<uint64_t> scratch_mask;
+    // per-batch pod operands of the indexed kernel
+    DevBuf<uint8_t> idx_scratch;
+
+    // options
+    int opt_kernel = KSCHED_KERNEL_AUTO;
+    bool opt_timing = false;
+    const char *last_kernel = "none";
+
+    // timing
+    struct EvPair {
+        hipEvent_t a, b;
+    };
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail_hip(ksched_ctx *c, hipError_t e, const char *what) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    c->last_error = buf;
+    return e == hipErrorOutOfMemory ? KSCHED_E_NOMEM : KSCHED_E_HIP;
+}
+
+#define HIPCHK(ctx, call)                                   \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #call); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int timing_begin(ksched_ctx *c, hipStream_t s, size_t *slot) {
+    if (c->ev_used == c->ev_pool.size()) {
+        ksched_ctx::EvPair ep;
+        HIPCHK(c, hipEventCreate(&ep.a));
+        HIPCHK(c, hipEventCreate(&ep.b));
+        c->ev_pool.push_back(ep);
+    }
+    *slot = c->ev_used++;
+    HIPCHK(c, hipEventRecord(c->ev_pool[*slot].a, s));
+    return KSCHED_OK;
+}
+
+// ---- mask kernel dispatch ---------------------------------------------------------------------
+
+struct DirectPtrs {
+    const int64_t *ncpu, *nmem;
+    const uint32_t *nlab;
+    const uint64_t *ntaint;
+    const int64_t *pcpu, *pmem;
+    const uint32_t *psel;
+    const uint64_t *ptol;
+    uint64_t *out_feas, *out_fit;
+};
+
+template <bool SEL, bool TAINT>
+void launch_direct_t(const DirectPtrs &q, const DirectArgs &a, dim3 grid, bool want_fit, hipStream_t s) {
+    if (want_fit)
+        hipLaunchKernelGGL((k_eval_direct<SEL, TAINT, true>), grid, dim3(64 * kDirectWaves), 0, s, q.ncpu, q.nmem, q.nlab,
+                           q.ntaint, q.pcpu, q.pmem, q.psel, q.ptol, q.out_feas, q.out_fit, a);
+    else
+        hipLaunchKernelGGL((k_eval_direct<SEL, TAINT, false>), grid, dim3(64 * kDirectWaves), 0, s, q.ncpu, q.nmem, q.nlab,
+                           q.ntaint, q.pcpu, q.pmem, q.psel, q.ptol, q.out_feas, q.out_fit, a);
+}
+
+int run_direct(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
+               const uint64_t *ptol, uint32_t flags, uint64_t *out_feas, uint64_t *out_fit, hipStream_t s) {
+    DirectPtrs q{};
+    q.ncpu = c->ncpu.ptr;
+    q.nmem = c->nmem.ptr;
+    q.nlab = c->nlab.ptr;
+    q.ntaint = c->have_taints ? c->ntaint.ptr : nullptr;
+    q.pcpu = pcpu;
+    q.pmem = pmem;
+    q.psel = psel;
+    q.ptol = ptol;
+    q.out_feas = out_feas;
+    q.out_fit = out_fit;
+    DirectArgs a{};
+    a.n = c->n;
+    a.p = p;
+    a.W = c->W;
+    a.do_fit = (flags & KSCHED_FIT) ? 1u : 0u;
+
+    const bool sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
+    const bool taint = (flags & KSCHED_TAINT) != 0;
+    const bool want_fit = (flags & KSCHED_WANT_FIT_MASK) && out_fit;
+
+    const uint32_t words_per_block = kDirectCW * kDirectWaves;
+    const uint32_t gx = (c->W + words_per_block - 1) / words_per_block;
+    const uint32_t pod_tiles = (p + 63) / 64;
+    // aim for >= ~2048 blocks so all 256 CUs (8 XCDs) stay busy, but keep a block on its node
+    // columns for as many pods as possible (node registers are loaded once per block)
+    uint32_t gy = std::max(1u, std::min(pod_tiles, (2048u + gx - 1) / gx));
+    a.pod_tiles_per_block = (pod_tiles + gy - 1) / gy;
+    gy = (pod_tiles + a.pod_tiles_per_block - 1) / a.pod_tiles_per_block;
+    dim3 grid(gx, gy);
+
+    // first pass: fit + taints + keys [0, 8)
+    a.key0 = 0;
+    a.nkeys = sel ? std::min(c->nkeys, (uint32_t)kDirectKeys) : 0;
+    a.accumulate = 0;
+    if (sel) {
+        if (taint) launch_direct_t<true, true>(q, a, grid, want_fit, s);
+        else launch_direct_t<true, false>(q, a, grid, want_fit, s);
+    } else {
+        if (taint) launch_direct_t<false, true>(q, a, grid, want_fit, s);
+        else launch_direct_t<false, false>(q, a, grid, want_fit, s);
+    }
+    // further passes: 8 more keys each, ANDed into the feasible mask
+    if (sel && out_feas) {
+        for (uint32_t k0 = kDirectKeys; k0 < c->nkeys; k0 += kDirectKeys) {
+            DirectArgs b = a;
+            b.key0 = k0;
+            b.nkeys = std::min(c->nkeys - k0, (uint32_t)kDirectKeys);
+            b.accumulate = 1;
+            b.do_fit = 0;
+            DirectPtrs r = q;
+            r.out_fit = nullptr;
+            r.ptol = nullptr;
+            launch_direct_t<true, false>(r, b, grid, false, s);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    c->last_kernel = "direct";
+    return KSCHED_OK;
+}
+
+int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
+                   const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags,
+                   uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, hipStream_t s) {
+    const bool pick_s = flags & KSCHED_PICK_SAMPLED, pick_b = flags & KSCHED_PICK_BESTFIT;
+    if (p == 0) return KSCHED_OK;
+    if (c->n == 0) {
+        // no nodes: empty mask rows, no binding possible (reference: choose() on an empty store
+        // yields None on every attempt, src/main.rs:56,70)
+        if ((pick_s || pick_b) && out_binding) HIPCHK(c, hipMemsetAsync(out_binding, 0xFF, (size_t)p * sizeof(int32_t), s));
+        return KSCHED_OK;
+    }
+    uint64_t *feas = out_feas;
+    if (!feas && (pick_s || pick_b)) {
+        HIPCHK(c, c->scratch_mask.reserve((size_t)p * c->W));
+        feas = c->scratch_mask.ptr;
+    }
+
+    size_t slot = 0;
+    if (c->opt_timing) {
+        int rc = timing_begin(c, s, &slot);
+        if (rc) return rc;
+    }
+    int rc;
+    bool use_indexed = false;
+    if (c->opt_kernel != KSCHED_KERNEL_DIRECT) use_indexed = indexed_applicable(c->idx, flags, psel != nullptr);
+    if (c->opt_kernel == KSCHED_KERNEL_INDEXED && !use_indexed) {
+        c->last_error = "indexed kernel not applicable to this snapshot/request";
+        return KSCHED_E_UNSUPPORTED;
+    }
+    if (use_indexed) {
+        const size_t need = indexed_scratch_bytes(c->idx, p);
+        HIPCHK(c, c->idx_scratch.reserve(need));
+        hipError_t e = run_indexed(c->idx, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, c->idx_scratch.ptr, s);
+        if (e != hipSuccess) return fail_hip(c, e, "run_indexed");
+        c->last_kernel = "indexed";
+        rc = KSCHED_OK;
+    } else {
+        rc = run_direct(c, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, s);
+    }
+    if (rc) return rc;
+    if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev_pool[slot].b, s));
+
+    if (pick_s) {
+        hipLaunchKernelGGL(k_pick_sampled, dim3((p + 255) / 256), dim3(256), 0, s, feas, samples, out_binding, p, c->n,
+                           c->W, attempts);
+    } else if (pick_b) {
+        hipLaunchKernelGGL(k_pick_bestfit, dim3((p + 3) / 4), dim3(256), 0, s, feas, c->bf_order.ptr, c->bf_rank.ptr,
+                           out_binding, p, c->n, c->W);
+    }
+    HIPCHK(c, hipGetLastError());
+    return KSCHED_OK;
+}
+
+int check_eval_args(const ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *samples,
+                    uint32_t attempts, uint32_t flags, const uint64_t *out_feas, const uint64_t *out_fit,
+                    const int32_t *out_binding) {
+    const uint32_t known = KSCHED_FIT | KSCHED_SEL | KSCHED_TAINT | KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT |
+                           KSCHED_WANT_FIT_MASK;
+    if (flags & ~known) return KSCHED_E_INVAL;
+    if ((flags & KSCHED_PICK_SAMPLED) && (flags & KSCHED_PICK_BESTFIT)) return KSCHED_E_INVAL;
+    if (p > 0 && (!pcpu || !pmem)) return KSCHED_E_INVAL;
+    if (flags & KSCHED_PICK_SAMPLED) {
+        if (!out_binding || attempts == 0 || attempts > KSCHED_MAX_ATTEMPTS) return KSCHED_E_INVAL;
+        if (p > 0 && !samples) return KSCHED_E_INVAL;
+    }
+    if ((flags & KSCHED_PICK_BESTFIT) && !out_binding) return KSCHED_E_INVAL;
+    if ((flags & KSCHED_WANT_FIT_MASK) && !out_fit) return KSCHED_E_INVAL;
+    if (!(flags & KSCHED_WANT_FIT_MASK) && out_fit) return KSCHED_E_INVAL;
+    if (!(flags & (KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT)) && !out_feas && !out_fit) return KSCHED_E_INVAL;
+    (void)c;
+    return KSCHED_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t ksched_abi_version(void) { return KSCHED_ABI_VERSION; }
+
+uint32_t ksched_mask_words(uint32_t n_nodes) { return (uint32_t)(((uint64_t)n_nodes + 63u) / 64u); }
+
+const char *ksched_strerror(int code) {
+    switch (code) {
+        case KSCHED_OK: return "ok";
+        case KSCHED_E_INVAL: return "invalid argument";
+        case KSCHED_E_NODEVICE: return "no HIP device (this library has no CPU fallback)";
+        case KSCHED_E_HIP: return "HIP runtime error";
+        case KSCHED_E_NOMEM: return "out of memory";
+        case KSCHED_E_STATE: return "ksched_set_nodes has not been called";
+        case KSCHED_E_UNSUPPORTED: return "unsupported request";
+        default: return "unknown error";
+    }
+}
+
+int ksched_create(ksched_ctx **out, int device_id) {
+    if (!out) return KSCHED_E_INVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return KSCHED_E_NODEVICE;
+    if (device_id < 0 || device_id >= count) return KSCHED_E_INVAL;
+    ksched_ctx *c = new (std::nothrow) ksched_ctx();
+    if (!c) return KSCHED_E_NOMEM;
+    c->device = device_id;
+    DeviceGuard g(device_id);
+    if (!g.ok || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return KSCHED_E_HIP;
+    }
+    *out = c;
+    return KSCHED_OK;
+}
+
+void ksched_destroy(ksched_ctx *c) {
+    if (!c) return;
+    {
+        DeviceGuard g(c->device);
+        (void)hipDeviceSynchronize();
+        c->ncpu.release(); c->nmem.release(); c->nlab.release(); c->ntaint.release();
+        c->bf_order.release(); c->bf_rank.release();
+        c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
+        c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release();
+        c->scratch_mask.release(); c->idx_scratch.release();
+        indexed_release(c->idx);
+        for (auto &ep : c->ev_pool) {
+            (void)hipEventDestroy(ep.a);
+            (void)hipEventDestroy(ep.b);
+        }
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+const char *ksched_last_error(const ksched_ctx *c) { return c ? c->last_error.c_str() : ""; }
+uint32_t ksched_num_nodes(const ksched_ctx *c) { return (c && c->have_nodes) ? c->n : 0; }
+uint32_t ksched_num_keys(const ksched_ctx *c) { return (c && c->have_nodes) ? c->nkeys : 0; }
+const char *ksched_last_kernel(const ksched_ctx *c) { return c ? c->last_kernel : "none"; }
+
+int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
+    if (!c) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    switch (option) {
+        case KSCHED_OPT_KERNEL:
+            if (value < KSCHED_KERNEL_AUTO || value > KSCHED_KERNEL_INDEXED) return KSCHED_E_INVAL;
+            c->opt_kernel = (int)value;
+            return KSCHED_OK;
+        case KSCHED_OPT_TIMING:
+            c->opt_timing = value != 0;
+            return KSCHED_OK;
+        default:
+            return KSCHED_E_INVAL;
+    }
+}
+
+int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_t *mem, const uint32_t *lab,
+                     uint32_t n_keys, const uint64_t *taints) {
+    if (!c) return KSCHED_E_INVAL;
+    if (n > 0 && (!cpu || !mem)) return KSCHED_E_INVAL;
+    if (n_keys > KSCHED_MAX_KEYS) return KSCHED_E_INVAL;
+    if (n_keys > 0 && n > 0 && !lab) return KSCHED_E_INVAL;
+    if (lab)
+        for (size_t i = 0; i < (size_t)n_keys * n; ++i)
+            if (lab[i] == KSCHED_SEL_NEVER) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    // the previous snapshot may still be in use by enqueued work
+    HIPCHK(c, hipDeviceSynchronize());
+    c->have_nodes = false;
+    c->n = n;
+    c->nkeys = n_keys;
+    c->W = ksched_mask_words(n);
+    c->have_taints = taints != nullptr;
+    HIPCHK(c, c->ncpu.reserve(n));
+    HIPCHK(c, c->nmem.reserve(n));
+    HIPCHK(c, c->nlab.reserve((size_t)n * n_keys));
+    HIPCHK(c, c->ntaint.reserve(n));
+    HIPCHK(c, c->bf_order.reserve(n));
+    HIPCHK(c, c->bf_rank.reserve(n));
+    if (n > 0) {
+        HIPCHK(c, hipMemcpy(c->ncpu.ptr, cpu, (size_t)n * 8, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->nmem.ptr, mem, (size_t)n * 8, hipMemcpyHostToDevice));
+        if (n_keys) HIPCHK(c, hipMemcpy(c->nlab.ptr, lab, (size_t)n * n_keys * 4, hipMemcpyHostToDevice));
+        if (taints) HIPCHK(c, hipMemcpy(c->ntaint.ptr, taints, (size_t)n * 8, hipMemcpyHostToDevice));
+        // best-fit candidate order of the snapshot: ascending (avail_mem, avail_cpu, node)
+        std::vector<uint32_t> order(n), rank(n);
+        std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            if (mem[x] != mem[y]) return mem[x] < mem[y];
+            if (cpu[x] != cpu[y]) return cpu[x] < cpu[y];
+            return x < y;
+        });
+        for (uint32_t i = 0; i < n; ++i) rank[order[i]] = i;
+        HIPCHK(c, hipMemcpy(c->bf_order.ptr, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->bf_rank.ptr, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    hipError_t e = indexed_build(c->idx, n, cpu, mem, lab, n_keys, taints);
+    if (e != hipSuccess) return fail_hip(c, e, "indexed_build");
+    c->have_nodes = true;
+    return KSCHED_OK;
+}
+
+int ksched_eval_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
+                       const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags,
+                       uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, void *hip_stream) {
+    if (!c) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_nodes) return KSCHED_E_STATE;
+    int rc = check_eval_args(c, p, pcpu, pmem, samples, attempts, flags, out_feas, out_fit, out_binding);
+    if (rc) return rc;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    return eval_on_device(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_feas, out_fit, out_binding,
+                          (hipStream_t)hip_stream);
+}
+
+int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
+                const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, uint64_t *out_feas,
+                uint64_t *out_fit, int32_t *out_binding) {
+    if (!c) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_nodes) return KSCHED_E_STATE;
+    int rc = check_eval_args(c, p, pcpu, pmem, samples, attempts, flags, out_feas, out_fit, out_binding);
+    if (rc) return rc;
+    if (p == 0) return KSCHED_OK;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    hipStream_t s = c->stream;
+    const size_t W = c->W;
+    const bool pick = flags & (KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT);
+    const bool use_sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
+    const bool use_tol = (flags & KSCHED_TAINT) && ptol;
+
+    HIPCHK(c, c->pcpu.reserve(p));
+    HIPCHK(c, c->pmem.reserve(p));
+    HIPCHK(c, hipMemcpyAsync(c->pcpu.ptr, pcpu, (size_t)p * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->pmem.ptr, pmem, (size_t)p * 8, hipMemcpyHostToDevice, s));
+    if (use_sel) {
+        HIPCHK(c, c->psel.reserve((size_t)p * c->nkeys));
+        HIPCHK(c, hipMemcpyAsync(c->psel.ptr, psel, (size_t)p * c->nkeys * 4, hipMemcpyHostToDevice, s));
+    }
+    if (use_tol) {
+        HIPCHK(c, c->ptol.reserve(p));
+        HIPCHK(c, hipMemcpyAsync(c->ptol.ptr, ptol, (size_t)p * 8, hipMemcpyHostToDevice, s));
+    }
+    if (flags & KSCHED_PICK_SAMPLED) {
+        HIPCHK(c, c->psamples.reserve((size_t)p * attempts));
+        HIPCHK(c, hipMemcpyAsync(c->psamples.ptr, samples, (size_t)p * attempts * 4, hipMemcpyHostToDevice, s));
+    }
+    uint64_t *d_feas = nullptr, *d_fit = nullptr;
+    int32_t *d_bind = nullptr;
+    if (out_feas || pick) {
+        HIPCHK(c, c->feas.reserve((size_t)p * W));
+        d_feas = c->feas.ptr;
+    }
+    if (out_fit) {
+        HIPCHK(c, c->fit.reserve((size_t)p * W));
+        d_fit = c->fit.ptr;
+    }
+    if (pick) {
+        HIPCHK(c, c->binding.reserve(p));
+        d_bind = c->binding.ptr;
+    }
+    rc = eval_on_device(c, p, c->pcpu.ptr, c->pmem.ptr, use_sel ? c->psel.ptr : nullptr, use_tol ? c->ptol.ptr : nullptr,
+                        c->psamples.ptr, attempts, flags, d_feas, d_fit, d_bind, s);
+    if (rc) return rc;
+    if (out_feas && W) HIPCHK(c, hipMemcpyAsync(out_feas, d_feas, (size_t)p * W * 8, hipMemcpyDeviceToHost, s));
+    if (out_fit && W) HIPCHK(c, hipMemcpyAsync(out_fit, d_fit, (size_t)p * W * 8, hipMemcpyDeviceToHost, s));
+    if (pick && out_binding) HIPCHK(c, hipMemcpyAsync(out_binding, d_bind, (size_t)p * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return KSCHED_OK;
+}
+
+int ksched_reason(const uint64_t *feasible_row, const uint64_t *fit_row, uint32_t node, uint32_t flags) {
+    if (!feasible_row) return KSCHED_E_INVAL;
+    const uint32_t w = node >> 6, b = node & 63u;
+    if ((feasible_row[w] >> b) & 1ull) return KSCHED_REASON_OK;
+    // reference order: resources first (src/predicates.rs:68-70), then the selector (:72-74)
+    if ((flags & KSCHED_FIT) && fit_row && !((fit_row[w] >> b) & 1ull)) return KSCHED_REASON_NOT_ENOUGH_RESOURCES;
+    if ((flags & KSCHED_SEL) && !(flags & KSCHED_TAINT)) return KSCHED_REASON_NODE_SELECTOR_MISMATCH;
+    if ((flags & KSCHED_TAINT) && !(flags & KSCHED_SEL)) return KSCHED_REASON_TAINT_NOT_TOLERATED;
+    // both extension and selector active: the two masks cannot tell them apart
+    return KSCHED_REASON_NODE_SELECTOR_MISMATCH;
+}
+
+int ksched_kernel_time_ms(ksched_ctx *c, double *total_ms, uint64_t *launches) {
+    if (!c) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    double tot = 0;
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        HIPCHK(c, hipEventSynchronize(c->ev_pool[i].b));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = c->ev_used;
+    c->ev_used = 0;
+    return KSCHED_OK;
+}
+
+}  // extern "C"

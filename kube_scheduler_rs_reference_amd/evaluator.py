@@ -1,0 +1,206 @@
+"""Python face of the C ABI: `Evaluator` owns one `ksched_ctx` (one GPU).
+
+Two call styles, both straight through the C ABI (include/ksched.h):
+  * `eval(...)`        numpy arrays in host memory -> ksched_eval        (copies in/out, synchronous)
+  * `eval_device(...)` torch CUDA tensors          -> ksched_eval_device (enqueue on torch's stream)
+torch is used only as the owner of device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+
+
+def mask_words(n_nodes: int) -> int:
+    return (int(n_nodes) + 63) // 64
+
+
+def _np(a, dtype, name):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class EvalResult:
+    feasible: Optional[np.ndarray] = None  # [P, W] uint64
+    fit: Optional[np.ndarray] = None       # [P, W] uint64
+    binding: Optional[np.ndarray] = None   # [P] int32
+
+
+class Evaluator:
+    def __init__(self, device: int = 0):
+        self._lib = L.load()
+        h = C.c_void_p()
+        rc = self._lib.ksched_create(C.byref(h), int(device))
+        if rc != L.OK:
+            raise L.KschedError(rc, "ksched_create")
+        self._h = h
+        self.device = int(device)
+        self.n = 0
+        self.n_keys = 0
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ksched_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int, where: str):
+        if rc != L.OK:
+            raise L.KschedError(rc, where, self._lib.ksched_last_error(self._h).decode())
+
+    # -- options / introspection ---------------------------------------------------------------
+    def set_option(self, option: int, value: int):
+        self._check(self._lib.ksched_set_option(self._h, option, value), "ksched_set_option")
+
+    def set_kernel(self, name: str):
+        self.set_option(L.OPT_KERNEL, {"auto": L.KERNEL_AUTO, "direct": L.KERNEL_DIRECT, "indexed": L.KERNEL_INDEXED}[name])
+
+    def set_timing(self, on: bool):
+        self.set_option(L.OPT_TIMING, 1 if on else 0)
+
+    def kernel_time_ms(self):
+        ms = C.c_double(0)
+        cnt = C.c_uint64(0)
+        self._check(self._lib.ksched_kernel_time_ms(self._h, C.byref(ms), C.byref(cnt)), "ksched_kernel_time_ms")
+        return ms.value, cnt.value
+
+    @property
+    def last_kernel(self) -> str:
+        return self._lib.ksched_last_kernel(self._h).decode()
+
+    @property
+    def W(self) -> int:
+        return mask_words(self.n)
+
+    # -- snapshot --------------------------------------------------------------------------------
+    def set_nodes(self, avail_cpu_milli, avail_mem_bytes, label_val_ids=None, taints=None):
+        cpu = _np(avail_cpu_milli, np.int64, "avail_cpu_milli")
+        mem = _np(avail_mem_bytes, np.int64, "avail_mem_bytes")
+        n = cpu.shape[0]
+        if mem.shape != (n,):
+            raise ValueError("avail_mem_bytes shape")
+        lab = _np(label_val_ids, np.uint32, "label_val_ids")
+        n_keys = 0
+        if lab is not None:
+            if lab.ndim != 2 or lab.shape[1] != n:
+                raise ValueError("label_val_ids must be [n_keys][n]")
+            n_keys = lab.shape[0]
+        tnt = _np(taints, np.uint64, "taints")
+        if tnt is not None and tnt.shape != (n,):
+            raise ValueError("taints shape")
+        rc = self._lib.ksched_set_nodes(self._h, n, _ptr(cpu), _ptr(mem), _ptr(lab) if n_keys else None, n_keys, _ptr(tnt))
+        self._check(rc, "ksched_set_nodes")
+        self.n = n
+        self.n_keys = n_keys
+
+    # -- evaluation, host buffers ------------------------------------------------------------------
+    def eval(self, req_cpu_milli, req_mem_bytes, sel_val_ids=None, tolerations=None, samples=None, flags: int = L.FIT,
+             want_mask: bool = True) -> EvalResult:
+        cpu = _np(req_cpu_milli, np.int64, "req_cpu_milli")
+        mem = _np(req_mem_bytes, np.int64, "req_mem_bytes")
+        p = cpu.shape[0]
+        sel = _np(sel_val_ids, np.uint32, "sel_val_ids")
+        if sel is not None and sel.shape != (self.n_keys, p):
+            raise ValueError(f"sel_val_ids must be [{self.n_keys}][{p}]")
+        tol = _np(tolerations, np.uint64, "tolerations")
+        smp = _np(samples, np.uint32, "samples")
+        attempts = 0
+        if flags & L.PICK_SAMPLED:
+            if smp is None or smp.ndim != 2 or smp.shape[0] != p:
+                raise ValueError("samples must be [p][attempts]")
+            attempts = smp.shape[1]
+        W = self.W
+        res = EvalResult()
+        if want_mask:
+            res.feasible = np.empty((p, W), dtype=np.uint64)
+        if flags & L.WANT_FIT_MASK:
+            res.fit = np.empty((p, W), dtype=np.uint64)
+        if flags & (L.PICK_SAMPLED | L.PICK_BESTFIT):
+            res.binding = np.empty((p,), dtype=np.int32)
+        rc = self._lib.ksched_eval(self._h, p, _ptr(cpu), _ptr(mem), _ptr(sel), _ptr(tol), _ptr(smp), attempts, flags,
+                                   _ptr(res.feasible), _ptr(res.fit), _ptr(res.binding))
+        self._check(rc, "ksched_eval")
+        return res
+
+    # -- evaluation, device buffers (torch tensors) ----------------------------------------------
+    def eval_device(self, req_cpu_milli, req_mem_bytes, sel_val_ids=None, tolerations=None, samples=None,
+                    flags: int = L.FIT, out_feasible=None, out_fit=None, out_binding=None, stream=None):
+        """All arguments are torch CUDA tensors on this evaluator's device (int64 stands in for
+        uint64, int32 for uint32).  Work is enqueued on `stream` (default: torch's current stream)."""
+        import torch
+
+        def dp(t, dtypes, shape=None):
+            if t is None:
+                return None
+            if not t.is_cuda or t.device.index != self.device or not t.is_contiguous() or t.dtype not in dtypes:
+                raise ValueError(f"expected contiguous {dtypes} CUDA tensor on cuda:{self.device}")
+            if shape is not None and tuple(t.shape) != tuple(shape):
+                raise ValueError(f"expected shape {shape}, got {tuple(t.shape)}")
+            return C.c_void_p(t.data_ptr())
+
+        p = int(req_cpu_milli.shape[0])
+        W = self.W
+        i64 = (torch.int64,)
+        u64 = (torch.int64, torch.uint64)
+        u32 = (torch.int32, torch.uint32)
+        attempts = int(samples.shape[1]) if (flags & L.PICK_SAMPLED and samples is not None) else 0
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        rc = self._lib.ksched_eval_device(
+            self._h, p, dp(req_cpu_milli, i64, (p,)), dp(req_mem_bytes, i64, (p,)),
+            dp(sel_val_ids, u32, (self.n_keys, p)) if sel_val_ids is not None else None,
+            dp(tolerations, u64, (p,)), dp(samples, u32), attempts, flags,
+            dp(out_feasible, u64, (p, W)), dp(out_fit, u64, (p, W)), dp(out_binding, (torch.int32,), (p,)),
+            C.c_void_p(stream.cuda_stream))
+        self._check(rc, "ksched_eval_device")
+
+    # -- reasons -------------------------------------------------------------------------------------
+    def reason(self, feasible_row: np.ndarray, fit_row: Optional[np.ndarray], node: int, flags: int) -> int:
+        f = np.ascontiguousarray(feasible_row, dtype=np.uint64)
+        r = None if fit_row is None else np.ascontiguousarray(fit_row, dtype=np.uint64)
+        return self._lib.ksched_reason(_ptr(f), _ptr(r), int(node), int(flags))
+
+
+# ---- pure helpers on masks (numpy; no predicate logic here) -----------------------------------------
+def unpack_mask(mask: np.ndarray, n_nodes: int) -> np.ndarray:
+    """[P, W] uint64 -> [P, n_nodes] bool (bit node%64 of word node/64)."""
+    p = mask.shape[0]
+    if n_nodes == 0:
+        return np.zeros((p, 0), dtype=bool)
+    b = np.unpackbits(np.ascontiguousarray(mask).view(np.uint8), axis=1, bitorder="little")
+    return b[:, :n_nodes].astype(bool)
+
+
+def pack_mask(bits: np.ndarray) -> np.ndarray:
+    """[P, N] bool -> [P, W] uint64, padding bits zero."""
+    p, n = bits.shape
+    W = mask_words(n)
+    if W == 0:
+        return np.zeros((p, 0), dtype=np.uint64)
+    padded = np.zeros((p, W * 64), dtype=np.uint8)
+    padded[:, :n] = bits
+    return np.packbits(padded, axis=1, bitorder="little").view(np.uint64).reshape(p, W)

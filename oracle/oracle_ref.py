@@ -1,0 +1,228 @@
+"""Pure-Python, exact restatement of the reference's predicate path on Kubernetes-shaped dicts.
+
+TEST INFRASTRUCTURE ONLY -- same rules as oracle/oracle.h: only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this; the product never does.
+
+Follows acrlabs/kube-scheduler-rs-reference src/predicates.rs:14-77, src/util.rs:17-36,54-75 and
+src/main.rs:49-71 line by line (citations on each function).  Arithmetic is `fractions.Fraction`
+(arbitrary precision), so it doubles as an independent check of oracle.c's 128-bit integers.
+
+Pinning: `does_node_selector_match` is pinned by the reference's tests
+(src/predicates/test.rs:42-58).  The resource-fit arithmetic (kube_quantity 0.6.1, un-vendored)
+has no reference test: parity unpinned there (see oracle.h).
+
+Objects are plain dicts in the API server's JSON shape; an absent key is Rust's `None`.
+"""
+from __future__ import annotations
+
+import re
+from fractions import Fraction
+from typing import Iterable, List, Optional, Sequence
+
+ATTEMPTS = 5  # src/main.rs:49
+
+
+class ReferencePanic(Exception):
+    """A situation where the reference would panic (expect / unwrap / map index)."""
+
+
+# ---- quantities (role of kube_quantity::ParsedQuantity) ------------------------------------------
+_DEC = {"n": -9, "u": -6, "m": -3, "": 0, "k": 3, "M": 6, "G": 9, "T": 12, "P": 15, "E": 18}
+_BIN = {"Ki": 10, "Mi": 20, "Gi": 30, "Ti": 40, "Pi": 50, "Ei": 60}
+_QRE = re.compile(r"^([+-]?)(\d*)(?:\.(\d*))?((?:[eE][+-]?\d+)|[KMGTPE]i|[numkMGTPE]?)$")
+
+
+def parse_quantity(s: str) -> Fraction:
+    """Kubernetes resource.Quantity text -> exact value (cores, bytes)."""
+    if not isinstance(s, str):
+        raise ReferencePanic(f"quantity is not a string: {s!r}")
+    m = _QRE.match(s)
+    if not m or not (m.group(2) or m.group(3)):
+        raise ReferencePanic(f"invalid quantity {s!r}")  # try_into().expect(...), src/util.rs:65,68
+    sign, ip, fp, suf = m.group(1), m.group(2) or "0", m.group(3) or "", m.group(4)
+    val = Fraction(int(ip + fp), 10 ** len(fp))
+    if suf in _BIN:
+        val *= 2 ** _BIN[suf]
+    elif suf and suf[0] in "eE" and len(suf) > 1:
+        val *= Fraction(10) ** int(suf[1:])
+    else:
+        val *= Fraction(10) ** _DEC[suf]
+    return -val if sign == "-" else val
+
+
+class PodResources:
+    """src/util.rs:17-36"""
+
+    def __init__(self):  # PodResources::new, src/util.rs:22-29
+        self.cpu = parse_quantity("0")
+        self.memory = parse_quantity("0")
+
+    def sub_assign(self, other: "PodResources"):  # src/util.rs:31-36
+        self.cpu -= other.cpu
+        self.memory -= other.memory
+
+
+def total_pod_resources(pod: dict) -> PodResources:
+    """src/util.rs:54-75"""
+    res = PodResources()  # :55
+    spec = pod.get("spec")
+    if spec is not None:  # :57
+        for c in spec.get("containers") or []:  # :58 -- containers only: no initContainers, no overhead
+            resources = c.get("resources")
+            requests = resources.get("requests") if resources is not None else None
+            if requests is not None:  # :59-63
+                if "cpu" in requests:  # :64
+                    res.cpu += parse_quantity(requests["cpu"])  # :65
+                if "memory" in requests:  # :67
+                    res.memory += parse_quantity(requests["memory"])  # :68
+    return res
+
+
+def list_pods_on_node(all_pods: Iterable[dict], node_name: str) -> List[dict]:
+    """src/predicates.rs:21-25,34: LIST with field selector spec.nodeName=<node>; every phase counts."""
+    return [p for p in all_pods if (p.get("spec") or {}).get("nodeName") == node_name]
+
+
+def node_name(node: dict) -> str:
+    return (node.get("metadata") or {}).get("name", "")
+
+
+def can_pod_fit(pod: dict, node: dict, pods_on_node: Sequence[dict]) -> bool:
+    """src/predicates.rs:20-43 with the LIST result of :34 injected."""
+    available = PodResources()  # :27
+    status = node.get("status")
+    allocatable = status.get("allocatable") if status is not None else None
+    if allocatable is not None:  # :28
+        if "cpu" not in allocatable or "memory" not in allocatable:
+            raise ReferencePanic("allocatable lacks cpu/memory (BTreeMap index panics, src/predicates.rs:29-31)")
+        available.cpu = parse_quantity(allocatable["cpu"])  # :29
+        available.memory = parse_quantity(allocatable["memory"])  # :30-31
+    for p in pods_on_node:  # :36
+        available.sub_assign(total_pod_resources(p))  # :37
+    pod_requests = total_pod_resources(pod)  # :40
+    return pod_requests.cpu <= available.cpu and pod_requests.memory <= available.memory  # :42
+
+
+def does_node_selector_match(pod: dict, node: dict) -> bool:
+    """src/predicates.rs:45-61"""
+    matches = True  # :46
+    spec = pod.get("spec")
+    node_selector = spec.get("nodeSelector") if spec is not None else None
+    if node_selector is not None:  # :47
+        for pk in sorted(node_selector):  # :48 BTreeMap iteration order
+            pv = node_selector[pk]
+            labels = (node.get("metadata") or {}).get("labels")
+            if labels is not None:  # :49
+                if pk not in labels or labels[pk] != pv:  # :50  labels.get(pk) != Some(pv)
+                    matches = False
+                    break
+            else:  # :54-57
+                matches = False
+                break
+    return matches  # :60
+
+
+def check_node_validity(pod: dict, node: dict, pods_on_node: Sequence[dict]) -> Optional[str]:
+    """src/predicates.rs:63-77.  None = Ok(()); otherwise the Debug name of InvalidNodeReason."""
+    if not can_pod_fit(pod, node, pods_on_node):  # :68
+        return "NotEnoughResources"  # :69
+    if not does_node_selector_match(pod, node):  # :72
+        return "NodeSelectorMismatch"  # :73
+    return None  # :76
+
+
+def select_node_for_pod(pod: dict, nodes: Sequence[dict], all_pods: Sequence[dict], samples: Sequence[int],
+                        attempts: int = ATTEMPTS) -> Optional[int]:
+    """src/main.rs:51-71 with the `choose` draws injected; returns the node index or None."""
+    chosen = None  # :52
+    for i in range(attempts):  # :53
+        if len(nodes) == 0:  # :56 choose() on an empty slice
+            continue
+        s = samples[i]
+        if s >= len(nodes):  # not reachable in the reference; the ABI treats it as an infeasible draw
+            continue
+        candidate = nodes[s]  # :57
+        if check_node_validity(pod, candidate, list_pods_on_node(all_pods, node_name(candidate))) is None:  # :61
+            chosen = s  # :64
+            break  # :65
+    return chosen  # :70
+
+
+# ---- extensions (BASELINE.json config 5; semantics in DESIGN.md) -------------------------------------
+def _toleration_matches(t: dict, taint: dict) -> bool:
+    if t.get("effect") and t.get("effect") != taint.get("effect", ""):
+        return False
+    op = t.get("operator") or "Equal"
+    if not t.get("key"):
+        return op == "Exists"
+    if t.get("key") != taint.get("key", ""):
+        return False
+    if op == "Exists":
+        return True
+    return op == "Equal" and (t.get("value") or "") == (taint.get("value") or "")
+
+
+def tolerates_node_taints(pod: dict, node: dict) -> bool:
+    tols = (pod.get("spec") or {}).get("tolerations") or []
+    for taint in (node.get("spec") or {}).get("taints") or []:
+        if taint.get("effect") not in ("NoSchedule", "NoExecute"):
+            continue
+        if not any(_toleration_matches(t, taint) for t in tols):
+            return False
+    return True
+
+
+def available_of(node: dict, all_pods: Sequence[dict]) -> PodResources:
+    """allocatable - sum(requests of the node's LIST), the left side of src/predicates.rs:42."""
+    available = PodResources()
+    status = node.get("status")
+    allocatable = status.get("allocatable") if status is not None else None
+    if allocatable is not None:
+        if "cpu" not in allocatable or "memory" not in allocatable:
+            raise ReferencePanic("allocatable lacks cpu/memory")
+        available.cpu = parse_quantity(allocatable["cpu"])
+        available.memory = parse_quantity(allocatable["memory"])
+    for p in list_pods_on_node(all_pods, node_name(node)):
+        available.sub_assign(total_pod_resources(p))
+    return available
+
+
+def pick_bestfit(pod: dict, nodes: Sequence[dict], all_pods: Sequence[dict], use_fit=True, use_sel=True,
+                 use_taint=False) -> Optional[int]:
+    """Extension E1: lexicographic min over feasible nodes of (mem residual, cpu residual, node index)."""
+    req = total_pod_resources(pod)
+    best = None
+    for i, node in enumerate(nodes):
+        on = list_pods_on_node(all_pods, node_name(node))
+        if use_fit and not can_pod_fit(pod, node, on):
+            continue
+        if use_sel and not does_node_selector_match(pod, node):
+            continue
+        if use_taint and not tolerates_node_taints(pod, node):
+            continue
+        av = available_of(node, all_pods)
+        key = (av.memory - req.memory, av.cpu - req.cpu, i)
+        if best is None or key < best:
+            best = key
+    return None if best is None else best[2]
+
+
+def eval_matrix(pods: Sequence[dict], nodes: Sequence[dict], all_pods: Sequence[dict], use_fit=True, use_sel=True,
+                use_taint=False):
+    """feasible[p][n], fit[p][n] as nested lists of bool, one per-pair reference evaluation each."""
+    lists = [list_pods_on_node(all_pods, node_name(n)) for n in nodes]
+    feas, fits = [], []
+    for pod in pods:
+        frow, rrow = [], []
+        for node, on in zip(nodes, lists):
+            fit = can_pod_fit(pod, node, on) if use_fit else True
+            ok = fit
+            if ok and use_sel:
+                ok = does_node_selector_match(pod, node)
+            if ok and use_taint:
+                ok = tolerates_node_taints(pod, node)
+            frow.append(ok)
+            rrow.append(fit)
+        feas.append(frow)
+        fits.append(rrow)
+    return feas, fits

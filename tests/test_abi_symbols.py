@@ -1,0 +1,89 @@
+"""The C-ABI shared library loads and exports every symbol include/ksched.h declares (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from tests.conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "ksched.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ksched_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("ksched_create", "ksched_destroy", "ksched_set_nodes", "ksched_eval", "ksched_eval_device", "ksched_strerror"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(built):
+    from kube_scheduler_rs_reference_amd import _lib
+    lib = _lib.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in ksched.h but not exported"
+    # and the Python binding table covers exactly the header
+    assert sorted(_lib.SYMBOLS) == declared_functions()
+
+
+def test_constants_match_header(built):
+    from kube_scheduler_rs_reference_amd import _lib
+    text = open(HEADER).read()
+    defs = {m.group(1): m.group(2) for m in re.finditer(r"#define\s+KSCHED_([A-Z_0-9]+)\s+\(?(-?(?:0x)?[0-9A-Fa-f]+)u?\)?", text)}
+    for k, v in defs.items():
+        if hasattr(_lib, k):
+            assert getattr(_lib, k) == int(v, 0), k
+    assert _lib.load().ksched_abi_version() == int(defs["ABI_VERSION"], 0)
+    assert _lib.load().ksched_mask_words(0) == 0
+    assert _lib.load().ksched_mask_words(64) == 1
+    assert _lib.load().ksched_mask_words(65) == 2
+
+
+def test_no_cpu_fallback(built):
+    """Without a GPU the product refuses to run instead of falling back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from kube_scheduler_rs_reference_amd import Evaluator, KschedError, _lib
+    with pytest.raises(KschedError) as ei:
+        Evaluator(0)
+    assert ei.value.code == _lib.E_NODEVICE
+
+
+def test_null_arguments_are_errors_not_crashes(built):
+    from kube_scheduler_rs_reference_amd import _lib
+    lib = _lib.load()
+    assert lib.ksched_create(None, 0) == _lib.E_INVAL
+    assert lib.ksched_set_nodes(None, 0, None, None, None, 0, None) == _lib.E_INVAL
+    assert lib.ksched_eval(None, 0, None, None, None, None, None, 0, 0, None, None, None) == _lib.E_INVAL
+    lib.ksched_destroy(None)
+    assert b"no CPU fallback" in lib.ksched_strerror(_lib.E_NODEVICE)
+
+
+def test_reason_helper(built):
+    import numpy as np
+    from kube_scheduler_rs_reference_amd import _lib
+    lib = _lib.load()
+    feas = np.array([0b0001], dtype=np.uint64)
+    fit = np.array([0b0011], dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    fl = _lib.FIT | _lib.SEL
+    assert lib.ksched_reason(p(feas), p(fit), 0, fl) == _lib.REASON_OK
+    assert lib.ksched_reason(p(feas), p(fit), 1, fl) == _lib.REASON_NODE_SELECTOR_MISMATCH
+    assert lib.ksched_reason(p(feas), p(fit), 2, fl) == _lib.REASON_NOT_ENOUGH_RESOURCES  # fit first, src/predicates.rs:68-70
+
+
+def test_product_does_not_import_the_oracle():
+    """The product package must never route through oracle/ (parity claims depend on it)."""
+    pkg = os.path.join(ROOT, "kube_scheduler_rs_reference_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".rs")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "oracle.h" not in src and "liboracle" not in src, f
