@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X: pod x node predicate evaluations per second.
+
+    python bench.py --gpus N --steps K --warmup W [--workload C3] [--kernel auto|direct|indexed]
+
+A "step" is one pass of the hot path over one batch of synthetic pods, inputs already resident in
+HBM: the mask kernel (feasible bits for every (pod, node) pair of this rank's pod rows) + the
+sampled pick (select_node_for_pod with injected draws) and, for N > 1, the all-gather of the int32
+bindings over RCCL.  One evaluation = one (pod, node) feasibility bit.
+
+Workloads (per GPU; weak scaling: rank r evaluates its own P pods against the replicated snapshot):
+    C2  10k pods x 1k nodes, fit only                       BASELINE.json configs[1] (launch-bound)
+    C3  100k pods x 5k nodes, fit + nodeSelector (8 keys)   BASELINE.json configs[2]  <- default
+    C4s 125k pods x 10k nodes, fit + sel                    configs[3] = 8 of these (1M x 10k)
+    C5s 125k pods x 50k nodes, fit + sel + taints, best fit configs[4] = 8 of these (1M x 50k)
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant (mask) kernel: algorithmic bytes
+per launch / its HIP-event duration measured live on the launch stream inside the timed steps.
+`cpu_baseline` is the oracle (CPU restatement, kind "port") timed on this box's host cores on a
+bounded sample of the same workload; it is a reported baseline, never the thing measured above.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+HBM_COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling, same table
+
+WORKLOADS = {
+    # name: (config, P per GPU, N, flags, pick, description)
+    "C2": ("C2", 10_000, 1_000, ("FIT",), "sampled", "C2: 10k pods x 1k nodes, fit only (BASELINE.json configs[1])"),
+    "C3": ("C3", 100_000, 5_000, ("FIT", "SEL"), "sampled",
+           "C3: 100k pods x 5k nodes, fit + nodeSelector over 8 label keys (BASELINE.json configs[2])"),
+    "C4s": ("C4", 125_000, 10_000, ("FIT", "SEL"), "sampled",
+            "C4 shard: 125k pods x 10k nodes per GPU, fit + sel (BASELINE.json configs[3] = 8 shards)"),
+    "C5s": ("C5", 125_000, 50_000, ("FIT", "SEL", "TAINT"), "bestfit",
+            "C5 shard: 125k pods x 50k nodes per GPU, fit + sel + taints, best-fit pick (configs[4] = 8 shards)"),
+}
+
+
+def algorithmic_bytes(P, N, n_keys, taint, masks=1):
+    """SURVEY.md section 8d for the mask kernel: every input column read once, every mask word written once."""
+    W = (N + 63) // 64
+    b_pod = 16 + 4 * n_keys + (8 if taint else 0)
+    b_node = 16 + 4 * n_keys + (8 if taint else 0)
+    return P * b_pod + N * b_node + P * W * 8 * masks
+
+
+def cpu_baseline(c, flags_names, budget_s=12.0):
+    """Time the oracle (object-level C restatement, per-pair string/map evaluation; quantities parsed
+    once, LIST once per node) on all host cores on a bounded sample of this workload's pods."""
+    from oracle import capi
+    flags = sum(getattr(capi, f) for f in flags_names)
+    threads = capi.num_threads()
+    nodes, bound = c.node_objects(), c.bound_pod_objects()
+    s = capi.ObjectSet()
+    cn, cb = s.nodes(nodes), s.pods(bound)
+
+    def run(P_s, th):
+        pods = c.pod_objects(0, P_s)
+        cp = s.pods(pods)
+        t0 = time.perf_counter()
+        capi.eval_objects(pods, nodes, bound, flags, threads=th, prebuilt=(s, cp, cn, cb))
+        return time.perf_counter() - t0
+
+    probe = min(c.P, 64 * max(1, threads))
+    t = run(probe, threads)
+    rate = probe * c.N / max(t, 1e-9)
+    P_s = int(min(c.P, max(probe, rate * budget_s / c.N)))
+    t = run(P_s, threads)
+    value = P_s * c.N / t
+    # single core, smaller sample
+    P_1 = max(1, min(P_s, int(P_s / max(1, threads))))
+    t1 = run(P_1, 1)
+    # second, stronger CPU baseline: scalar loop on the encoded integer columns
+    t0 = time.perf_counter()
+    P_e = min(c.P, 20_000)
+    capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels if c.n_keys else None, c.node_taints if c.n_taints else None,
+                      c.req_cpu[:P_e], c.req_mem[:P_e], c.pod_sel[:, :P_e] if c.n_keys else None,
+                      c.pod_tol[:P_e] if c.n_taints else None, None, flags, threads=threads)
+    te = time.perf_counter() - t0
+    return {
+        "value": value, "unit": "evals/s", "cores": threads, "kind": "port",
+        "sample": f"{P_s} pods x {c.N} nodes of the same workload, object-level oracle (oracle.c ora_eval_objects: "
+                  f"per-pair string/map evaluation, quantities parsed once), {threads} threads, {t:.1f} s",
+        "single_core_value": P_1 * c.N / t1,
+        "encoded_loop_value": P_e * c.N / te,
+        "encoded_loop_note": f"scalar loop on the encoded integer columns (ora_eval_encoded), {threads} threads, {P_e} pods",
+        "host_cores": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "indexed"])
+    ap.add_argument("--pods", type=int, default=None, help="override pods per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mask", action="store_true", help="bindings only (not the graded form)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from kube_scheduler_rs_reference_amd import Evaluator, _lib as L, synth
+    from kube_scheduler_rs_reference_amd.dist import ShardedScheduler
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg, P_gpu, N, flag_names, pick, desc = WORKLOADS[args.workload]
+    if args.pods:
+        P_gpu = args.pods
+    P_total = P_gpu * world
+    c = synth.make_config(cfg, P=P_total, N=N)  # same seeded cluster on every rank; each takes its rows
+    flags = sum(getattr(L, f) for f in flag_names)
+    flags |= L.PICK_SAMPLED if pick == "sampled" else L.PICK_BESTFIT
+    taint = "TAINT" in flag_names
+
+    ev = Evaluator(local_rank)
+    ev.set_kernel(args.kernel)
+    ev.set_nodes(**c.node_columns())
+    sched = ShardedScheduler(P_total, dev)
+    lo, hi = sched.lo, sched.hi
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    d_cpu, d_mem = t(c.req_cpu[lo:hi], np.int64), t(c.req_mem[lo:hi], np.int64)
+    d_sel = t(c.pod_sel[:, lo:hi], np.int32) if c.n_keys else None
+    d_tol = t(c.pod_tol[lo:hi], np.int64) if taint else None
+    d_smp = t(c.samples[lo:hi], np.int32) if pick == "sampled" else None
+    W = ev.W
+    d_mask = None if args.no_mask else torch.empty((hi - lo, W), dtype=torch.int64, device=dev)
+
+    def local_eval(binding_out):
+        ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=d_mask, out_binding=binding_out)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sched.step(local_eval)
+    sync()
+    ev.set_timing(True)
+    ev.kernel_time_ms()  # reset
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bindings = sched.step(local_eval)
+    sync()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = ev.kernel_time_ms()
+    ev.set_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # sanity inside the bench: bindings of the last step agree with a spot check of the mask
+    bound_frac = float((bindings >= 0).float().mean().item())
+
+    if rank == 0:
+        evals = float(P_total) * N * args.steps
+        value = evals / elapsed
+        avg_kernel_s = (kern_ms / max(launches, 1)) * 1e-3
+        alg = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint)
+        achieved = alg / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                rec = json.load(open(tpath)).get(f"{args.workload}:{ev.last_kernel}")
+                traffic = rec["hbm_bytes_per_launch"] if rec else None
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "pod x node predicate evals/s", "value": value, "unit": "evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": desc, "pods_per_gpu": P_gpu, "pods_total": P_total, "nodes": N,
+                       "predicates": "+".join(flag_names), "pick": pick, "mask_written": not args.no_mask,
+                       "kernel": ev.last_kernel, "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
+                       "allgather(int32 bindings)" if world > 1 else "single GPU",
+                       "bound_fraction": bound_frac},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
+                         "kernel": f"mask kernel ({ev.last_kernel})", "algorithmic_bytes_per_launch": alg,
+                         "avg_kernel_us": avg_kernel_s * 1e6, "launches_timed": int(launches),
+                         "mask_kernel_evals_per_s": (hi - lo) * N / avg_kernel_s if avg_kernel_s > 0 else 0.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(c, flag_names)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ev.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,289 @@
+"""Parity of the HIP path (through the C ABI) against the oracle -- the first gate.
+
+Bit-exact (integer/bitmask work): every mask word and every binding must be identical.  Sizes
+here are ones the encoded-level oracle finishes in seconds; BASELINE.json's full sizes are
+covered by size-independent properties in test_gpu_properties.py.
+"""
+import numpy as np
+import pytest
+
+from kube_scheduler_rs_reference_amd import (FIT, PICK_BESTFIT, PICK_SAMPLED, SEL, SEL_NEVER, TAINT, WANT_FIT_MASK,
+                                             KschedError, _lib, synth, unpack_mask)
+from oracle import capi
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = ["direct", "auto"]
+
+
+def oracle_eval(c, flags, samples=True):
+    return capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels if c.n_keys else None,
+                             c.node_taints if c.n_taints else None, c.req_cpu, c.req_mem,
+                             c.pod_sel if c.n_keys else None, c.pod_tol if c.n_taints else None,
+                             c.samples if samples else None, flags)
+
+
+def hip_eval(ev, c, flags):
+    ev.set_nodes(**c.node_columns())
+    pc = c.pod_columns()
+    return ev.eval(pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], pc["tolerations"], pc["samples"], flags)
+
+
+def check(ev, c, flags):
+    r = hip_eval(ev, c, flags)
+    feas, fit, bind = oracle_eval(c, flags)
+    assert np.array_equal(r.feasible, feas), "feasible mask"
+    if flags & WANT_FIT_MASK:
+        assert np.array_equal(r.fit, fit), "fit mask"
+    if flags & (PICK_SAMPLED | PICK_BESTFIT):
+        assert np.array_equal(r.binding, bind), "binding"
+    return r
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_c1_100x20(evaluator, kernel):  # BASELINE.json configs[0]
+    evaluator.set_kernel(kernel)
+    check(evaluator, synth.make_config("C1"), FIT | SEL | WANT_FIT_MASK | PICK_SAMPLED)
+    evaluator.set_kernel("auto")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_c2_10k_x_1k_fit_only(evaluator, kernel):  # BASELINE.json configs[1]
+    evaluator.set_kernel(kernel)
+    c = synth.make_config("C2")
+    r = check(evaluator, c, FIT | PICK_SAMPLED)
+    d = unpack_mask(r.feasible, c.N).mean()
+    assert 0.05 < d < 0.99
+    evaluator.set_kernel("auto")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_c3_reduced_fit_sel(evaluator, kernel):  # configs[2] at a size the oracle does in seconds: 20k x 5k
+    evaluator.set_kernel(kernel)
+    c = synth.make_config("C3", P=20_000)
+    check(evaluator, c, FIT | SEL | WANT_FIT_MASK | PICK_SAMPLED)
+    evaluator.set_kernel("auto")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_c5_reduced_taints_bestfit(evaluator, kernel):  # configs[4] shape reduced: 4k x 50k, all predicates
+    evaluator.set_kernel(kernel)
+    c = synth.make_config("C5", P=4_000)
+    check(evaluator, c, FIT | SEL | TAINT | PICK_BESTFIT)
+    evaluator.set_kernel("auto")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("P,N", [(1, 1), (1, 64), (64, 1), (63, 65), (65, 63), (129, 1025), (1000, 4097), (257, 16 * 64 + 1)])
+def test_ragged_shapes(evaluator, kernel, P, N):
+    evaluator.set_kernel(kernel)
+    c = synth.make_cluster(P, N, n_keys=8, n_taints=16, seed=P * 1000 + N)
+    r = check(evaluator, c, FIT | SEL | TAINT | WANT_FIT_MASK | PICK_BESTFIT)
+    # padding bits of the last word are zero
+    if N % 64:
+        assert not (r.feasible[:, -1] >> np.uint64(N % 64)).any()
+        assert not (r.fit[:, -1] >> np.uint64(N % 64)).any()
+    check(evaluator, c, FIT | SEL | TAINT | PICK_SAMPLED)
+    evaluator.set_kernel("auto")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("flags", [FIT, SEL, TAINT, FIT | SEL, FIT | TAINT, SEL | TAINT, FIT | SEL | TAINT, 0])
+def test_predicate_subsets(evaluator, kernel, flags):
+    """Predicates not selected are treated as true."""
+    evaluator.set_kernel(kernel)
+    c = synth.make_cluster(300, 700, n_keys=8, n_taints=16, seed=77)
+    ev = evaluator
+    ev.set_nodes(**c.node_columns())
+    pc = c.pod_columns()
+    r = ev.eval(pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], pc["tolerations"], None, flags)
+    feas, _, _ = oracle_eval(c, flags, samples=False)
+    assert np.array_equal(r.feasible, feas)
+    if flags == 0:
+        assert unpack_mask(r.feasible, c.N).all()
+    evaluator.set_kernel("auto")
+
+
+def test_edge_values(evaluator):
+    """Extremes of the integer domain: negative available, zero requests, i64 limits, exact fit."""
+    i64 = np.iinfo(np.int64)
+    avail_cpu = np.array([0, -1, 1, i64.max, i64.min, 1000, 1000, 5], dtype=np.int64)
+    avail_mem = np.array([0, 0, -5, i64.max, i64.min, 1 << 40, (1 << 40) - 1, i64.max], dtype=np.int64)
+    req_cpu = np.array([0, 1, 1000, i64.max, i64.min, -1, 1001, 5], dtype=np.int64)
+    req_mem = np.array([0, 0, 1 << 40, i64.max, i64.min, 1, 0, i64.max], dtype=np.int64)
+    ev = evaluator
+    ev.set_nodes(avail_cpu, avail_mem)
+    for kernel in KERNELS:
+        ev.set_kernel(kernel)
+        r = ev.eval(req_cpu, req_mem, flags=FIT)
+        feas, _, _ = capi.eval_encoded(avail_cpu, avail_mem, None, None, req_cpu, req_mem, None, None, None, capi.FIT)
+        assert np.array_equal(r.feasible, feas)
+        want = (req_cpu[:, None] <= avail_cpu[None, :]) & (req_mem[:, None] <= avail_mem[None, :])
+        assert np.array_equal(unpack_mask(r.feasible, 8), want)
+    ev.set_kernel("auto")
+
+
+def test_selector_semantics_encoded(evaluator):
+    """0 = unconstrained, SEL_NEVER never matches, absent label (0) never satisfies a constraint."""
+    lab = np.array([[1, 2, 0, 1], [0, 5, 5, 5]], dtype=np.uint32)  # [2 keys][4 nodes]
+    big = np.full(4, 1 << 40, dtype=np.int64)
+    sel = np.array([[0, 1, 2, 0, SEL_NEVER, 1, 3], [0, 0, 0, 5, 0, 5, 0]], dtype=np.uint32)  # [2][7 pods]
+    zero = np.zeros(7, dtype=np.int64)
+    want = np.array([[1, 1, 1, 1], [1, 0, 0, 1], [0, 1, 0, 0], [0, 1, 1, 1], [0, 0, 0, 0], [0, 0, 0, 1], [0, 0, 0, 0]], dtype=bool)
+    ev = evaluator
+    ev.set_nodes(big, big, lab)
+    for kernel in KERNELS:
+        ev.set_kernel(kernel)
+        r = ev.eval(zero, zero, sel, flags=FIT | SEL)
+        assert np.array_equal(unpack_mask(r.feasible, 4), want)
+    ev.set_kernel("auto")
+
+
+def test_many_keys_multi_pass(evaluator):
+    """More label keys than one pass of the direct kernel handles (8): 19 keys."""
+    rng = np.random.default_rng(5)
+    N, P, K = 500, 333, 19
+    lab = rng.integers(0, 4, size=(K, N), dtype=np.uint32)
+    sel = np.where(rng.random((K, P)) < 0.1, rng.integers(1, 4, size=(K, P)), 0).astype(np.uint32)
+    cpu = rng.integers(0, 1000, N).astype(np.int64)
+    mem = rng.integers(0, 1000, N).astype(np.int64)
+    rc = rng.integers(0, 1000, P).astype(np.int64)
+    rm = rng.integers(0, 1000, P).astype(np.int64)
+    ev = evaluator
+    ev.set_nodes(cpu, mem, lab)
+    for kernel in KERNELS:
+        ev.set_kernel(kernel)
+        r = ev.eval(rc, rm, sel, flags=FIT | SEL | WANT_FIT_MASK)
+        feas, fit, _ = capi.eval_encoded(cpu, mem, lab, None, rc, rm, sel, None, None, capi.FIT | capi.SEL | capi.WANT_FIT_MASK)
+        assert np.array_equal(r.feasible, feas) and np.array_equal(r.fit, fit)
+    ev.set_kernel("auto")
+
+
+def test_empty_inputs(evaluator):
+    ev = evaluator
+    # zero nodes: empty rows, no binding (reference: choose() on an empty store, src/main.rs:56,70)
+    ev.set_nodes(np.zeros(0, np.int64), np.zeros(0, np.int64))
+    r = ev.eval(np.zeros(5, np.int64), np.zeros(5, np.int64), samples=np.zeros((5, 5), np.uint32), flags=FIT | PICK_SAMPLED)
+    assert r.feasible.shape == (5, 0) and (r.binding == -1).all()
+    r = ev.eval(np.zeros(5, np.int64), np.zeros(5, np.int64), flags=FIT | PICK_BESTFIT)
+    assert (r.binding == -1).all()
+    # zero pods
+    ev.set_nodes(np.ones(10, np.int64), np.ones(10, np.int64))
+    r = ev.eval(np.zeros(0, np.int64), np.zeros(0, np.int64), flags=FIT)
+    assert r.feasible.shape == (0, 1)
+
+
+def test_error_codes(evaluator):
+    ev = evaluator
+    ev.set_nodes(np.ones(10, np.int64), np.ones(10, np.int64))
+    z = np.zeros(4, np.int64)
+    with pytest.raises(KschedError) as e:
+        ev.eval(z, z, flags=PICK_SAMPLED | PICK_BESTFIT, samples=np.zeros((4, 5), np.uint32))
+    assert e.value.code == _lib.E_INVAL
+    with pytest.raises(KschedError) as e:
+        ev.eval(z, z, flags=0x1000)
+    assert e.value.code == _lib.E_INVAL
+    with pytest.raises(KschedError):  # label id equal to the reserved sentinel
+        ev.set_nodes(np.ones(2, np.int64), np.ones(2, np.int64), np.array([[SEL_NEVER, 1]], dtype=np.uint32))
+    ev.set_nodes(np.ones(10, np.int64), np.ones(10, np.int64))
+
+
+def test_sampled_pick_semantics(evaluator):
+    """D-P1 / D-P3 on the encoded path: first feasible draw wins, draws may repeat, none -> -1."""
+    avail = np.array([1, 1, 1, 1, 1, 1, 1, 8], dtype=np.int64) * 1000
+    mem = np.full(8, 1 << 30, dtype=np.int64)
+    ev = evaluator
+    ev.set_nodes(avail, mem)
+    rc = np.array([4000, 4000, 500], dtype=np.int64)
+    rm = np.array([1, 1, 1], dtype=np.int64)
+    samples = np.array([[3, 3, 7, 1, 0], [0, 1, 2, 3, 4], [2, 0, 1, 3, 3]], dtype=np.uint32)
+    r = ev.eval(rc, rm, samples=samples, flags=FIT | PICK_SAMPLED)
+    assert r.binding.tolist() == [7, -1, 2]
+    # an out-of-range draw is an infeasible draw
+    samples[0] = [99, 3, 7, 1, 0]
+    r = ev.eval(rc, rm, samples=samples, flags=FIT | PICK_SAMPLED)
+    assert r.binding.tolist() == [7, -1, 2]
+
+
+def test_bestfit_semantics(evaluator):
+    """Lexicographic (mem residual, cpu residual, node index); ties -> lowest index; none -> -1."""
+    cpu = np.array([8000, 4000, 4000, 2000, 9000], dtype=np.int64)
+    mem = np.array([100, 50, 50, 10, 50], dtype=np.int64)
+    ev = evaluator
+    ev.set_nodes(cpu, mem)
+    rc = np.array([1000, 3000, 8500, 100, 99999], dtype=np.int64)
+    rm = np.array([20, 20, 20, 5, 1], dtype=np.int64)
+    r = ev.eval(rc, rm, flags=FIT | PICK_BESTFIT)
+    # pod0: feasible {0,1,2,4}: min mem 50 -> {1,2,4}; min cpu 4000 -> {1,2}; lowest index 1
+    # pod1: feasible {0,1,2,4} -> 1 ; pod2: only node 4 (cpu 9000 >= 8500, mem 50 >= 20); pod3: node 3 ; pod4: none
+    assert r.binding.tolist() == [1, 1, 4, 3, -1]
+    _, _, want = capi.eval_encoded(cpu, mem, None, None, rc, rm, None, None, None, capi.FIT | capi.PICK_BESTFIT)
+    assert r.binding.tolist() == want.tolist()
+
+
+def test_bestfit_sparse_rows_fall_back_to_scan(evaluator):
+    """Pods whose only feasible nodes sit deep in the best-fit order (beyond the probe window)."""
+    N = 3000
+    cpu = np.arange(N, dtype=np.int64) + 10
+    mem = np.arange(N, dtype=np.int64)[::-1].copy() + 10
+    ev = evaluator
+    ev.set_nodes(cpu, mem)
+    rc = np.array([N + 9, N - 100, 0, N + 10], dtype=np.int64)   # needs the largest cpu = smallest mem ... last in bf order
+    rm = np.array([10, 10, N + 9, 10], dtype=np.int64)
+    r = ev.eval(rc, rm, flags=FIT | PICK_BESTFIT)
+    _, _, want = capi.eval_encoded(cpu, mem, None, None, rc, rm, None, None, None, capi.FIT | capi.PICK_BESTFIT)
+    assert r.binding.tolist() == want.tolist()
+
+
+def test_device_entry_point_matches_host_entry_point(evaluator):
+    import torch
+    c = synth.make_cluster(3000, 2500, n_keys=8, n_taints=16, seed=31)
+    ev = evaluator
+    ev.set_nodes(**c.node_columns())
+    flags = FIT | SEL | TAINT | WANT_FIT_MASK | PICK_SAMPLED
+    pc = c.pod_columns()
+    host = ev.eval(pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], pc["tolerations"], pc["samples"], flags)
+    dev = torch.device("cuda:0")
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    feas = torch.empty((c.P, ev.W), dtype=torch.int64, device=dev)
+    fit = torch.empty((c.P, ev.W), dtype=torch.int64, device=dev)
+    bind = torch.empty((c.P,), dtype=torch.int32, device=dev)
+    ev.eval_device(t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.pod_tol, np.int64),
+                   t(c.samples, np.int32), flags, out_feasible=feas, out_fit=fit, out_binding=bind)
+    torch.cuda.synchronize()
+    assert np.array_equal(feas.cpu().numpy().view(np.uint64), host.feasible)
+    assert np.array_equal(fit.cpu().numpy().view(np.uint64), host.fit)
+    assert np.array_equal(bind.cpu().numpy(), host.binding)
+    # pick without an output mask uses the internal scratch mask
+    bind2 = torch.empty((c.P,), dtype=torch.int32, device=dev)
+    ev.eval_device(t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.pod_tol, np.int64),
+                   t(c.samples, np.int32), FIT | SEL | TAINT | PICK_SAMPLED, out_binding=bind2)
+    torch.cuda.synchronize()
+    assert np.array_equal(bind2.cpu().numpy(), host.binding)
+
+
+def test_reasons_rebuilt_from_masks(evaluator):
+    """check_node_validity's Err order (src/predicates.rs:68-74) from the two masks."""
+    c = synth.make_cluster(200, 300, n_keys=8, n_taints=0, seed=41)
+    ev = evaluator
+    r = hip_eval(ev, c, FIT | SEL | WANT_FIT_MASK)
+    feas = unpack_mask(r.feasible, c.N)
+    fit = unpack_mask(r.fit, c.N)
+    seen = set()
+    for p in range(0, c.P, 7):
+        for n in range(0, c.N, 11):
+            code = ev.reason(r.feasible[p], r.fit[p], n, FIT | SEL)
+            want = 0 if feas[p, n] else (1 if not fit[p, n] else 2)
+            assert code == want
+            seen.add(code)
+    assert seen == {0, 1, 2}
+
+
+def test_snapshot_replacement(evaluator):
+    """set_nodes twice: the second snapshot fully replaces the first (different N and keys)."""
+    ev = evaluator
+    a = synth.make_cluster(100, 900, n_keys=8, n_taints=16, seed=1)
+    b = synth.make_cluster(100, 130, n_keys=3, n_taints=0, seed=2)
+    check(ev, a, FIT | SEL | TAINT)
+    check(ev, b, FIT | SEL)
+    check(ev, a, FIT | SEL | TAINT)
