@@ -1,0 +1,191 @@
+#include "encoder.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+namespace ksched_host {
+
+DeviceEvaluator::DeviceEvaluator(int device) {
+    int rc = ksched_create(&h_, device);
+    if (rc != KSCHED_OK) throw EncodeError(std::string("ksched_create: ") + ksched_strerror(rc));
+}
+DeviceEvaluator::~DeviceEvaluator() { ksched_destroy(h_); }
+void DeviceEvaluator::check(int rc, const char *where) const {
+    if (rc != KSCHED_OK)
+        throw EncodeError(std::string(where) + ": " + ksched_strerror(rc) + " (" + ksched_last_error(h_) + ")");
+}
+
+Snapshot::Snapshot(int device) : dev_(std::make_shared<DeviceEvaluator>(device)) {}
+
+bool toleration_matches(const corev1::Toleration &t, const TaintId &x) {
+    const auto &[key, value, effect] = x;
+    if (t.effect && !t.effect->empty() && *t.effect != effect) return false;
+    const std::string op = (t.operator_ && !t.operator_->empty()) ? *t.operator_ : "Equal";
+    if (!t.key || t.key->empty()) return op == "Exists";  // empty key + Exists tolerates everything
+    if (*t.key != key) return false;
+    if (op == "Exists") return true;
+    return op == "Equal" && t.value.value_or("") == value;
+}
+
+void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client) {
+    const uint32_t n = (uint32_t)nodes.size();
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return corev1::name_any(nodes[a].metadata) < corev1::name_any(nodes[b].metadata);
+    });
+    NodeColumns c;
+    c.n = n;
+    c.names.resize(n);
+    c.avail_cpu_milli.resize(n);
+    c.avail_mem_bytes.resize(n);
+    c.taints.assign(n, 0);
+    node_labels_.assign(n, {});
+    node_has_labels_.assign(n, false);
+    taint_ids_.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        const corev1::Node &node = nodes[order[i]];
+        c.names[i] = corev1::name_any(node.metadata);
+        // src/predicates.rs:27-32
+        PodResources avail;
+        if (node.status && node.status->allocatable) {
+            const auto &al = *node.status->allocatable;
+            auto cpu = al.find("cpu"), mem = al.find("memory");
+            if (cpu == al.end() || mem == al.end())
+                throw EncodeError("node " + c.names[i] + ": allocatable lacks cpu or memory (reference panics, src/predicates.rs:29-31)");
+            try {
+                avail.cpu = ParsedQuantity::try_from(cpu->second);
+                avail.memory = ParsedQuantity::try_from(mem->second);
+            } catch (const QuantityError &e) {
+                throw EncodeError("node " + c.names[i] + ": invalid node spec: " + e.what());
+            }
+        }
+        // src/predicates.rs:34-38: every pod the LIST returns is subtracted, any phase
+        if (client) {
+            for (const auto &p : client->list_pods_on_node(c.names[i])) {
+                try {
+                    avail -= total_pod_resources(p);
+                } catch (const QuantityError &e) {
+                    throw EncodeError("pod " + full_name(p.metadata) + ": invalid pod spec: " + e.what());
+                }
+            }
+        }
+        try {
+            c.avail_cpu_milli[i] = avail.cpu.to_milli();
+            c.avail_mem_bytes[i] = avail.memory.to_units();
+        } catch (const QuantityError &e) {
+            throw EncodeError("node " + c.names[i] + ": outside the exact integer domain: " + e.what());
+        }
+        if (node.metadata.labels) {
+            node_labels_[i] = *node.metadata.labels;
+            node_has_labels_[i] = true;
+        }
+        if (node.spec && node.spec->taints) {
+            for (const auto &t : *node.spec->taints) {
+                if (t.effect != "NoSchedule" && t.effect != "NoExecute") continue;  // PreferNoSchedule never filters
+                TaintId id{t.key, t.value.value_or(""), t.effect};
+                auto it = taint_ids_.find(id);
+                if (it == taint_ids_.end()) {
+                    if (taint_ids_.size() >= 64) throw EncodeError("more than 64 distinct taints in one snapshot");
+                    it = taint_ids_.emplace(id, (uint32_t)taint_ids_.size()).first;
+                }
+                c.taints[i] |= 1ull << it->second;
+            }
+        }
+    }
+    c.keys = cols_.keys;  // keep the label columns that were in use
+    cols_ = std::move(c);
+    encode_labels();
+    upload();
+}
+
+void Snapshot::encode_labels() {
+    const uint32_t n = cols_.n;
+    cols_.n_keys = (uint32_t)cols_.keys.size();
+    cols_.label_val_ids.assign((size_t)cols_.n_keys * n, 0u);
+    value_ids_.assign(cols_.n_keys, {});
+    for (uint32_t k = 0; k < cols_.n_keys; ++k) {
+        auto &dict = value_ids_[k];
+        for (uint32_t i = 0; i < n; ++i) {
+            auto it = node_labels_[i].find(cols_.keys[k]);
+            if (it == node_labels_[i].end()) continue;  // 0 = key absent on this node
+            auto [d, fresh] = dict.emplace(it->second, (uint32_t)dict.size() + 1u);
+            (void)fresh;
+            cols_.label_val_ids[(size_t)k * n + i] = d->second;  // "" is a value like any other: non-zero id
+        }
+    }
+}
+
+void Snapshot::upload() {
+    dev_->check(ksched_set_nodes(dev_->handle(), cols_.n, cols_.avail_cpu_milli.data(), cols_.avail_mem_bytes.data(),
+                                 cols_.n_keys ? cols_.label_val_ids.data() : nullptr, cols_.n_keys,
+                                 taint_ids_.empty() ? nullptr : cols_.taints.data()),
+                "ksched_set_nodes");
+    ++generation_;
+}
+
+void Snapshot::ensure_keys(const std::set<std::string> &keys) {
+    bool grew = false;
+    for (const auto &k : keys) {
+        if (std::find(cols_.keys.begin(), cols_.keys.end(), k) == cols_.keys.end()) {
+            if (cols_.keys.size() >= KSCHED_MAX_KEYS)
+                throw EncodeError("more than KSCHED_MAX_KEYS distinct nodeSelector keys in use; split the batch");
+            cols_.keys.push_back(k);
+            grew = true;
+        }
+    }
+    if (grew) {
+        encode_labels();
+        upload();
+    }
+}
+
+int Snapshot::index_of(const std::string &node_name) const {
+    auto it = std::lower_bound(cols_.names.begin(), cols_.names.end(), node_name);
+    if (it == cols_.names.end() || *it != node_name) return -1;
+    return (int)(it - cols_.names.begin());
+}
+
+PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
+    std::set<std::string> keys;
+    for (const auto *p : pods)
+        if (p->spec && p->spec->node_selector)
+            for (const auto &kv : *p->spec->node_selector) keys.insert(kv.first);
+    ensure_keys(keys);
+
+    PodColumns pc;
+    pc.p = (uint32_t)pods.size();
+    pc.n_keys = cols_.n_keys;
+    pc.req_cpu_milli.resize(pc.p);
+    pc.req_mem_bytes.resize(pc.p);
+    pc.sel_val_ids.assign((size_t)pc.n_keys * pc.p, 0u);
+    pc.tolerations.assign(pc.p, 0ull);
+    for (uint32_t i = 0; i < pc.p; ++i) {
+        const corev1::Pod &pod = *pods[i];
+        try {
+            const PodResources r = total_pod_resources(pod);  // src/predicates.rs:40
+            pc.req_cpu_milli[i] = r.cpu.to_milli();
+            pc.req_mem_bytes[i] = r.memory.to_units();
+        } catch (const QuantityError &e) {
+            throw EncodeError("pod " + full_name(pod.metadata) + ": invalid pod spec: " + e.what());
+        }
+        if (pod.spec && pod.spec->node_selector) {
+            for (const auto &[k, v] : *pod.spec->node_selector) {  // src/predicates.rs:48-53
+                const uint32_t col = (uint32_t)(std::find(cols_.keys.begin(), cols_.keys.end(), k) - cols_.keys.begin());
+                auto it = value_ids_[col].find(v);
+                pc.sel_val_ids[(size_t)col * pc.p + i] = (it == value_ids_[col].end()) ? KSCHED_SEL_NEVER : it->second;
+            }
+        }
+        if (pod.spec && pod.spec->tolerations) {
+            for (const auto &[id, bit] : taint_ids_)
+                for (const auto &t : *pod.spec->tolerations)
+                    if (toleration_matches(t, id)) {
+                        pc.tolerations[i] |= 1ull << bit;
+                        break;
+                    }
+        }
+    }
+    return pc;
+}
+
+}  // namespace ksched_host

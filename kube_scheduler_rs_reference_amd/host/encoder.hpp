@@ -1,0 +1,101 @@
+// encoder.hpp -- corev1 objects -> the integer SoA columns of include/ksched.h, and the
+// device-resident snapshot built from them.
+//
+// This is the wire-format step on either side of the kernel: quantity strings become exact
+// int64 milli-cores / bytes, label strings become dictionary ids (exact interning, never a
+// hash), taints become bit positions.  Nodes are put in canonical order (ascending name).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/ksched.h"
+#include "corev1.hpp"
+#include "util.hpp"
+
+namespace ksched_host {
+
+struct EncodeError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// RAII over the C ABI handle.
+class DeviceEvaluator {
+public:
+    explicit DeviceEvaluator(int device);
+    ~DeviceEvaluator();
+    DeviceEvaluator(const DeviceEvaluator &) = delete;
+    DeviceEvaluator &operator=(const DeviceEvaluator &) = delete;
+    ksched_ctx *handle() const { return h_; }
+    void check(int rc, const char *where) const;  // throws EncodeError with ksched_strerror text
+
+private:
+    ksched_ctx *h_ = nullptr;
+};
+
+// Encoded pod batch (the arguments of ksched_eval).
+struct PodColumns {
+    uint32_t p = 0, n_keys = 0;
+    std::vector<int64_t> req_cpu_milli, req_mem_bytes;
+    std::vector<uint32_t> sel_val_ids;  // [n_keys][p]
+    std::vector<uint64_t> tolerations;  // [p]
+};
+
+// Encoded node snapshot (the arguments of ksched_set_nodes), host copy.
+struct NodeColumns {
+    uint32_t n = 0, n_keys = 0;
+    std::vector<std::string> names;            // canonical order
+    std::vector<int64_t> avail_cpu_milli, avail_mem_bytes;
+    std::vector<uint32_t> label_val_ids;       // [n_keys][n]
+    std::vector<uint64_t> taints;              // [n]
+    std::vector<std::string> keys;             // column k <-> label key
+};
+
+using TaintId = std::tuple<std::string, std::string, std::string>;  // key, value, effect
+
+class Snapshot {
+public:
+    explicit Snapshot(int device);
+
+    // Encode `nodes` (any order) against the pods `client` LISTs per node and upload.
+    // available[n] = allocatable[n] - sum(total_pod_resources(p) for p in LIST(n))
+    // (src/predicates.rs:27-38).  A node whose allocatable map lacks cpu or memory, or whose
+    // quantities do not parse, throws EncodeError (the reference panics there, :29-31).
+    void rebuild(const std::vector<corev1::Node> &nodes, PodLister *client);
+
+    // Make sure every label key in `keys` has a column (re-uploads the label columns if not).
+    void ensure_keys(const std::set<std::string> &keys);
+
+    // Encode pods against this snapshot's dictionaries.  Adds columns for selector keys that
+    // have none yet (ensure_keys).  A selector value no node carries becomes KSCHED_SEL_NEVER.
+    PodColumns encode_pods(const std::vector<const corev1::Pod *> &pods);
+
+    const NodeColumns &columns() const { return cols_; }
+    int index_of(const std::string &node_name) const;  // canonical index or -1
+    uint32_t n() const { return cols_.n; }
+    uint32_t mask_words() const { return ksched_mask_words(cols_.n); }
+    bool has_taints() const { return !taint_ids_.empty(); }
+    DeviceEvaluator &device() { return *dev_; }
+    uint64_t generation() const { return generation_; }
+
+private:
+    void encode_labels();
+    void upload();
+
+    std::shared_ptr<DeviceEvaluator> dev_;
+    NodeColumns cols_;
+    std::vector<corev1::StringMap> node_labels_;            // canonical order; empty map when labels is None
+    std::vector<bool> node_has_labels_;
+    std::vector<std::map<std::string, uint32_t>> value_ids_;  // per column: value string -> id (1..)
+    std::map<TaintId, uint32_t> taint_ids_;                 // NoSchedule / NoExecute taints -> bit
+    uint64_t generation_ = 0;
+};
+
+// K8s ToleratesTaint (extension E2): does toleration `t` tolerate taint `x`?
+bool toleration_matches(const corev1::Toleration &t, const TaintId &x);
+
+}  // namespace ksched_host

@@ -1,0 +1,43 @@
+#include "util.hpp"
+
+#include "encoder.hpp"
+
+namespace ksched_host {
+
+std::vector<corev1::Pod> StaticPodLister::list_pods_on_node(const std::string &node_name) {
+    std::vector<corev1::Pod> out;
+    for (const auto &p : pods)
+        if (p.spec && p.spec->node_name && *p.spec->node_name == node_name) out.push_back(p);
+    return out;
+}
+
+PodResources::PodResources() : cpu(ParsedQuantity::try_from("0")), memory(ParsedQuantity::try_from("0")) {}
+
+bool is_pod_bound(const corev1::Pod &pod) { return pod.spec && pod.spec->node_name.has_value(); }
+
+std::string full_name(const corev1::ObjectMeta &meta) {
+    if (meta.namespace_) return *meta.namespace_ + "/" + corev1::name_any(meta);
+    return corev1::name_any(meta);
+}
+
+// Containers only: init containers, overhead and limits never count (src/util.rs:58-69).
+PodResources total_pod_resources(const corev1::Pod &pod) {
+    PodResources r;
+    if (pod.spec) {
+        for (const auto &c : pod.spec->containers) {
+            if (c.resources && c.resources->requests) {
+                const auto &req = *c.resources->requests;
+                if (auto it = req.find("cpu"); it != req.end()) r.cpu += ParsedQuantity::try_from(it->second);
+                if (auto it = req.find("memory"); it != req.end()) r.memory += ParsedQuantity::try_from(it->second);
+            }
+        }
+    }
+    return r;
+}
+
+void Context::refresh_snapshot() {
+    if (!snapshot) snapshot = std::make_shared<Snapshot>(device);
+    snapshot->rebuild(node_store, client.get());
+}
+
+}  // namespace ksched_host
