@@ -25,7 +25,7 @@ HOST_SRCS := $(wildcard $(HOST)/*.cpp)
 HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/ksched.h include/ksched_host.h
 
 .PHONY: all lib host oracle clean
-ifneq ($(HOST_SRCS),)
+ifneq ($(wildcard $(HOST)/host_c_api.cpp),)
 all: lib host oracle
 else
 all: lib oracle

@@ -13,7 +13,7 @@ from oracle import capi
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["direct", "auto"]
+KERNELS = ["direct", "indexed"]
 
 
 def oracle_eval(c, flags, samples=True):
@@ -287,3 +287,48 @@ def test_snapshot_replacement(evaluator):
     check(ev, a, FIT | SEL | TAINT)
     check(ev, b, FIT | SEL)
     check(ev, a, FIT | SEL | TAINT)
+
+
+def test_auto_prefers_indexed_and_falls_back(evaluator):
+    """auto = indexed when the snapshot fits the LDS index, direct otherwise (huge sparse label ids)."""
+    ev = evaluator
+    ev.set_kernel("auto")
+    c = synth.make_cluster(200, 300, n_keys=8, n_taints=16, seed=3)
+    check(ev, c, FIT | SEL | TAINT)
+    assert ev.last_kernel == "indexed"
+    # label ids far too sparse for one bitmap row per id: indexed is not applicable
+    rng = np.random.default_rng(1)
+    N, P = 300, 100
+    lab = rng.integers(1, 4_000_000, size=(2, N)).astype(np.uint32)
+    sel = np.zeros((2, P), dtype=np.uint32)
+    sel[0, ::3] = lab[0, rng.integers(0, N, size=len(sel[0, ::3]))]
+    big = np.full(N, 1 << 40, dtype=np.int64)
+    zero = np.zeros(P, dtype=np.int64)
+    ev.set_nodes(big, big, lab)
+    r = ev.eval(zero, zero, sel, flags=FIT | SEL)
+    assert ev.last_kernel == "direct"
+    feas, _, _ = capi.eval_encoded(big, big, lab, None, zero, zero, sel, None, None, capi.FIT | capi.SEL)
+    assert np.array_equal(r.feasible, feas)
+    ev.set_kernel("indexed")
+    with pytest.raises(KschedError) as e:
+        ev.eval(zero, zero, sel, flags=FIT | SEL)
+    assert e.value.code == _lib.E_UNSUPPORTED
+    ev.set_kernel("auto")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_duplicate_values_and_ties(evaluator, kernel):
+    """Many nodes share the same avail values (ties in the sorted order), pods sit exactly on them."""
+    rng = np.random.default_rng(9)
+    N, P = 2500, 700
+    cpu = rng.choice(np.array([0, 1000, 1000, 2000, 4000, -500], dtype=np.int64), N)
+    mem = rng.choice(np.array([0, 1 << 30, 1 << 30, 1 << 31, -1], dtype=np.int64), N)
+    rc = rng.choice(np.array([0, 999, 1000, 1001, 2000, 4000, 4001, -500, -501], dtype=np.int64), P)
+    rm = rng.choice(np.array([0, (1 << 30) - 1, 1 << 30, (1 << 30) + 1, 1 << 31, -1, -2], dtype=np.int64), P)
+    ev = evaluator
+    ev.set_kernel(kernel)
+    ev.set_nodes(cpu, mem)
+    r = ev.eval(rc, rm, flags=FIT)
+    want = (rc[:, None] <= cpu[None, :]) & (rm[:, None] <= mem[None, :])
+    assert np.array_equal(unpack_mask(r.feasible, N), want)
+    ev.set_kernel("auto")
