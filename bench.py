@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--pods", type=int, default=None, help="override pods per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mask", action="store_true", help="bindings only (not the graded form)")
+    ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (timing experiments; results invalid)")
     args = ap.parse_args()
 
     import torch
@@ -143,6 +144,8 @@ def main():
 
     ev = Evaluator(local_rank)
     ev.set_kernel(args.kernel)
+    if args.debug:
+        ev.set_option(L.OPT_DEBUG, args.debug)
     ev.set_nodes(**c.node_columns())
     sched = ShardedScheduler(P_total, dev)
     lo, hi = sched.lo, sched.hi

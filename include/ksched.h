@@ -83,6 +83,8 @@ extern "C" {
 #define KSCHED_KERNEL_INDEXED 2 /* LDS-resident per-tile bitmap index, word-level */
 /* KSCHED_OPT_TIMING: 1 = bracket the mask kernel with hipEvents (adds two event records per call) */
 #define KSCHED_OPT_TIMING 2
+/* KSCHED_OPT_DEBUG: ablation bits for kernel timing experiments (tools/); any non-zero value makes results invalid */
+#define KSCHED_OPT_DEBUG 3
 
 typedef struct ksched_ctx ksched_ctx;
 

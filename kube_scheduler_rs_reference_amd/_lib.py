@@ -41,6 +41,7 @@ REASON_NAMES = {0: "Ok", 1: "NotEnoughResources", 2: "NodeSelectorMismatch", 3: 
 
 OPT_KERNEL = 1
 OPT_TIMING = 2
+OPT_DEBUG = 3
 KERNEL_AUTO = 0
 KERNEL_DIRECT = 1
 KERNEL_INDEXED = 2

@@ -173,19 +173,43 @@ __global__ __launch_bounds__(256) void k_pick_sampled(const uint64_t *__restrict
 // Best fit (extension E1): argmin over feasible nodes of (avail_mem - req_mem, avail_cpu - req_cpu,
 // node index), lexicographic.  Both residuals are pod-independent shifts of the node's own
 // (avail_mem, avail_cpu), so the order of candidates is a property of the snapshot: bf_order
-// lists nodes in that order, bf_rank is its inverse, and the pick is the first feasible node
-// in bf_order.  One wave per pod: probe the head of bf_order 64 candidates at a time, and if the
-// first kProbe*64 candidates are all infeasible fall back to a coalesced scan of the row.
-constexpr int kBestfitProbe = 4;
+// lists nodes in that order, bf_rank is its inverse, bf_mem[i] = avail_mem[bf_order[i]] (sorted),
+// and the pick is the first feasible node in bf_order.  One wave per pod:
+//   1. with KSCHED_FIT, every candidate before the first i with bf_mem[i] >= req_mem fails on
+//      memory, so a 64-ary search over bf_mem (3 rounds for N <= 262144) finds where to start;
+//   2. probe candidates 64 at a time (gather their mask bits, ballot, first set lane wins);
+//   3. after kBestfitProbe fruitless probes fall back to a coalesced scan of the pod's row,
+//      taking the minimum bf_rank over its set bits (cost ~ number of feasible nodes, which is
+//      small for exactly the pods that get here).
+constexpr int kBestfitProbe = 8;
 __global__ __launch_bounds__(256) void k_pick_bestfit(const uint64_t *__restrict__ mask, const uint32_t *__restrict__ bf_order,
-                                                       const uint32_t *__restrict__ bf_rank, int32_t *__restrict__ binding,
-                                                       uint32_t p, uint32_t n, uint32_t W) {
+                                                       const uint32_t *__restrict__ bf_rank, const int64_t *__restrict__ bf_mem,
+                                                       const int64_t *__restrict__ req_mem, int32_t *__restrict__ binding,
+                                                       uint32_t p, uint32_t n, uint32_t W, uint32_t do_fit) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t pod = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (pod >= p) return;
     const uint64_t *row = mask + (size_t)pod * W;
+    uint32_t start = 0;
+    if (do_fit) {
+        const int64_t req = req_mem[pod];
+        uint32_t lo = 0, len = n;  // the answer (first i with bf_mem[i] >= req, or lo + len) lies in [lo, lo + len]
+        while (len > 0) {
+            const uint32_t step = (len + 63u) / 64u;
+            const uint32_t end = lo + len;
+            const uint32_t seg = lo + lane * step;  // lane's segment [seg, min(seg + step, end))
+            bool less = false;
+            if (seg < end) less = bf_mem[min(seg + step, end) - 1u] < req;  // last element of the segment
+            const uint32_t nseg = (len + step - 1u) / step;
+            const uint32_t c = (uint32_t)__popcll(__ballot(less));  // segments entirely below req (a prefix)
+            lo += c * step;
+            len = (c >= nseg) ? 0u : (min(lo + step, end) - lo - 1u);
+            if (c >= nseg) lo = end;
+        }
+        start = lo;
+    }
     for (int it = 0; it < kBestfitProbe; ++it) {
-        const uint32_t idx = (uint32_t)it * 64u + lane;
+        const uint32_t idx = start + (uint32_t)it * 64u + lane;
         uint32_t node = 0;
         bool bit = false;
         if (idx < n) {
@@ -199,7 +223,7 @@ __global__ __launch_bounds__(256) void k_pick_bestfit(const uint64_t *__restrict
             if (lane == 0) binding[pod] = (int32_t)win;
             return;
         }
-        if ((uint32_t)(it + 1) * 64u >= n) {
+        if (start + (uint32_t)(it + 1) * 64u >= n) {
             if (lane == 0) binding[pod] = -1;
             return;
         }

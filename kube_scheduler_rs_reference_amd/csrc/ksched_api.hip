@@ -59,6 +59,7 @@ struct ksched_ctx {
     DevBuf<uint32_t> nlab;
     DevBuf<uint64_t> ntaint;
     DevBuf<uint32_t> bf_order, bf_rank;
+    DevBuf<int64_t> bf_mem;
     IndexedSnapshot idx;  // per-tile bitmap index (kernels_indexed.hpp)
 
     // scratch for the host-pointer path
@@ -74,6 +75,7 @@ struct ksched_ctx {
     // options
     int opt_kernel = KSCHED_KERNEL_AUTO;
     bool opt_timing = false;
+    uint32_t opt_debug = 0;
     const char *last_kernel = "none";
 
     // timing
@@ -240,7 +242,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     if (use_indexed) {
         const size_t need = indexed_scratch_bytes(c->idx, p);
         HIPCHK(c, c->idx_scratch.reserve(need));
-        hipError_t e = run_indexed(c->idx, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, c->idx_scratch.ptr, s);
+        hipError_t e = run_indexed(c->idx, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, c->idx_scratch.ptr, s, c->opt_debug);
         if (e != hipSuccess) return fail_hip(c, e, "run_indexed");
         c->last_kernel = "indexed";
         rc = KSCHED_OK;
@@ -255,7 +257,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
                            c->W, attempts);
     } else if (pick_b) {
         hipLaunchKernelGGL(k_pick_bestfit, dim3((p + 3) / 4), dim3(256), 0, s, feas, c->bf_order.ptr, c->bf_rank.ptr,
-                           out_binding, p, c->n, c->W);
+                           c->bf_mem.ptr, pmem, out_binding, p, c->n, c->W, (flags & KSCHED_FIT) ? 1u : 0u);
     }
     HIPCHK(c, hipGetLastError());
     return KSCHED_OK;
@@ -326,7 +328,7 @@ void ksched_destroy(ksched_ctx *c) {
         DeviceGuard g(c->device);
         (void)hipDeviceSynchronize();
         c->ncpu.release(); c->nmem.release(); c->nlab.release(); c->ntaint.release();
-        c->bf_order.release(); c->bf_rank.release();
+        c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release();
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
         c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release();
         c->scratch_mask.release(); c->idx_scratch.release();
@@ -355,6 +357,9 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
             return KSCHED_OK;
         case KSCHED_OPT_TIMING:
             c->opt_timing = value != 0;
+            return KSCHED_OK;
+        case KSCHED_OPT_DEBUG:
+            c->opt_debug = (uint32_t)value;
             return KSCHED_OK;
         default:
             return KSCHED_E_INVAL;
@@ -386,6 +391,7 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     HIPCHK(c, c->ntaint.reserve(n));
     HIPCHK(c, c->bf_order.reserve(n));
     HIPCHK(c, c->bf_rank.reserve(n));
+    HIPCHK(c, c->bf_mem.reserve(n));
     if (n > 0) {
         HIPCHK(c, hipMemcpy(c->ncpu.ptr, cpu, (size_t)n * 8, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->nmem.ptr, mem, (size_t)n * 8, hipMemcpyHostToDevice));
@@ -399,7 +405,12 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
             if (cpu[x] != cpu[y]) return cpu[x] < cpu[y];
             return x < y;
         });
-        for (uint32_t i = 0; i < n; ++i) rank[order[i]] = i;
+        std::vector<int64_t> bfmem(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            rank[order[i]] = i;
+            bfmem[i] = mem[order[i]];
+        }
+        HIPCHK(c, hipMemcpy(c->bf_mem.ptr, bfmem.data(), (size_t)n * 8, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->bf_order.ptr, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->bf_rank.ptr, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     }
