@@ -15,7 +15,14 @@ void DeviceEvaluator::check(int rc, const char *where) const {
         throw EncodeError(std::string(where) + ": " + ksched_strerror(rc) + " (" + ksched_last_error(h_) + ")");
 }
 
-Snapshot::Snapshot(int device) : dev_(std::make_shared<DeviceEvaluator>(device)) {}
+Snapshot::Snapshot(int device) {
+    if (device != kEncodeOnly) dev_ = std::make_shared<DeviceEvaluator>(device);
+}
+
+DeviceEvaluator &Snapshot::device() {
+    if (!dev_) throw EncodeError("this Snapshot was created encode-only (no device): evaluation is not possible");
+    return *dev_;
+}
 
 bool toleration_matches(const corev1::Toleration &t, const TaintId &x) {
     const auto &[key, value, effect] = x;
@@ -27,7 +34,7 @@ bool toleration_matches(const corev1::Toleration &t, const TaintId &x) {
     return op == "Equal" && t.value.value_or("") == value;
 }
 
-void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client) {
+void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client, bool with_resources) {
     const uint32_t n = (uint32_t)nodes.size();
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
@@ -48,7 +55,7 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
         c.names[i] = corev1::name_any(node.metadata);
         // src/predicates.rs:27-32
         PodResources avail;
-        if (node.status && node.status->allocatable) {
+        if (with_resources && node.status && node.status->allocatable) {
             const auto &al = *node.status->allocatable;
             auto cpu = al.find("cpu"), mem = al.find("memory");
             if (cpu == al.end() || mem == al.end())
@@ -61,7 +68,8 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
             }
         }
         // src/predicates.rs:34-38: every pod the LIST returns is subtracted, any phase
-        if (client) {
+        if (with_resources && client) {
+            ++client->list_calls;
             for (const auto &p : client->list_pods_on_node(c.names[i])) {
                 try {
                     avail -= total_pod_resources(p);
@@ -117,11 +125,12 @@ void Snapshot::encode_labels() {
 }
 
 void Snapshot::upload() {
+    ++generation_;
+    if (!dev_) return;  // encode-only snapshot (host tests of the wire-format step)
     dev_->check(ksched_set_nodes(dev_->handle(), cols_.n, cols_.avail_cpu_milli.data(), cols_.avail_mem_bytes.data(),
                                  cols_.n_keys ? cols_.label_val_ids.data() : nullptr, cols_.n_keys,
                                  taint_ids_.empty() ? nullptr : cols_.taints.data()),
                 "ksched_set_nodes");
-    ++generation_;
 }
 
 void Snapshot::ensure_keys(const std::set<std::string> &keys) {

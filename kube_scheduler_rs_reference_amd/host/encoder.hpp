@@ -59,13 +59,18 @@ using TaintId = std::tuple<std::string, std::string, std::string>;  // key, valu
 
 class Snapshot {
 public:
+    // device = HIP device index; kEncodeOnly builds the columns on the host and uploads nothing
+    // (used to test the wire-format step where there is no GPU; such a snapshot cannot evaluate).
+    static constexpr int kEncodeOnly = -1;
     explicit Snapshot(int device);
 
     // Encode `nodes` (any order) against the pods `client` LISTs per node and upload.
     // available[n] = allocatable[n] - sum(total_pod_resources(p) for p in LIST(n))
     // (src/predicates.rs:27-38).  A node whose allocatable map lacks cpu or memory, or whose
     // quantities do not parse, throws EncodeError (the reference panics there, :29-31).
-    void rebuild(const std::vector<corev1::Node> &nodes, PodLister *client);
+    // with_resources = false skips allocatable and the LISTs (columns stay 0): the selector predicate
+    // alone never reads them (src/predicates.rs:45-61).
+    void rebuild(const std::vector<corev1::Node> &nodes, PodLister *client, bool with_resources = true);
 
     // Make sure every label key in `keys` has a column (re-uploads the label columns if not).
     void ensure_keys(const std::set<std::string> &keys);
@@ -79,7 +84,8 @@ public:
     uint32_t n() const { return cols_.n; }
     uint32_t mask_words() const { return ksched_mask_words(cols_.n); }
     bool has_taints() const { return !taint_ids_.empty(); }
-    DeviceEvaluator &device() { return *dev_; }
+    DeviceEvaluator &device();
+    const std::map<TaintId, uint32_t> &taint_ids() const { return taint_ids_; }
     uint64_t generation() const { return generation_; }
 
 private:

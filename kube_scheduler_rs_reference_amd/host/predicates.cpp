@@ -1,0 +1,121 @@
+#include "predicates.hpp"
+
+#include <cstdlib>
+#include <mutex>
+
+namespace ksched_host {
+namespace predicates {
+
+const char *debug_name(InvalidNodeReason r) {
+    switch (r) {
+        case InvalidNodeReason::NotEnoughResources: return "NotEnoughResources";
+        case InvalidNodeReason::NodeSelectorMismatch: return "NodeSelectorMismatch";
+        case InvalidNodeReason::TaintNotTolerated: return "TaintNotTolerated";
+    }
+    return "?";
+}
+
+namespace {
+
+// One-pod x one-node evaluation on the device: bit 0 of the single mask word.
+bool eval_pair(Snapshot &snap, const corev1::Pod &pod, uint32_t flags) {
+    PodColumns pc = snap.encode_pods({&pod});  // may add label columns -> re-upload
+    uint64_t word = 0;
+    DeviceEvaluator &dev = snap.device();
+    dev.check(ksched_eval(dev.handle(), 1, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(),
+                          pc.n_keys ? pc.sel_val_ids.data() : nullptr, nullptr, nullptr, 0, flags, &word, nullptr, nullptr),
+              "ksched_eval");
+    return word & 1ull;
+}
+
+Snapshot &pair_snapshot(Context &ctx) {
+    if (!ctx.pair_snapshot) ctx.pair_snapshot = std::make_shared<Snapshot>(ctx.device);
+    return *ctx.pair_snapshot;
+}
+
+// does_node_selector_match has no Context argument (src/predicates.rs:45), so its evaluator is a
+// process-wide one on device $KSCHED_DEVICE (default 0), serialised by a mutex.
+std::mutex g_sel_mu;
+std::shared_ptr<Snapshot> g_sel_snapshot;
+
+}  // namespace
+
+bool can_pod_fit(const corev1::Pod &pod, const corev1::Node &node, Context &ctx) {
+    // src/predicates.rs:21-38: available = allocatable - every pod the LIST for this node returns.
+    // Snapshot::rebuild issues exactly that LIST (one call) and uploads the one-node columns.
+    Snapshot &snap = pair_snapshot(ctx);
+    snap.rebuild({node}, ctx.client.get());
+    return eval_pair(snap, pod, KSCHED_FIT);  // :40-42 on the device
+}
+
+bool does_node_selector_match(const corev1::Pod &pod, const corev1::Node &node) {
+    std::lock_guard<std::mutex> lk(g_sel_mu);
+    if (!g_sel_snapshot) {
+        const char *d = std::getenv("KSCHED_DEVICE");
+        g_sel_snapshot = std::make_shared<Snapshot>(d ? std::atoi(d) : 0);
+    }
+    g_sel_snapshot->rebuild({node}, nullptr, /*with_resources=*/false);
+    return eval_pair(*g_sel_snapshot, pod, KSCHED_SEL);
+}
+
+Validity check_node_validity(const corev1::Pod &pod, const corev1::Node &node, Context &ctx) {
+    // One device call gives both masks; the order of the reasons is the reference's (:68-74).
+    Snapshot &snap = pair_snapshot(ctx);
+    snap.rebuild({node}, ctx.client.get());
+    PodColumns pc = snap.encode_pods({&pod});
+    uint64_t feas = 0, fit = 0;
+    DeviceEvaluator &dev = snap.device();
+    dev.check(ksched_eval(dev.handle(), 1, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(),
+                          pc.n_keys ? pc.sel_val_ids.data() : nullptr, nullptr, nullptr, 0,
+                          KSCHED_FIT | KSCHED_SEL | KSCHED_WANT_FIT_MASK, &feas, &fit, nullptr),
+              "ksched_eval");
+    const int r = ksched_reason(&feas, &fit, 0, KSCHED_FIT | KSCHED_SEL);
+    if (r == KSCHED_REASON_OK) return std::nullopt;
+    return r == KSCHED_REASON_NOT_ENOUGH_RESOURCES ? InvalidNodeReason::NotEnoughResources : InvalidNodeReason::NodeSelectorMismatch;
+}
+
+Validity BatchValidity::validity(uint32_t pod, uint32_t node) const {
+    const int r = ksched_reason(feasible.data() + (size_t)pod * W, fit.data() + (size_t)pod * W, node, flags);
+    switch (r) {
+        case KSCHED_REASON_OK: return std::nullopt;
+        case KSCHED_REASON_NOT_ENOUGH_RESOURCES: return InvalidNodeReason::NotEnoughResources;
+        case KSCHED_REASON_TAINT_NOT_TOLERATED: return InvalidNodeReason::TaintNotTolerated;
+        default: return InvalidNodeReason::NodeSelectorMismatch;
+    }
+}
+
+uint64_t BatchValidity::feasible_count(uint32_t pod) const {
+    uint64_t c = 0;
+    for (uint32_t w = 0; w < W; ++w) c += (uint64_t)__builtin_popcountll(feasible[(size_t)pod * W + w]);
+    return c;
+}
+
+BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, bool taints, uint32_t pick_flags,
+                                        const std::vector<uint32_t> *samples, uint32_t attempts) {
+    if (!ctx.snapshot) ctx.refresh_snapshot();
+    Snapshot &snap = *ctx.snapshot;
+    PodColumns pc = snap.encode_pods(pods);
+    BatchValidity out;
+    out.p = pc.p;
+    out.n = snap.n();
+    out.W = snap.mask_words();
+    out.flags = KSCHED_FIT | KSCHED_SEL | ((taints && snap.has_taints()) ? KSCHED_TAINT : 0u);
+    out.feasible.assign((size_t)out.p * out.W, 0ull);
+    out.fit.assign((size_t)out.p * out.W, 0ull);
+    const uint32_t pick = pick_flags & (KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT);
+    if (pick) out.binding.assign(out.p, -1);
+    if (out.p == 0) return out;
+    if ((pick & KSCHED_PICK_SAMPLED) && (!samples || samples->size() != (size_t)out.p * attempts))
+        throw EncodeError("check_node_validity_batch: samples must hold p * attempts indices");
+    DeviceEvaluator &dev = snap.device();
+    dev.check(ksched_eval(dev.handle(), pc.p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(),
+                          pc.n_keys ? pc.sel_val_ids.data() : nullptr, (out.flags & KSCHED_TAINT) ? pc.tolerations.data() : nullptr,
+                          (pick & KSCHED_PICK_SAMPLED) ? samples->data() : nullptr, attempts,
+                          out.flags | KSCHED_WANT_FIT_MASK | pick, out.feasible.data(), out.fit.data(),
+                          pick ? out.binding.data() : nullptr),
+              "ksched_eval");
+    return out;
+}
+
+}  // namespace predicates
+}  // namespace ksched_host

@@ -1,0 +1,66 @@
+// predicates.hpp -- host mirror of the reference's `predicates` module (src/predicates.rs:1-80).
+//
+// Same names, argument meaning and results as the Rust items; every evaluation runs on the
+// MI355X through the C ABI (include/ksched.h) -- there is no CPU implementation of a predicate in
+// this file, and without a HIP device every function here throws EncodeError.
+//
+//   Rust                                                        here
+//   ----------------------------------------------------------  -------------------------------------------
+//   enum InvalidNodeReason {NotEnoughResources,                 enum class InvalidNodeReason (same order;
+//        NodeSelectorMismatch}            src/predicates.rs:14-18   debug_name() == the {:?} text)
+//   async fn can_pod_fit(&Pod,&Node,&Context) -> bool   :20-43  can_pod_fit(pod, node, ctx)
+//   fn does_node_selector_match(&Pod,&Node) -> bool     :45-61  does_node_selector_match(pod, node)
+//   pub async fn check_node_validity(..)                :63-77  check_node_validity(pod, node, ctx)
+//        -> Result<(), InvalidNodeReason>                         -> Validity (nullopt == Ok(()))
+//
+// The per-pair entry points keep the reference's cost model on purpose (one LIST per call, :34):
+// they exist so the reference's call sites and unit tests read the same.  The batched entry point
+// check_node_validity_batch is the one the accelerated reconciler uses: all pods x all nodes of
+// ctx.snapshot in one ksched_eval.
+#pragma once
+#include <cstdint>
+#include <optional>
+#include <vector>
+
+#include "corev1.hpp"
+#include "encoder.hpp"
+#include "util.hpp"
+
+namespace ksched_host {
+namespace predicates {
+
+enum class InvalidNodeReason {
+    NotEnoughResources,    // src/predicates.rs:16
+    NodeSelectorMismatch,  // src/predicates.rs:17
+    TaintNotTolerated,     // extension E2 only (BASELINE.json configs[4]); never produced by the reference's path
+};
+// #[derive(Debug)] text, as printed at src/main.rs:62
+const char *debug_name(InvalidNodeReason r);
+
+using Validity = std::optional<InvalidNodeReason>;  // Result<(), InvalidNodeReason>: nullopt == Ok(())
+
+bool can_pod_fit(const corev1::Pod &pod, const corev1::Node &node, Context &ctx);
+bool does_node_selector_match(const corev1::Pod &pod, const corev1::Node &node);
+Validity check_node_validity(const corev1::Pod &pod, const corev1::Node &node, Context &ctx);
+
+// Both masks of one batch against ctx.snapshot, pod-major (include/ksched.h conventions).
+struct BatchValidity {
+    uint32_t p = 0, n = 0, W = 0;
+    uint32_t flags = 0;
+    std::vector<uint64_t> feasible, fit;  // [p][W]
+    std::vector<int32_t> binding;         // [p] when a pick was requested, canonical node index or -1
+
+    bool is_valid(uint32_t pod, uint32_t node) const { return (feasible[(size_t)pod * W + (node >> 6)] >> (node & 63u)) & 1ull; }
+    // check_node_validity's result for the pair, rebuilt in the reference's order (fit first)
+    Validity validity(uint32_t pod, uint32_t node) const;
+    uint64_t feasible_count(uint32_t pod) const;
+};
+
+// check_node_validity for every (pod, node) pair.  `pick_flags` may add KSCHED_PICK_SAMPLED (with
+// `samples`, [p][attempts] canonical node indices) or KSCHED_PICK_BESTFIT; `taints` adds extension E2.
+BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, bool taints = false,
+                                        uint32_t pick_flags = 0, const std::vector<uint32_t> *samples = nullptr,
+                                        uint32_t attempts = 0);
+
+}  // namespace predicates
+}  // namespace ksched_host
