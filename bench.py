@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's metric on MI355X: pod x node predicate evaluations per second.
 
-    python bench.py --gpus N --steps K --warmup W [--workload C3] [--kernel auto|direct|indexed]
+    python bench.py --gpus N --steps K --warmup W [--workload C3] [--kernel auto|direct|fused] [--packed]
 
 A "step" is one pass of the hot path over one batch of synthetic pods, inputs already resident in
 HBM: the mask kernel (feasible bits for every (pod, node) pair of this rank's pod rows) + the
@@ -105,10 +105,12 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "indexed"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "fused"])
     ap.add_argument("--pods", type=int, default=None, help="override pods per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mask", action="store_true", help="bindings only (not the graded form)")
+    ap.add_argument("--packed", action="store_true",
+                    help="mask rows packed at W words (default: rows pitched to ksched_mask_pitch(n) = W rounded up to 128 B)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (timing experiments; results invalid)")
     args = ap.parse_args()
 
@@ -155,7 +157,8 @@ def main():
     d_tol = t(c.pod_tol[lo:hi], np.int64) if taint else None
     d_smp = t(c.samples[lo:hi], np.int32) if pick == "sampled" else None
     W = ev.W
-    d_mask = None if args.no_mask else torch.empty((hi - lo, W), dtype=torch.int64, device=dev)
+    d_mask = None if args.no_mask else ev.alloc_mask(hi - lo, pitched=not args.packed)
+    pitch = int(d_mask.stride(0)) if d_mask is not None else W
 
     def local_eval(binding_out):
         ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=d_mask, out_binding=binding_out)
@@ -205,6 +208,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": desc, "pods_per_gpu": P_gpu, "pods_total": P_total, "nodes": N,
                        "predicates": "+".join(flag_names), "pick": pick, "mask_written": not args.no_mask,
+                       "mask_row_pitch_words": pitch, "mask_words": W,
                        "kernel": ev.last_kernel, "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
                        "allgather(int32 bindings)" if world > 1 else "single GPU",
                        "bound_fraction": bound_frac},

@@ -79,12 +79,16 @@ extern "C" {
 /* kernel selection for ksched_set_option(ctx, KSCHED_OPT_KERNEL, v) */
 #define KSCHED_OPT_KERNEL 1
 #define KSCHED_KERNEL_AUTO 0
-#define KSCHED_KERNEL_DIRECT 1  /* lanes = nodes, compare-is-ballot */
-#define KSCHED_KERNEL_INDEXED 2 /* LDS-resident per-tile bitmap index, word-level */
+#define KSCHED_KERNEL_DIRECT 1  /* lanes = nodes, compare-is-ballot; always applicable */
+#define KSCHED_KERNEL_FUSED 3   /* LDS-resident per-tile bitmap index, one launch: rank search + row AND + store (default when applicable) */
 /* KSCHED_OPT_TIMING: 1 = bracket the mask kernel with hipEvents (adds two event records per call) */
 #define KSCHED_OPT_TIMING 2
 /* KSCHED_OPT_DEBUG: ablation bits for kernel timing experiments (tools/); any non-zero value makes results invalid */
 #define KSCHED_OPT_DEBUG 3
+
+/* KSCHED_OPT_TRACE: 1 = the fused kernel records per-block phase timestamps (diagnostics; see ksched_trace_read) */
+#define KSCHED_OPT_TRACE 4
+#define KSCHED_TRACE_WORDS 8u /* uint64 words per block: t_entry, t_staged_issue, t_barrier, t_phase1, t_group0, t_loop_end, t_drained, xcc_id */
 
 typedef struct ksched_ctx ksched_ctx;
 
@@ -146,6 +150,18 @@ int ksched_eval_device(ksched_ctx *ctx, uint32_t p, const int64_t *req_cpu_milli
                        uint32_t attempts, uint32_t flags, uint64_t *out_feasible, uint64_t *out_fit,
                        int32_t *out_binding, void *hip_stream);
 
+/* Same, with the output masks pitched: row `pod` of out_feasible / out_fit starts at word
+ * pod * mask_pitch_words (mask_pitch_words >= ksched_mask_words(n)); words [W, pitch) of a row are padding
+ * and are written as zero or left untouched.  ksched_mask_pitch(n) rounds W up to a multiple of 16 words
+ * (128 bytes), which keeps every row on cache-line boundaries: on MI355X the mask stream then runs at the
+ * HBM write ceiling instead of ~70 % of it ("row pitch").  ksched_eval_device == this with
+ * mask_pitch_words = W. */
+int ksched_eval_device_pitched(ksched_ctx *ctx, uint32_t p, const int64_t *req_cpu_milli, const int64_t *req_mem_bytes,
+                               const uint32_t *sel_val_ids, const uint64_t *tolerations, const uint32_t *samples,
+                               uint32_t attempts, uint32_t flags, uint64_t *out_feasible, uint64_t *out_fit,
+                               int32_t *out_binding, uint32_t mask_pitch_words, void *hip_stream);
+uint32_t ksched_mask_pitch(uint32_t n_nodes);
+
 /* ---- reasons ------------------------------------------------------------------------------
  * Host helper: rebuild check_node_validity's result for one pair from the two masks, in the
  * reference's order (fit first: src/predicates.rs:68-70, then selector: :72-74).
@@ -159,6 +175,9 @@ int ksched_reason(const uint64_t *feasible_row, const uint64_t *fit_row, uint32_
  * kernel milliseconds and launch count since the last reset (both reset by the call).
  */
 int ksched_kernel_time_ms(ksched_ctx *ctx, double *total_ms, uint64_t *launches);
+/* Diagnostics: copy out the trace of the last fused launch (KSCHED_OPT_TRACE = 1): up to max_blocks records of
+ * KSCHED_TRACE_WORDS uint64 (100 MHz timestamps); returns the number of blocks of that launch, <0 on error. */
+int ksched_trace_read(ksched_ctx *ctx, uint64_t *out, uint32_t max_blocks);
 /* name of the mask kernel variant the last ksched_eval* used ("direct", "indexed", ...) */
 const char *ksched_last_kernel(const ksched_ctx *ctx);
 

@@ -42,9 +42,11 @@ REASON_NAMES = {0: "Ok", 1: "NotEnoughResources", 2: "NodeSelectorMismatch", 3: 
 OPT_KERNEL = 1
 OPT_TIMING = 2
 OPT_DEBUG = 3
+OPT_TRACE = 4
+TRACE_WORDS = 8
 KERNEL_AUTO = 0
 KERNEL_DIRECT = 1
-KERNEL_INDEXED = 2
+KERNEL_FUSED = 3
 
 # every symbol include/ksched.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
@@ -62,8 +64,11 @@ SYMBOLS = {
     "ksched_num_keys": (_u32, [_vp]),
     "ksched_eval": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "ksched_eval_device": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "ksched_eval_device_pitched": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
+    "ksched_mask_pitch": (_u32, [_u32]),
     "ksched_reason": (C.c_int, [_vp, _vp, _u32, _u32]),
     "ksched_kernel_time_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "ksched_trace_read": (C.c_int, [_vp, _vp, C.c_uint32]),
     "ksched_last_kernel": (C.c_char_p, [_vp]),
 }
 

@@ -18,8 +18,8 @@
 // Cost model (measured numbers live in DESIGN.md): per (pod, 64 nodes) the VALU issues are
 // 2 x v_cmp_i64 (fit) + one v_cmp_u32 per *constrained* key (unconstrained keys are skipped by a
 // scalar branch) + 3 for taints + 2 x v_writelane.  That makes this kernel VALU-bound well below
-// the HBM write roofline; it is the general, always-applicable path.  The indexed kernel
-// (kernels_indexed.hpp) is the fast path.
+// the HBM write roofline; it is the general, always-applicable path.  The fused kernel
+// (kernels_fused.hpp) is the fast path.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,6 +37,7 @@ constexpr int kDirectKeys = 8;    // label keys handled per pass
 
 struct DirectArgs {
     uint32_t n, p, W;
+    uint32_t pitch;                // words between consecutive pod rows of the output masks (>= W)
     uint32_t key0, nkeys;          // this pass handles keys [key0, key0 + nkeys), nkeys <= kDirectKeys
     uint32_t pod_tiles_per_block;  // 64-pod tiles walked by one block
     uint32_t do_fit;               // KSCHED_FIT selected
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(64 * kDirectWaves) void k_eval_direct(
 
         // ---- lane l stores CW consecutive words of pod row p0 + l --------------------------
         if (lane < jmax) {
-            const size_t row = (size_t)(p0 + lane) * a.W;
+            const size_t row = (size_t)(p0 + lane) * a.pitch;
 #pragma unroll
             for (int c = 0; c < kDirectCW; ++c) {
                 if (w0 + c < a.W) {
@@ -154,12 +155,12 @@ __global__ __launch_bounds__(64 * kDirectWaves) void k_eval_direct(
 // `attempts` sampled node indices whose feasible bit is set wins; none -> -1 (NoNodeFound,
 // src/main.rs:117).  One lane per pod.
 __global__ __launch_bounds__(256) void k_pick_sampled(const uint64_t *__restrict__ mask, const uint32_t *__restrict__ samples,
-                                                       int32_t *__restrict__ binding, uint32_t p, uint32_t n, uint32_t W,
+                                                       int32_t *__restrict__ binding, uint32_t p, uint32_t n, uint32_t pitch,
                                                        uint32_t attempts) {
     const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
     if (pod >= p) return;
     int32_t b = -1;
-    const uint64_t *row = mask + (size_t)pod * W;
+    const uint64_t *row = mask + (size_t)pod * pitch;
     for (uint32_t i = 0; i < attempts; ++i) {
         const uint32_t s = samples[(size_t)pod * attempts + i];
         if (s < n && ((row[s >> 6] >> (s & 63u)) & 1ull)) {
@@ -185,11 +186,11 @@ constexpr int kBestfitProbe = 8;
 __global__ __launch_bounds__(256) void k_pick_bestfit(const uint64_t *__restrict__ mask, const uint32_t *__restrict__ bf_order,
                                                        const uint32_t *__restrict__ bf_rank, const int64_t *__restrict__ bf_mem,
                                                        const int64_t *__restrict__ req_mem, int32_t *__restrict__ binding,
-                                                       uint32_t p, uint32_t n, uint32_t W, uint32_t do_fit) {
+                                                       uint32_t p, uint32_t n, uint32_t W, uint32_t pitch, uint32_t do_fit) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t pod = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (pod >= p) return;
-    const uint64_t *row = mask + (size_t)pod * W;
+    const uint64_t *row = mask + (size_t)pod * pitch;
     uint32_t start = 0;
     if (do_fit) {
         const int64_t req = req_mem[pod];

@@ -17,7 +17,8 @@
 #include <vector>
 
 #include "kernels_direct.hpp"
-#include "kernels_indexed.hpp"
+#include "kernels_fused.hpp"
+#include "tile_index.hpp"
 
 using namespace ksched;
 
@@ -69,13 +70,14 @@ struct ksched_ctx {
     DevBuf<int32_t> binding;
     // scratch mask when a pick is requested without an output mask
     DevBuf<uint64_t> scratch_mask;
-    // per-batch pod operands of the indexed kernel
-    DevBuf<uint8_t> idx_scratch;
 
     // options
     int opt_kernel = KSCHED_KERNEL_AUTO;
     bool opt_timing = false;
     uint32_t opt_debug = 0;
+    bool opt_trace = false;
+    DevBuf<uint64_t> trace;
+    uint32_t trace_blocks_last = 0;
     const char *last_kernel = "none";
 
     // timing
@@ -113,7 +115,7 @@ struct DeviceGuard {
     }
 };
 
-int timing_begin(ksched_ctx *c, hipStream_t s, size_t *slot) {
+int timing_slot(ksched_ctx *c, size_t *slot) {
     if (c->ev_used == c->ev_pool.size()) {
         ksched_ctx::EvPair ep;
         HIPCHK(c, hipEventCreate(&ep.a));
@@ -121,7 +123,6 @@ int timing_begin(ksched_ctx *c, hipStream_t s, size_t *slot) {
         c->ev_pool.push_back(ep);
     }
     *slot = c->ev_used++;
-    HIPCHK(c, hipEventRecord(c->ev_pool[*slot].a, s));
     return KSCHED_OK;
 }
 
@@ -148,7 +149,7 @@ void launch_direct_t(const DirectPtrs &q, const DirectArgs &a, dim3 grid, bool w
 }
 
 int run_direct(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
-               const uint64_t *ptol, uint32_t flags, uint64_t *out_feas, uint64_t *out_fit, hipStream_t s) {
+               const uint64_t *ptol, uint32_t flags, uint64_t *out_feas, uint64_t *out_fit, uint32_t pitch, hipStream_t s) {
     DirectPtrs q{};
     q.ncpu = c->ncpu.ptr;
     q.nmem = c->nmem.ptr;
@@ -164,6 +165,7 @@ int run_direct(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pm
     a.n = c->n;
     a.p = p;
     a.W = c->W;
+    a.pitch = pitch;
     a.do_fit = (flags & KSCHED_FIT) ? 1u : 0u;
 
     const bool sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
@@ -212,7 +214,7 @@ int run_direct(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pm
 
 int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                    const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags,
-                   uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, hipStream_t s) {
+                   uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, uint32_t pitch, hipStream_t s) {
     const bool pick_s = flags & KSCHED_PICK_SAMPLED, pick_b = flags & KSCHED_PICK_BESTFIT;
     if (p == 0) return KSCHED_OK;
     if (c->n == 0) {
@@ -223,41 +225,53 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     }
     uint64_t *feas = out_feas;
     if (!feas && (pick_s || pick_b)) {
-        HIPCHK(c, c->scratch_mask.reserve((size_t)p * c->W));
+        HIPCHK(c, c->scratch_mask.reserve((size_t)p * pitch));
         feas = c->scratch_mask.ptr;
     }
 
-    size_t slot = 0;
-    if (c->opt_timing) {
-        int rc = timing_begin(c, s, &slot);
-        if (rc) return rc;
-    }
+    // kernel choice is needed before timing: the fused kernel carries its events on the dispatch
+    // packet itself (hipExtLaunchKernel), the multi-launch paths are bracketed by stream events.
     int rc;
-    bool use_indexed = false;
-    if (c->opt_kernel != KSCHED_KERNEL_DIRECT) use_indexed = indexed_applicable(c->idx, flags, psel != nullptr);
-    if (c->opt_kernel == KSCHED_KERNEL_INDEXED && !use_indexed) {
-        c->last_error = "indexed kernel not applicable to this snapshot/request";
+    // kernel choice: fused (one launch over the bitmap index) when the snapshot has an index that
+    // fits LDS, else the always-applicable direct kernel; KSCHED_OPT_KERNEL can force one.
+    const bool can_fused = fused_applicable(c->idx, flags);
+    int kern = c->opt_kernel;
+    if (kern == KSCHED_KERNEL_AUTO) kern = can_fused ? KSCHED_KERNEL_FUSED : KSCHED_KERNEL_DIRECT;
+    if (kern == KSCHED_KERNEL_FUSED && !can_fused) {
+        c->last_error = "fused kernel not applicable to this snapshot/request (bitmap index does not fit LDS)";
         return KSCHED_E_UNSUPPORTED;
     }
-    if (use_indexed) {
-        const size_t need = indexed_scratch_bytes(c->idx, p);
-        HIPCHK(c, c->idx_scratch.reserve(need));
-        hipError_t e = run_indexed(c->idx, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, c->idx_scratch.ptr, s, c->opt_debug);
-        if (e != hipSuccess) return fail_hip(c, e, "run_indexed");
-        c->last_kernel = "indexed";
+    size_t slot = 0;
+    if (c->opt_timing) {
+        int trc = timing_slot(c, &slot);
+        if (trc) return trc;
+        if (kern != KSCHED_KERNEL_FUSED) HIPCHK(c, hipEventRecord(c->ev_pool[slot].a, s));
+    }
+    if (kern == KSCHED_KERNEL_FUSED) {
+        constexpr uint32_t kTraceBlocks = 8192;
+        if (c->opt_trace) {
+            DeviceGuard g2(c->device);
+            HIPCHK(c, c->trace.reserve((size_t)kTraceBlocks * KSCHED_TRACE_WORDS));
+            HIPCHK(c, hipMemsetAsync(c->trace.ptr, 0, (size_t)kTraceBlocks * KSCHED_TRACE_WORDS * 8, s));
+        }
+        hipError_t e = run_fused(c->idx, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, pitch, s, c->opt_debug,
+                                 c->opt_timing ? c->ev_pool[slot].a : nullptr, c->opt_timing ? c->ev_pool[slot].b : nullptr,
+                                 c->opt_trace ? c->trace.ptr : nullptr, kTraceBlocks);
+        if (e != hipSuccess) return fail_hip(c, e, "run_fused");
+        c->last_kernel = "fused";
         rc = KSCHED_OK;
     } else {
-        rc = run_direct(c, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, s);
+        rc = run_direct(c, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, pitch, s);
     }
     if (rc) return rc;
-    if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev_pool[slot].b, s));
+    if (c->opt_timing && kern != KSCHED_KERNEL_FUSED) HIPCHK(c, hipEventRecord(c->ev_pool[slot].b, s));
 
     if (pick_s) {
         hipLaunchKernelGGL(k_pick_sampled, dim3((p + 255) / 256), dim3(256), 0, s, feas, samples, out_binding, p, c->n,
-                           c->W, attempts);
+                           pitch, attempts);
     } else if (pick_b) {
         hipLaunchKernelGGL(k_pick_bestfit, dim3((p + 3) / 4), dim3(256), 0, s, feas, c->bf_order.ptr, c->bf_rank.ptr,
-                           c->bf_mem.ptr, pmem, out_binding, p, c->n, c->W, (flags & KSCHED_FIT) ? 1u : 0u);
+                           c->bf_mem.ptr, pmem, out_binding, p, c->n, c->W, pitch, (flags & KSCHED_FIT) ? 1u : 0u);
     }
     HIPCHK(c, hipGetLastError());
     return KSCHED_OK;
@@ -331,7 +345,7 @@ void ksched_destroy(ksched_ctx *c) {
         c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release();
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
         c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release();
-        c->scratch_mask.release(); c->idx_scratch.release();
+        c->scratch_mask.release(); c->trace.release();
         indexed_release(c->idx);
         for (auto &ep : c->ev_pool) {
             (void)hipEventDestroy(ep.a);
@@ -352,7 +366,7 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
     std::lock_guard<std::mutex> lk(c->mu);
     switch (option) {
         case KSCHED_OPT_KERNEL:
-            if (value < KSCHED_KERNEL_AUTO || value > KSCHED_KERNEL_INDEXED) return KSCHED_E_INVAL;
+            if (value != KSCHED_KERNEL_AUTO && value != KSCHED_KERNEL_DIRECT && value != KSCHED_KERNEL_FUSED) return KSCHED_E_INVAL;
             c->opt_kernel = (int)value;
             return KSCHED_OK;
         case KSCHED_OPT_TIMING:
@@ -360,6 +374,9 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
             return KSCHED_OK;
         case KSCHED_OPT_DEBUG:
             c->opt_debug = (uint32_t)value;
+            return KSCHED_OK;
+        case KSCHED_OPT_TRACE:
+            c->opt_trace = value != 0;
             return KSCHED_OK;
         default:
             return KSCHED_E_INVAL;
@@ -420,19 +437,30 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     return KSCHED_OK;
 }
 
-int ksched_eval_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
-                       const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags,
-                       uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, void *hip_stream) {
+int ksched_eval_device_pitched(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
+                               const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags,
+                               uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, uint32_t mask_pitch_words,
+                               void *hip_stream) {
     if (!c) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->have_nodes) return KSCHED_E_STATE;
     int rc = check_eval_args(c, p, pcpu, pmem, samples, attempts, flags, out_feas, out_fit, out_binding);
     if (rc) return rc;
+    if (mask_pitch_words < c->W) return KSCHED_E_INVAL;
     DeviceGuard g(c->device);
     if (!g.ok) return KSCHED_E_HIP;
     return eval_on_device(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_feas, out_fit, out_binding,
-                          (hipStream_t)hip_stream);
+                          mask_pitch_words, (hipStream_t)hip_stream);
 }
+
+int ksched_eval_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
+                       const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags,
+                       uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, void *hip_stream) {
+    return ksched_eval_device_pitched(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_feas, out_fit, out_binding,
+                                      ksched_mask_words(ksched_num_nodes(c)), hip_stream);
+}
+
+uint32_t ksched_mask_pitch(uint32_t n_nodes) { return (ksched_mask_words(n_nodes) + 15u) & ~15u; }
 
 int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                 const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, uint64_t *out_feas,
@@ -447,6 +475,7 @@ int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *p
     if (!g.ok) return KSCHED_E_HIP;
     hipStream_t s = c->stream;
     const size_t W = c->W;
+    const size_t pitch = ksched_mask_pitch(c->n);
     const bool pick = flags & (KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT);
     const bool use_sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
     const bool use_tol = (flags & KSCHED_TAINT) && ptol;
@@ -470,11 +499,11 @@ int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *p
     uint64_t *d_feas = nullptr, *d_fit = nullptr;
     int32_t *d_bind = nullptr;
     if (out_feas || pick) {
-        HIPCHK(c, c->feas.reserve((size_t)p * W));
+        HIPCHK(c, c->feas.reserve((size_t)p * pitch));
         d_feas = c->feas.ptr;
     }
     if (out_fit) {
-        HIPCHK(c, c->fit.reserve((size_t)p * W));
+        HIPCHK(c, c->fit.reserve((size_t)p * pitch));
         d_fit = c->fit.ptr;
     }
     if (pick) {
@@ -482,10 +511,13 @@ int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *p
         d_bind = c->binding.ptr;
     }
     rc = eval_on_device(c, p, c->pcpu.ptr, c->pmem.ptr, use_sel ? c->psel.ptr : nullptr, use_tol ? c->ptol.ptr : nullptr,
-                        c->psamples.ptr, attempts, flags, d_feas, d_fit, d_bind, s);
+                        c->psamples.ptr, attempts, flags, d_feas, d_fit, d_bind, (uint32_t)pitch, s);
     if (rc) return rc;
-    if (out_feas && W) HIPCHK(c, hipMemcpyAsync(out_feas, d_feas, (size_t)p * W * 8, hipMemcpyDeviceToHost, s));
-    if (out_fit && W) HIPCHK(c, hipMemcpyAsync(out_fit, d_fit, (size_t)p * W * 8, hipMemcpyDeviceToHost, s));
+    // device rows are line-aligned (pitch words apart); the caller's rows are packed (W words)
+    if (out_feas && W)
+        HIPCHK(c, hipMemcpy2DAsync(out_feas, W * 8, d_feas, pitch * 8, W * 8, p, hipMemcpyDeviceToHost, s));
+    if (out_fit && W)
+        HIPCHK(c, hipMemcpy2DAsync(out_fit, W * 8, d_fit, pitch * 8, W * 8, p, hipMemcpyDeviceToHost, s));
     if (pick && out_binding) HIPCHK(c, hipMemcpyAsync(out_binding, d_bind, (size_t)p * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     return KSCHED_OK;
@@ -501,6 +533,17 @@ int ksched_reason(const uint64_t *feasible_row, const uint64_t *fit_row, uint32_
     if ((flags & KSCHED_TAINT) && !(flags & KSCHED_SEL)) return KSCHED_REASON_TAINT_NOT_TOLERATED;
     // both extension and selector active: the two masks cannot tell them apart
     return KSCHED_REASON_NODE_SELECTOR_MISMATCH;
+}
+
+int ksched_trace_read(ksched_ctx *c, uint64_t *out, uint32_t max_blocks) {
+    if (!c || !out) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->trace.ptr) return 0;
+    DeviceGuard g(c->device);
+    HIPCHK(c, hipDeviceSynchronize());
+    const uint32_t nb = std::min<uint32_t>(max_blocks, 8192u);
+    HIPCHK(c, hipMemcpy(out, c->trace.ptr, (size_t)nb * KSCHED_TRACE_WORDS * 8, hipMemcpyDeviceToHost));
+    return (int)nb;
 }
 
 int ksched_kernel_time_ms(ksched_ctx *c, double *total_ms, uint64_t *launches) {

@@ -77,7 +77,7 @@ class Evaluator:
         self._check(self._lib.ksched_set_option(self._h, option, value), "ksched_set_option")
 
     def set_kernel(self, name: str):
-        self.set_option(L.OPT_KERNEL, {"auto": L.KERNEL_AUTO, "direct": L.KERNEL_DIRECT, "indexed": L.KERNEL_INDEXED}[name])
+        self.set_option(L.OPT_KERNEL, {"auto": L.KERNEL_AUTO, "direct": L.KERNEL_DIRECT, "fused": L.KERNEL_FUSED}[name])
 
     def set_timing(self, on: bool):
         self.set_option(L.OPT_TIMING, 1 if on else 0)
@@ -87,6 +87,14 @@ class Evaluator:
         cnt = C.c_uint64(0)
         self._check(self._lib.ksched_kernel_time_ms(self._h, C.byref(ms), C.byref(cnt)), "ksched_kernel_time_ms")
         return ms.value, cnt.value
+
+    def trace_read(self, max_blocks: int = 8192) -> np.ndarray:
+        """Diagnostics: per-block phase timestamps of the last fused launch (set_option(OPT_TRACE, 1) first)."""
+        out = np.zeros((max_blocks, L.TRACE_WORDS), dtype=np.uint64)
+        n = self._lib.ksched_trace_read(self._h, out.ctypes.data_as(C.c_void_p), max_blocks)
+        if n < 0:
+            self._check(n, "ksched_trace_read")
+        return out[:n]
 
     @property
     def last_kernel(self) -> str:
@@ -162,6 +170,19 @@ class Evaluator:
                 raise ValueError(f"expected shape {shape}, got {tuple(t.shape)}")
             return C.c_void_p(t.data_ptr())
 
+        def mask_ptr(t, pitch):
+            """[p, W] view of a (possibly pitched) mask buffer: rows `pitch` words apart."""
+            if t is None:
+                return None, pitch
+            if not t.is_cuda or t.device.index != self.device or t.dtype not in u64 or t.dim() != 2:
+                raise ValueError(f"mask must be a 2-D int64/uint64 CUDA tensor on cuda:{self.device}")
+            if tuple(t.shape) != (p, W) or (W and t.stride(1) != 1) or (p > 1 and t.stride(0) < W):
+                raise ValueError(f"mask must be [{p}, {W}] with unit column stride, got {tuple(t.shape)} strides {t.stride()}")
+            tp = int(t.stride(0)) if p > 1 else max(W, pitch or W)
+            if pitch is not None and tp != pitch and p > 1:
+                raise ValueError("out_feasible and out_fit must share one row pitch")
+            return C.c_void_p(t.data_ptr()), tp
+
         p = int(req_cpu_milli.shape[0])
         W = self.W
         i64 = (torch.int64,)
@@ -170,13 +191,25 @@ class Evaluator:
         attempts = int(samples.shape[1]) if (flags & L.PICK_SAMPLED and samples is not None) else 0
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
-        rc = self._lib.ksched_eval_device(
+        pf, pitch = mask_ptr(out_feasible, None)
+        pr, pitch = mask_ptr(out_fit, pitch)
+        rc = self._lib.ksched_eval_device_pitched(
             self._h, p, dp(req_cpu_milli, i64, (p,)), dp(req_mem_bytes, i64, (p,)),
             dp(sel_val_ids, u32, (self.n_keys, p)) if sel_val_ids is not None else None,
             dp(tolerations, u64, (p,)), dp(samples, u32), attempts, flags,
-            dp(out_feasible, u64, (p, W)), dp(out_fit, u64, (p, W)), dp(out_binding, (torch.int32,), (p,)),
+            pf, pr, dp(out_binding, (torch.int32,), (p,)), pitch if pitch is not None else W,
             C.c_void_p(stream.cuda_stream))
-        self._check(rc, "ksched_eval_device")
+        self._check(rc, "ksched_eval_device_pitched")
+
+    def alloc_mask(self, p: int, pitched: bool = True):
+        """A [p, W] int64 mask tensor on this device.  pitched=True pads the row pitch to
+        ksched_mask_pitch(n) words (cache-line aligned rows: the fast layout); the returned tensor
+        is the [p, W] view of it."""
+        import torch
+        W = self.W
+        pitch = int(self._lib.ksched_mask_pitch(self.n)) if pitched else W
+        buf = torch.empty((p, max(pitch, 1)), dtype=torch.int64, device=f"cuda:{self.device}")
+        return buf[:, :W]
 
     # -- reasons -------------------------------------------------------------------------------------
     def reason(self, feasible_row: np.ndarray, fit_row: Optional[np.ndarray], node: int, flags: int) -> int:

@@ -38,7 +38,7 @@ def test_c_oracle_reproduces_golden(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", ["direct", "indexed"])
+@pytest.mark.parametrize("kernel", ["direct", "fused"])
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
 def test_hip_reproduces_golden(evaluator, path, kernel):
     from kube_scheduler_rs_reference_amd import FIT, SEL, TAINT, PICK_BESTFIT, PICK_SAMPLED, WANT_FIT_MASK

@@ -13,7 +13,7 @@ from oracle import capi
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["direct", "indexed"]
+KERNELS = ["direct", "fused"]
 
 
 def oracle_eval(c, flags, samples=True):
@@ -289,14 +289,14 @@ def test_snapshot_replacement(evaluator):
     check(ev, a, FIT | SEL | TAINT)
 
 
-def test_auto_prefers_indexed_and_falls_back(evaluator):
-    """auto = indexed when the snapshot fits the LDS index, direct otherwise (huge sparse label ids)."""
+def test_auto_prefers_fused_and_falls_back(evaluator):
+    """auto = fused when the snapshot fits the LDS index, direct otherwise (huge sparse label ids)."""
     ev = evaluator
     ev.set_kernel("auto")
     c = synth.make_cluster(200, 300, n_keys=8, n_taints=16, seed=3)
     check(ev, c, FIT | SEL | TAINT)
-    assert ev.last_kernel == "indexed"
-    # label ids far too sparse for one bitmap row per id: indexed is not applicable
+    assert ev.last_kernel == "fused"
+    # label ids far too sparse for one bitmap row per id: the bitmap index is not built
     rng = np.random.default_rng(1)
     N, P = 300, 100
     lab = rng.integers(1, 4_000_000, size=(2, N)).astype(np.uint32)
@@ -309,10 +309,11 @@ def test_auto_prefers_indexed_and_falls_back(evaluator):
     assert ev.last_kernel == "direct"
     feas, _, _ = capi.eval_encoded(big, big, lab, None, zero, zero, sel, None, None, capi.FIT | capi.SEL)
     assert np.array_equal(r.feasible, feas)
-    ev.set_kernel("indexed")
-    with pytest.raises(KschedError) as e:
-        ev.eval(zero, zero, sel, flags=FIT | SEL)
-    assert e.value.code == _lib.E_UNSUPPORTED
+    for forced in ("fused",):
+        ev.set_kernel(forced)
+        with pytest.raises(KschedError) as e:
+            ev.eval(zero, zero, sel, flags=FIT | SEL)
+        assert e.value.code == _lib.E_UNSUPPORTED
     ev.set_kernel("auto")
 
 
@@ -331,4 +332,38 @@ def test_duplicate_values_and_ties(evaluator, kernel):
     r = ev.eval(rc, rm, flags=FIT)
     want = (rc[:, None] <= cpu[None, :]) & (rm[:, None] <= mem[None, :])
     assert np.array_equal(unpack_mask(r.feasible, N), want)
+    ev.set_kernel("auto")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("P,N", [(300, 700), (1000, 5000), (129, 1025), (64, 64 * 16)])
+def test_pitched_device_masks(evaluator, kernel, P, N):
+    """ksched_eval_device_pitched: rows pitch words apart; the [P, W] view equals the packed oracle mask,
+    and padding words are zero or untouched (pre-filled sentinel)."""
+    import torch
+    ev = evaluator
+    ev.set_kernel(kernel)
+    c = synth.make_cluster(P, N, n_keys=8, n_taints=16, seed=P + N)
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", ev.device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    flags = FIT | SEL | TAINT | WANT_FIT_MASK | PICK_BESTFIT
+    feas, fit, bind = oracle_eval(c, flags, samples=False)
+    for pitched in (True, False):
+        m = ev.alloc_mask(P, pitched=pitched)
+        f = ev.alloc_mask(P, pitched=pitched)
+        sentinel = 0x5A5A5A5A5A5A5A5A
+        m.untyped_storage().fill_(0x5A)
+        f.untyped_storage().fill_(0x5A)
+        b = torch.empty((P,), dtype=torch.int32, device=dev)
+        ev.eval_device(t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.pod_tol, np.int64), None,
+                       flags, out_feasible=m, out_fit=f, out_binding=b)
+        torch.cuda.synchronize()
+        assert np.array_equal(m.cpu().numpy().view(np.uint64), feas)
+        assert np.array_equal(f.cpu().numpy().view(np.uint64), fit)
+        assert np.array_equal(b.cpu().numpy(), bind)
+        if pitched and m.stride(0) > ev.W:
+            full = torch.as_strided(m, (P, m.stride(0)), (m.stride(0), 1))
+            pad = full[:, ev.W:].cpu().numpy().view(np.uint64)
+            assert np.isin(pad, np.array([0, sentinel], dtype=np.uint64)).all()
     ev.set_kernel("auto")

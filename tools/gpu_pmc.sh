@@ -1,11 +1,11 @@
 #!/bin/bash
 # PMC passes for the mask kernel (separate runs, --pmc only + kernel-trace as the pool's gpurun requires)
-TAG=${1:-pmc}; WL=${2:-C3}; K=${3:-indexed}
+TAG=${1:-pmc}; WL=${2:-C3}; K=${3:-fused}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; REPO=$PWD
 cd /tmp
 rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ|TCC|TCP|TA|GRBM)_[A-Z0-9_]+\b" | sort -u > $OUT/counters.txt; wc -l $OUT/counters.txt
 run() { name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $REPO/bench.py --workload $WL --kernel $K --steps 10 --warmup 2 --no-cpu-baseline > $OUT/$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $REPO/bench.py --workload $WL --kernel $K --steps 10 --warmup 2 --no-cpu-baseline $BENCH_EXTRA > $OUT/$name.log 2>&1
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" <<'PY'
 import csv,sys,collections

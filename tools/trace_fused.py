@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Diagnostics: per-block phase timeline of the fused mask kernel (KSCHED_OPT_TRACE).
+usage: python tools/trace_fused.py [--workload C3] [--pods N] [--debug BITS]"""
+import argparse, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from kube_scheduler_rs_reference_amd import Evaluator, _lib as L, synth
+from bench import WORKLOADS
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="C3"); ap.add_argument("--pods", type=int, default=None)
+ap.add_argument("--debug", type=int, default=0); ap.add_argument("--packed", action="store_true"); ap.add_argument("--nodes", type=int, default=None); ap.add_argument("--kill", type=int, default=0, help="make the last K nodes infeasible")
+a = ap.parse_args()
+cfg, P, N, flag_names, pick, desc = WORKLOADS[a.workload]
+P = a.pods or P
+N = a.nodes or N
+c = synth.make_config(cfg, P=P, N=N)
+flags = sum(getattr(L, f) for f in flag_names)
+if a.kill:
+    c.avail_cpu[-a.kill:] = -1
+    c.avail_mem[-a.kill:] = -1
+dev = torch.device("cuda:0")
+ev = Evaluator(0); ev.set_kernel("fused"); ev.set_nodes(**c.node_columns())
+if a.debug: ev.set_option(L.OPT_DEBUG, a.debug)
+t = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x).view(dt)).to(dev)
+d_cpu, d_mem = t(c.req_cpu, np.int64), t(c.req_mem, np.int64)
+d_sel = t(c.pod_sel, np.int32) if c.n_keys else None
+d_tol = t(c.pod_tol, np.int64) if "TAINT" in flag_names else None
+mask = ev.alloc_mask(P, pitched=not a.packed)
+for i in range(5):
+    ev.eval_device(d_cpu, d_mem, d_sel, d_tol, None, flags, out_feasible=mask)
+torch.cuda.synchronize()
+ev.set_option(L.OPT_TRACE, 1)
+ev.eval_device(d_cpu, d_mem, d_sel, d_tol, None, flags, out_feasible=mask)
+torch.cuda.synchronize()
+tr = ev.trace_read()
+live = tr[:, 0] > 0
+tr = tr[live]
+t0 = tr[:, 0].min()
+rel = (tr[:, :7].astype(np.int64) - np.int64(t0)) * 0.01  # us (100 MHz)
+names = ["entry", "staged_issue", "barrier", "phase1", "group0", "loop_end", "drained"]
+print(f"{a.workload} P={P} N={N} blocks traced={len(tr)}  (times in us since the first block's entry)")
+for i, n in enumerate(names):
+    v = rel[:, i][tr[:, i] > 0]
+    if len(v): print(f"  {n:13s} min {v.min():7.2f}  median {np.median(v):7.2f}  p90 {np.percentile(v,90):7.2f}  max {v.max():7.2f}")
+d = rel[:, 1:7] - rel[:, 0:6]
+for i in range(6):
+    v = d[:, i]
+    print(f"  d[{names[i]}->{names[i+1]}] median {np.median(v):6.2f}  p90 {np.percentile(v,90):6.2f} max {v.max():6.2f}")
+print("  blocks per XCC:", np.bincount(tr[:, 7].astype(np.int64), minlength=8))
+xcc = tr[:, 7].astype(np.int64)
+print("  drained per XCC (median/max):", " ".join(f"{np.median(rel[xcc==x,6]):.1f}/{rel[xcc==x,6].max():.1f}" for x in range(8)))
+h, e = np.histogram(rel[:, 6], bins=12)
+print("  drained histogram:", " ".join(f"{e[i]:.1f}:{h[i]}" for i in range(len(h))))
+ids = np.nonzero(live)[0]
+tiles = ev.W // 16 + (1 if ev.W % 16 else 0)
+tile_of = (ids >> 3) % tiles
+for i, n in enumerate(names):
+    print(f"  {n:13s} median by tile:", " ".join(f"{np.median(rel[tile_of==t, i]):.1f}" for t in range(tiles)))
+late = np.argsort(-rel[:, 6])[:12]
+print("  latest blocks (block id, tile, chunk, xcc, drained):", [(int(ids[i]), int((ids[i] >> 3) % tiles), int(((ids[i] >> 3) // tiles) * 8 + (ids[i] & 7)), int(xcc[i]), round(float(rel[i, 6]), 1)) for i in late])
