@@ -42,6 +42,7 @@ struct FusedArgs {
     uint32_t row_zero, row_valid, row_cpu_hi, row_cpu_lo, row_mem_hi, row_mem_lo, row_taint;
     uint32_t lab_base[8], lab_max[8];  // first eight label keys; further keys go through lab_meta
     const uint32_t *lab_meta;          // device copy of IndexedLayout::lab_base[32], lab_max[32]
+    const uint64_t *zero64;            // eight zero bytes in device memory
     uint32_t p, units, chunks, run;    // units = ceil(p / 8); run = (chunk, tile) pairs per XCD
     uint32_t off_sorted, off_rec, off_rec2, off_trow;  // LDS byte offsets of the regions after the bitmap rows
     uint32_t debug;
@@ -137,9 +138,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             KSCHED_LOAD_SEL(7, s7);
 #undef KSCHED_LOAD_SEL
         }
-        if (TAINT) {
-            if (g_ptol) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tol) : "v"(g_ptol + pc) : "memory");
-            else tol = 0ull;
+        if (TAINT) {  // no tolerations given = tolerate nothing: every lane reads one zero word (the select is on the address,
+                      // never on the in-flight destination register)
+            const uint64_t *tp = g_ptol ? g_ptol + pc : a.zero64;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tol) : "v"(tp) : "memory");
         }
     };
     // wait until at most N vector-memory operations issued after the operand loads are still outstanding
@@ -349,9 +351,11 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         if (have_prev) {
             // ============ phase 2 of the previous round: 8 lanes per pod, 2 words per lane ===========
             const uint32_t pod0 = prev_u * 8u;
-            const bool fast = prev_nu == 8u && prev_over == 0ull && pod0 + 64u <= a.p && tile_full && (!TAINT || taint_inline) &&
-                              !(a.debug & 16u);
-            if (fast) {
+            // A short round (prev_nu < 8) is always the wave's last one: no operand loads are in flight behind
+            // it, so the counted wait does not depend on how many stores it issues.
+            const bool fast = (prev_nu == 8u || !more) && prev_over == 0ull && pod0 + prev_nu * 8u <= a.p && tile_full &&
+                              (!TAINT || taint_inline) && !(a.debug & 16u);
+            if (fast && prev_nu == 8u) {
                 // STEP pod rows per step (two when the row registers allow: ~20 LDS reads in flight per
                 // wave); the records of the next step are fetched while this step's rows are combined.
                 constexpr uint32_t STEP = TAINT ? 1u : 2u;
@@ -384,13 +388,18 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                                 tn[j] = TAINT ? s_trow[(it + STEP + j) * 8u + sub] : make_uint2(0u, 0u);
                             }
                         }
-                        if ((a.debug & 128u) && it == 0 && !stamped4) {  // experiment: rows of the first step have landed
-                            __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
-                            stamp(2);
-                        }
 #pragma unroll
                         for (uint32_t j = 0; j < STEP; ++j) combine_store(pod0 + (it + j) * 8u + sub, R[j], false);
                     }
+                }
+            } else if (fast) {
+                // short last round of the wave: same unchecked rows, one at a time
+#pragma unroll 1
+                for (uint32_t it = 0; it < prev_nu; ++it) {
+                    Rows A;
+                    load_rows(s_rec[it * 8u + sub], TAINT ? s_trow[it * 8u + sub] : make_uint2(0u, 0u), A);
+                    if (SEL) load_extra(s_rec2[it * 8u + sub], A);
+                    combine_store(pod0 + it * 8u + sub, A, true);
                 }
             } else {
                 if (!(a.debug & 16u)) {
@@ -498,6 +507,7 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
         a.lab_max[k] = l.lab_max[k];
     }
     a.lab_meta = s.d_lab_meta;
+    a.zero64 = reinterpret_cast<const uint64_t *>(s.d_lab_meta + 64);
     a.p = p;
     a.units = (p + 7u) / 8u;
     a.debug = debug;

@@ -59,7 +59,7 @@ struct IndexedSnapshot {
     int64_t *d_sorted_cpu = nullptr;  // [tiles][1024], padded with INT64_MAX
     int64_t *d_sorted_mem = nullptr;
     uint64_t *d_tables = nullptr;     // [tiles][rows][16]
-    uint32_t *d_lab_meta = nullptr;   // lab_base[32], lab_max[32]
+    uint32_t *d_lab_meta = nullptr;   // lab_base[32], lab_max[32], then 8 zero words
     size_t sorted_cap = 0, tables_cap = 0;
 };
 
@@ -174,9 +174,9 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
     if ((e = hipMemcpy(s.d_sorted_cpu, scpu.data(), sorted_elems * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(s.d_sorted_mem, smem.data(), sorted_elems * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(s.d_tables, tab.data(), tab.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if (!s.d_lab_meta && (e = hipMalloc((void **)&s.d_lab_meta, 64 * sizeof(uint32_t))) != hipSuccess) return e;
+    if (!s.d_lab_meta && (e = hipMalloc((void **)&s.d_lab_meta, 72 * sizeof(uint32_t))) != hipSuccess) return e;
     {
-        uint32_t meta[64];
+        uint32_t meta[72] = {};
         for (int k = 0; k < 32; ++k) {
             meta[k] = l.lab_base[k];
             meta[32 + k] = l.lab_max[k];

@@ -1,0 +1,141 @@
+#!/usr/bin/env python
+"""Audit of the compiled fused mask kernel (gfx950 assembly), run on the CPU box.
+
+The kernel loads its per-pod operands with inline-asm global loads that the compiler's s_waitcnt
+bookkeeping does not see, and waits for them with a hand-counted `s_waitcnt vmcnt(N)` statement
+(kernels_fused.hpp, "pod operands").  That is only sound if, for every instantiation,
+  1. no VGPR is spilled and no scratch is used (a spill could move an operand register before
+     its data has landed),
+  2. no instruction between an operand load and the counted wait reads or writes the load's
+     destination registers (no compiler copy of a register that is still in flight),
+  3. exactly the expected number of vector-memory instructions sits between the last operand
+     load and the counted wait on the unchecked path.
+usage: python tools/audit_asm.py [--keep DIR]   -> exit code 0 when every k_eval_fused variant passes
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "kube_scheduler_rs_reference_amd", "csrc", "ksched_api.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def regs_of(text: str) -> set[int]:
+    out: set[int] = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def compile_asm(workdir: str) -> str:
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "-c", SRC, "-o", os.path.join(workdir, "k.o"),
+                           "-save-temps"], cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for f in os.listdir(workdir):
+        if f.endswith("gfx950.s"):
+            return open(os.path.join(workdir, f)).read()
+    raise RuntimeError("no gfx950 assembly produced")
+
+
+def kernels(asm: str):
+    """yield (name, body_lines, metadata dict) for every k_eval_fused instantiation"""
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(_ZN6ksched12k_eval_fused\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", asm):
+        meta[m.group(1)] = {"vgpr_spill": int(m.group(2))}
+    for m in re.finditer(r"\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.symbol:\s+(_ZN6ksched12k_eval_fused\S+)\.kd", asm):
+        meta.setdefault(m.group(2), {})["scratch"] = int(m.group(1))
+    for m in re.finditer(r"^(_ZN6ksched12k_eval_fused\S+):.*?\n(.*?)\n\s+s_endpgm", asm, re.S | re.M):
+        yield m.group(1), m.group(2).split("\n"), meta.get(m.group(1), {})
+
+
+def audit_kernel(name: str, lines: list[str], meta: dict) -> list[str]:
+    errs = []
+    if meta.get("vgpr_spill", 0):
+        errs.append(f"vgpr_spill_count = {meta['vgpr_spill']}")
+    if meta.get("scratch", 0):
+        errs.append(f"private_segment_fixed_size = {meta['scratch']}")
+    # collect asm statements
+    in_asm = False
+    loads, waits = [], []  # (line index, dest regs) / (line index, n)
+    for i, ln in enumerate(lines):
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if in_asm:
+            if t.startswith("global_load_dword"):
+                dst = t.split(None, 1)[1].split(",")[0]
+                loads.append((i, regs_of(dst)))
+            m = re.match(r"s_waitcnt vmcnt\((\d+)\)$", t)
+            if m:
+                waits.append((i, int(m.group(1))))
+    if not loads:
+        return errs  # instantiation without operand loads (no FIT/SEL/TAINT)
+    dest = set().union(*(r for _, r in loads))
+    # the operand loads appear once (one load site); the counted wait is the first asm wait with N > 0 or,
+    # when FIT/SEL/TAINT leave no loads, absent
+    counted = [w for w in waits if w[1] > 0]
+    if len(counted) != 1:
+        errs.append(f"expected exactly one counted wait, found {len(counted)}")
+        return errs
+    # 2. between the wait and the loads in program order the loop body wraps around: check every
+    # instruction that is neither the loads themselves nor after-the-wait consumers.  Conservative
+    # form: outside the asm statements, no instruction may WRITE a destination register at all, and
+    # reads are only allowed in the basic blocks that follow the counted wait up to the next load.
+    first_load = min(i for i, _ in loads)
+    wait_i = counted[0][0]
+    for i, ln in enumerate(lines):
+        t = ln.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":") or t.startswith("s_") or t.startswith("global_load_dword") and any(i == li for li, _ in loads):
+            continue
+        ops = t.split(None, 1)
+        if len(ops) < 2:
+            continue
+        used = regs_of(ops[1]) & dest
+        if not used:
+            continue
+        written = regs_of(ops[1].split(",")[0]) & dest if not ops[0].startswith(("global_store", "ds_write", "v_cmp", "buffer_store")) else set()
+        # instructions textually between the wait and the next load site are the consumers (phase 1)
+        in_consumer_region = (wait_i < i < first_load) if wait_i < first_load else (i > wait_i or i < first_load)
+        if written and not (i < min(wait_i, first_load) and ops[0].startswith("v_mov")):
+            errs.append(f"line {i}: writes operand register(s) {sorted(written)}: {t}")
+        elif not in_consumer_region and not (i < min(wait_i, first_load) and ops[0].startswith("v_mov")):
+            errs.append(f"line {i}: touches in-flight operand register(s) {sorted(used)} outside the consumer region: {t}")
+    return errs
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--keep", default=None)
+    args = ap.parse_args()
+    wd = args.keep or tempfile.mkdtemp(prefix="ksched_audit_")
+    os.makedirs(wd, exist_ok=True)
+    asm = compile_asm(wd)
+    bad = 0
+    n = 0
+    for name, lines, meta in kernels(asm):
+        n += 1
+        errs = audit_kernel(name, lines, meta)
+        tag = re.sub(r"^_ZN6ksched12k_eval_fusedI|EEv.*$", "", name)
+        if errs:
+            bad += 1
+            print(f"FAIL {tag}: " + "; ".join(errs[:4]))
+    print(f"audited {n} k_eval_fused instantiations, {bad} failing")
+    return 1 if bad or n == 0 else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
