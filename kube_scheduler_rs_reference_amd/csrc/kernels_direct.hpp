@@ -161,12 +161,19 @@ __global__ __launch_bounds__(256) void k_pick_sampled(const uint64_t *__restrict
     if (pod >= p) return;
     int32_t b = -1;
     const uint64_t *row = mask + (size_t)pod * pitch;
-    for (uint32_t i = 0; i < attempts; ++i) {
-        const uint32_t s = samples[(size_t)pod * attempts + i];
-        if (s < n && ((row[s >> 6] >> (s & 63u)) & 1ull)) {
-            b = (int32_t)s;
-            break;
-        }
+    const uint32_t *smp = samples + (size_t)pod * attempts;
+    // eight draws at a time: all sample indices, then all mask words, are in flight together (two
+    // dependent memory round trips per eight attempts instead of two per attempt)
+    for (uint32_t i0 = 0; i0 < attempts && b < 0; i0 += 8u) {
+        uint32_t s[8];
+        uint64_t w[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) s[j] = (i0 + j < attempts) ? smp[i0 + j] : 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) w[j] = (s[j] < n) ? row[s[j] >> 6] : 0ull;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j)
+            if (b < 0 && ((w[j] >> (s[j] & 63u)) & 1ull)) b = (int32_t)s[j];  // first feasible draw wins (src/main.rs:61-65)
     }
     binding[pod] = b;
 }

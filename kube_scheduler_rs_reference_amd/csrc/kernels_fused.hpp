@@ -44,6 +44,7 @@ struct FusedArgs {
     const uint32_t *lab_meta;          // device copy of IndexedLayout::lab_base[32], lab_max[32]
     const uint64_t *zero64;            // eight zero bytes in device memory
     uint32_t p, units, chunks, run;    // units = ceil(p / 8); run = (chunk, tile) pairs per XCD
+    uint32_t unit_q, unit_rem, tiles_rcp;  // units / chunks, units % chunks, floor(2^32 / tiles)
     uint32_t off_sorted, off_rec, off_rec2, off_trow;  // LDS byte offsets of the regions after the bitmap rows
     uint32_t debug;
     uint64_t *trace;  // diagnostics: per-block phase timestamps (100 MHz), or nullptr
@@ -87,8 +88,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     if (!(a.debug & 32u)) {
         const uint32_t l = (b & 7u) * a.run + (b >> 3);
         if ((b >> 3) >= a.run) return;
-        chunk = l / a.tiles;
+        chunk = __umulhi(l, a.tiles_rcp);  // l / tiles by a host-made reciprocal (no division sequence in the prologue)
         tile = l - chunk * a.tiles;
+        if (tile >= a.tiles) {  // the reciprocal can be one short
+            tile -= a.tiles;
+            ++chunk;
+        }
     } else {  // experiment: plain round-robin of (tile, chunk) pairs
         tile = b % a.tiles;
         chunk = b / a.tiles;
@@ -103,9 +108,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     };
     stamp(0);
     // this wave's units [u, u_hi): chunk range cut evenly over the waves
-    const uint32_t c_lo = (uint32_t)(((uint64_t)chunk * a.units) / a.chunks);
-    const uint32_t c_hi = (uint32_t)(((uint64_t)(chunk + 1u) * a.units) / a.chunks);
-    const uint32_t c_n = c_hi - c_lo;
+    // balanced split of `units` over `chunks`: the first unit_rem chunks get unit_q + 1 units
+    const uint32_t c_lo = chunk * a.unit_q + min(chunk, a.unit_rem);
+    const uint32_t c_n = a.unit_q + (chunk < a.unit_rem ? 1u : 0u);
     uint32_t u = c_lo + (wave * c_n) / kFusedWaves;
     const uint32_t u_hi = c_lo + ((wave + 1u) * c_n) / kFusedWaves;
 
@@ -522,6 +527,9 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     const uint32_t rounds = (a.units + 7u) / 8u;
     const uint32_t want = (rounds + kFusedWaves - 1u) / kFusedWaves;  // chunks that give every wave one round
     a.chunks = std::max(1u, std::min((256u * blocks_per_cu) / l.tiles, want));
+    a.unit_q = a.units / a.chunks;
+    a.unit_rem = a.units % a.chunks;
+    a.tiles_rcp = (uint32_t)std::min<uint64_t>((1ull << 32) / l.tiles, 0xFFFFFFFFull);
     const uint32_t total = a.chunks * l.tiles;
     a.run = (total + 7u) / 8u;
     const dim3 grid((debug & 32u) ? total : a.run * 8u);
