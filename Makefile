@@ -3,7 +3,7 @@
 #
 #   make            -> lib (HIP C-ABI library) + host (C++ host mirror) + oracle (test-only CPU restatement)
 #   make lib        -> kube_scheduler_rs_reference_amd/libksched_hip.so     hipcc, gfx950 only
-#   make host       -> kube_scheduler_rs_reference_amd/libksched_host.so    g++, links libksched_hip.so
+#   make host       -> kube_scheduler_rs_reference_amd/libksched_host.so    g++, links libksched_hip.so; + tests/cpp/host_tests
 #   make oracle     -> oracle/liboracle.so                                  gcc, test infrastructure only
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
@@ -22,26 +22,26 @@ LIB_HOST := $(PKG)/libksched_host.so
 LIB_ORA  := oracle/liboracle.so
 
 HOST_SRCS := $(wildcard $(HOST)/*.cpp)
-HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/ksched.h include/ksched_host.h
+HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/ksched.h
+HOST_TEST := tests/cpp/host_tests
 
 .PHONY: all lib host oracle clean
-ifneq ($(wildcard $(HOST)/host_c_api.cpp),)
 all: lib host oracle
-else
-all: lib oracle
-endif
 
 lib: $(LIB_HIP)
 $(LIB_HIP): $(CSRC)/ksched_api.hip $(wildcard $(CSRC)/*.hpp) include/ksched.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ksched_api.hip
 
-host: $(LIB_HOST)
+host: $(LIB_HOST) $(HOST_TEST)
 $(LIB_HOST): $(HOST_SRCS) $(HOST_HDRS) $(LIB_HIP)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRCS) -L$(PKG) -lksched_hip -Wl,-rpath,'$$ORIGIN' -lpthread
+# C++ tests of the host mirror (tests/cpp/host_tests.cpp; driven by tests/test_host_mirror.py)
+$(HOST_TEST): tests/cpp/host_tests.cpp $(LIB_HOST) $(HOST_HDRS)
+	$(CXX) $(CXXFLAGS) -o $@ tests/cpp/host_tests.cpp -L$(PKG) -lksched_host -lksched_hip -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lpthread
 
 oracle: $(LIB_ORA)
 $(LIB_ORA): oracle/oracle.c oracle/oracle.h
 	$(CC) $(CFLAGS) -shared -o $@ oracle/oracle.c
 
 clean:
-	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA)
+	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA) $(HOST_TEST)

@@ -41,6 +41,9 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         return corev1::name_any(nodes[a].metadata) < corev1::name_any(nodes[b].metadata);
     });
+    store_of_canonical_ = order;
+    canonical_of_store_.assign(n, 0u);
+    for (uint32_t i = 0; i < n; ++i) canonical_of_store_[order[i]] = i;
     NodeColumns c;
     c.n = n;
     c.names.resize(n);

@@ -81,6 +81,9 @@ public:
 
     const NodeColumns &columns() const { return cols_; }
     int index_of(const std::string &node_name) const;  // canonical index or -1
+    // canonical index <-> position in the vector given to rebuild() (the node store's own order)
+    uint32_t store_index(uint32_t canonical) const { return store_of_canonical_[canonical]; }
+    uint32_t canonical_index(uint32_t store) const { return canonical_of_store_[store]; }
     uint32_t n() const { return cols_.n; }
     uint32_t mask_words() const { return ksched_mask_words(cols_.n); }
     bool has_taints() const { return !taint_ids_.empty(); }
@@ -94,6 +97,7 @@ private:
 
     std::shared_ptr<DeviceEvaluator> dev_;
     NodeColumns cols_;
+    std::vector<uint32_t> store_of_canonical_, canonical_of_store_;
     std::vector<corev1::StringMap> node_labels_;            // canonical order; empty map when labels is None
     std::vector<bool> node_has_labels_;
     std::vector<std::map<std::string, uint32_t>> value_ids_;  // per column: value string -> id (1..)

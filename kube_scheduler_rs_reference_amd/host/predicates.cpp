@@ -104,7 +104,7 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
     out.fit.assign((size_t)out.p * out.W, 0ull);
     const uint32_t pick = pick_flags & (KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT);
     if (pick) out.binding.assign(out.p, -1);
-    if (out.p == 0) return out;
+    if (out.p == 0 || out.n == 0) return out;  // no pods, or an empty store: nothing is feasible
     if ((pick & KSCHED_PICK_SAMPLED) && (!samples || samples->size() != (size_t)out.p * attempts))
         throw EncodeError("check_node_validity_batch: samples must hold p * attempts indices");
     DeviceEvaluator &dev = snap.device();

@@ -1,0 +1,140 @@
+#include "scheduler.hpp"
+
+namespace ksched_host {
+
+std::optional<size_t> SplitMixChooser::choose(size_t n) {
+    if (n == 0) return std::nullopt;
+    uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (size_t)(z % n);
+}
+
+std::optional<size_t> ScriptedChooser::choose(size_t n) {
+    if (n == 0 || next >= script.size()) return std::nullopt;
+    return script[next++] % n;
+}
+
+const char *error_text(ReconcileError e) {
+    switch (e) {
+        case ReconcileError::CreateBindingFailed: return "create-binding-failed";
+        case ReconcileError::CreateBindingObjectFailed: return "create-binding-object-failed";
+        case ReconcileError::NoNodeFound: return "no-node-found";
+    }
+    return "?";
+}
+
+std::optional<corev1::Node> select_node_for_pod(const corev1::Pod &pod, Context &ctx, NodeChooser &chooser,
+                                                std::vector<RejectedCandidate> *rejected) {
+    std::optional<corev1::Node> node;
+    for (uint32_t attempt = 0; attempt < ATTEMPTS; ++attempt) {  // src/main.rs:53
+        // ctx.node_store.state().choose(&mut rng): a uniform draw with replacement; an empty store yields None (:56)
+        const std::optional<size_t> idx = chooser.choose(ctx.node_store.size());
+        if (!idx) continue;
+        const corev1::Node &candidate = ctx.node_store[*idx];
+        const predicates::Validity v = predicates::check_node_validity(pod, candidate, ctx);  // :61
+        if (v) {
+            if (rejected) rejected->push_back({corev1::name_any(candidate.metadata), *v});  // the WARN line at :62
+        } else {
+            node = candidate;  // :64-65
+            break;
+        }
+    }
+    return node;  // :70
+}
+
+BatchSelection select_nodes_for_pods(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser, bool want_rejected) {
+    if (!ctx.snapshot) ctx.refresh_snapshot();
+    Snapshot &snap = *ctx.snapshot;
+    const uint32_t p = (uint32_t)pods.size(), n = snap.n();
+    BatchSelection out;
+    out.node_store_index.assign(p, -1);
+    if (want_rejected) out.rejected.resize(p);
+    // the draws, in the reference's order: pod by pod, attempt by attempt, over the store's own ordering;
+    // converted to canonical column indices for the device (an empty store gives "no draw" = index n)
+    std::vector<uint32_t> samples((size_t)p * ATTEMPTS, n);
+    for (uint32_t i = 0; i < p; ++i)
+        for (uint32_t t = 0; t < ATTEMPTS; ++t) {
+            const std::optional<size_t> idx = chooser.choose(ctx.node_store.size());
+            if (idx) samples[(size_t)i * ATTEMPTS + t] = snap.canonical_index((uint32_t)*idx);
+        }
+    if (n == 0 || p == 0) return out;
+    out.validity = predicates::check_node_validity_batch(pods, ctx, /*taints=*/false, KSCHED_PICK_SAMPLED, &samples, ATTEMPTS);
+    for (uint32_t i = 0; i < p; ++i) {
+        const int32_t b = out.validity.binding[i];
+        if (b >= 0) out.node_store_index[i] = (int32_t)snap.store_index((uint32_t)b);
+        if (want_rejected) {
+            for (uint32_t t = 0; t < ATTEMPTS; ++t) {
+                const uint32_t s = samples[(size_t)i * ATTEMPTS + t];
+                if (s >= n) continue;
+                const predicates::Validity v = out.validity.validity(i, s);
+                if (!v) break;  // this draw won
+                out.rejected[i].push_back({snap.columns().names[s], *v});
+            }
+        }
+    }
+    return out;
+}
+
+Action error_policy(const corev1::Pod &, ReconcileError) { return Action::RequeueAfter5Min; }  // src/main.rs:122-125
+
+namespace {
+
+ReconcileOutcome bind(const corev1::Pod &pod, const corev1::Node *chosen, BindingSink &sink) {
+    ReconcileOutcome r;
+    if (!chosen) {  // src/main.rs:116-118
+        r.ok = false;
+        r.error = ReconcileError::NoNodeFound;
+        r.action = error_policy(pod, r.error);
+        return r;
+    }
+    const std::string pod_name = corev1::name_any(pod.metadata);
+    if (!pod.metadata.namespace_) {
+        // `pod.namespace().unwrap()` panics in the reference (src/main.rs:80); a pod without a namespace
+        // cannot come from the API server.  Map it to the binding-object failure instead of unwinding.
+        r.ok = false;
+        r.error = ReconcileError::CreateBindingObjectFailed;
+        r.action = error_policy(pod, r.error);
+        return r;
+    }
+    Binding b;
+    b.metadata = pod.metadata;  // src/main.rs:88-91
+    b.target_name = corev1::name_any(chosen->metadata);
+    if (!sink.create_pod_binding(pod_name, *pod.metadata.namespace_, b)) {  // :103-108
+        r.ok = false;
+        r.error = ReconcileError::CreateBindingFailed;
+        r.action = error_policy(pod, r.error);
+        return r;
+    }
+    r.bound_to = b.target_name;
+    return r;  // Ok(Action::await_change()), :119
+}
+
+}  // namespace
+
+ReconcileOutcome reconcile(const corev1::Pod &pod, Context &ctx, NodeChooser &chooser, BindingSink &sink) {
+    if (is_pod_bound(pod)) return ReconcileOutcome{};  // src/main.rs:74-76
+    const std::optional<corev1::Node> chosen = select_node_for_pod(pod, ctx, chooser);
+    return bind(pod, chosen ? &*chosen : nullptr, sink);
+}
+
+std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
+                                              BindingSink &sink) {
+    std::vector<ReconcileOutcome> out(pods.size());
+    std::vector<const corev1::Pod *> pending;
+    std::vector<size_t> where;
+    for (size_t i = 0; i < pods.size(); ++i) {
+        if (is_pod_bound(*pods[i])) continue;  // Ok(await_change) without touching the evaluator
+        pending.push_back(pods[i]);
+        where.push_back(i);
+    }
+    const BatchSelection sel = select_nodes_for_pods(pending, ctx, chooser);
+    for (size_t j = 0; j < pending.size(); ++j) {
+        const int32_t idx = sel.node_store_index[j];
+        out[where[j]] = bind(*pending[j], idx >= 0 ? &ctx.node_store[(size_t)idx] : nullptr, sink);
+    }
+    return out;
+}
+
+}  // namespace ksched_host

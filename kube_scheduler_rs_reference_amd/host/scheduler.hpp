@@ -1,0 +1,110 @@
+// scheduler.hpp -- host mirror of the pick and reconcile path of the reference's main.rs.
+//
+//   Rust (src/main.rs)                                           here
+//   -----------------------------------------------------------  ------------------------------------------
+//   const ATTEMPTS: u32 = 5                                  :49  ATTEMPTS
+//   async fn select_node_for_pod(&Pod,&Context)->Option<Node> :51  select_node_for_pod(pod, ctx, chooser)
+//   async fn reconcile(Arc<Pod>, Arc<Context>)              :73  reconcile(pod, ctx, chooser, sink)
+//   fn error_policy(..) -> Action::requeue(5 min)          :122  error_policy(...)
+//   enum ReconcileError (src/error.rs:5-15)                      ReconcileError (same variants, same #[error] text)
+//
+// The reference draws candidates with rand::thread_rng() (src/main.rs:56), so its pick cannot be
+// reproduced; here the draw is an injected NodeChooser (SliceRandom::choose over the node store's
+// current state).  The batched entry point select_nodes_for_pods does the same thing for a whole
+// batch in one device call (KSCHED_PICK_SAMPLED): every pod gets ATTEMPTS draws, the first
+// feasible one wins, none -> no node (NoNodeFound).
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <optional>
+#include <string>
+#include <vector>
+
+#include "corev1.hpp"
+#include "predicates.hpp"
+#include "util.hpp"
+
+namespace ksched_host {
+
+constexpr uint32_t ATTEMPTS = 5;  // src/main.rs:49
+
+// rand::seq::SliceRandom::choose on a slice of length n: an index in [0, n), or nothing when n == 0.
+struct NodeChooser {
+    virtual ~NodeChooser() = default;
+    virtual std::optional<size_t> choose(size_t n) = 0;
+};
+
+// Deterministic chooser for tests and benchmarks: SplitMix64 stream.
+struct SplitMixChooser : NodeChooser {
+    uint64_t state;
+    explicit SplitMixChooser(uint64_t seed) : state(seed) {}
+    std::optional<size_t> choose(size_t n) override;
+};
+
+// Replays a fixed list of indices (golden tests: samples [3,3,7,1,0]).
+struct ScriptedChooser : NodeChooser {
+    std::vector<size_t> script;
+    size_t next = 0;
+    std::optional<size_t> choose(size_t n) override;
+};
+
+// what the reference logs at WARN for every rejected candidate (src/main.rs:62)
+struct RejectedCandidate {
+    std::string node_name;
+    predicates::InvalidNodeReason reason;
+};
+
+// src/main.rs:51-71, one pod, per-pair predicate calls (reference cost model: one LIST per probe).
+std::optional<corev1::Node> select_node_for_pod(const corev1::Pod &pod, Context &ctx, NodeChooser &chooser,
+                                                std::vector<RejectedCandidate> *rejected = nullptr);
+
+// The same pick for a batch against ctx.snapshot, one device call.  Draws are made up front, ATTEMPTS per
+// pod in pod order (the reference stops drawing after the first success; with an injected chooser the
+// results are identical draw for draw because unused draws do not influence the outcome).
+// Returns for every pod the chosen node's index into ctx.node_store, or -1.
+struct BatchSelection {
+    std::vector<int32_t> node_store_index;             // [p] index into ctx.node_store or -1
+    std::vector<std::vector<RejectedCandidate>> rejected;  // [p] candidates tried and refused, in order (filled on request)
+    predicates::BatchValidity validity;                // both masks (canonical node order) for callers that want more
+};
+BatchSelection select_nodes_for_pods(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
+                                     bool want_rejected = false);
+
+// ---- reconcile ------------------------------------------------------------------------------------
+
+enum class ReconcileError { CreateBindingFailed, CreateBindingObjectFailed, NoNodeFound };  // src/error.rs:5-15
+const char *error_text(ReconcileError e);  // the #[error("...")] strings
+
+// corev1::Binding as reconcile builds it (src/main.rs:83-91): the pod's metadata, target = node name
+struct Binding {
+    corev1::ObjectMeta metadata;
+    std::string target_name;
+};
+
+// ctx.client.send(Binding::create_pod(..)) (src/main.rs:94-103): false = the POST failed
+struct BindingSink {
+    virtual ~BindingSink() = default;
+    virtual bool create_pod_binding(const std::string &pod_name, const std::string &pod_namespace, const Binding &b) = 0;
+};
+
+enum class Action { AwaitChange, RequeueAfter5Min };  // Action::await_change() / Action::requeue(5 * 60 s)
+
+struct ReconcileOutcome {
+    bool ok = true;
+    ReconcileError error = ReconcileError::NoNodeFound;  // valid when !ok
+    Action action = Action::AwaitChange;                 // error_policy applied when !ok
+    std::optional<std::string> bound_to;                 // node name when a binding was created
+};
+
+// src/main.rs:73-120 for one pod.
+ReconcileOutcome reconcile(const corev1::Pod &pod, Context &ctx, NodeChooser &chooser, BindingSink &sink);
+
+// The batching reconciler: bound pods are skipped (src/main.rs:74-76), the rest go
+// through ONE batched evaluation and pick, then each gets its own binding POST and outcome.
+std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
+                                              BindingSink &sink);
+
+// src/main.rs:122-125
+Action error_policy(const corev1::Pod &pod, ReconcileError error);
+
+}  // namespace ksched_host

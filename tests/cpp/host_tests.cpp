@@ -1,0 +1,494 @@
+// host_tests.cpp -- tests of the host mirror (kube_scheduler_rs_reference_amd/host), written to read like
+// the reference's own src/predicates/test.rs: the same two fixtures (test_pod, test_node), the same three
+// known answers (KAT-S1..S3), then the derived vectors of SURVEY.md section 8c.
+//
+//   host_tests cpu   wire-format and host logic only (no device is touched)
+//   host_tests gpu   everything that evaluates a predicate: runs on the MI355X through the C ABI
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../kube_scheduler_rs_reference_amd/host/encoder.hpp"
+#include "../../kube_scheduler_rs_reference_amd/host/predicates.hpp"
+#include "../../kube_scheduler_rs_reference_amd/host/scheduler.hpp"
+#include "../../kube_scheduler_rs_reference_amd/host/util.hpp"
+
+using namespace ksched_host;
+using predicates::InvalidNodeReason;
+
+static int g_fail = 0, g_run = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            ++g_fail;                                                            \
+            std::printf("    FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);     \
+        }                                                                        \
+    } while (0)
+#define CHECK_THROWS(expr)                                                      \
+    do {                                                                        \
+        bool threw_ = false;                                                    \
+        try {                                                                   \
+            (void)(expr);                                                       \
+        } catch (const std::exception &) {                                      \
+            threw_ = true;                                                      \
+        }                                                                       \
+        if (!threw_) {                                                          \
+            ++g_fail;                                                           \
+            std::printf("    FAILED %s:%d: no exception: %s\n", __FILE__, __LINE__, #expr); \
+        }                                                                       \
+    } while (0)
+
+static void run(const char *name, const std::function<void()> &f) {
+    ++g_run;
+    const int before = g_fail;
+    try {
+        f();
+    } catch (const std::exception &e) {
+        ++g_fail;
+        std::printf("    EXCEPTION in %s: %s\n", name, e.what());
+    }
+    std::printf("%s %s\n", g_fail == before ? "ok  " : "FAIL", name);
+}
+
+// ---- fixtures, as in src/predicates/test.rs:8-40 -------------------------------------------------------
+static const char *POD_NAMESPACE = "test";
+static const char *POD_NAME = "pod1";
+static const char *NODE_NAME = "node1";
+
+static corev1::Pod test_pod(const char *k = nullptr, const char *v = nullptr) {  // #[default(None)] selector_key
+    corev1::Pod pod;
+    pod.metadata.namespace_ = POD_NAMESPACE;
+    pod.metadata.name = POD_NAME;
+    if (k) {
+        corev1::PodSpec spec;
+        spec.node_selector = corev1::StringMap{{k, v}};
+        pod.spec = spec;
+    }
+    return pod;
+}
+
+static corev1::Node test_node() {
+    corev1::Node node;
+    node.metadata.name = NODE_NAME;
+    node.metadata.labels = corev1::StringMap{{"name", NODE_NAME}};
+    return node;
+}
+
+// ---- helpers for the derived vectors ---------------------------------------------------------------------
+static corev1::Container container(const char *cpu, const char *mem) {
+    corev1::Container c;
+    c.name = "c";
+    corev1::ResourceRequirements rr;
+    std::map<std::string, corev1::Quantity> req;
+    if (cpu) req["cpu"] = cpu;
+    if (mem) req["memory"] = mem;
+    rr.requests = req;
+    c.resources = rr;
+    return c;
+}
+
+static corev1::Pod pod_with(const std::string &name, std::vector<corev1::Container> cs, const char *node_name = nullptr) {
+    corev1::Pod p;
+    p.metadata.namespace_ = POD_NAMESPACE;
+    p.metadata.name = name;
+    corev1::PodSpec spec;
+    spec.containers = std::move(cs);
+    if (node_name) spec.node_name = std::string(node_name);
+    p.spec = spec;
+    return p;
+}
+
+static corev1::Node node_with(const std::string &name, const char *cpu, const char *mem) {
+    corev1::Node n;
+    n.metadata.name = name;
+    if (cpu || mem) {
+        corev1::NodeStatus st;
+        std::map<std::string, corev1::Quantity> al;
+        if (cpu) al["cpu"] = cpu;
+        if (mem) al["memory"] = mem;
+        st.allocatable = al;
+        n.status = st;
+    }
+    return n;
+}
+
+static Context make_ctx(std::vector<corev1::Node> nodes, std::vector<corev1::Pod> cluster_pods = {}) {
+    Context ctx;
+    auto lister = std::make_shared<StaticPodLister>();
+    lister->pods = std::move(cluster_pods);
+    ctx.client = lister;
+    ctx.node_store = std::move(nodes);
+    return ctx;
+}
+
+struct RecordingSink : BindingSink {
+    std::vector<std::pair<std::string, std::string>> posts;  // pod full name -> node
+    bool fail = false;
+    bool create_pod_binding(const std::string &pod_name, const std::string &ns, const Binding &b) override {
+        if (fail) return false;
+        posts.push_back({ns + "/" + pod_name, b.target_name});
+        return true;
+    }
+};
+
+// =========================================== CPU-side tests ================================================
+static void cpu_tests() {
+    run("quantity: canonical domain D (SURVEY.md 8c)", [] {
+        CHECK(ParsedQuantity::try_from("500m").to_milli() == 500);
+        CHECK(ParsedQuantity::try_from("2").to_milli() == 2000);
+        CHECK(ParsedQuantity::try_from("0").to_units() == 0);
+        CHECK(ParsedQuantity::try_from("134217728").to_units() == 134217728);
+        CHECK(ParsedQuantity::try_from("1k").to_units() == 1000);
+        CHECK(ParsedQuantity::try_from("3M").to_units() == 3000000);
+        CHECK(ParsedQuantity::try_from("128Mi").to_units() == 128ll << 20);
+        CHECK(ParsedQuantity::try_from("1Gi").to_units() == 1ll << 30);  // true Kubernetes semantics (documented divergence)
+        CHECK(ParsedQuantity::try_from("1.5").to_milli() == 1500);
+        CHECK(ParsedQuantity::try_from("1e3").to_units() == 1000);
+        CHECK(ParsedQuantity::try_from("-250m").to_milli() == -250);
+        CHECK_THROWS(ParsedQuantity::try_from(""));
+        CHECK_THROWS(ParsedQuantity::try_from("abc"));
+        CHECK_THROWS(ParsedQuantity::try_from("1Xi"));
+        CHECK_THROWS(ParsedQuantity::try_from("100n").to_milli());  // finer than a milli-core: outside the exact domain
+    });
+    run("quantity: += -= <= (src/util.rs:33-34,65; src/predicates.rs:42)", [] {
+        ParsedQuantity a = ParsedQuantity::try_from("250m"), b = ParsedQuantity::try_from("250m");
+        a += b;
+        CHECK(a.to_milli() == 500);
+        a -= ParsedQuantity::try_from("1");
+        CHECK(a.to_milli() == -500);
+        CHECK(a <= ParsedQuantity::try_from("0"));
+        CHECK(!(ParsedQuantity::try_from("1") <= ParsedQuantity::try_from("999m")));
+        CHECK(ParsedQuantity::try_from("1") <= ParsedQuantity::try_from("1000m"));
+    });
+    run("total_pod_resources: containers only, requests only (D-R6, D-R7; src/util.rs:54-75)", [] {
+        corev1::Pod p = pod_with("p", {container("250m", "64Mi"), container("250m", nullptr)});
+        corev1::Container bare;
+        bare.name = "no-resources";
+        p.spec->containers.push_back(bare);
+        p.spec->init_containers.push_back(container("64", "1Ti"));  // ignored
+        PodResources r = total_pod_resources(p);
+        CHECK(r.cpu.to_milli() == 500);
+        CHECK(r.memory.to_units() == 64ll << 20);
+        corev1::Pod nospec;
+        PodResources z = total_pod_resources(nospec);
+        CHECK(z.cpu.to_milli() == 0 && z.memory.to_units() == 0);
+        corev1::Pod bad = pod_with("bad", {container("lots", nullptr)});
+        CHECK_THROWS(total_pod_resources(bad));  // the reference panics: "invalid pod spec: cpu request"
+    });
+    run("is_pod_bound / full_name (src/util.rs:38-52)", [] {
+        CHECK(!is_pod_bound(test_pod()));
+        CHECK(!is_pod_bound(test_pod("a", "b")));
+        CHECK(is_pod_bound(pod_with("x", {}, "node1")));
+        CHECK(full_name(test_pod().metadata) == "test/pod1");
+        CHECK(full_name(test_node().metadata) == "node1");
+    });
+    run("InvalidNodeReason / ReconcileError text (src/predicates.rs:14-18, src/error.rs:5-15)", [] {
+        CHECK(std::string(predicates::debug_name(InvalidNodeReason::NotEnoughResources)) == "NotEnoughResources");
+        CHECK(std::string(predicates::debug_name(InvalidNodeReason::NodeSelectorMismatch)) == "NodeSelectorMismatch");
+        CHECK((int)InvalidNodeReason::NotEnoughResources == 0 && (int)InvalidNodeReason::NodeSelectorMismatch == 1);
+        CHECK(std::string(error_text(ReconcileError::NoNodeFound)) == "no-node-found");
+        CHECK(std::string(error_text(ReconcileError::CreateBindingFailed)) == "create-binding-failed");
+        CHECK(std::string(error_text(ReconcileError::CreateBindingObjectFailed)) == "create-binding-object-failed");
+        CHECK(ATTEMPTS == 5);
+    });
+    run("encoder: canonical order, available = allocatable - LIST, label interning, taints", [] {
+        std::vector<corev1::Node> nodes = {node_with("node-b", "4", "8589934592"), node_with("node-a", "2", "4294967296"),
+                                           node_with("node-c", nullptr, nullptr)};
+        nodes[0].metadata.labels = corev1::StringMap{{"zone", "z1"}, {"disk", ""}};
+        nodes[1].metadata.labels = corev1::StringMap{{"zone", "z2"}};
+        corev1::NodeSpec ns;
+        ns.taints = std::vector<corev1::Taint>{{"dedicated", std::string("gpu"), "NoSchedule"}, {"soft", std::nullopt, "PreferNoSchedule"}};
+        nodes[0].spec = ns;
+        StaticPodLister lister;
+        lister.pods = {pod_with("r1", {container("500m", "1073741824")}, "node-a"), pod_with("r2", {container("3", "0")}, "node-a"),
+                       pod_with("done", {container("1", "1")}, "node-b")};
+        lister.pods[2].status = corev1::PodStatus{std::string("Succeeded")};  // D-R8: still subtracted
+        Snapshot snap(Snapshot::kEncodeOnly);
+        snap.rebuild(nodes, &lister);
+        const NodeColumns &c = snap.columns();
+        CHECK(c.n == 3);
+        CHECK(c.names[0] == "node-a" && c.names[1] == "node-b" && c.names[2] == "node-c");
+        CHECK(c.avail_cpu_milli[0] == 2000 - 500 - 3000);  // over-committed: negative (D-R4)
+        CHECK(c.avail_mem_bytes[0] == 4294967296ll - 1073741824ll);
+        CHECK(c.avail_cpu_milli[1] == 3000 && c.avail_mem_bytes[1] == 8589934592ll - 1);
+        CHECK(c.avail_cpu_milli[2] == 0 && c.avail_mem_bytes[2] == 0);  // no status: 0/0 (D-R5)
+        CHECK(lister.list_calls == 3);                                   // one LIST per node
+        CHECK(snap.store_index(0) == 1 && snap.canonical_index(0) == 1 && snap.index_of("node-c") == 2 && snap.index_of("nope") == -1);
+        CHECK(c.taints[1] == 1ull && c.taints[0] == 0ull);               // PreferNoSchedule never filters
+        // label columns appear when a pod asks for the key
+        corev1::Pod p1 = test_pod("zone", "z1"), p2 = test_pod("disk", ""), p3 = test_pod("zone", "nowhere"), p4 = test_pod();
+        corev1::Toleration tol;
+        tol.key = std::string("dedicated");
+        tol.operator_ = std::string("Exists");
+        p4.spec = corev1::PodSpec{};
+        p4.spec->tolerations = std::vector<corev1::Toleration>{tol};
+        PodColumns pc = snap.encode_pods({&p1, &p2, &p3, &p4});
+        CHECK(pc.p == 4 && pc.n_keys == 2);
+        const NodeColumns &c2 = snap.columns();
+        const uint32_t kz = (uint32_t)(std::find(c2.keys.begin(), c2.keys.end(), "zone") - c2.keys.begin());
+        const uint32_t kd = (uint32_t)(std::find(c2.keys.begin(), c2.keys.end(), "disk") - c2.keys.begin());
+        CHECK(kz < 2 && kd < 2);
+        CHECK(c2.label_val_ids[kz * 3 + 1] != 0 && c2.label_val_ids[kz * 3 + 0] != 0 && c2.label_val_ids[kz * 3 + 2] == 0);
+        CHECK(c2.label_val_ids[kd * 3 + 1] != 0);  // "" is a value, not "absent" (D-S9)
+        CHECK(pc.sel_val_ids[kz * 4 + 0] == c2.label_val_ids[kz * 3 + 1]);
+        CHECK(pc.sel_val_ids[kd * 4 + 1] == c2.label_val_ids[kd * 3 + 1]);
+        CHECK(pc.sel_val_ids[kz * 4 + 2] == KSCHED_SEL_NEVER);
+        CHECK(pc.sel_val_ids[kz * 4 + 3] == 0 && pc.sel_val_ids[kd * 4 + 3] == 0);
+        CHECK(pc.tolerations[3] == 1ull && pc.tolerations[0] == 0ull);
+        // allocatable present but lacking memory: the reference panics (src/predicates.rs:29-31)
+        std::vector<corev1::Node> badn = {node_with("x", "1", nullptr)};
+        Snapshot s2(Snapshot::kEncodeOnly);
+        CHECK_THROWS(s2.rebuild(badn, nullptr));
+        CHECK_THROWS(snap.device());  // encode-only snapshots cannot evaluate
+    });
+    run("toleration_matches (extension E2)", [] {
+        TaintId t{"k", "v", "NoSchedule"};
+        corev1::Toleration a;
+        a.key = std::string("k");
+        a.value = std::string("v");
+        CHECK(toleration_matches(a, t));  // default operator Equal
+        a.value = std::string("w");
+        CHECK(!toleration_matches(a, t));
+        a.operator_ = std::string("Exists");
+        CHECK(toleration_matches(a, t));
+        a.effect = std::string("NoExecute");
+        CHECK(!toleration_matches(a, t));
+        corev1::Toleration all;
+        all.operator_ = std::string("Exists");
+        CHECK(toleration_matches(all, t));
+    });
+    run("choosers: scripted and SplitMix draws", [] {
+        ScriptedChooser s;
+        s.script = {3, 3, 7, 1, 0};
+        CHECK(*s.choose(10) == 3 && *s.choose(10) == 3 && *s.choose(10) == 7 && *s.choose(10) == 1 && *s.choose(10) == 0);
+        CHECK(!s.choose(10).has_value());
+        CHECK(!s.choose(0).has_value());
+        SplitMixChooser a(42), b(42);
+        for (int i = 0; i < 100; ++i) {
+            auto x = a.choose(17), y = b.choose(17);
+            CHECK(x && y && *x == *y && *x < 17);
+        }
+        CHECK(!a.choose(0).has_value());
+    });
+}
+
+// =========================================== GPU-side tests ================================================
+static void gpu_tests() {
+    using predicates::can_pod_fit;
+    using predicates::check_node_validity;
+    using predicates::does_node_selector_match;
+
+    // --- the reference's three tests, src/predicates/test.rs:42-58 ---
+    run("test_does_node_selector_match_no_selector (KAT-S1)", [] { CHECK(does_node_selector_match(test_pod(), test_node()) == true); });
+    run("test_does_node_selector_match_false (KAT-S2)", [] { CHECK(does_node_selector_match(test_pod("foo", "bar"), test_node()) == false); });
+    run("test_does_node_selector_match_true (KAT-S3)", [] { CHECK(does_node_selector_match(test_pod("name", NODE_NAME), test_node()) == true); });
+
+    run("does_node_selector_match: D-S4..D-S9", [] {
+        corev1::Pod empty_sel = test_pod();
+        empty_sel.spec = corev1::PodSpec{};
+        empty_sel.spec->node_selector = corev1::StringMap{};
+        CHECK(does_node_selector_match(empty_sel, test_node()));  // D-S4
+        corev1::Node nolabels;
+        nolabels.metadata.name = "bare";
+        CHECK(!does_node_selector_match(test_pod("a", "b"), nolabels));  // D-S5
+        CHECK(does_node_selector_match(test_pod(), nolabels));           // D-S6
+        CHECK(!does_node_selector_match(test_pod("name", "other"), test_node()));  // D-S7
+        corev1::Pod two = test_pod("a", "1");
+        (*two.spec->node_selector)["b"] = "2";
+        corev1::Node n3 = test_node();
+        n3.metadata.labels = corev1::StringMap{{"a", "1"}, {"b", "2"}, {"c", "3"}};
+        CHECK(does_node_selector_match(two, n3));  // D-S8
+        n3.metadata.labels = corev1::StringMap{{"a", "1"}, {"b", "9"}};
+        CHECK(!does_node_selector_match(two, n3));
+        corev1::Node ne = test_node();
+        ne.metadata.labels = corev1::StringMap{{"a", ""}};
+        CHECK(does_node_selector_match(test_pod("a", ""), ne));  // D-S9
+        CHECK(!does_node_selector_match(test_pod("a", ""), test_node()));
+    });
+
+    run("can_pod_fit: D-R1..D-R8", [] {
+        const char *GiB = "1073741824";
+        {  // D-R1
+            Context ctx = make_ctx({node_with("n", "1", GiB)});
+            CHECK(can_pod_fit(pod_with("p", {container("500m", "134217728")}), ctx.node_store[0], ctx));
+            CHECK(std::static_pointer_cast<StaticPodLister>(ctx.client)->list_calls == 1);  // one LIST per evaluation
+        }
+        {  // D-R2 exact fit, D-R3 one byte over
+            Context ctx = make_ctx({node_with("n", "2", GiB)});
+            CHECK(can_pod_fit(pod_with("p", {container("2", GiB)}), ctx.node_store[0], ctx));
+            CHECK(!can_pod_fit(pod_with("p", {container("1", "1073741825")}), ctx.node_store[0], ctx));
+            CHECK(!can_pod_fit(pod_with("p", {container("2001m", "1")}), ctx.node_store[0], ctx));
+        }
+        {  // D-R4 over-committed node, zero-request pod: 0 <= -x is false
+            Context ctx = make_ctx({node_with("n", "1", GiB)}, {pod_with("hog", {container("1500m", "1")}, "n")});
+            CHECK(!can_pod_fit(pod_with("p", {}), ctx.node_store[0], ctx));
+        }
+        {  // D-R5 no status: only a zero-request pod fits
+            Context ctx = make_ctx({node_with("n", nullptr, nullptr)});
+            CHECK(can_pod_fit(pod_with("p", {}), ctx.node_store[0], ctx));
+            CHECK(!can_pod_fit(pod_with("p", {container("1m", nullptr)}), ctx.node_store[0], ctx));
+        }
+        {  // D-R6 two containers + one without resources; D-R7 init container ignored
+            Context ctx = make_ctx({node_with("n", "500m", GiB)});
+            corev1::Pod p = pod_with("p", {container("250m", nullptr), container("250m", nullptr)});
+            corev1::Container bare;
+            bare.name = "bare";
+            p.spec->containers.push_back(bare);
+            p.spec->init_containers.push_back(container("64", "1Ti"));
+            CHECK(can_pod_fit(p, ctx.node_store[0], ctx));
+            p.spec->containers.push_back(container("1m", nullptr));
+            CHECK(!can_pod_fit(p, ctx.node_store[0], ctx));
+        }
+        {  // D-R8 a Succeeded pod bound to the node still counts
+            corev1::Pod done = pod_with("done", {container("600m", "1")}, "n");
+            done.status = corev1::PodStatus{std::string("Succeeded")};
+            Context ctx = make_ctx({node_with("n", "1", GiB)}, {done});
+            CHECK(!can_pod_fit(pod_with("p", {container("500m", "1")}), ctx.node_store[0], ctx));
+            CHECK(can_pod_fit(pod_with("p", {container("400m", "1")}), ctx.node_store[0], ctx));
+        }
+        {  // allocatable lacks memory: the reference panics; here an exception, never a bit
+            Context ctx = make_ctx({node_with("n", "1", nullptr)});
+            CHECK_THROWS(can_pod_fit(pod_with("p", {}), ctx.node_store[0], ctx));
+        }
+    });
+
+    run("check_node_validity: order of reasons (D-V1, D-V2; src/predicates.rs:68-74)", [] {
+        corev1::Node n = node_with("n", "1", "1073741824");
+        n.metadata.labels = corev1::StringMap{{"zone", "a"}};
+        Context ctx = make_ctx({n});
+        corev1::Pod big_wrong = pod_with("p", {container("2", "1")});
+        big_wrong.spec->node_selector = corev1::StringMap{{"zone", "b"}};
+        auto v1 = check_node_validity(big_wrong, n, ctx);
+        CHECK(v1 && *v1 == InvalidNodeReason::NotEnoughResources);  // both fail: resources win
+        corev1::Pod small_wrong = pod_with("p", {container("100m", "1")});
+        small_wrong.spec->node_selector = corev1::StringMap{{"zone", "b"}};
+        auto v2 = check_node_validity(small_wrong, n, ctx);
+        CHECK(v2 && *v2 == InvalidNodeReason::NodeSelectorMismatch);
+        corev1::Pod ok = pod_with("p", {container("100m", "1")});
+        ok.spec->node_selector = corev1::StringMap{{"zone", "a"}};
+        CHECK(!check_node_validity(ok, n, ctx).has_value());
+    });
+
+    run("select_node_for_pod: D-P1..D-P3 (src/main.rs:51-71)", [] {
+        std::vector<corev1::Node> nodes;
+        for (int i = 0; i < 10; ++i) nodes.push_back(node_with("node-" + std::to_string(i), i == 7 ? "4" : "100m", "1073741824"));
+        Context ctx = make_ctx(nodes);
+        corev1::Pod pod = pod_with("p", {container("1", "1")});
+        ScriptedChooser s;
+        s.script = {3, 3, 7, 1, 0};
+        std::vector<RejectedCandidate> rej;
+        auto got = select_node_for_pod(pod, ctx, s, &rej);
+        CHECK(got && corev1::name_any(got->metadata) == "node-7");  // D-P1: third attempt
+        CHECK(rej.size() == 2 && rej[0].node_name == "node-3" && rej[0].reason == InvalidNodeReason::NotEnoughResources);
+        CHECK(s.next == 3);  // the reference stops drawing after the first success
+        ScriptedChooser miss;
+        miss.script = {0, 1, 2, 3, 4};
+        CHECK(!select_node_for_pod(pod, ctx, miss).has_value());  // D-P3: a feasible node exists, the draws miss it
+        Context empty = make_ctx({});
+        ScriptedChooser any;
+        any.script = {1, 2, 3};
+        CHECK(!select_node_for_pod(pod, empty, any).has_value());  // D-P2: empty store
+    });
+
+    run("select_nodes_for_pods (batched) == select_node_for_pod draw for draw", [] {
+        // 100 pods x 20 nodes (BASELINE.json configs[0] shape), labels + bound load
+        std::vector<corev1::Node> nodes;
+        std::vector<corev1::Pod> bound;
+        for (int i = 0; i < 20; ++i) {
+            corev1::Node n = node_with("node-" + std::to_string(100 + (i * 7) % 20), (i % 3) ? "4" : "2", "8589934592");
+            n.metadata.labels = corev1::StringMap{{"zone", (i % 2) ? "a" : "b"}, {"tier", std::to_string(i % 4)}};
+            if (i % 5 == 0) n.metadata.labels.reset();
+            nodes.push_back(n);
+            bound.push_back(pod_with("load-" + std::to_string(i), {container((i % 4) ? "1500m" : "3900m", "1073741824")},
+                                     corev1::name_any(n.metadata).c_str()));
+        }
+        std::vector<corev1::Pod> pods;
+        for (int i = 0; i < 100; ++i) {
+            corev1::Pod p = pod_with("pod-" + std::to_string(i), {container((i % 3) ? "500m" : "2500m", "2147483648")});
+            if (i % 4 == 1) p.spec->node_selector = corev1::StringMap{{"zone", "a"}};
+            if (i % 4 == 2) p.spec->node_selector = corev1::StringMap{{"zone", "b"}, {"tier", "2"}};
+            if (i % 10 == 3) p.spec->node_selector = corev1::StringMap{{"gpu", "yes"}};
+            pods.push_back(p);
+        }
+        Context ctx = make_ctx(nodes, bound);
+        std::vector<const corev1::Pod *> ptrs;
+        for (auto &p : pods) ptrs.push_back(&p);
+        SplitMixChooser c1(7);
+        BatchSelection sel = select_nodes_for_pods(ptrs, ctx, c1, /*want_rejected=*/true);
+        CHECK(sel.node_store_index.size() == 100);
+        // per-pod reference loop with the same draw stream: consume ATTEMPTS draws per pod
+        SplitMixChooser c2(7);
+        int bound_n = 0;
+        for (int i = 0; i < 100; ++i) {
+            ScriptedChooser five;
+            for (uint32_t t = 0; t < ATTEMPTS; ++t) five.script.push_back(*c2.choose(nodes.size()));
+            std::vector<RejectedCandidate> rej;
+            auto one = select_node_for_pod(pods[i], ctx, five, &rej);
+            const int32_t idx = sel.node_store_index[i];
+            CHECK(one.has_value() == (idx >= 0));
+            if (one && idx >= 0) CHECK(corev1::name_any(one->metadata) == corev1::name_any(nodes[idx].metadata));
+            CHECK(rej.size() == sel.rejected[i].size());
+            for (size_t k = 0; k < rej.size() && k < sel.rejected[i].size(); ++k)
+                CHECK(rej[k].node_name == sel.rejected[i][k].node_name && rej[k].reason == sel.rejected[i][k].reason);
+            bound_n += idx >= 0;
+        }
+        CHECK(bound_n > 10 && bound_n < 100);
+        // every (pod, node) bit of the batch equals the per-pair check_node_validity
+        for (int i = 0; i < 100; i += 9)
+            for (int j = 0; j < 20; ++j) {
+                auto v = check_node_validity(pods[i], nodes[j], ctx);
+                auto b = sel.validity.validity(i, ctx.snapshot->canonical_index(j));
+                CHECK(v.has_value() == b.has_value());
+                if (v && b) CHECK(*v == *b);
+            }
+    });
+
+    run("reconcile / reconcile_batch (src/main.rs:73-125)", [] {
+        std::vector<corev1::Node> nodes = {node_with("node-a", "4", "8589934592"), node_with("node-b", "100m", "1")};
+        Context ctx = make_ctx(nodes);
+        RecordingSink sink;
+        corev1::Pod fits = pod_with("fits", {container("1", "1")});
+        corev1::Pod never = pod_with("never", {container("64", "1")});
+        corev1::Pod already = pod_with("already", {container("1", "1")}, "node-a");
+        ScriptedChooser c;
+        c.script = {1, 0};
+        ReconcileOutcome r = reconcile(fits, ctx, c, sink);
+        CHECK(r.ok && r.action == Action::AwaitChange && r.bound_to && *r.bound_to == "node-a");
+        CHECK(sink.posts.size() == 1 && sink.posts[0].first == "test/fits" && sink.posts[0].second == "node-a");
+        ScriptedChooser c2;
+        c2.script = {0, 1, 0, 1, 0};
+        r = reconcile(never, ctx, c2, sink);
+        CHECK(!r.ok && r.error == ReconcileError::NoNodeFound && r.action == Action::RequeueAfter5Min);
+        ScriptedChooser c3;
+        r = reconcile(already, ctx, c3, sink);
+        CHECK(r.ok && !r.bound_to && c3.next == 0);  // bound pods are skipped before any draw
+        sink.fail = true;
+        ScriptedChooser c4;
+        c4.script = {0};
+        r = reconcile(fits, ctx, c4, sink);
+        CHECK(!r.ok && r.error == ReconcileError::CreateBindingFailed);
+        sink.fail = false;
+        sink.posts.clear();
+        SplitMixChooser c5(99);
+        std::vector<const corev1::Pod *> batch = {&fits, &never, &already, &fits};
+        std::vector<ReconcileOutcome> out = reconcile_batch(batch, ctx, c5, sink);
+        CHECK(out.size() == 4);
+        CHECK(!out[1].ok && out[1].error == ReconcileError::NoNodeFound);
+        CHECK(out[2].ok && !out[2].bound_to);
+        for (int i : {0, 3}) CHECK(out[i].ok ? (out[i].bound_to && *out[i].bound_to == "node-a") : out[i].error == ReconcileError::NoNodeFound);
+    });
+}
+
+int main(int argc, char **argv) {
+    const std::string mode = argc > 1 ? argv[1] : "cpu";
+    if (mode == "cpu") cpu_tests();
+    else if (mode == "gpu") gpu_tests();
+    else {
+        std::printf("usage: host_tests cpu|gpu\n");
+        return 2;
+    }
+    std::printf("%d test(s), %d failed check(s)\n", g_run, g_fail);
+    return g_fail ? 1 : 0;
+}

@@ -1,0 +1,38 @@
+"""The C++ host mirror of the reference's predicates / util / main modules (kube_scheduler_rs_reference_amd/host).
+Its tests are C++ (tests/cpp/host_tests.cpp) so that they read like the reference's own src/predicates/test.rs;
+this file builds and runs them: the wire-format half here on the CPU, the predicate half on the GPU."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "host_tests")
+
+
+def _build():
+    if os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.check_call(["make", "-C", ROOT, "-s", "host"])
+    assert os.path.exists(BIN), "tests/cpp/host_tests has not been built (make host)"
+
+
+def _run(mode):
+    _build()
+    r = subprocess.run([BIN, mode], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failed check(s)" in r.stdout
+    return r.stdout
+
+
+def test_host_mirror_cpu():
+    out = _run("cpu")
+    assert out.count("ok  ") >= 8
+
+
+@pytest.mark.gpu
+def test_host_mirror_gpu():
+    """KAT-S1..S3 of src/predicates/test.rs and the derived vectors, evaluated on the device through the C ABI."""
+    out = _run("gpu")
+    assert "test_does_node_selector_match_true (KAT-S3)" in out
+    assert out.count("ok  ") >= 9
