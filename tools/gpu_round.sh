@@ -1,0 +1,72 @@
+#!/bin/bash
+# One GPU-box session that produces the round's evidence set.  usage: bash tools/gpu_round.sh <tag> [steps...]
+#   steps (default: all): test bench prof pmc lines trace smoke
+# Everything lands under gpurun_out/<tag>/ ; tools/collect_profiles.py copies the summaries into profiles/.
+TAG=${1:-r}; shift
+STEPS=${@:-"test bench prof pmc lines trace smoke"}
+REPO=$PWD; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+has() { [[ " $STEPS " == *" $1 "* ]]; }
+stamp() { echo "[$(date +%H:%M:%S)] $*"; }
+
+if has test; then
+  stamp "pytest -m gpu"
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  tail -4 $OUT/pytest_gpu.log
+fi
+if has smoke; then
+  stamp "smoke"
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
+fi
+if has bench; then
+  stamp "bench (default command)"
+  timeout 600 python bench.py > $OUT/bench_default.log 2>&1; tail -1 $OUT/bench_default.log > $OUT/bench_default.json
+  python - <<PY
+import json
+d=json.load(open("$OUT/bench_default.json")); r=d["roofline"]; c=d["cpu_baseline"]
+print("default: %.3e evals/s step %.1f us kernel %.1f us %.0f GB/s frac %.3f | cpu %.3e (%d cores) single %.3e encoded %.3e" % (d["value"], d["ms_per_step"]*1e3, r["avg_kernel_us"], r["achieved"], r["frac"], c["value"], c["cores"], c["single_core_value"], c["encoded_loop_value"]))
+PY
+fi
+if has prof; then
+  stamp "rocprofv3 --kernel-trace --stats -- python bench.py"
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -o r -- python $REPO/bench.py > $OUT/prof_default.log 2>&1
+  cd $REPO
+  grep "^{\"metric" $OUT/prof_default.log > $OUT/prof_default_bench.json
+  f=$(find $OUT/prof_default -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/prof_default_kernel_stats.csv && head -6 $f
+fi
+if has pmc; then
+  stamp "PMC passes (separate runs: FETCH_SIZE, WRITE_SIZE; calibration + bench)"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $REPO/tools/pmc_calib $REPO/tools/pmc_calib.hip 2>&1 | tail -2
+  cd /tmp
+  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -o p -- $REPO/tools/pmc_calib > $OUT/calib_fetch.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -o p -- $REPO/tools/pmc_calib > $OUT/calib_write.log 2>&1
+  for wl in ${PMC_WLS:-C3 C4s}; do
+    timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${wl}_fetch -o p -- python $REPO/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${wl}_fetch.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${wl}_write -o p -- python $REPO/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${wl}_write.log 2>&1
+  done
+  # a third pass: SQ activity of the mask kernel (VALU / LDS / wait split) on the default workload
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/C3_sq -o p -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/C3_sq.log 2>&1
+  cd $REPO
+  python tools/pmc_traffic.py $OUT ${PMC_WLS:-C3 C4s} > $OUT/pmc_traffic.log 2>&1; tail -30 $OUT/pmc_traffic.log
+  # drop the bulky raw traces, keep the counter csvs
+  find $OUT -name "*kernel_trace.csv" -size +2M -delete
+fi
+if has lines; then
+  stamp "bench lines of the other workloads"
+  for wl in ${LINE_WLS:-C2 C4s C5s}; do
+    timeout 600 python bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_${wl}.json
+    python - <<PY
+import json
+try:
+    d=json.load(open("$OUT/bench_${wl}.json")); r=d["roofline"]
+    print("$wl: %.3e evals/s  step %.1f us  kernel %.1f us  %.0f GB/s  frac %.3f" % (d["value"], d["ms_per_step"]*1e3, r["avg_kernel_us"], r["achieved"], r["frac"]))
+except Exception as e:
+    print("$wl: FAILED", e)
+PY
+  done
+fi
+if has trace; then
+  stamp "fused kernel phase trace (C3)"
+  timeout 300 python tools/trace_fused.py --workload C3 > $OUT/trace_C3.txt 2>&1; head -20 $OUT/trace_C3.txt
+fi
+stamp "done"
