@@ -8,7 +8,7 @@
 // area.  After the staging barrier the 16 waves of a block are independent; each walks its own
 // pods in rounds of up to 64 through two phases:
 //   phase 1 (lane = pod): load the pod's requests / selector ids / tolerations (coalesced), run the
-//       two branch-free binary searches on the sorted arrays in LDS (the rank lookups), turn selector
+//       two branch-free descents of the breadth-first (Eytzinger) search trees in LDS (the rank lookups), turn selector
 //       ids into bitmap row offsets (src/predicates.rs:45-61), park a 16-byte record in the wave's
 //       LDS area.
 //   phase 2 (8 lanes per pod, 16 bytes = 2 mask words per lane): read the record (LDS broadcast),
@@ -268,16 +268,23 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         uint4 rec;
         rec.x = rec.y = 0;
         if (FIT) {
-            uint32_t lc = 0, lm = 0;  // r = #sorted values < req, two interleaved searches
+            // r = #sorted values < req: two interleaved descents of the tile's implicit search trees.  The sorted
+            // arrays are stored in breadth-first (Eytzinger) order (tile_index.hpp): the candidates of one level are
+            // contiguous, so the 64 lanes of a step hit distinct LDS banks (levels 0..5: conflict-free; deeper levels:
+            // random 2-3-way) instead of the 16-32-way conflicts of power-of-two strides in a plain sorted array.
+            uint32_t lc = 0, lm = 0;
             if (!(a.debug & 2u)) {
+                uint32_t kc = 1, km = 1;
 #pragma unroll
-                for (uint32_t step = kTileNodes / 2; step >= 1; step >>= 1) {
-                    const int64_t vc = s_cpu[lc + step - 1], vm = s_mem[lm + step - 1];
-                    lc += (vc < rc) ? step : 0u;
-                    lm += (vm < rm) ? step : 0u;
+                for (uint32_t level = 0; level < 10; ++level) {
+                    const int64_t vc = s_cpu[kc], vm = s_mem[km];
+                    kc = 2u * kc + ((vc < rc) ? 1u : 0u);  // right child when the node's value is below the request
+                    km = 2u * km + ((vm < rm) ? 1u : 0u);
                 }
-                lc += (s_cpu[lc] < rc) ? 1u : 0u;  // 1023 -> 1024
-                lm += (s_mem[lm] < rm) ? 1u : 0u;
+                lc = kc - (uint32_t)kTileNodes;  // the gap reached = #values < req among sorted[0..1022]
+                lm = km - (uint32_t)kTileNodes;
+                lc += (lc == (uint32_t)kTileNodes - 1u && s_cpu[0] < rc) ? 1u : 0u;  // slot 0 holds sorted[1023]: 1023 -> 1024
+                lm += (lm == (uint32_t)kTileNodes - 1u && s_mem[0] < rm) ? 1u : 0u;
             }
             rec.x = ((a.row_cpu_hi + (lc >> 5)) * RS) | (((a.row_cpu_lo + (lc & 31u)) * RS) << 16);
             rec.y = ((a.row_mem_hi + (lm >> 5)) * RS) | (((a.row_mem_lo + (lm & 31u)) * RS) << 16);

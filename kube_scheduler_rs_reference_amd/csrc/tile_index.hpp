@@ -9,7 +9,8 @@
 // Per tile of kTileNodes = 1024 nodes = 16 mask words:
 //   * fit   -- src/predicates.rs:42  req <= avail.  Sort the tile's avail values; node n gets its
 //              position pos[n] in that order (ties broken by node index, so pos is a
-//              permutation).  For a pod, r = #values < req (lower bound, binary search in LDS);
+//              permutation).  For a pod, r = #values < req (lower bound; descent of the tile's
+//              breadth-first search tree in LDS);
 //              then  req <= avail[n]  <=>  pos[n] >= r, exactly, for any int64 inputs.
 //              pos >= r is evaluated two-level, pos = 32*hi + lo, r = 32*rh + rl:
 //                  pos >= r  <=>  hi > rh  ||  (hi == rh && lo >= rl)
@@ -56,7 +57,7 @@ struct IndexedLayout {
 struct IndexedSnapshot {
     bool built = false;
     IndexedLayout lay{};
-    int64_t *d_sorted_cpu = nullptr;  // [tiles][1024], padded with INT64_MAX
+    int64_t *d_sorted_cpu = nullptr;  // [tiles][1024] search trees (eytzinger_from_sorted), padded with INT64_MAX
     int64_t *d_sorted_mem = nullptr;
     uint64_t *d_tables = nullptr;     // [tiles][rows][16]
     uint32_t *d_lab_meta = nullptr;   // lab_base[32], lab_max[32], then 8 zero words
@@ -72,6 +73,16 @@ inline void indexed_release(IndexedSnapshot &s) {
 }
 
 inline uint32_t indexed_lds_bytes(const IndexedLayout &l) { return l.rows * 128u; }
+
+// Breadth-first (Eytzinger) image of a sorted array of kTileNodes values: slot k in [1, 1024) is node k of
+// the perfect binary search tree over sorted[0..1022] (node k at level L = floor(log2 k), j = k - 2^L, holds
+// sorted[(2j + 1) * 2^(9 - L) - 1]); slot 0 holds sorted[1023].  The kernel descends from k = 1 with
+// k = 2k + (tree[k] < req); after 10 levels k - 1024 is the number of values among sorted[0..1022] below req.
+inline void eytzinger_from_sorted(const int64_t *sorted, int64_t *tree) {
+    tree[0] = sorted[kTileNodes - 1];
+    for (uint32_t level = 0; level < 10; ++level)
+        for (uint32_t j = 0; j < (1u << level); ++j) tree[(1u << level) + j] = sorted[((2u * j + 1u) << (9u - level)) - 1u];
+}
 // Build the per-tile index on the host and upload it.  Leaves s.built == false (and returns
 // hipSuccess) when the snapshot is outside what the indexed kernel supports; the caller then
 // uses the direct kernel.
@@ -117,6 +128,7 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
     std::vector<uint64_t> tab((size_t)l.tiles * tile_words, 0ull);
     std::vector<int64_t> scpu((size_t)l.tiles * kTileNodes, INT64_MAX), smem((size_t)l.tiles * kTileNodes, INT64_MAX);
     std::vector<uint32_t> ord(kTileNodes);
+    std::vector<int64_t> sorted_tmp(kTileNodes);
     for (uint32_t t = 0; t < l.tiles; ++t) {
         const uint32_t base = t * kTileNodes;
         const uint32_t m = std::min<uint32_t>(kTileNodes, n - base);
@@ -126,7 +138,9 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
         // fit: positions in the sorted order of each resource
         for (int res = 0; res < 2; ++res) {
             const int64_t *v = res == 0 ? cpu : mem;
-            int64_t *sorted = (res == 0 ? scpu.data() : smem.data()) + (size_t)t * kTileNodes;
+            int64_t *tree = (res == 0 ? scpu.data() : smem.data()) + (size_t)t * kTileNodes;
+            int64_t *sorted = sorted_tmp.data();
+            std::fill(sorted, sorted + kTileNodes, INT64_MAX);
             const uint32_t row_hi = res == 0 ? l.row_cpu_hi : l.row_mem_hi;
             const uint32_t row_lo = res == 0 ? l.row_cpu_lo : l.row_mem_lo;
             std::iota(ord.begin(), ord.begin() + m, 0u);
@@ -138,6 +152,7 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
                 for (uint32_t h = 0; h <= hi; ++h) setbit(row_hi + h, local);  // GEH[h] = {hi >= h}
                 for (uint32_t q = 0; q <= lo; ++q) setbit(row_lo + q, local);  // GEL[q] = {lo >= q}
             }
+            eytzinger_from_sorted(sorted, tree);
         }
         // labels
         for (uint32_t k = 0; k < nkeys; ++k)

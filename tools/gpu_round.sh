@@ -65,6 +65,20 @@ except Exception as e:
 PY
   done
 fi
+if has ab; then
+  stamp "A/B: bench with kernel debug bits ${AB_BITS:-64} (results of a debug run are not valid outputs; timing only)"
+  for wl in ${AB_WLS:-C3 C4s}; do for bits in ${AB_BITS:-64}; do
+    timeout 600 python bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline --debug $bits 2>&1 | tail -1 > $OUT/ab_${wl}_${bits}.json
+    python - <<PY
+import json
+try:
+    d=json.load(open("$OUT/ab_${wl}_${bits}.json")); r=d["roofline"]
+    print("$wl debug=$bits: step %.1f us  kernel %.1f us  frac %.3f" % (d["ms_per_step"]*1e3, r["avg_kernel_us"], r["frac"]))
+except Exception as e:
+    print("$wl debug=$bits: FAILED", e)
+PY
+  done; done
+fi
 if has trace; then
   stamp "fused kernel phase trace (C3)"
   timeout 300 python tools/trace_fused.py --workload C3 > $OUT/trace_C3.txt 2>&1; head -20 $OUT/trace_C3.txt
