@@ -9,7 +9,7 @@
  *   reference                                            replaced by
  *   ---------------------------------------------------  ------------------------------------------
  *   node_store snapshot + per-evaluation LIST            ksched_set_nodes   (columns of `available`)
- *     src/main.rs:56, src/predicates.rs:21-38
+ *     src/main.rs:56, src/predicates.rs:21-38            ksched_update_nodes (sparse rows, from watch events)
  *   can_pod_fit            src/predicates.rs:20-43       KSCHED_FIT   bit of ksched_eval*
  *   does_node_selector_match  src/predicates.rs:45-61    KSCHED_SEL   bit of ksched_eval*
  *   check_node_validity    src/predicates.rs:63-77       feasible = fit AND sel (+ fit mask for the reason)
@@ -117,6 +117,16 @@ int ksched_set_option(ksched_ctx *ctx, int option, int64_t value);
  */
 int ksched_set_nodes(ksched_ctx *ctx, uint32_t n, const int64_t *avail_cpu_milli, const int64_t *avail_mem_bytes,
                      const uint32_t *label_val_ids, uint32_t n_keys, const uint64_t *taints);
+
+/* Incremental form of the same step: `available` of `count` nodes changed -- a pod was
+ * bound to or removed from them (src/predicates.rs:36-38 subtracts every pod the LIST returns; here the caller
+ * keeps that sum current from watch events instead of re-LISTing).  node_index[i] is a canonical node index
+ * (< ksched_num_nodes); the two value arrays hold the node's NEW available cpu / memory.  Labels and taints are
+ * not touched (use ksched_set_nodes when the node set or its labels change).  Only the affected 1024-node tiles
+ * of the library's indexes are rebuilt.  Waits for evaluations already enqueued on this ctx's device.
+ */
+int ksched_update_nodes(ksched_ctx *ctx, uint32_t count, const uint32_t *node_index, const int64_t *avail_cpu_milli,
+                        const int64_t *avail_mem_bytes);
 
 /* number of nodes / keys of the current snapshot (0 before ksched_set_nodes) */
 uint32_t ksched_num_nodes(const ksched_ctx *ctx);

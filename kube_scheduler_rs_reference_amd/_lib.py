@@ -60,6 +60,7 @@ SYMBOLS = {
     "ksched_mask_words": (_u32, [_u32]),
     "ksched_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
     "ksched_set_nodes": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _u32, _vp]),
+    "ksched_update_nodes": (C.c_int, [_vp, _u32, _vp, _vp, _vp]),
     "ksched_num_nodes": (_u32, [_vp]),
     "ksched_num_keys": (_u32, [_vp]),
     "ksched_eval": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),

@@ -61,7 +61,8 @@ struct ksched_ctx {
     DevBuf<uint64_t> ntaint;
     DevBuf<uint32_t> bf_order, bf_rank;
     DevBuf<int64_t> bf_mem;
-    IndexedSnapshot idx;  // per-tile bitmap index (kernels_indexed.hpp)
+    IndexedSnapshot idx;  // per-tile bitmap index (tile_index.hpp)
+    std::vector<int64_t> h_cpu, h_mem;  // host image of `available` (ksched_update_nodes patches single rows)
 
     // scratch for the host-pointer path
     DevBuf<int64_t> pcpu, pmem;
@@ -123,6 +124,28 @@ int timing_slot(ksched_ctx *c, size_t *slot) {
         c->ev_pool.push_back(ep);
     }
     *slot = c->ev_used++;
+    return KSCHED_OK;
+}
+
+// best-fit candidate order of the snapshot: ascending (avail_mem, avail_cpu, node)
+int upload_bestfit_order(ksched_ctx *c) {
+    const uint32_t n = c->n;
+    const int64_t *cpu = c->h_cpu.data(), *mem = c->h_mem.data();
+    std::vector<uint32_t> order(n), rank(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        if (mem[x] != mem[y]) return mem[x] < mem[y];
+        if (cpu[x] != cpu[y]) return cpu[x] < cpu[y];
+        return x < y;
+    });
+    std::vector<int64_t> bfmem(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        rank[order[i]] = i;
+        bfmem[i] = mem[order[i]];
+    }
+    HIPCHK(c, hipMemcpy(c->bf_mem.ptr, bfmem.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->bf_order.ptr, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->bf_rank.ptr, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     return KSCHED_OK;
 }
 
@@ -409,31 +432,68 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     HIPCHK(c, c->bf_order.reserve(n));
     HIPCHK(c, c->bf_rank.reserve(n));
     HIPCHK(c, c->bf_mem.reserve(n));
+    int rc_bf = KSCHED_OK;
     if (n > 0) {
         HIPCHK(c, hipMemcpy(c->ncpu.ptr, cpu, (size_t)n * 8, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->nmem.ptr, mem, (size_t)n * 8, hipMemcpyHostToDevice));
         if (n_keys) HIPCHK(c, hipMemcpy(c->nlab.ptr, lab, (size_t)n * n_keys * 4, hipMemcpyHostToDevice));
         if (taints) HIPCHK(c, hipMemcpy(c->ntaint.ptr, taints, (size_t)n * 8, hipMemcpyHostToDevice));
-        // best-fit candidate order of the snapshot: ascending (avail_mem, avail_cpu, node)
-        std::vector<uint32_t> order(n), rank(n);
-        std::iota(order.begin(), order.end(), 0u);
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            if (mem[x] != mem[y]) return mem[x] < mem[y];
-            if (cpu[x] != cpu[y]) return cpu[x] < cpu[y];
-            return x < y;
-        });
-        std::vector<int64_t> bfmem(n);
-        for (uint32_t i = 0; i < n; ++i) {
-            rank[order[i]] = i;
-            bfmem[i] = mem[order[i]];
-        }
-        HIPCHK(c, hipMemcpy(c->bf_mem.ptr, bfmem.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->bf_order.ptr, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->bf_rank.ptr, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        c->h_cpu.assign(cpu, cpu + n);
+        c->h_mem.assign(mem, mem + n);
+        rc_bf = upload_bestfit_order(c);
+    } else {
+        c->h_cpu.clear();
+        c->h_mem.clear();
     }
+    if (rc_bf) return rc_bf;
     hipError_t e = indexed_build(c->idx, n, cpu, mem, lab, n_keys, taints);
     if (e != hipSuccess) return fail_hip(c, e, "indexed_build");
     c->have_nodes = true;
+    return KSCHED_OK;
+}
+
+int ksched_update_nodes(ksched_ctx *c, uint32_t count, const uint32_t *node_index, const int64_t *cpu, const int64_t *mem) {
+    if (!c) return KSCHED_E_INVAL;
+    if (count > 0 && (!node_index || !cpu || !mem)) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_nodes) return KSCHED_E_STATE;
+    for (uint32_t i = 0; i < count; ++i)
+        if (node_index[i] >= c->n) return KSCHED_E_INVAL;
+    if (count == 0) return KSCHED_OK;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    // evaluations already enqueued read the snapshot as it was
+    HIPCHK(c, hipDeviceSynchronize());
+    std::vector<uint32_t> tiles;
+    for (uint32_t i = 0; i < count; ++i) {  // a node listed twice takes its last values
+        const uint32_t n = node_index[i];
+        c->h_cpu[n] = cpu[i];
+        c->h_mem[n] = mem[i];
+        tiles.push_back(n / kTileNodes);
+    }
+    std::sort(tiles.begin(), tiles.end());
+    tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
+    // device columns (direct kernel, best-fit pick): sparse rows one by one, else the tile ranges that changed
+    if (count <= 32) {
+        for (uint32_t i = 0; i < count; ++i) {
+            const uint32_t n = node_index[i];
+            HIPCHK(c, hipMemcpy(c->ncpu.ptr + n, &c->h_cpu[n], 8, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(c->nmem.ptr + n, &c->h_mem[n], 8, hipMemcpyHostToDevice));
+        }
+    } else {
+        for (uint32_t t : tiles) {
+            const size_t lo = (size_t)t * kTileNodes, len = std::min<size_t>(kTileNodes, c->n - lo);
+            HIPCHK(c, hipMemcpy(c->ncpu.ptr + lo, c->h_cpu.data() + lo, len * 8, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(c->nmem.ptr + lo, c->h_mem.data() + lo, len * 8, hipMemcpyHostToDevice));
+        }
+    }
+    int rc = upload_bestfit_order(c);
+    if (rc) return rc;
+    if (c->idx.built)
+        for (uint32_t t : tiles) {
+            hipError_t e = indexed_update_tile(c->idx, t, c->h_cpu.data(), c->h_mem.data());
+            if (e != hipSuccess) return fail_hip(c, e, "indexed_update_tile");
+        }
     return KSCHED_OK;
 }
 

@@ -62,6 +62,9 @@ struct IndexedSnapshot {
     uint64_t *d_tables = nullptr;     // [tiles][rows][16]
     uint32_t *d_lab_meta = nullptr;   // lab_base[32], lab_max[32], then 8 zero words
     size_t sorted_cap = 0, tables_cap = 0;
+    // host images of the three device arrays, kept so that ksched_update_nodes can rebuild the fit part of single tiles
+    std::vector<uint64_t> h_tables;
+    std::vector<int64_t> h_sorted_cpu, h_sorted_mem;
 };
 
 inline void indexed_release(IndexedSnapshot &s) {
@@ -69,7 +72,7 @@ inline void indexed_release(IndexedSnapshot &s) {
     if (s.d_sorted_mem) (void)hipFree(s.d_sorted_mem);
     if (s.d_tables) (void)hipFree(s.d_tables);
     if (s.d_lab_meta) (void)hipFree(s.d_lab_meta);
-    s = IndexedSnapshot{};
+    s = IndexedSnapshot{};  // also drops the host images
 }
 
 inline uint32_t indexed_lds_bytes(const IndexedLayout &l) { return l.rows * 128u; }
@@ -83,6 +86,35 @@ inline void eytzinger_from_sorted(const int64_t *sorted, int64_t *tree) {
     for (uint32_t level = 0; level < 10; ++level)
         for (uint32_t j = 0; j < (1u << level); ++j) tree[(1u << level) + j] = sorted[((2u * j + 1u) << (9u - level)) - 1u];
 }
+// Fit part of one tile: the rows GEH/GEL of both resources and the two search trees, from the tile's current
+// `available` values (src/predicates.rs:27-38).  Rewrites those rows from scratch (they are contiguous:
+// [row_cpu_hi, row_cpu_hi + 2 * (kFitHi + kFitLo))), so it serves both the full build and ksched_update_nodes.
+inline void index_tile_fit(const IndexedLayout &l, uint32_t t, const int64_t *cpu, const int64_t *mem, uint64_t *T, int64_t *tree_cpu,
+                           int64_t *tree_mem) {
+    const uint32_t base = t * kTileNodes;
+    const uint32_t m = std::min<uint32_t>(kTileNodes, l.n - base);
+    std::fill(T + (size_t)l.row_cpu_hi * kTileWords, T + (size_t)(l.row_cpu_hi + 2 * (kFitHi + kFitLo)) * kTileWords, 0ull);
+    auto setbit = [&](uint32_t row, uint32_t local) { T[(size_t)row * kTileWords + (local >> 6)] |= 1ull << (local & 63u); };
+    uint32_t ord[kTileNodes];
+    int64_t sorted[kTileNodes];
+    for (int res = 0; res < 2; ++res) {
+        const int64_t *v = res == 0 ? cpu : mem;
+        const uint32_t row_hi = res == 0 ? l.row_cpu_hi : l.row_mem_hi;
+        const uint32_t row_lo = res == 0 ? l.row_cpu_lo : l.row_mem_lo;
+        std::fill(sorted, sorted + kTileNodes, INT64_MAX);
+        std::iota(ord, ord + m, 0u);
+        std::stable_sort(ord, ord + m, [&](uint32_t a, uint32_t b) { return v[base + a] < v[base + b]; });
+        for (uint32_t pos = 0; pos < m; ++pos) {
+            const uint32_t local = ord[pos];
+            sorted[pos] = v[base + local];
+            const uint32_t hi = pos >> 5, lo = pos & 31u;
+            for (uint32_t h = 0; h <= hi; ++h) setbit(row_hi + h, local);  // GEH[h] = {hi >= h}
+            for (uint32_t q = 0; q <= lo; ++q) setbit(row_lo + q, local);  // GEL[q] = {lo >= q}
+        }
+        eytzinger_from_sorted(sorted, res == 0 ? tree_cpu : tree_mem);
+    }
+}
+
 // Build the per-tile index on the host and upload it.  Leaves s.built == false (and returns
 // hipSuccess) when the snapshot is outside what the indexed kernel supports; the caller then
 // uses the direct kernel.
@@ -127,33 +159,13 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
     const size_t tile_words = (size_t)l.rows * kTileWords;
     std::vector<uint64_t> tab((size_t)l.tiles * tile_words, 0ull);
     std::vector<int64_t> scpu((size_t)l.tiles * kTileNodes, INT64_MAX), smem((size_t)l.tiles * kTileNodes, INT64_MAX);
-    std::vector<uint32_t> ord(kTileNodes);
-    std::vector<int64_t> sorted_tmp(kTileNodes);
     for (uint32_t t = 0; t < l.tiles; ++t) {
         const uint32_t base = t * kTileNodes;
         const uint32_t m = std::min<uint32_t>(kTileNodes, n - base);
         uint64_t *T = tab.data() + (size_t)t * tile_words;
         auto setbit = [&](uint32_t row, uint32_t local) { T[(size_t)row * kTileWords + (local >> 6)] |= 1ull << (local & 63u); };
         for (uint32_t i = 0; i < m; ++i) setbit(l.row_valid, i);
-        // fit: positions in the sorted order of each resource
-        for (int res = 0; res < 2; ++res) {
-            const int64_t *v = res == 0 ? cpu : mem;
-            int64_t *tree = (res == 0 ? scpu.data() : smem.data()) + (size_t)t * kTileNodes;
-            int64_t *sorted = sorted_tmp.data();
-            std::fill(sorted, sorted + kTileNodes, INT64_MAX);
-            const uint32_t row_hi = res == 0 ? l.row_cpu_hi : l.row_mem_hi;
-            const uint32_t row_lo = res == 0 ? l.row_cpu_lo : l.row_mem_lo;
-            std::iota(ord.begin(), ord.begin() + m, 0u);
-            std::stable_sort(ord.begin(), ord.begin() + m, [&](uint32_t a, uint32_t b) { return v[base + a] < v[base + b]; });
-            for (uint32_t pos = 0; pos < m; ++pos) {
-                const uint32_t local = ord[pos];
-                sorted[pos] = v[base + local];
-                const uint32_t hi = pos >> 5, lo = pos & 31u;
-                for (uint32_t h = 0; h <= hi; ++h) setbit(row_hi + h, local);  // GEH[h] = {hi >= h}
-                for (uint32_t q = 0; q <= lo; ++q) setbit(row_lo + q, local);  // GEL[q] = {lo >= q}
-            }
-            eytzinger_from_sorted(sorted, tree);
-        }
+        index_tile_fit(l, t, cpu, mem, T, scpu.data() + (size_t)t * kTileNodes, smem.data() + (size_t)t * kTileNodes);
         // labels
         for (uint32_t k = 0; k < nkeys; ++k)
             for (uint32_t i = 0; i < m; ++i) {
@@ -198,9 +210,27 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
         }
         if ((e = hipMemcpy(s.d_lab_meta, meta, sizeof meta, hipMemcpyHostToDevice)) != hipSuccess) return e;
     }
+    s.h_tables = std::move(tab);
+    s.h_sorted_cpu = std::move(scpu);
+    s.h_sorted_mem = std::move(smem);
     s.lay = l;
     s.built = true;
     return hipSuccess;
+}
+
+// ksched_update_nodes: `available` changed on some nodes of tile t -> rebuild that tile's fit rows and search
+// trees on the host image and re-upload just those (label and taint rows are untouched).
+inline hipError_t indexed_update_tile(IndexedSnapshot &s, uint32_t t, const int64_t *cpu, const int64_t *mem) {
+    const IndexedLayout &l = s.lay;
+    const size_t tile_words = (size_t)l.rows * kTileWords;
+    uint64_t *T = s.h_tables.data() + (size_t)t * tile_words;
+    int64_t *tc = s.h_sorted_cpu.data() + (size_t)t * kTileNodes, *tm = s.h_sorted_mem.data() + (size_t)t * kTileNodes;
+    index_tile_fit(l, t, cpu, mem, T, tc, tm);
+    hipError_t e;
+    const size_t fit_off = (size_t)l.row_cpu_hi * kTileWords, fit_words = (size_t)2 * (kFitHi + kFitLo) * kTileWords;
+    if ((e = hipMemcpy(s.d_tables + (size_t)t * tile_words + fit_off, T + fit_off, fit_words * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMemcpy(s.d_sorted_cpu + (size_t)t * kTileNodes, tc, kTileNodes * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    return hipMemcpy(s.d_sorted_mem + (size_t)t * kTileNodes, tm, kTileNodes * 8, hipMemcpyHostToDevice);
 }
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));

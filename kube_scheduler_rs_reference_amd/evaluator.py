@@ -125,6 +125,15 @@ class Evaluator:
         self.n = n
         self.n_keys = n_keys
 
+    def update_nodes(self, node_index, avail_cpu_milli, avail_mem_bytes):
+        """New `available` values for the listed canonical node indices (ksched_update_nodes)."""
+        idx = _np(node_index, np.uint32, "node_index")
+        cpu = _np(avail_cpu_milli, np.int64, "avail_cpu_milli")
+        mem = _np(avail_mem_bytes, np.int64, "avail_mem_bytes")
+        if idx.ndim != 1 or cpu.shape != idx.shape or mem.shape != idx.shape:
+            raise ValueError("node_index, avail_cpu_milli, avail_mem_bytes must be 1-D of one length")
+        self._check(self._lib.ksched_update_nodes(self._h, idx.shape[0], _ptr(idx), _ptr(cpu), _ptr(mem)), "ksched_update_nodes")
+
     # -- evaluation, host buffers ------------------------------------------------------------------
     def eval(self, req_cpu_milli, req_mem_bytes, sel_val_ids=None, tolerations=None, samples=None, flags: int = L.FIT,
              want_mask: bool = True) -> EvalResult:

@@ -136,6 +136,50 @@ void Snapshot::upload() {
                 "ksched_set_nodes");
 }
 
+size_t Snapshot::apply_pod_events(const std::vector<std::pair<const corev1::Pod *, bool>> &events) {
+    std::vector<uint32_t> touched;
+    size_t applied = 0;
+    for (const auto &[pod, bound] : events) {
+        if (!pod->spec || !pod->spec->node_name) continue;
+        const int idx = index_of(*pod->spec->node_name);
+        if (idx < 0) continue;
+        int64_t dc, dm;
+        try {
+            const PodResources r = total_pod_resources(*pod);  // the same sum the LIST loop subtracts (src/predicates.rs:37)
+            dc = r.cpu.to_milli();
+            dm = r.memory.to_units();
+        } catch (const QuantityError &e) {
+            throw EncodeError("pod " + full_name(pod->metadata) + ": invalid pod spec: " + e.what());
+        }
+        int64_t &cpu = cols_.avail_cpu_milli[(size_t)idx], &mem = cols_.avail_mem_bytes[(size_t)idx];
+        int64_t ncpu, nmem;
+        const bool over = bound ? (__builtin_sub_overflow(cpu, dc, &ncpu) || __builtin_sub_overflow(mem, dm, &nmem))
+                                : (__builtin_add_overflow(cpu, dc, &ncpu) || __builtin_add_overflow(mem, dm, &nmem));
+        if (over) throw EncodeError("node " + cols_.names[(size_t)idx] + ": available leaves the int64 domain");
+        cpu = ncpu;
+        mem = nmem;
+        touched.push_back((uint32_t)idx);
+        ++applied;
+    }
+    if (touched.empty()) return 0;
+    std::sort(touched.begin(), touched.end());
+    touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+    ++generation_;
+    if (dev_) {
+        std::vector<int64_t> cpu(touched.size()), mem(touched.size());
+        for (size_t i = 0; i < touched.size(); ++i) {
+            cpu[i] = cols_.avail_cpu_milli[touched[i]];
+            mem[i] = cols_.avail_mem_bytes[touched[i]];
+        }
+        dev_->check(ksched_update_nodes(dev_->handle(), (uint32_t)touched.size(), touched.data(), cpu.data(), mem.data()),
+                    "ksched_update_nodes");
+    }
+    return applied;
+}
+
+bool Snapshot::apply_bound_pod(const corev1::Pod &pod) { return apply_pod_events({{&pod, true}}) == 1; }
+bool Snapshot::apply_deleted_pod(const corev1::Pod &pod) { return apply_pod_events({{&pod, false}}) == 1; }
+
 void Snapshot::ensure_keys(const std::set<std::string> &keys) {
     bool grew = false;
     for (const auto &k : keys) {

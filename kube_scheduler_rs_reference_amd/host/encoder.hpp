@@ -72,6 +72,19 @@ public:
     // alone never reads them (src/predicates.rs:45-61).
     void rebuild(const std::vector<corev1::Node> &nodes, PodLister *client, bool with_resources = true);
 
+    // Keep `available` current from pod watch events instead of one LIST per evaluation.
+    // The reference subtracts total_pod_resources of every pod the LIST for the node returns
+    // (src/predicates.rs:34-38); a pod that appears on / disappears from a node changes exactly that sum:
+    //   apply_bound_pod   : pod.spec.nodeName now names a node of this snapshot -> available -= requests
+    //   apply_deleted_pod : such a pod is gone from the API server              -> available += requests
+    // Both patch the host columns and push the changed rows with ksched_update_nodes (only the node's 1024-node
+    // tile is re-indexed on the device).  Return false (and change nothing) when the pod has no nodeName or the
+    // node is not in this snapshot.  Arithmetic leaving int64 throws EncodeError.
+    bool apply_bound_pod(const corev1::Pod &pod);
+    bool apply_deleted_pod(const corev1::Pod &pod);
+    // Many events, one device update.  second = true: bound, false: deleted.  Returns how many were applied.
+    size_t apply_pod_events(const std::vector<std::pair<const corev1::Pod *, bool>> &events);
+
     // Make sure every label key in `keys` has a column (re-uploads the label columns if not).
     void ensure_keys(const std::set<std::string> &keys);
 

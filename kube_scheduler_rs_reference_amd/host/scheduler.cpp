@@ -137,4 +137,50 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
     return out;
 }
 
+std::vector<ReconcileOutcome> reconcile_batch_sequential(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
+                                                         BindingSink &sink, uint32_t max_rounds, SequentialStats *stats) {
+    std::vector<ReconcileOutcome> out(pods.size());
+    std::vector<size_t> pending;
+    for (size_t i = 0; i < pods.size(); ++i)
+        if (!is_pod_bound(*pods[i])) pending.push_back(i);  // src/main.rs:74-76
+    if (!ctx.snapshot) ctx.refresh_snapshot();
+    SequentialStats st;
+    while (!pending.empty() && st.rounds < max_rounds) {
+        ++st.rounds;
+        std::vector<const corev1::Pod *> batch;
+        for (size_t i : pending) batch.push_back(pods[i]);
+        const BatchSelection sel = select_nodes_for_pods(batch, ctx, chooser);  // one device evaluation + pick
+        std::vector<size_t> next;
+        std::vector<bool> taken(ctx.node_store.size(), false);
+        std::vector<corev1::Pod> landed;  // copies carrying spec.nodeName, for the snapshot update
+        for (size_t j = 0; j < pending.size(); ++j) {
+            const size_t i = pending[j];
+            const int32_t idx = sel.node_store_index[j];
+            if (idx < 0) {  // no feasible draw against the current state
+                out[i] = bind(*pods[i], nullptr, sink);
+                continue;
+            }
+            if (taken[(size_t)idx]) {  // an earlier pod of this round shrank that node: look again next round
+                ++st.conflicts;
+                next.push_back(i);
+                continue;
+            }
+            out[i] = bind(*pods[i], &ctx.node_store[(size_t)idx], sink);
+            if (!out[i].ok) continue;  // the POST failed: nothing landed on the node
+            taken[(size_t)idx] = true;
+            corev1::Pod p = *pods[i];
+            if (!p.spec) p.spec = corev1::PodSpec{};
+            p.spec->node_name = *out[i].bound_to;
+            landed.push_back(std::move(p));
+        }
+        std::vector<std::pair<const corev1::Pod *, bool>> events;
+        for (const auto &p : landed) events.emplace_back(&p, true);
+        ctx.snapshot->apply_pod_events(events);
+        pending.swap(next);
+    }
+    for (size_t i : pending) out[i] = bind(*pods[i], nullptr, sink);  // still colliding after max_rounds
+    if (stats) *stats = st;
+    return out;
+}
+
 }  // namespace ksched_host

@@ -104,6 +104,25 @@ ReconcileOutcome reconcile(const corev1::Pod &pod, Context &ctx, NodeChooser &ch
 std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
                                               BindingSink &sink);
 
+// In-batch capacity accounting -- OPT-IN and OUTSIDE the parity claim: the reference has no
+// assume/reserve step (src/main.rs:78-119), so reconciles racing on one API-server state may over-commit a node,
+// and reconcile_batch above reproduces exactly that.  This variant never over-commits:
+//   round r: every still-pending pod is evaluated and picked ON THE DEVICE against the current snapshot (fresh
+//   ATTEMPTS draws per round, as a requeued reconcile would make); per node only the FIRST pod (batch order) bound
+//   to it in this round is accepted -- the device just said it fits what is available now -- its binding is
+//   POSTed and Snapshot::apply_bound_pod shrinks the node's `available` (ksched_update_nodes); the other pods
+//   that drew the same node go to the next round and are re-evaluated against the shrunk snapshot.
+// A pod with no feasible draw in its round gets NoNodeFound (the reference's outcome, src/main.rs:117); pods still
+// colliding after `max_rounds` get NoNodeFound too.  Every feasibility decision is the device's; the host only
+// groups bindings by node.  The accepted bindings are a legal serial execution of the reference (round order,
+// then batch order) in which each pod saw all earlier bindings.
+struct SequentialStats {
+    uint32_t rounds = 0;
+    uint32_t conflicts = 0;  // (pod, round) pairs deferred because an earlier pod of the round took the node
+};
+std::vector<ReconcileOutcome> reconcile_batch_sequential(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
+                                                         BindingSink &sink, uint32_t max_rounds = 64, SequentialStats *stats = nullptr);
+
 // src/main.rs:122-125
 Action error_policy(const corev1::Pod &pod, ReconcileError error);
 

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -243,6 +245,40 @@ static void cpu_tests() {
         CHECK_THROWS(s2.rebuild(badn, nullptr));
         CHECK_THROWS(snap.device());  // encode-only snapshots cannot evaluate
     });
+    run("snapshot builder: apply_bound_pod / apply_deleted_pod == re-LIST (SURVEY.md 8f n1; src/predicates.rs:34-38)", [] {
+        std::vector<corev1::Node> nodes = {node_with("node-b", "4", "8589934592"), node_with("node-a", "2", "4294967296")};
+        StaticPodLister lister;
+        lister.pods = {pod_with("r1", {container("500m", "1073741824")}, "node-a")};
+        Snapshot inc(Snapshot::kEncodeOnly);
+        inc.rebuild(nodes, &lister);
+        const uint64_t g0 = inc.generation();
+        // a pod lands on node-b, another on node-a, then r1 goes away: patch the columns event by event
+        corev1::Pod n1 = pod_with("n1", {container("1500m", "1000"), container("250m", nullptr)}, "node-b");
+        corev1::Pod n2 = pod_with("n2", {container("3", "4294967296")}, "node-a");  // over-commits node-a: goes negative (D-R4)
+        CHECK(inc.apply_bound_pod(n1));
+        CHECK(inc.apply_pod_events({{&n2, true}, {&lister.pods[0], false}}) == 2);
+        CHECK(inc.generation() > g0);
+        // the same cluster state, re-LISTed from scratch as the reference does per evaluation
+        StaticPodLister after;
+        after.pods = {n1, n2};
+        Snapshot full(Snapshot::kEncodeOnly);
+        full.rebuild(nodes, &after);
+        CHECK(inc.columns().avail_cpu_milli == full.columns().avail_cpu_milli);
+        CHECK(inc.columns().avail_mem_bytes == full.columns().avail_mem_bytes);
+        CHECK(inc.columns().avail_cpu_milli[0] == 2000 - 3000 && inc.columns().avail_mem_bytes[0] == 0);
+        CHECK(inc.columns().avail_cpu_milli[1] == 4000 - 1750 && inc.columns().avail_mem_bytes[1] == 8589934592ll - 1000);
+        // not applicable: unbound pod, unknown node -> false, nothing changes
+        corev1::Pod unbound = pod_with("u", {container("1", "1")});
+        corev1::Pod elsewhere = pod_with("e", {container("1", "1")}, "node-zz");
+        CHECK(!inc.apply_bound_pod(unbound) && !inc.apply_deleted_pod(elsewhere));
+        CHECK(inc.columns().avail_cpu_milli == full.columns().avail_cpu_milli);
+        // delete then bind again is the identity
+        CHECK(inc.apply_deleted_pod(n1) && inc.apply_bound_pod(n1));
+        CHECK(inc.columns().avail_cpu_milli == full.columns().avail_cpu_milli && inc.columns().avail_mem_bytes == full.columns().avail_mem_bytes);
+        // unparsable requests are an error, as in rebuild (the reference panics, src/util.rs:65,68)
+        corev1::Pod bad = pod_with("bad", {container("lots", nullptr)}, "node-a");
+        CHECK_THROWS(inc.apply_bound_pod(bad));
+    });
     run("toleration_matches (extension E2)", [] {
         TaintId t{"k", "v", "NoSchedule"};
         corev1::Toleration a;
@@ -478,6 +514,94 @@ static void gpu_tests() {
         CHECK(!out[1].ok && out[1].error == ReconcileError::NoNodeFound);
         CHECK(out[2].ok && !out[2].bound_to);
         for (int i : {0, 3}) CHECK(out[i].ok ? (out[i].bound_to && *out[i].bound_to == "node-a") : out[i].error == ReconcileError::NoNodeFound);
+    });
+
+    run("snapshot builder on the device: incremental ksched_update_nodes == fresh ksched_set_nodes (8f n1)", [] {
+        // 1500 nodes (two index tiles, the second partial); pods bind to a few of them one event at a time
+        std::vector<corev1::Node> nodes;
+        for (int i = 0; i < 1500; ++i) {
+            char name[32];
+            std::snprintf(name, sizeof name, "node-%04d", i);
+            nodes.push_back(node_with(name, (i % 3 == 0) ? "4" : "2", "8589934592"));
+            nodes.back().metadata.labels = corev1::StringMap{{"zone", (i % 2) ? "a" : "b"}};
+        }
+        std::vector<corev1::Pod> probes = {pod_with("small", {container("500m", "1")}), pod_with("mid", {container("1800m", "1")}),
+                                           pod_with("big", {container("3500m", "1")}), test_pod("zone", "a")};
+        std::vector<const corev1::Pod *> pp;
+        for (auto &p : probes) pp.push_back(&p);
+        Context inc = make_ctx(nodes);
+        inc.refresh_snapshot();
+        std::vector<corev1::Pod> landed;
+        SplitMixChooser rng(5);
+        for (int e = 0; e < 40; ++e) {
+            char name[32];
+            std::snprintf(name, sizeof name, "node-%04d", (int)*rng.choose(1500));
+            landed.push_back(pod_with("l" + std::to_string(e), {container((e % 2) ? "700m" : "1500m", "1073741824")}, name));
+            CHECK(inc.snapshot->apply_bound_pod(landed.back()));
+        }
+        CHECK(inc.snapshot->apply_deleted_pod(landed[3]));
+        landed.erase(landed.begin() + 3);
+        Context full = make_ctx(nodes, landed);  // the same state, re-LISTed and uploaded from scratch
+        full.refresh_snapshot();
+        const predicates::BatchValidity a = predicates::check_node_validity_batch(pp, inc, false, KSCHED_PICK_BESTFIT);
+        const predicates::BatchValidity b = predicates::check_node_validity_batch(pp, full, false, KSCHED_PICK_BESTFIT);
+        CHECK(a.feasible == b.feasible && a.fit == b.fit && a.binding == b.binding);
+        CHECK(a.feasible_count(2) < a.feasible_count(0));  // the events mattered
+        CHECK(std::static_pointer_cast<StaticPodLister>(inc.client)->list_calls == 1500);  // no LIST after the first build
+    });
+
+    run("reconcile_batch_sequential: in-batch capacity accounting never over-commits (8f n3, opt-in)", [] {
+        // 6 nodes x 2 CPU; 20 pods x 1 CPU: at most 12 can land.  The reference-faithful batch over-commits.
+        std::vector<corev1::Node> nodes;
+        for (int i = 0; i < 6; ++i) nodes.push_back(node_with("n" + std::to_string(i), "2", "8589934592"));
+        std::vector<corev1::Pod> pods;
+        for (int i = 0; i < 20; ++i) pods.push_back(pod_with("p" + std::to_string(i), {container("1", "1073741824")}));
+        std::vector<const corev1::Pod *> pp;
+        for (auto &p : pods) pp.push_back(&p);
+        auto landed_per_node = [&](const std::vector<ReconcileOutcome> &out) {
+            std::map<std::string, int> m;
+            for (const auto &o : out)
+                if (o.ok && o.bound_to) ++m[*o.bound_to];
+            return m;
+        };
+        {
+            Context ctx = make_ctx(nodes);
+            RecordingSink sink;
+            SplitMixChooser c(7);
+            int worst = 0, total = 0;
+            for (const auto &[node, cnt] : landed_per_node(reconcile_batch(pp, ctx, c, sink))) worst = std::max(worst, cnt), total += cnt;
+            CHECK(total == 20 && worst > 2);  // every pod saw the same snapshot: legal for the reference, over-committed
+        }
+        {
+            Context ctx = make_ctx(nodes);
+            RecordingSink sink;
+            SplitMixChooser c(7);
+            SequentialStats st;
+            const std::vector<ReconcileOutcome> out = reconcile_batch_sequential(pp, ctx, c, sink, 64, &st);
+            int total = 0;
+            for (const auto &[node, cnt] : landed_per_node(out)) {
+                CHECK(cnt <= 2);
+                total += cnt;
+            }
+            CHECK(total <= 12 && total >= 8);
+            CHECK((int)sink.posts.size() == total);
+            CHECK(st.rounds >= 2 && st.conflicts > 0);
+            int none = 0;
+            for (const auto &o : out)
+                if (!o.ok) {
+                    CHECK(o.error == ReconcileError::NoNodeFound && o.action == Action::RequeueAfter5Min);
+                    ++none;
+                }
+            CHECK(none == 20 - total);
+            // the snapshot now carries the batch's bindings: what is left is exactly capacity - landed
+            const NodeColumns &cols = ctx.snapshot->columns();
+            int64_t left = 0;
+            for (int64_t v : cols.avail_cpu_milli) {
+                CHECK(v >= 0);
+                left += v;
+            }
+            CHECK(left == 12000 - 1000 * total);
+        }
     });
 }
 

@@ -60,6 +60,7 @@ def test_null_arguments_are_errors_not_crashes(built):
     lib = _lib.load()
     assert lib.ksched_create(None, 0) == _lib.E_INVAL
     assert lib.ksched_set_nodes(None, 0, None, None, None, 0, None) == _lib.E_INVAL
+    assert lib.ksched_update_nodes(None, 0, None, None, None) == _lib.E_INVAL
     assert lib.ksched_eval(None, 0, None, None, None, None, None, 0, 0, None, None, None) == _lib.E_INVAL
     lib.ksched_destroy(None)
     assert b"no CPU fallback" in lib.ksched_strerror(_lib.E_NODEVICE)

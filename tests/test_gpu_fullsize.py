@@ -1,0 +1,120 @@
+"""BASELINE.json's full single-GPU sizes (C3 100k x 5k, the C4 shard 125k x 10k, the C5 shard 125k x 50k) through
+size-independent properties -- the oracle cannot finish P x N pairs of these sizes in seconds, so parity at full
+size is shown by:
+
+  * fused == direct on every mask word (two independent HIP implementations: bitmap index vs per-pair compares);
+  * a seeded sample of pod rows == the oracle, word for word (plus the first and last rows: range ends);
+  * feasible is a subset of fit; padding bits beyond node N are zero;
+  * pod-permutation equivariance of a checksum of row checksums (rows do not depend on their neighbours or on
+    which block / wave / round evaluated them);
+  * bindings are consistent with the mask (sampled: the bound draw's bit is set and every earlier draw's is clear;
+    best fit: equals the oracle's pick on the sampled rows, and the bound node's bit is set everywhere).
+
+Everything stays on the device; only the sampled rows and per-row checksums come back.
+"""
+import numpy as np
+import pytest
+
+from kube_scheduler_rs_reference_amd import FIT, PICK_BESTFIT, PICK_SAMPLED, SEL, TAINT, WANT_FIT_MASK, synth
+from oracle import capi
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "C3": ("C3", 100_000, 5_000, FIT | SEL, PICK_SAMPLED),
+    "C4s": ("C4", 125_000, 10_000, FIT | SEL, PICK_SAMPLED),
+    "C5s": ("C5", 125_000, 50_000, FIT | SEL | TAINT, PICK_BESTFIT),
+}
+ROWS_CHECKED = 192
+
+
+def _row_checksums(mask):
+    """[P, W] int64 device tensor -> [P] int64: position-weighted wrapping sum of the row's words."""
+    import torch
+    W = mask.shape[1]
+    w = (torch.arange(1, W + 1, device=mask.device, dtype=torch.int64) * 0x9E3779B97F4A7C1) | 1
+    return (mask * w).sum(dim=1)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_full_size_properties(evaluator, name):
+    import torch
+    cfg, P, N, preds, pick = CASES[name]
+    c = synth.make_config(cfg, P=P, N=N)
+    ev = evaluator
+    dev = torch.device("cuda", ev.device)
+    ev.set_nodes(**c.node_columns())
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    d_cpu, d_mem = t(c.req_cpu, np.int64), t(c.req_mem, np.int64)
+    d_sel = t(c.pod_sel, np.int32)
+    d_tol = t(c.pod_tol, np.int64) if preds & TAINT else None
+    d_smp = t(c.samples, np.int32)
+    flags = preds | WANT_FIT_MASK | pick
+    W = ev.W
+
+    def run(kernel, cpu, mem, sel, tol, smp):
+        ev.set_kernel(kernel)
+        feas, fit = ev.alloc_mask(P), ev.alloc_mask(P)
+        bind = torch.empty((P,), dtype=torch.int32, device=dev)
+        ev.eval_device(cpu, mem, sel, tol, smp if pick == PICK_SAMPLED else None, flags, out_feasible=feas, out_fit=fit, out_binding=bind)
+        torch.cuda.synchronize()
+        assert ev.last_kernel == kernel
+        return feas, fit, bind
+
+    feas, fit, bind = run("fused", d_cpu, d_mem, d_sel, d_tol, d_smp)
+    feas_d, fit_d, bind_d = run("direct", d_cpu, d_mem, d_sel, d_tol, d_smp)
+    # two independent implementations agree on every word and every binding
+    assert torch.equal(feas, feas_d), "fused != direct (feasible)"
+    assert torch.equal(fit, fit_d), "fused != direct (fit)"
+    assert torch.equal(bind, bind_d)
+    del feas_d, fit_d, bind_d
+    # feasible is a subset of fit; padding bits are zero
+    assert not (feas & ~fit).any()
+    if N % 64:
+        pad = torch.tensor(-1 << (N % 64), dtype=torch.int64, device=dev)
+        assert not (feas[:, W - 1] & pad).any() and not (fit[:, W - 1] & pad).any()
+    density = float(sum(int((feas[i:i + 4096] != 0).sum()) for i in range(0, P, 4096))) / (P * W)
+    assert density > 0.2, "mask is almost empty: the workload is degenerate"
+
+    # sampled rows == oracle
+    rng = np.random.default_rng(0xC0FFEE)
+    rows = np.unique(np.concatenate([rng.choice(P, ROWS_CHECKED, replace=False), [0, 1, P - 2, P - 1]]))
+    sub_tol = c.pod_tol[rows] if preds & TAINT else None
+    o_feas, o_fit, o_bind = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, c.node_taints if preds & TAINT else None,
+                                              c.req_cpu[rows], c.req_mem[rows], np.ascontiguousarray(c.pod_sel[:, rows]), sub_tol,
+                                              np.ascontiguousarray(c.samples[rows]), flags)
+    r = torch.from_numpy(rows).to(dev)
+    assert np.array_equal(feas[r].cpu().numpy().view(np.uint64), o_feas)
+    assert np.array_equal(fit[r].cpu().numpy().view(np.uint64), o_fit)
+    assert np.array_equal(bind[r].cpu().numpy(), o_bind)
+
+    # bindings consistent with the mask, for every pod
+    b = bind.to(torch.int64)
+    has = b >= 0
+    bc = b.clamp(min=0)
+    word = feas.gather(1, (bc >> 6).unsqueeze(1)).squeeze(1)
+    bit = (word >> (bc & 63)) & 1
+    assert bool((bit[has] == 1).all()), "a bound node's bit is clear"
+    assert bool((b < N).all())
+    if pick == PICK_SAMPLED:
+        s = d_smp.to(torch.int64)  # [P, attempts]
+        ok = s < N
+        sc = s.clamp(max=N - 1)
+        bits = ((feas.gather(1, sc >> 6) >> (sc & 63)) & 1).bool() & ok  # feasibility of every draw
+        first = torch.where(bits.any(dim=1), bits.int().argmax(dim=1), torch.full((P,), -1, device=dev))
+        want = torch.where(first >= 0, s.gather(1, first.clamp(min=0).unsqueeze(1)).squeeze(1), torch.full((P,), -1, device=dev))
+        assert torch.equal(want, b), "sampled pick is not the first feasible draw (src/main.rs:53-66)"
+    else:
+        # no feasible node <=> -1
+        nonempty = torch.cat([(feas[i:i + 8192] != 0).any(dim=1) for i in range(0, P, 8192)])
+        assert torch.equal(nonempty, has)
+
+    # pod-permutation equivariance of the checksum of row checksums
+    cs = _row_checksums(feas)
+    perm = torch.from_numpy(np.random.default_rng(7).permutation(P)).to(dev)
+    feas_p, _, bind_p = run("fused", d_cpu[perm].contiguous(), d_mem[perm].contiguous(), d_sel[:, perm].contiguous(),
+                            d_tol[perm].contiguous() if d_tol is not None else None, d_smp[perm].contiguous())
+    assert torch.equal(_row_checksums(feas_p), cs[perm])
+    assert torch.equal(bind_p, bind[perm])
+    assert int(_row_checksums(feas_p).sum()) == int(cs.sum())
+    ev.set_kernel("auto")

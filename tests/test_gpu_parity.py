@@ -2,7 +2,7 @@
 
 Bit-exact (integer/bitmask work): every mask word and every binding must be identical.  Sizes
 here are ones the encoded-level oracle finishes in seconds; BASELINE.json's full sizes are
-covered by size-independent properties in test_gpu_properties.py.
+covered by size-independent properties in test_gpu_fullsize.py.
 """
 import numpy as np
 import pytest
@@ -366,4 +366,42 @@ def test_pitched_device_masks(evaluator, kernel, P, N):
             full = torch.as_strided(m, (P, m.stride(0)), (m.stride(0), 1))
             pad = full[:, ev.W:].cpu().numpy().view(np.uint64)
             assert np.isin(pad, np.array([0, sentinel], dtype=np.uint64)).all()
+    ev.set_kernel("auto")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("count", [1, 7, 200])
+def test_update_nodes_matches_fresh_snapshot(evaluator, kernel, count):
+    """ksched_update_nodes: patching `available` of some nodes == a fresh ksched_set_nodes
+    with the patched columns == the oracle; covers both kernels, both picks, a partial last tile and a node
+    listed twice (last value wins)."""
+    ev = evaluator
+    ev.set_kernel(kernel)
+    c = synth.make_cluster(700, 2500, n_keys=8, n_taints=16, seed=1234 + count)
+    ev.set_nodes(**c.node_columns())
+    rng = np.random.default_rng(count)
+    idx = rng.choice(c.N, size=count, replace=False).astype(np.uint32)
+    idx[-1] = c.N - 1  # the partial last tile
+    new_cpu = c.avail_cpu[idx] - rng.integers(0, 8000, size=count)
+    new_mem = c.avail_mem[idx] - rng.integers(0, 1 << 34, size=count)
+    if count > 1:  # duplicate entry: the later one must win
+        idx[0] = idx[1]
+    ev.update_nodes(idx, new_cpu, new_mem)
+    cpu, mem = c.avail_cpu.copy(), c.avail_mem.copy()
+    for i, n in enumerate(idx):
+        cpu[n], mem[n] = new_cpu[i], new_mem[i]
+    pc = c.pod_columns()
+    for pick in (PICK_SAMPLED, PICK_BESTFIT):
+        flags = FIT | SEL | TAINT | WANT_FIT_MASK | pick
+        r = ev.eval(pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], pc["tolerations"], pc["samples"], flags)
+        feas, fit, bind = capi.eval_encoded(cpu, mem, c.node_labels, c.node_taints, c.req_cpu, c.req_mem, c.pod_sel, c.pod_tol,
+                                            c.samples, flags)
+        assert np.array_equal(r.feasible, feas) and np.array_equal(r.fit, fit) and np.array_equal(r.binding, bind)
+    # and it really changed something
+    old, _, _ = oracle_eval(c, FIT | SEL | TAINT)
+    assert not np.array_equal(old, feas)
+    # errors: index out of range, null arrays
+    with pytest.raises(KschedError) as e:
+        ev.update_nodes(np.array([c.N], np.uint32), np.zeros(1, np.int64), np.zeros(1, np.int64))
+    assert e.value.code == _lib.E_INVAL
     ev.set_kernel("auto")
