@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libksched_hip.so")
+# KSCHED_LIB: an alternative build of the SAME library (tools/build_variants.sh, A/B timing of kernel variants)
+LIB_PATH = os.environ.get("KSCHED_LIB") or os.path.join(_PKG_DIR, "libksched_hip.so")
 
 # --- constants mirrored from include/ksched.h --------------------------------------------------
 ABI_VERSION = 1

@@ -31,6 +31,18 @@
 
 #include "tile_index.hpp"
 
+// Build-time variants of the fused kernel (tools/build_variants.sh builds one library per setting; the shipped
+// library uses the defaults below, chosen from the measurements under profiles/):
+//   KSCHED_SPLIT_STAGE  1 = stage the search trees first, run the first round's rank searches while the bitmap
+//                           rows are still landing (two barriers); 0 = stage everything, one barrier
+//   KSCHED_STORE_POLICY 0 = plain stores (write-back L2), 1 = nt, 2 = sc1 (write-through), 3 = sc0 sc1
+#ifndef KSCHED_SPLIT_STAGE
+#define KSCHED_SPLIT_STAGE 1
+#endif
+#ifndef KSCHED_STORE_POLICY
+#define KSCHED_STORE_POLICY 0
+#endif
+
 namespace ksched {
 
 constexpr uint32_t kFusedThreads = 1024;
@@ -215,7 +227,17 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         if (FIT) return (R.c0 & (R.c1 | R.c2)) & (R.m0 & (R.m1 | R.m2));  // pos >= rank, both resources
         return R.c0;
     };
-    auto store16 = [&](uint64_t *dst, size_t o, const u32x4 f) { *reinterpret_cast<u32x4_a8 *>(dst + o) = f; };
+    auto store16 = [&](uint64_t *dst, size_t o, const u32x4 f) {
+#if KSCHED_STORE_POLICY == 1
+        __builtin_nontemporal_store(f, reinterpret_cast<u32x4_a8 *>(dst + o));
+#elif KSCHED_STORE_POLICY == 2
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + o), "v"(f) : "memory");
+#elif KSCHED_STORE_POLICY == 3
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + o), "v"(f) : "memory");
+#else
+        *reinterpret_cast<u32x4_a8 *>(dst + o) = f;
+#endif
+    };
     auto combine_store = [&](uint32_t pod, const Rows &R, bool extra) {
         const size_t o = (size_t)pod * a.pitch + w0;
         u32x4 f = fit_of(R);
@@ -341,6 +363,40 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         if (more) issue_ops(u * 8u + lane);
         if ((a.debug & 128u) && have_prev && !stamped4) stamp(1);  // experiment: after the 2nd round's operand loads were issued
         if (first) {
+#if KSCHED_SPLIT_STAGE
+            // Stage the tile global -> LDS without a VGPR round trip (global_load_lds_dwordx4: per-lane global address,
+            // LDS destination = M0 + lane*16), in two steps so that the first round's rank searches overlap the
+            // landing of the bitmap rows: (1) the two search trees (16 KiB), wait, barrier; (2) the bitmap rows are
+            // issued and left in flight -- phase 1 only reads the trees; the rows are awaited (vmcnt(0) + barrier)
+            // right after the first phase 1, before any phase 2.  The DMA is inline asm: the compiler's own
+            // LDS-DMA tracking would drain it (vmcnt(0)) at the first LDS read.
+            auto stage = [&](const void *gsrc, uint32_t lds_off, uint32_t bytes) {
+                const uint8_t *g = static_cast<const uint8_t *>(gsrc);
+                for (uint32_t off = wave * 1024u; off < bytes; off += kFusedWaves * 1024u) {
+                    const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
+                        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)(smem + lds_off + off));
+                    if (off + lane * 16u < bytes) {
+                        uint32_t keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep)
+                                     : "v"(g + off + lane * 16u), "s"(lds_dst)
+                                     : "memory");
+                    }
+                }
+            };
+            if (FIT) {
+                stage(g_sorted_cpu + (size_t)tile * kTileNodes, a.off_sorted, kTileNodes * 8u);
+                stage(g_sorted_mem + (size_t)tile * kTileNodes, a.off_sorted + kTileNodes * 8u, kTileNodes * 8u);
+            }
+            if (!(a.debug & 128u)) stamp(1);
+            // Drains this wave's tree DMAs AND its first operand loads (issued earlier).  Needed even without FIT: the
+            // counted wait below assumes that only stores are younger than the operand loads; in the first trip the row
+            // DMAs are, so the operands must have landed before those are issued.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (FIT) __syncthreads();
+            if (!(a.debug & 128u)) stamp(2);
+            if (!(a.debug & 8u)) stage(g_tables + (size_t)tile * a.rows * kTileWords, 0u, a.rows * 128u);
+#else
             // stage the tile: bitmap rows + sorted arrays, global -> LDS without a VGPR round trip
             // (global_load_lds_dwordx4: per-lane global address, LDS destination = wave-uniform base + lane*16)
             auto stage = [&](const void *gsrc, uint32_t lds_off, uint32_t bytes) {
@@ -359,6 +415,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             if (!(a.debug & 128u)) stamp(1);
             __syncthreads();
             if (!(a.debug & 128u)) stamp(2);
+#endif
         }
         if (have_prev) {
             // ============ phase 2 of the previous round: 8 lanes per pod, 2 words per lane ===========
@@ -431,17 +488,26 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        const bool had_more = more;
+        if (more) {
+            KSCHED_WAIT_OPS(kFastStores);  // operands of round u have landed; up to kFastStores younger stores may be in flight
+            prev_over = phase1(u * 8u);
+            prev_extra = extra_any;
+            if (!have_prev) stamp(3);
+            prev_u = u;
+            prev_nu = min(8u, u_hi - u);
+            have_prev = true;
+            u += 8u;
+            more = u < u_hi;
+        }
+#if KSCHED_SPLIT_STAGE
+        if (first) {  // every wave's first trip (block-uniform): the bitmap rows have landed before any phase 2 reads them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no operand loads of the next round are in flight yet
+            __syncthreads();
+        }
+#endif
         first = false;
-        if (!more) break;
-        KSCHED_WAIT_OPS(kFastStores);  // operands of round u have landed; up to kFastStores younger stores may be in flight
-        prev_over = phase1(u * 8u);
-        prev_extra = extra_any;
-        if (!have_prev) stamp(3);
-        prev_u = u;
-        prev_nu = min(8u, u_hi - u);
-        have_prev = true;
-        u += 8u;
-        more = u < u_hi;
+        if (!had_more) break;
     }
 #undef KSCHED_WAIT_OPS
     if (a.trace && lane == 0) {  // every wave: latest loop end / drain of the block
