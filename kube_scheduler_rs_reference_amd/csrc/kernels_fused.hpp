@@ -42,10 +42,18 @@
 #ifndef KSCHED_STORE_POLICY
 #define KSCHED_STORE_POLICY 0
 #endif
+//   KSCHED_STAGGER      N > 0: the upper half of a block's waves sleeps 64*N cycles before its first rank search, so
+//                           the lower half's first stores start while the upper half searches (experiment)
+#ifndef KSCHED_STAGGER
+#define KSCHED_STAGGER 0
+#endif
+#ifndef KSCHED_FUSED_THREADS
+#define KSCHED_FUSED_THREADS 1024
+#endif
 
 namespace ksched {
 
-constexpr uint32_t kFusedThreads = 1024;
+constexpr uint32_t kFusedThreads = KSCHED_FUSED_THREADS;
 constexpr uint32_t kFusedWaves = kFusedThreads / 64;
 
 // Kernel arguments: plain scalars only (they live in SGPRs; keep this small).
@@ -227,13 +235,22 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         if (FIT) return (R.c0 & (R.c1 | R.c2)) & (R.m0 & (R.m1 | R.m2));  // pos >= rank, both resources
         return R.c0;
     };
+    // The asm forms are opaque to the compiler's hazard recognizer: a VALU write of the data registers right after a
+    // store of more than 64 bits needs 2 wait states on gfx950 (the compiler inserts them for its own stores), hence
+    // the s_nop 1 inside the statement.
     auto store16 = [&](uint64_t *dst, size_t o, const u32x4 f) {
 #if KSCHED_STORE_POLICY == 1
         __builtin_nontemporal_store(f, reinterpret_cast<u32x4_a8 *>(dst + o));
 #elif KSCHED_STORE_POLICY == 2
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + o), "v"(f) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + o), "v"(f) : "memory");
 #elif KSCHED_STORE_POLICY == 3
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + o), "v"(f) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst + o), "v"(f) : "memory");
+#elif KSCHED_STORE_POLICY == 4
+        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(dst + o), "v"(f) : "memory");
+#elif KSCHED_STORE_POLICY == 5
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(dst + o), "v"(f) : "memory");
+#elif KSCHED_STORE_POLICY == 6
+        asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(dst + o), "v"(f) : "memory");
 #else
         *reinterpret_cast<u32x4_a8 *>(dst + o) = f;
 #endif
@@ -490,6 +507,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         }
         const bool had_more = more;
         if (more) {
+#if KSCHED_STAGGER
+            if (first && wave >= kFusedWaves / 2u) __builtin_amdgcn_s_sleep(KSCHED_STAGGER);
+#endif
             KSCHED_WAIT_OPS(kFastStores);  // operands of round u have landed; up to kFastStores younger stores may be in flight
             prev_over = phase1(u * 8u);
             prev_extra = extra_any;

@@ -382,8 +382,11 @@ def test_update_nodes_matches_fresh_snapshot(evaluator, kernel, count):
     rng = np.random.default_rng(count)
     idx = rng.choice(c.N, size=count, replace=False).astype(np.uint32)
     idx[-1] = c.N - 1  # the partial last tile
-    new_cpu = c.avail_cpu[idx] - rng.integers(0, 8000, size=count)
-    new_mem = c.avail_mem[idx] - rng.integers(0, 1 << 34, size=count)
+    # every patched node flips: one that some pod could use becomes over-committed, the others become huge
+    old, _, _ = oracle_eval(c, FIT | SEL | TAINT)
+    usable = unpack_mask(old, c.N)[:, idx].any(axis=0)
+    new_cpu = np.where(usable, -1 - rng.integers(0, 8000, size=count), 1 << 50).astype(np.int64)
+    new_mem = np.where(usable, c.avail_mem[idx] - rng.integers(0, 1 << 34, size=count), 1 << 60).astype(np.int64)
     if count > 1:  # duplicate entry: the later one must win
         idx[0] = idx[1]
     ev.update_nodes(idx, new_cpu, new_mem)
@@ -398,7 +401,6 @@ def test_update_nodes_matches_fresh_snapshot(evaluator, kernel, count):
                                             c.samples, flags)
         assert np.array_equal(r.feasible, feas) and np.array_equal(r.fit, fit) and np.array_equal(r.binding, bind)
     # and it really changed something
-    old, _, _ = oracle_eval(c, FIT | SEL | TAINT)
     assert not np.array_equal(old, feas)
     # errors: index out of range, null arrays
     with pytest.raises(KschedError) as e:
