@@ -24,6 +24,7 @@ LIB_ORA  := oracle/liboracle.so
 HOST_SRCS := $(wildcard $(HOST)/*.cpp)
 HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/ksched.h
 HOST_TEST := tests/cpp/host_tests
+INDEX_TEST := tests/cpp/index_tests
 
 .PHONY: all lib host oracle clean
 all: lib host oracle
@@ -32,7 +33,10 @@ lib: $(LIB_HIP)
 $(LIB_HIP): $(CSRC)/ksched_api.hip $(wildcard $(CSRC)/*.hpp) include/ksched.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ksched_api.hip
 
-host: $(LIB_HOST) $(HOST_TEST)
+host: $(LIB_HOST) $(HOST_TEST) $(INDEX_TEST)
+# host-only check of the bitmap index arithmetic (no GPU, no HIP runtime call): tests/test_index_host.py runs it
+$(INDEX_TEST): tests/cpp/index_tests.cpp $(CSRC)/tile_index.hpp
+	$(CXX) -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -o $@ tests/cpp/index_tests.cpp
 $(LIB_HOST): $(HOST_SRCS) $(HOST_HDRS) $(LIB_HIP)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRCS) -L$(PKG) -lksched_hip -Wl,-rpath,'$$ORIGIN' -lpthread
 # C++ tests of the host mirror (tests/cpp/host_tests.cpp; driven by tests/test_host_mirror.py)
@@ -44,4 +48,4 @@ $(LIB_ORA): oracle/oracle.c oracle/oracle.h
 	$(CC) $(CFLAGS) -shared -o $@ oracle/oracle.c
 
 clean:
-	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA) $(HOST_TEST)
+	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA) $(HOST_TEST) $(INDEX_TEST)

@@ -1,27 +1,40 @@
 // kernels_fused.hpp -- "fused" mask kernel: ONE launch per evaluation over the per-tile bitmap
 // index of tile_index.hpp (same snapshot structures, same arithmetic; see that file for why
-//   req <= avail[n]  <=>  pos[n] >= rank(req)            (src/predicates.rs:42)
+//   req <= avail[n]  <=>  pos[n] >= rank(req)  <=>  lr[n] >= cnt[rank][sub-tile of n]     (src/predicates.rs:42)
 // is exact for any int64 inputs, and how selector / taint predicates become ANDs of bitmap rows).
 //
 // A block owns one tile (kTileNodes = 1024 nodes = 16 mask words) and a contiguous range of pods.
-// LDS holds the tile's bitmap rows, its two sorted resource arrays and a small per-wave record
-// area.  After the staging barrier the 16 waves of a block are independent; each walks its own
-// pods in rounds of up to 64 through two phases:
+// LDS holds the tile's bitmap rows, its aux block (two search trees, two cnt tables) and a small
+// per-wave record area.  After the staging barrier the 16 waves of a block are independent; each
+// walks its own pods in rounds of up to 64 through two phases:
 //   phase 1 (lane = pod): load the pod's requests / selector ids / tolerations (coalesced), run the
-//       two branch-free descents of the breadth-first (Eytzinger) search trees in LDS (the rank lookups), turn selector
-//       ids into bitmap row offsets (src/predicates.rs:45-61), park a 16-byte record in the wave's
-//       LDS area.
-//   phase 2 (8 lanes per pod, 16 bytes = 2 mask words per lane): read the record (LDS broadcast),
-//       AND the rows it names (ds_read_b128, v_bitop3), store.  One wave store instruction emits
-//       eight 128-byte row segments; there is no global load in this phase.
+//       two branch-free descents of the breadth-first (Eytzinger) search trees in LDS (the rank lookups),
+//       fetch cnt[rank] of each resource (8 bytes: one row number per sub-tile), turn selector ids into
+//       bitmap row offsets (src/predicates.rs:45-61; the constrained keys are scattered into the pod's
+//       record with one 2-byte LDS store each), park the records in the wave's LDS area.
+//   phase 2 (8 lanes per pod, 16 bytes = 2 mask words = one sub-tile per lane): read the records, AND
+//       the row chunks they name (ds_read_b128: ONE per resource for the fit, one per constrained-key
+//       slot, one per taint group), store.  One wave store instruction emits eight 128-byte row
+//       segments; there is no global load in this phase.
 // The loads of the next round are issued before phase 2 of the current one.
+//
+// The kernel is bound by instruction issue (VALU ~55 %, LDS ~40 % of the cycles at C4, rocprofv3 SQ counters in
+// profiles/), not by LDS or HBM bandwidth alone, so both phases are written to minimise VALU work: records hold
+// ready-made LDS byte offsets (one add per row address), the fit's row is one byte read + one shift-add per
+// resource, and the mask stores use an SGPR base + 32-bit lane offset (one add per store instead of a 64-bit
+// multiply-add).
+//
+// Phase-2 lane layout: ds_read_b128 is served in four fixed groups of 16 lanes ({0-3,12-15,20-27},
+// {4-11,16-19,28-31} and the same +32; MI355X_MICROARCH.md "LDS"), and only lanes of one group can
+// conflict.  The 8 lanes of a pod are therefore placed inside ONE group (a pod's 8 chunks of a row
+// are 128 contiguous bytes = 32 distinct banks), two pods per group: a group conflicts only when its
+// two pods read different rows of the same bank half.
 //
 // Work split (host side, run_fused): the unit is 8 pods (one phase-2 instruction).  Units are cut
 // evenly into `chunks` pod ranges; the (chunk, tile) blocks are dealt to the 8 XCDs in contiguous
 // chunk-major runs (block id % 8 = XCD, observed dispatch order; speed only), so the 128-byte
-// segments of one pod row that adjacent tiles write meet in ONE L2 and leave it as whole cache
-// lines (measured with tools/ubench2: 4.5-5.4 TB/s grouped vs 3.8 TB/s ungrouped when rows are
-// not line-aligned).  Inside a block the chunk's units are cut evenly over the 16 waves.
+// segments of one pod row that adjacent tiles write meet in ONE L2 (tools/ubench3.hip: the pattern
+// streams at the flat-store rate).  Inside a block the chunk's units are cut evenly over the 16 waves.
 #pragma once
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
@@ -31,21 +44,13 @@
 
 #include "tile_index.hpp"
 
-// Build-time variants of the fused kernel (tools/build_variants.sh builds one library per setting; the shipped
-// library uses the defaults below, chosen from the measurements under profiles/):
-//   KSCHED_SPLIT_STAGE  1 = stage the search trees first, run the first round's rank searches while the bitmap
-//                           rows are still landing (two barriers); 0 = stage everything, one barrier
-//   KSCHED_STORE_POLICY 0 = plain stores (write-back L2), 1 = nt, 2 = sc1 (write-through), 3 = sc0 sc1
-#ifndef KSCHED_SPLIT_STAGE
-#define KSCHED_SPLIT_STAGE 1
-#endif
+// Build-time variants (tools/build_variants.sh builds one library per setting for A/B timing; the shipped library
+// uses the defaults below, chosen from the measurements under profiles/):
+//   KSCHED_STORE_POLICY  mask stores: 0 = plain (write-back L2), 1 = nt, 2 = sc1 (write-through: no dirty lines are
+//                        left for the end-of-kernel L2 flush), 3 = sc0 sc1, 4 = sc1 nt, 5 = sc0 sc1 nt
+//   KSCHED_FUSED_THREADS threads per block (waves x 64)
 #ifndef KSCHED_STORE_POLICY
-#define KSCHED_STORE_POLICY 0
-#endif
-//   KSCHED_STAGGER      N > 0: the upper half of a block's waves sleeps 64*N cycles before its first rank search, so
-//                           the lower half's first stores start while the upper half searches (experiment)
-#ifndef KSCHED_STAGGER
-#define KSCHED_STAGGER 0
+#define KSCHED_STORE_POLICY 2
 #endif
 #ifndef KSCHED_FUSED_THREADS
 #define KSCHED_FUSED_THREADS 1024
@@ -59,33 +64,33 @@ constexpr uint32_t kFusedWaves = kFusedThreads / 64;
 // Kernel arguments: plain scalars only (they live in SGPRs; keep this small).
 struct FusedArgs {
     uint32_t W, pitch, tiles, rows, nkeys, ngroups;
-    uint32_t row_zero, row_valid, row_cpu_hi, row_cpu_lo, row_mem_hi, row_mem_lo, row_taint;
+    uint32_t row_zero, row_valid, row_cpu, row_mem, row_taint;
     uint32_t lab_base[8], lab_max[8];  // first eight label keys; further keys go through lab_meta
     const uint32_t *lab_meta;          // device copy of IndexedLayout::lab_base[32], lab_max[32]
     const uint64_t *zero64;            // eight zero bytes in device memory
     uint32_t p, units, chunks, run;    // units = ceil(p / 8); run = (chunk, tile) pairs per XCD
     uint32_t unit_q, unit_rem, tiles_rcp;  // units / chunks, units % chunks, floor(2^32 / tiles)
-    uint32_t off_sorted, off_rec, off_rec2, off_trow;  // LDS byte offsets of the regions after the bitmap rows
+    uint32_t off_aux, off_fit, off_lab, off_trow;  // LDS byte offsets of the regions after the bitmap rows
     uint32_t debug;
     uint64_t *trace;  // diagnostics: per-block phase timestamps (100 MHz), or nullptr
 };
 
-// LDS carve-up: [rows * 128 : bitmap rows][2 * 8 KiB : sorted cpu, mem][16 waves * 64 * 16 B : records]
-//                [16 * 64 * 8 B : label rows 5..8][16 * 64 * 8 B : taint rows]
+// LDS carve-up: [rows * 128 : bitmap rows][aux block: 2 search trees + 2 cnt tables (FIT)]
+//               per wave x 64 pods: [16 B fit record (FIT)][16 B label rows 1..8 (SEL)][8 B taint rows (TAINT)]
 inline uint32_t fused_lds_bytes(const IndexedLayout &l, bool fit, bool sel, bool taint, FusedArgs *a = nullptr) {
     uint32_t off = l.rows * 128u;
-    const uint32_t off_sorted = off;
-    if (fit) off += 2u * kTileNodes * 8u;
-    const uint32_t off_rec = off;
-    off += kFusedWaves * 64u * 16u;
-    const uint32_t off_rec2 = off;
-    if (sel) off += kFusedWaves * 64u * 8u;
+    const uint32_t off_aux = off;
+    if (fit) off += kAuxWords * 8u;
+    const uint32_t off_fit = off;
+    if (fit) off += kFusedWaves * 64u * 16u;
+    const uint32_t off_lab = off;
+    if (sel) off += kFusedWaves * 64u * 16u;
     const uint32_t off_trow = off;
     if (taint) off += kFusedWaves * 64u * 8u;
     if (a) {
-        a->off_sorted = off_sorted;
-        a->off_rec = off_rec;
-        a->off_rec2 = off_rec2;
+        a->off_aux = off_aux;
+        a->off_fit = off_fit;
+        a->off_lab = off_lab;
         a->off_trow = off_trow;
     }
     return off;
@@ -94,11 +99,11 @@ inline uint32_t fused_lds_bytes(const IndexedLayout &l, bool fit, bool sel, bool
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 
-template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool WIDE>
+template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT>
 __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
-    const uint64_t *__restrict__ g_tables, const int64_t *__restrict__ g_sorted_cpu, const int64_t *__restrict__ g_sorted_mem,
-    const int64_t *__restrict__ g_pcpu, const int64_t *__restrict__ g_pmem, const uint32_t *__restrict__ g_psel,
-    const uint64_t *__restrict__ g_ptol, uint64_t *__restrict__ out_feas, uint64_t *__restrict__ out_fit, const FusedArgs a) {
+    const uint64_t *__restrict__ g_tables, const uint64_t *__restrict__ g_aux, const int64_t *__restrict__ g_pcpu,
+    const int64_t *__restrict__ g_pmem, const uint32_t *__restrict__ g_psel, const uint64_t *__restrict__ g_ptol,
+    uint64_t *__restrict__ out_feas, uint64_t *__restrict__ out_fit, const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t b = blockIdx.x;
     // (chunk, tile) pairs in chunk-major order are dealt to the XCDs in contiguous runs: XCD x = block id % 8
@@ -176,63 +181,79 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                  : "+v"(rc), "+v"(rm), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7), "+v"(tol)  \
                  : "n"(N)                                                                                                             \
                  : "memory")
-    const int64_t *s_cpu = reinterpret_cast<const int64_t *>(smem + a.off_sorted);
-    const int64_t *s_mem = s_cpu + kTileNodes;
-    uint4 *s_rec = reinterpret_cast<uint4 *>(smem + a.off_rec) + wave * 64u;
-    uint2 *s_rec2 = reinterpret_cast<uint2 *>(smem + a.off_rec2) + wave * 64u;  // label rows 5..8 of a pod (selector keys 5..8)
-    uint2 *s_trow = reinterpret_cast<uint2 *>(smem + a.off_trow) + wave * 64u;  // four taint rows per pod
+    // aux block of the tile: [tree cpu 1024][tree mem 1024][cnt cpu kCntEntries][cnt mem kCntEntries] (8-byte words)
+    const int64_t *s_cpu = reinterpret_cast<const int64_t *>(smem + a.off_aux);
+    const int64_t *s_mem = s_cpu + kAuxTreeWords;
+    const uint2 *s_cnt_cpu = reinterpret_cast<const uint2 *>(s_cpu + 2u * kAuxTreeWords);
+    const uint2 *s_cnt_mem = s_cnt_cpu + kCntEntries;
+    // per-wave records of the current round (one entry per pod of the round)
+    // (row "offsets" are LDS byte offsets of chunk 0 of the row: row * 128; the rows a record can name sit below 64 KiB)
+    uint4 *s_fit = reinterpret_cast<uint4 *>(smem + a.off_fit) + wave * 64u;   // cnt[rank]: 8 bytes of cpu (x, y), 8 of memory (z, w)
+    uint4 *s_lab = reinterpret_cast<uint4 *>(smem + a.off_lab) + wave * 64u;   // row offsets of the pod's constrained keys 1..8 (8 x 16 bit)
+    uint2 *s_trow = reinterpret_cast<uint2 *>(smem + a.off_trow) + wave * 64u;  // four taint row offsets per pod
 
-    const uint32_t wp = lane & 7u, sub = lane >> 3;
+    // phase-2 lane layout (file header): quad q = (lane & 31) >> 2 -> pod 0,2,2,0,3,1,1,3 of the half, chunk base
+    // 0,0,4,4,0,0,4,4; `sub` = pod of the 8-pod step, `wp` = chunk (sub-tile) of the row
+    const uint32_t quad = (lane & 31u) >> 2;
+    const uint32_t wp = ((0xCCu >> quad) & 1u) * 4u + (lane & 3u);
+    const uint32_t sub = (lane >> 5) * 4u + ((0x31130220u >> (4u * quad)) & 15u);
     const uint32_t w0 = tile * kTileWords + 2u * wp;  // first mask word of this lane in phase 2
     // a lane may store 16 bytes when both words lie inside the row pitch (words in [W, pitch) are padding)
     const bool has0 = w0 < a.pitch, has1 = w0 + 1u < a.pitch;
     const bool tile_full = (tile + 1u) * kTileWords <= a.pitch;  // block-uniform
     const bool taint_inline = a.ngroups <= 4u;
-    // Records hold row numbers scaled by RS: byte offsets (RS = 128; one SDWA add per address) when the
-    // table is below 64 KiB, else 16-byte units (RS = 8; extract + shift-add).
-    constexpr uint32_t RS = WIDE ? 8u : 128u;
-    const uint8_t *Tb = smem + wp * 16u;
-    auto ldrow = [&](uint32_t field) -> u32x4 { return *reinterpret_cast<const u32x4 *>(Tb + (WIDE ? field * 16u : field)); };
+    const uint8_t *Tb = smem + wp * 16u;  // this lane's chunk of row 0
+    const uint8_t *Tb_cpu = Tb + a.row_cpu * 128u;  // ... of the first fit row of cpu; memory's rows follow at a constant distance (tile_index.hpp)
+    auto ldoff = [&](uint32_t off) -> u32x4 { return *reinterpret_cast<const u32x4 *>(Tb + off); };  // off = row * 128
+    auto ldrow = [&](uint32_t row) -> u32x4 { return ldoff(row * 128u); };
     auto lo16 = [](uint32_t x) { return x & 0xFFFFu; };
     auto hi16 = [](uint32_t x) { return x >> 16; };
+    // This lane's view of the records of pod `sub` of step 0; step `it` is a constant distance further (it * 8 pods), which
+    // folds into the LDS instructions' offset fields (pointer + constant, never index arithmetic on the lane part).
+    const uint8_t *fit_lane = reinterpret_cast<const uint8_t *>(s_fit + sub) + wp;  // [0] = cnt byte of cpu, [8] = of memory (one per sub-tile)
+    const uint2 *lab_lane = reinterpret_cast<const uint2 *>(s_lab + sub);           // [0] = row offsets of keys 1..4, [1] = keys 5..8
+    const uint2 *trow_lane = s_trow + sub;
 
     // Row loads of one pod-row of phase 2 (issued together, consumed later: two iterations are
-    // interleaved by hand so that ~20 LDS reads are in flight per wave).
+    // interleaved by hand so that many LDS reads are in flight per wave).
     struct Rows {
-        u32x4 c0, c1, c2, m0, m1, m2, l0, l1, l2, l3, t0, t1, t2, t3, x0, x1, x2, x3;
+        u32x4 c0, m0, l0, l1, l2, l3, t0, t1, t2, t3, x0, x1, x2, x3;
     };
     auto load_extra = [&](const uint2 r2, Rows &R) {  // label rows 5..8 (rounds where some pod constrains more than four keys)
-        R.x0 = ldrow(lo16(r2.x));
-        R.x1 = ldrow(hi16(r2.x));
-        R.x2 = ldrow(lo16(r2.y));
-        R.x3 = ldrow(hi16(r2.y));
+        R.x0 = ldoff(lo16(r2.x));
+        R.x1 = ldoff(hi16(r2.x));
+        R.x2 = ldoff(lo16(r2.y));
+        R.x3 = ldoff(hi16(r2.y));
     };
-    auto load_rows = [&](const uint4 r, const uint2 tr, Rows &R) {
+    // cc, cm: this lane's cnt bytes (the row {lr >= cnt[rank][wp]} of each resource); lb, tr: record halves
+    auto load_rows = [&](const uint32_t cc, const uint32_t cm, const uint2 lb, const uint2 tr, Rows &R) {
         if (FIT) {
-            R.c0 = ldrow(lo16(r.x));
-            R.c1 = ldrow(lo16(r.x) + RS);
-            R.c2 = ldrow(hi16(r.x));
-            R.m0 = ldrow(lo16(r.y));
-            R.m1 = ldrow(lo16(r.y) + RS);
-            R.m2 = ldrow(hi16(r.y));
+            R.c0 = *reinterpret_cast<const u32x4 *>(Tb_cpu + cc * 128u);
+            R.m0 = *reinterpret_cast<const u32x4 *>(Tb_cpu + cm * 128u + (uint32_t)kFitRows * 128u);  // the distance folds into the read's offset field
         } else {
-            R.c0 = ldrow(a.row_valid * RS);
+            R.c0 = ldrow(a.row_valid);
         }
         if (SEL) {
-            R.l0 = ldrow(lo16(r.z));
-            R.l1 = ldrow(hi16(r.z));
-            R.l2 = ldrow(lo16(r.w));
-            R.l3 = ldrow(hi16(r.w));
+            R.l0 = ldoff(lo16(lb.x));
+            R.l1 = ldoff(hi16(lb.x));
+            R.l2 = ldoff(lo16(lb.y));
+            R.l3 = ldoff(hi16(lb.y));
         }
         if (TAINT) {
-            R.t0 = ldrow(lo16(tr.x));
-            R.t1 = ldrow(hi16(tr.x));
-            R.t2 = ldrow(lo16(tr.y));
-            R.t3 = ldrow(hi16(tr.y));
+            R.t0 = ldoff(lo16(tr.x));
+            R.t1 = ldoff(hi16(tr.x));
+            R.t2 = ldoff(lo16(tr.y));
+            R.t3 = ldoff(hi16(tr.y));
         }
     };
+    // records of pod row `it * 8 + sub` of the round, as this lane needs them
+    auto rec_cc = [&](uint32_t it) -> uint32_t { return FIT ? (uint32_t)(fit_lane + it * 128u)[0] : 0u; };
+    auto rec_cm = [&](uint32_t it) -> uint32_t { return FIT ? (uint32_t)(fit_lane + it * 128u)[8] : 0u; };
+    auto rec_lb = [&](uint32_t it) -> uint2 { return SEL ? (lab_lane + it * 16u)[0] : make_uint2(0u, 0u); };
+    auto rec_lx = [&](uint32_t it) -> uint2 { return (lab_lane + it * 16u)[1]; };
+    auto rec_tr = [&](uint32_t it) -> uint2 { return TAINT ? (trow_lane + it * 8u)[0] : make_uint2(0u, 0u); };
     auto fit_of = [&](const Rows &R) -> u32x4 {
-        if (FIT) return (R.c0 & (R.c1 | R.c2)) & (R.m0 & (R.m1 | R.m2));  // pos >= rank, both resources
+        if (FIT) return R.c0 & R.m0;  // pos >= rank, both resources
         return R.c0;
     };
     // The asm forms are opaque to the compiler's hazard recognizer: a VALU write of the data registers right after a
@@ -249,29 +270,52 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(dst + o), "v"(f) : "memory");
 #elif KSCHED_STORE_POLICY == 5
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(dst + o), "v"(f) : "memory");
-#elif KSCHED_STORE_POLICY == 6
-        asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(dst + o), "v"(f) : "memory");
 #else
         *reinterpret_cast<u32x4_a8 *>(dst + o) = f;
 #endif
     };
-    auto combine_store = [&](uint32_t pod, const Rows &R, bool extra) {
-        const size_t o = (size_t)pod * a.pitch + w0;
+    // Unchecked stores of a round: wave-uniform base of the step's first pod row (SGPR pair, scalar arithmetic) + this
+    // lane's constant 32-bit byte offset: no per-lane address arithmetic at all (it was a 64-bit multiply-add per store).
+    const uint32_t lane_off = (sub * a.pitch + w0) * 8u;  // of pod `sub` within a step
+    const uint32_t step_bytes = a.pitch * 64u;            // 8 pod rows
+    auto store_rel = [&](uint64_t base, uint32_t voff, const u32x4 f) {
+#if KSCHED_STORE_POLICY == 2
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(f), "s"(base) : "memory");
+#elif KSCHED_STORE_POLICY == 3
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(f), "s"(base) : "memory");
+#elif KSCHED_STORE_POLICY == 4
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(voff), "v"(f), "s"(base) : "memory");
+#elif KSCHED_STORE_POLICY == 5
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt\n\ts_nop 1" ::"v"(voff), "v"(f), "s"(base) : "memory");
+#elif KSCHED_STORE_POLICY == 1
+        __builtin_nontemporal_store(f, reinterpret_cast<u32x4_a8 *>(reinterpret_cast<uint8_t *>(base) + voff));
+#else
+        *reinterpret_cast<u32x4_a8 *>(reinterpret_cast<uint8_t *>(base) + voff) = f;
+#endif
+    };
+    auto uniform64 = [](uint64_t x) -> uint64_t {  // provably wave-uniform (an SGPR pair for the asm operand)
+        // (the builtin returns a signed int: widen through uint32_t, or the low half sign-extends into the high one)
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)), lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+        return ((uint64_t)hi << 32) | (uint64_t)lo;
+    };
+    uint64_t rb_feas = 0, rb_fit = 0;  // bases of the round in flight (set at the top of phase 2)
+    auto combine_store = [&](uint32_t it, const Rows &R, bool extra) {  // pod row `it * 8 + sub` of the round
+        const uint64_t step = (uint64_t)it * step_bytes;  // scalar: the step moves the SGPR base, the lane offset stays put
         u32x4 f = fit_of(R);
-        if (WANT_FIT) store16(out_fit, o, f);
+        if (WANT_FIT) store_rel(rb_fit + step, lane_off, f);
         if (SEL) f = ((f & R.l0) & R.l1) & (R.l2 & R.l3);
         if (SEL && extra) f = ((f & R.x0) & R.x1) & (R.x2 & R.x3);
         if (TAINT) f = ((f & R.t0) & R.t1) & (R.t2 & R.t3);
-        store16(out_feas, o, f);  // out_feas is never null here (the API supplies a scratch mask when the caller gives none)
+        store_rel(rb_feas + step, lane_off, f);  // out_feas is never null here (the API supplies a scratch mask when the caller gives none)
     };
 
     // Checked form of one pod-row: end-of-range / partial-tile predicates and the overflow walks
     // (more than eight constrained keys, more than four taint groups).  Rare, not unrolled.
-    auto emit_checked = [&](uint32_t pod, const uint4 r, const uint2 r2, const uint2 tr, bool over) {
+    auto emit_checked = [&](uint32_t pod, uint32_t it, bool over) {
         const bool live = pod < a.p && has0;
         Rows R;
-        load_rows(r, tr, R);
-        if (SEL) load_extra(r2, R);
+        load_rows(rec_cc(it), rec_cm(it), rec_lb(it), rec_tr(it), R);
+        if (SEL) load_extra(rec_lx(it), R);
         u32x4 f = fit_of(R);
         const size_t o = (size_t)pod * a.pitch + w0;
         auto store = [&](uint64_t *dst) {
@@ -286,7 +330,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             } else if (live) {  // more than eight constrained keys: walk every key of this pod
                 for (uint32_t k = 0; k < a.nkeys; ++k) {
                     const uint32_t s = g_psel[(size_t)k * a.p + pod];
-                    if (s != 0u) f &= ldrow(((s <= a.lab_meta[32u + k]) ? (a.lab_meta[k] + s - 1u) : a.row_zero) * RS);
+                    if (s != 0u) f &= ldrow((s <= a.lab_meta[32u + k]) ? (a.lab_meta[k] + s - 1u) : a.row_zero);
                 }
             }
         }
@@ -295,7 +339,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                 f = ((f & R.t0) & R.t1) & (R.t2 & R.t3);
             } else if (live) {
                 const uint64_t t = g_ptol ? g_ptol[pod] : 0ull;
-                for (uint32_t g = 0; g < a.ngroups; ++g) f &= ldrow((a.row_taint + 16u * g + (uint32_t)((t >> (4u * g)) & 15ull)) * RS);
+                for (uint32_t g = 0; g < a.ngroups; ++g) f &= ldrow(a.row_taint + 16u * g + (uint32_t)((t >> (4u * g)) & 15ull));
             }
         }
         if (live && out_feas && !(a.debug & 1u)) store(out_feas);
@@ -304,8 +348,6 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     // ---- phase 1: lane = pod pod0 + lane (branch-free); returns the overflow ballot ---------------
     bool extra_any = false;
     auto phase1 = [&](uint32_t pod0) -> uint64_t {
-        uint4 rec;
-        rec.x = rec.y = 0;
         if (FIT) {
             // r = #sorted values < req: two interleaved descents of the tile's implicit search trees.  The sorted
             // arrays are stored in breadth-first (Eytzinger) order (tile_index.hpp): the candidates of one level are
@@ -325,37 +367,39 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                 lc += (lc == (uint32_t)kTileNodes - 1u && s_cpu[0] < rc) ? 1u : 0u;  // slot 0 holds sorted[1023]: 1023 -> 1024
                 lm += (lm == (uint32_t)kTileNodes - 1u && s_mem[0] < rm) ? 1u : 0u;
             }
-            rec.x = ((a.row_cpu_hi + (lc >> 5)) * RS) | (((a.row_cpu_lo + (lc & 31u)) * RS) << 16);
-            rec.y = ((a.row_mem_hi + (lm >> 5)) * RS) | (((a.row_mem_lo + (lm & 31u)) * RS) << 16);
+            // cnt[rank]: for each sub-tile, how many of its nodes sit below the request = the row {lr >= cnt} to read
+            const uint2 cc = s_cnt_cpu[lc], cm = s_cnt_mem[lm];
+            s_fit[lane] = make_uint4(cc.x, cc.y, cm.x, cm.y);
         }
-        const uint32_t rv = a.row_valid * RS;
-        uint32_t lr[8] = {rv, rv, rv, rv, rv, rv, rv, rv};
+        const uint32_t rv = a.row_valid * 128u;  // offsets, not row numbers, from here on
         uint32_t cnt = 0;
         if (SEL) {
+            // The record starts as eight times the all-valid row; the pod's j-th constrained key then overwrites slot j
+            // with one 2-byte LDS store (LDS operations of a wave execute in order), instead of a register compaction
+            // that costs a select per (key, slot) pair.
+            const uint32_t rv2 = rv | (rv << 16);
+            s_lab[lane] = make_uint4(rv2, rv2, rv2, rv2);
+            uint16_t *slots = reinterpret_cast<uint16_t *>(s_lab + lane);
             const uint32_t sv[8] = {s0, s1, s2, s3, s4, s5, s6, s7};
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k) {
                 const uint32_t s = (k < a.nkeys) ? sv[k] : 0u;
-                const bool on = s != 0u;
-                const uint32_t row = ((s <= a.lab_max[k]) ? (a.lab_base[k] + s - 1u) : a.row_zero) * RS;
-#pragma unroll
-                for (uint32_t j = 0; j <= k; ++j) lr[j] = (on && cnt == j) ? row : lr[j];  // the (cnt+1)-th constrained key goes to slot cnt
-                cnt += on ? 1u : 0u;
+                if (s != 0u) {
+                    // value id s of key k -> its row; ids without a row (KSCHED_SEL_NEVER, unknown) -> the all-zero row
+                    slots[cnt] = (uint16_t)((s <= a.lab_max[k]) ? (a.lab_base[k] + s - 1u) * 128u : a.row_zero * 128u);
+                    ++cnt;
+                }
             }
             if (a.nkeys > 8u) {  // keys 9.. : any constraint there sends the pod down the overflow walk
                 const uint32_t pc = min(pod0 + lane, a.p - 1u);
                 for (uint32_t k = 8; k < a.nkeys; ++k) cnt += (g_psel[(size_t)k * a.p + pc] != 0u) ? 9u : 0u;
             }
-            s_rec2[lane] = make_uint2(lr[4] | (lr[5] << 16), lr[6] | (lr[7] << 16));
         }
-        rec.z = lr[0] | (lr[1] << 16);
-        rec.w = lr[2] | (lr[3] << 16);
-        s_rec[lane] = rec;
         if (TAINT) {
             uint32_t t[4];
 #pragma unroll
             for (uint32_t g = 0; g < 4; ++g)
-                t[g] = (g < a.ngroups) ? (a.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * RS : rv;
+                t[g] = (g < a.ngroups) ? (a.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * 128u : rv;
             s_trow[lane] = make_uint2(t[0] | (t[1] << 16), t[2] | (t[3] << 16));
         }
         extra_any = __ballot(cnt > 4u) != 0ull;  // some pod of the round needs label rows 5..8
@@ -380,41 +424,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         if (more) issue_ops(u * 8u + lane);
         if ((a.debug & 128u) && have_prev && !stamped4) stamp(1);  // experiment: after the 2nd round's operand loads were issued
         if (first) {
-#if KSCHED_SPLIT_STAGE
-            // Stage the tile global -> LDS without a VGPR round trip (global_load_lds_dwordx4: per-lane global address,
-            // LDS destination = M0 + lane*16), in two steps so that the first round's rank searches overlap the
-            // landing of the bitmap rows: (1) the two search trees (16 KiB), wait, barrier; (2) the bitmap rows are
-            // issued and left in flight -- phase 1 only reads the trees; the rows are awaited (vmcnt(0) + barrier)
-            // right after the first phase 1, before any phase 2.  The DMA is inline asm: the compiler's own
-            // LDS-DMA tracking would drain it (vmcnt(0)) at the first LDS read.
-            auto stage = [&](const void *gsrc, uint32_t lds_off, uint32_t bytes) {
-                const uint8_t *g = static_cast<const uint8_t *>(gsrc);
-                for (uint32_t off = wave * 1024u; off < bytes; off += kFusedWaves * 1024u) {
-                    const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
-                        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)(smem + lds_off + off));
-                    if (off + lane * 16u < bytes) {
-                        uint32_t keep;
-                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep)
-                                     : "v"(g + off + lane * 16u), "s"(lds_dst)
-                                     : "memory");
-                    }
-                }
-            };
-            if (FIT) {
-                stage(g_sorted_cpu + (size_t)tile * kTileNodes, a.off_sorted, kTileNodes * 8u);
-                stage(g_sorted_mem + (size_t)tile * kTileNodes, a.off_sorted + kTileNodes * 8u, kTileNodes * 8u);
-            }
-            if (!(a.debug & 128u)) stamp(1);
-            // Drains this wave's tree DMAs AND its first operand loads (issued earlier).  Needed even without FIT: the
-            // counted wait below assumes that only stores are younger than the operand loads; in the first trip the row
-            // DMAs are, so the operands must have landed before those are issued.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (FIT) __syncthreads();
-            if (!(a.debug & 128u)) stamp(2);
-            if (!(a.debug & 8u)) stage(g_tables + (size_t)tile * a.rows * kTileWords, 0u, a.rows * 128u);
-#else
-            // stage the tile: bitmap rows + sorted arrays, global -> LDS without a VGPR round trip
+            // stage the tile: bitmap rows + aux block, global -> LDS without a VGPR round trip
             // (global_load_lds_dwordx4: per-lane global address, LDS destination = wave-uniform base + lane*16)
             auto stage = [&](const void *gsrc, uint32_t lds_off, uint32_t bytes) {
                 const uint8_t *g = static_cast<const uint8_t *>(gsrc);
@@ -424,58 +434,76 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                                                          (__attribute__((address_space(3))) void *)(smem + lds_off + off), 16, 0, 0);
                 }
             };
+            if (FIT) stage(g_aux + (size_t)tile * kAuxWords, a.off_aux, kAuxWords * 8u);  // needed first (phase 1)
             if (!(a.debug & 8u)) stage(g_tables + (size_t)tile * a.rows * kTileWords, 0u, a.rows * 128u);
-            if (FIT) {
-                stage(g_sorted_cpu + (size_t)tile * kTileNodes, a.off_sorted, kTileNodes * 8u);
-                stage(g_sorted_mem + (size_t)tile * kTileNodes, a.off_sorted + kTileNodes * 8u, kTileNodes * 8u);
-            }
             if (!(a.debug & 128u)) stamp(1);
             __syncthreads();
             if (!(a.debug & 128u)) stamp(2);
-#endif
         }
         if (have_prev) {
             // ============ phase 2 of the previous round: 8 lanes per pod, 2 words per lane ===========
             const uint32_t pod0 = prev_u * 8u;
+            rb_feas = uniform64(reinterpret_cast<uint64_t>(out_feas + (size_t)pod0 * a.pitch));
+            if (WANT_FIT) rb_fit = uniform64(reinterpret_cast<uint64_t>(out_fit + (size_t)pod0 * a.pitch));
             // A short round (prev_nu < 8) is always the wave's last one: no operand loads are in flight behind
             // it, so the counted wait does not depend on how many stores it issues.
             const bool fast = (prev_nu == 8u || !more) && prev_over == 0ull && pod0 + prev_nu * 8u <= a.p && tile_full &&
                               (!TAINT || taint_inline) && !(a.debug & 16u);
             if (fast && prev_nu == 8u) {
-                // STEP pod rows per step (two when the row registers allow: ~20 LDS reads in flight per
-                // wave); the records of the next step are fetched while this step's rows are combined.
-                constexpr uint32_t STEP = TAINT ? 1u : 2u;
-                uint4 rn[STEP];
-                uint2 tn[STEP];
+                // STEP pod rows per step; the records of the next step are fetched while this step's rows are combined.
+                constexpr uint32_t STEP = TAINT ? 1u : 2u;  // as many as the row registers allow (no spills: tools/audit_asm.py)
+                uint32_t cn[STEP], mn[STEP];
+                uint2 ln[STEP], tn[STEP];
 #pragma unroll
                 for (uint32_t j = 0; j < STEP; ++j) {
-                    rn[j] = s_rec[j * 8u + sub];
-                    tn[j] = TAINT ? s_trow[j * 8u + sub] : make_uint2(0u, 0u);
+                    cn[j] = rec_cc(j);
+                    mn[j] = rec_cm(j);
+                    ln[j] = rec_lb(j);
+                    tn[j] = rec_tr(j);
                 }
                 if (SEL && prev_extra) {  // wave-uniform: some pod constrains 5..8 keys, all pods read eight label rows
 #pragma unroll
                     for (uint32_t it = 0; it < 8; ++it) {
+                        // in two halves (rows 5..8 are loaded after the first ten have been combined): bounds the live
+                        // row registers of the widest instantiation below the 128-VGPR budget of a 1024-thread block
                         Rows A;
-                        const uint4 r = s_rec[it * 8u + sub];
-                        load_rows(r, TAINT ? s_trow[it * 8u + sub] : make_uint2(0u, 0u), A);
-                        load_extra(s_rec2[it * 8u + sub], A);
-                        combine_store(pod0 + it * 8u + sub, A, true);
+                        const uint64_t step = (uint64_t)it * step_bytes;
+                        load_rows(rec_cc(it), rec_cm(it), rec_lb(it), rec_tr(it), A);
+                        u32x4 f = fit_of(A);
+                        if (WANT_FIT) store_rel(rb_fit + step, lane_off, f);
+                        f = ((f & A.l0) & A.l1) & (A.l2 & A.l3);
+                        if (TAINT) f = ((f & A.t0) & A.t1) & (A.t2 & A.t3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_extra(rec_lx(it), A);
+                        f = ((f & A.x0) & A.x1) & (A.x2 & A.x3);
+                        store_rel(rb_feas + step, lane_off, f);
                     }
                 } else {
 #pragma unroll
                     for (uint32_t it = 0; it < 8; it += STEP) {
                         Rows R[STEP];
 #pragma unroll
-                        for (uint32_t j = 0; j < STEP; ++j) load_rows(rn[j], tn[j], R[j]);
-                        if (it + STEP < 8u) {
+                        for (uint32_t j = 0; j < STEP; ++j) load_rows(cn[j], mn[j], ln[j], tn[j], R[j]);
+                        if (!TAINT && it + STEP < 8u) {  // the next step's records, fetched ahead of this step's combine
 #pragma unroll
                             for (uint32_t j = 0; j < STEP; ++j) {
-                                rn[j] = s_rec[(it + STEP + j) * 8u + sub];
-                                tn[j] = TAINT ? s_trow[(it + STEP + j) * 8u + sub] : make_uint2(0u, 0u);
+                                cn[j] = rec_cc(it + STEP + j);
+                                mn[j] = rec_cm(it + STEP + j);
+                                ln[j] = rec_lb(it + STEP + j);
+                                tn[j] = rec_tr(it + STEP + j);
                             }
                         }
 #pragma unroll
-                        for (uint32_t j = 0; j < STEP; ++j) combine_store(pod0 + (it + j) * 8u + sub, R[j], false);
+                        for (uint32_t j = 0; j < STEP; ++j) combine_store(it + j, R[j], false);
+                        if (TAINT && it + STEP < 8u) {  // (with taint rows the registers do not allow the early fetch)
+#pragma unroll
+                            for (uint32_t j = 0; j < STEP; ++j) {
+                                cn[j] = rec_cc(it + STEP + j);
+                                mn[j] = rec_cm(it + STEP + j);
+                                ln[j] = rec_lb(it + STEP + j);
+                                tn[j] = rec_tr(it + STEP + j);
+                            }
+                        }
                     }
                 }
             } else if (fast) {
@@ -483,17 +511,16 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
 #pragma unroll 1
                 for (uint32_t it = 0; it < prev_nu; ++it) {
                     Rows A;
-                    load_rows(s_rec[it * 8u + sub], TAINT ? s_trow[it * 8u + sub] : make_uint2(0u, 0u), A);
-                    if (SEL) load_extra(s_rec2[it * 8u + sub], A);
-                    combine_store(pod0 + it * 8u + sub, A, true);
+                    load_rows(rec_cc(it), rec_cm(it), rec_lb(it), rec_tr(it), A);
+                    if (SEL) load_extra(rec_lx(it), A);
+                    combine_store(it, A, true);
                 }
             } else {
                 if (!(a.debug & 16u)) {
 #pragma unroll 1
                     for (uint32_t it = 0; it < prev_nu; ++it) {
                         const uint32_t pl = it * 8u + sub;
-                        emit_checked(pod0 + pl, s_rec[pl], SEL ? s_rec2[pl] : make_uint2(0u, 0u), TAINT ? s_trow[pl] : make_uint2(0u, 0u),
-                                     (prev_over >> pl) & 1ull);
+                        emit_checked(pod0 + pl, it, (prev_over >> pl) & 1ull);
                     }
                 }
                 // an unknown number of stores (and overflow-walk loads) went out: drain, so that the
@@ -505,29 +532,17 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        const bool had_more = more;
-        if (more) {
-#if KSCHED_STAGGER
-            if (first && wave >= kFusedWaves / 2u) __builtin_amdgcn_s_sleep(KSCHED_STAGGER);
-#endif
-            KSCHED_WAIT_OPS(kFastStores);  // operands of round u have landed; up to kFastStores younger stores may be in flight
-            prev_over = phase1(u * 8u);
-            prev_extra = extra_any;
-            if (!have_prev) stamp(3);
-            prev_u = u;
-            prev_nu = min(8u, u_hi - u);
-            have_prev = true;
-            u += 8u;
-            more = u < u_hi;
-        }
-#if KSCHED_SPLIT_STAGE
-        if (first) {  // every wave's first trip (block-uniform): the bitmap rows have landed before any phase 2 reads them
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no operand loads of the next round are in flight yet
-            __syncthreads();
-        }
-#endif
         first = false;
-        if (!had_more) break;
+        if (!more) break;
+        KSCHED_WAIT_OPS(kFastStores);  // operands of round u have landed; up to kFastStores younger stores may be in flight
+        prev_over = phase1(u * 8u);
+        prev_extra = extra_any;
+        if (!have_prev) stamp(3);
+        prev_u = u;
+        prev_nu = min(8u, u_hi - u);
+        have_prev = true;
+        u += 8u;
+        more = u < u_hi;
     }
 #undef KSCHED_WAIT_OPS
     if (a.trace && lane == 0) {  // every wave: latest loop end / drain of the block
@@ -554,25 +569,24 @@ struct FusedLaunch {
     hipEvent_t ev_start, ev_stop;  // optional: attached to the dispatch itself (exact kernel duration)
 };
 
-template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool WIDE>
+template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT>
 inline hipError_t launch_fused_k(const FusedLaunch &q, const FusedArgs &a) {
-    auto kern = k_eval_fused<FIT, SEL, TAINT, WANT_FIT, WIDE>;
+    auto kern = k_eval_fused<FIT, SEL, TAINT, WANT_FIT>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds);
     if (e != hipSuccess) return e;
     const IndexedSnapshot &s = *q.snap;
     if (q.ev_start || q.ev_stop)
-        hipExtLaunchKernelGGL(kern, q.grid, dim3(kFusedThreads), q.lds, q.stream, q.ev_start, q.ev_stop, 0, s.d_tables, s.d_sorted_cpu,
-                              s.d_sorted_mem, q.pcpu, q.pmem, q.psel, q.ptol, q.out_feas, q.out_fit, a);
+        hipExtLaunchKernelGGL(kern, q.grid, dim3(kFusedThreads), q.lds, q.stream, q.ev_start, q.ev_stop, 0, s.d_tables, s.d_aux, q.pcpu,
+                              q.pmem, q.psel, q.ptol, q.out_feas, q.out_fit, a);
     else
-        hipLaunchKernelGGL(kern, q.grid, dim3(kFusedThreads), q.lds, q.stream, s.d_tables, s.d_sorted_cpu, s.d_sorted_mem, q.pcpu, q.pmem,
-                           q.psel, q.ptol, q.out_feas, q.out_fit, a);
+        hipLaunchKernelGGL(kern, q.grid, dim3(kFusedThreads), q.lds, q.stream, s.d_tables, s.d_aux, q.pcpu, q.pmem, q.psel, q.ptol,
+                           q.out_feas, q.out_fit, a);
     return hipGetLastError();
 }
 
 template <bool FIT, bool SEL, bool TAINT>
-inline hipError_t launch_fused_t(bool want_fit, bool wide, const FusedLaunch &q, const FusedArgs &a) {
-    if (want_fit) return wide ? launch_fused_k<FIT, SEL, TAINT, true, true>(q, a) : launch_fused_k<FIT, SEL, TAINT, true, false>(q, a);
-    return wide ? launch_fused_k<FIT, SEL, TAINT, false, true>(q, a) : launch_fused_k<FIT, SEL, TAINT, false, false>(q, a);
+inline hipError_t launch_fused_t(bool want_fit, const FusedLaunch &q, const FusedArgs &a) {
+    return want_fit ? launch_fused_k<FIT, SEL, TAINT, true>(q, a) : launch_fused_k<FIT, SEL, TAINT, false>(q, a);
 }
 
 inline bool fused_applicable(const IndexedSnapshot &s, uint32_t flags) {
@@ -595,10 +609,8 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     a.ngroups = l.ngroups;
     a.row_zero = l.row_zero;
     a.row_valid = l.row_valid;
-    a.row_cpu_hi = l.row_cpu_hi;
-    a.row_cpu_lo = l.row_cpu_lo;
-    a.row_mem_hi = l.row_mem_hi;
-    a.row_mem_lo = l.row_mem_lo;
+    a.row_cpu = l.row_cpu;
+    a.row_mem = l.row_mem;
     a.row_taint = l.row_taint;
     for (int k = 0; k < 8; ++k) {
         a.lab_base[k] = l.lab_base[k];
@@ -629,9 +641,8 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     a.trace = (trace && grid.x <= trace_blocks) ? trace : nullptr;
     const bool want_fit = (flags & KSCHED_WANT_FIT_MASK) && out_fit;
     const int sel = do_sel ? 1 : 0, tnt = do_taint ? 1 : 0, fit = do_fit ? 1 : 0;
-    const bool wide = l.rows * 128u > 65536u - 128u;  // row byte offsets no longer fit 16 bits
     const FusedLaunch q{grid, lds, stream, &s, pcpu, pmem, psel, ptol, out_feas, out_fit, ev_start, ev_stop};
-#define KSCHED_FUSED_CASE(F, S, T) return launch_fused_t<F, S, T>(want_fit, wide, q, a)
+#define KSCHED_FUSED_CASE(F, S, T) return launch_fused_t<F, S, T>(want_fit, q, a)
     switch (fit * 4 + sel * 2 + tnt) {
         case 0: KSCHED_FUSED_CASE(false, false, false);
         case 1: KSCHED_FUSED_CASE(false, false, true);

@@ -6,16 +6,21 @@
 // order of magnitude under the HBM write roofline.  Here every predicate is turned into an AND
 // of precomputed node bitmaps, so one VALU op decides 32 (pod, node) pairs per lane.
 //
-// Per tile of kTileNodes = 1024 nodes = 16 mask words:
+// Per tile of kTileNodes = 1024 nodes = 16 mask words; a tile is 8 sub-tiles of 128 nodes (one
+// 16-byte chunk of a row = what one lane of the kernel's phase 2 owns):
 //   * fit   -- src/predicates.rs:42  req <= avail.  Sort the tile's avail values; node n gets its
 //              position pos[n] in that order (ties broken by node index, so pos is a
 //              permutation).  For a pod, r = #values < req (lower bound; descent of the tile's
-//              breadth-first search tree in LDS);
-//              then  req <= avail[n]  <=>  pos[n] >= r, exactly, for any int64 inputs.
-//              pos >= r is evaluated two-level, pos = 32*hi + lo, r = 32*rh + rl:
-//                  pos >= r  <=>  hi > rh  ||  (hi == rh && lo >= rl)
-//                            <=>  GEH[rh] & (GEH[rh+1] | GEL[rl])          (GEH[h] = {n: hi >= h})
-//              3 bitmap rows per resource instead of 1025 rows for a one-level table.
+//              breadth-first search tree in LDS); then
+//                  req <= avail[n]  <=>  pos[n] >= r,            exactly, for any int64 inputs.
+//              pos >= r is decided per sub-tile with ONE bitmap read per resource:
+//                  cnt[r][s] = #{nodes of sub-tile s with pos < r}          (a byte, 0..128)
+//                  lr[n]     = #{nodes of n's sub-tile with pos < pos[n]}   (n's local rank)
+//                  pos[n] >= r  <=>  lr[n] >= cnt[r][sub-tile of n]
+//              because the nodes of a sub-tile with pos < r are exactly its cnt[r][s] lowest-ranked
+//              ones.  Row c (0..128) of the resource's block of the table is {n : lr[n] >= c}; the
+//              lane owning sub-tile s reads chunk s of row cnt[r][s].  cnt is a table of 1025
+//              8-byte entries per resource (one byte per sub-tile), read once per pod and tile.
 //   * sel   -- src/predicates.rs:45-61.  One bitmap row per (key, value id): nodes carrying that
 //              value.  A pod ANDs the rows of the keys it constrains; unconstrained keys read the
 //              all-valid row; KSCHED_SEL_NEVER / unknown ids hit the all-zero row.
@@ -39,16 +44,24 @@ namespace ksched {
 
 constexpr int kTileWords = 16;
 constexpr int kTileNodes = kTileWords * 64;  // 1024
-constexpr int kFitHi = 34;                   // GEH[0..33] (GEH[32], GEH[33] are zero rows)
-constexpr int kFitLo = 32;                   // GEL[0..31]
+constexpr int kSubNodes = 128;               // nodes per sub-tile = bits per 16-byte chunk
+constexpr int kSubTiles = kTileNodes / kSubNodes;  // 8
+constexpr int kFitRows = kSubNodes + 1;      // rows {lr >= c}, c = 0..128, per resource
+constexpr int kCntEntries = kTileNodes + 2;  // cnt[r], r = 0..1024, padded to a multiple of 16 bytes
 constexpr int kIdxMaxKeys = 32;
 constexpr int kIdxMaxGroups = 16;            // 64 taint bits / 4
 constexpr uint32_t kLdsBudget = 160u * 1024u;
+// per-tile "aux" block (global image = LDS image): [tree cpu][tree mem][cnt cpu][cnt mem], 8-byte words
+constexpr uint32_t kAuxTreeWords = kTileNodes;
+constexpr uint32_t kAuxWords = 2u * kAuxTreeWords + 2u * kCntEntries;  // 4100 words = 32800 bytes
+// LDS the kernel needs besides the bitmap rows: the aux block and up to 40 bytes of per-pod records for
+// 16 waves x 64 pods (kernels_fused.hpp: fused_lds_bytes)
+constexpr uint32_t kLdsNonRowBytesMax = kAuxWords * 8u + 1024u * 40u;
 
 struct IndexedLayout {
     uint32_t n, W, tiles, rows, nkeys, ngroups;
     uint32_t row_zero, row_valid;
-    uint32_t row_cpu_hi, row_cpu_lo, row_mem_hi, row_mem_lo;
+    uint32_t row_cpu, row_mem;          // first of the kFitRows rows {lr >= c} of each resource
     uint32_t row_taint;                 // + 16 * group + subset
     uint32_t lab_base[kIdxMaxKeys];     // row of value id 1 of key k
     uint32_t lab_max[kIdxMaxKeys];      // largest id with a row
@@ -57,19 +70,16 @@ struct IndexedLayout {
 struct IndexedSnapshot {
     bool built = false;
     IndexedLayout lay{};
-    int64_t *d_sorted_cpu = nullptr;  // [tiles][1024] search trees (eytzinger_from_sorted), padded with INT64_MAX
-    int64_t *d_sorted_mem = nullptr;
     uint64_t *d_tables = nullptr;     // [tiles][rows][16]
+    uint64_t *d_aux = nullptr;        // [tiles][kAuxWords]: search trees (eytzinger_from_sorted, padded with INT64_MAX) + cnt tables
     uint32_t *d_lab_meta = nullptr;   // lab_base[32], lab_max[32], then 8 zero words
-    size_t sorted_cap = 0, tables_cap = 0;
-    // host images of the three device arrays, kept so that ksched_update_nodes can rebuild the fit part of single tiles
-    std::vector<uint64_t> h_tables;
-    std::vector<int64_t> h_sorted_cpu, h_sorted_mem;
+    size_t aux_cap = 0, tables_cap = 0;
+    // host images of the device arrays, kept so that ksched_update_nodes can rebuild the fit part of single tiles
+    std::vector<uint64_t> h_tables, h_aux;
 };
 
 inline void indexed_release(IndexedSnapshot &s) {
-    if (s.d_sorted_cpu) (void)hipFree(s.d_sorted_cpu);
-    if (s.d_sorted_mem) (void)hipFree(s.d_sorted_mem);
+    if (s.d_aux) (void)hipFree(s.d_aux);
     if (s.d_tables) (void)hipFree(s.d_tables);
     if (s.d_lab_meta) (void)hipFree(s.d_lab_meta);
     s = IndexedSnapshot{};  // also drops the host images
@@ -86,32 +96,41 @@ inline void eytzinger_from_sorted(const int64_t *sorted, int64_t *tree) {
     for (uint32_t level = 0; level < 10; ++level)
         for (uint32_t j = 0; j < (1u << level); ++j) tree[(1u << level) + j] = sorted[((2u * j + 1u) << (9u - level)) - 1u];
 }
-// Fit part of one tile: the rows GEH/GEL of both resources and the two search trees, from the tile's current
-// `available` values (src/predicates.rs:27-38).  Rewrites those rows from scratch (they are contiguous:
-// [row_cpu_hi, row_cpu_hi + 2 * (kFitHi + kFitLo))), so it serves both the full build and ksched_update_nodes.
-inline void index_tile_fit(const IndexedLayout &l, uint32_t t, const int64_t *cpu, const int64_t *mem, uint64_t *T, int64_t *tree_cpu,
-                           int64_t *tree_mem) {
+
+// Fit part of one tile: the rows {lr >= c} of both resources, the two search trees and the two cnt tables, from the
+// tile's current `available` values (src/predicates.rs:27-38).  Rewrites them from scratch (the rows are contiguous:
+// [row_cpu, row_cpu + 2 * kFitRows)), so it serves both the full build and ksched_update_nodes.
+//   T   : the tile's rows  [rows][16]
+//   aux : the tile's aux block [kAuxWords]
+inline void index_tile_fit(const IndexedLayout &l, uint32_t t, const int64_t *cpu, const int64_t *mem, uint64_t *T, uint64_t *aux) {
     const uint32_t base = t * kTileNodes;
     const uint32_t m = std::min<uint32_t>(kTileNodes, l.n - base);
-    std::fill(T + (size_t)l.row_cpu_hi * kTileWords, T + (size_t)(l.row_cpu_hi + 2 * (kFitHi + kFitLo)) * kTileWords, 0ull);
+    std::fill(T + (size_t)l.row_cpu * kTileWords, T + (size_t)(l.row_cpu + 2 * kFitRows) * kTileWords, 0ull);
     auto setbit = [&](uint32_t row, uint32_t local) { T[(size_t)row * kTileWords + (local >> 6)] |= 1ull << (local & 63u); };
     uint32_t ord[kTileNodes];
     int64_t sorted[kTileNodes];
     for (int res = 0; res < 2; ++res) {
         const int64_t *v = res == 0 ? cpu : mem;
-        const uint32_t row_hi = res == 0 ? l.row_cpu_hi : l.row_mem_hi;
-        const uint32_t row_lo = res == 0 ? l.row_cpu_lo : l.row_mem_lo;
+        const uint32_t row0 = res == 0 ? l.row_cpu : l.row_mem;
+        int64_t *tree = reinterpret_cast<int64_t *>(aux) + (size_t)res * kAuxTreeWords;
+        uint64_t *cnt = aux + 2u * kAuxTreeWords + (size_t)res * kCntEntries;
         std::fill(sorted, sorted + kTileNodes, INT64_MAX);
         std::iota(ord, ord + m, 0u);
         std::stable_sort(ord, ord + m, [&](uint32_t a, uint32_t b) { return v[base + a] < v[base + b]; });
+        // walk the nodes in position order: `seen[s]` = nodes of sub-tile s met so far = the local rank of the next one,
+        // and, packed one byte per sub-tile, exactly cnt[pos]
+        uint64_t packed = 0;  // byte s = seen[s]; a count of 128 needs the whole byte, never more
+        uint32_t seen[kSubTiles] = {};
         for (uint32_t pos = 0; pos < m; ++pos) {
-            const uint32_t local = ord[pos];
+            cnt[pos] = packed;
+            const uint32_t local = ord[pos], s = local / kSubNodes;
             sorted[pos] = v[base + local];
-            const uint32_t hi = pos >> 5, lo = pos & 31u;
-            for (uint32_t h = 0; h <= hi; ++h) setbit(row_hi + h, local);  // GEH[h] = {hi >= h}
-            for (uint32_t q = 0; q <= lo; ++q) setbit(row_lo + q, local);  // GEL[q] = {lo >= q}
+            const uint32_t lr = seen[s]++;
+            for (uint32_t c = 0; c <= lr; ++c) setbit(row0 + c, local);  // rows {lr >= c}
+            packed += 1ull << (8u * s);
         }
-        eytzinger_from_sorted(sorted, res == 0 ? tree_cpu : tree_mem);
+        for (uint32_t r = m; r < (uint32_t)kCntEntries; ++r) cnt[r] = packed;  // r = m..1024: every node is below the request
+        eytzinger_from_sorted(sorted, tree);
     }
 }
 
@@ -132,13 +151,11 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
         for (uint32_t i = 0; i < n; ++i) all_taints |= taints[i];
     l.ngroups = all_taints ? (uint32_t)((64 - __builtin_clzll(all_taints)) + 3) / 4 : 0;
 
+    // Row order: [zero, valid, taint rows, label rows, fit rows of cpu, fit rows of memory].  The rows a pod names by
+    // record (labels, taints, valid, zero) come first so that their BYTE offsets fit 16 bits (kernels_fused.hpp).
     uint32_t r = 0;
     l.row_zero = r++;
     l.row_valid = r++;
-    l.row_cpu_hi = r; r += kFitHi;
-    l.row_cpu_lo = r; r += kFitLo;
-    l.row_mem_hi = r; r += kFitHi;
-    l.row_mem_lo = r; r += kFitLo;
     l.row_taint = r; r += 16 * l.ngroups;
     uint64_t label_rows = 0;
     for (uint32_t k = 0; k < nkeys; ++k) {
@@ -147,25 +164,26 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
         l.lab_max[k] = mx;
         label_rows += mx;
     }
-    // all rows of a tile must fit in LDS and row ids must fit 16 bits (0xFFFF is a sentinel)
-    if (r + label_rows > 1280) return hipSuccess;
+    // all rows of a tile must fit in LDS next to the aux block and the per-pod records, and the named rows below 64 KiB
+    if ((r + label_rows + 2u * kFitRows) * 128u + kLdsNonRowBytesMax > kLdsBudget || (r + label_rows) * 128u > 65536u) return hipSuccess;
     for (uint32_t k = 0; k < nkeys; ++k) {
         l.lab_base[k] = r;
         r += l.lab_max[k];
     }
+    l.row_cpu = r; r += kFitRows;
+    l.row_mem = r; r += kFitRows;
     l.rows = r;
-    if (indexed_lds_bytes(l) > kLdsBudget) return hipSuccess;
 
     const size_t tile_words = (size_t)l.rows * kTileWords;
     std::vector<uint64_t> tab((size_t)l.tiles * tile_words, 0ull);
-    std::vector<int64_t> scpu((size_t)l.tiles * kTileNodes, INT64_MAX), smem((size_t)l.tiles * kTileNodes, INT64_MAX);
+    std::vector<uint64_t> aux((size_t)l.tiles * kAuxWords, 0ull);
     for (uint32_t t = 0; t < l.tiles; ++t) {
         const uint32_t base = t * kTileNodes;
         const uint32_t m = std::min<uint32_t>(kTileNodes, n - base);
         uint64_t *T = tab.data() + (size_t)t * tile_words;
         auto setbit = [&](uint32_t row, uint32_t local) { T[(size_t)row * kTileWords + (local >> 6)] |= 1ull << (local & 63u); };
         for (uint32_t i = 0; i < m; ++i) setbit(l.row_valid, i);
-        index_tile_fit(l, t, cpu, mem, T, scpu.data() + (size_t)t * kTileNodes, smem.data() + (size_t)t * kTileNodes);
+        index_tile_fit(l, t, cpu, mem, T, aux.data() + (size_t)t * kAuxWords);
         // labels
         for (uint32_t k = 0; k < nkeys; ++k)
             for (uint32_t i = 0; i < m; ++i) {
@@ -181,15 +199,12 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
             }
     }
     hipError_t e;
-    const size_t sorted_elems = (size_t)l.tiles * kTileNodes;
-    if (sorted_elems > s.sorted_cap) {
-        if (s.d_sorted_cpu) (void)hipFree(s.d_sorted_cpu);
-        if (s.d_sorted_mem) (void)hipFree(s.d_sorted_mem);
-        s.d_sorted_cpu = s.d_sorted_mem = nullptr;
-        s.sorted_cap = 0;
-        if ((e = hipMalloc((void **)&s.d_sorted_cpu, sorted_elems * 8)) != hipSuccess) return e;
-        if ((e = hipMalloc((void **)&s.d_sorted_mem, sorted_elems * 8)) != hipSuccess) return e;
-        s.sorted_cap = sorted_elems;
+    if (aux.size() > s.aux_cap) {
+        if (s.d_aux) (void)hipFree(s.d_aux);
+        s.d_aux = nullptr;
+        s.aux_cap = 0;
+        if ((e = hipMalloc((void **)&s.d_aux, aux.size() * 8)) != hipSuccess) return e;
+        s.aux_cap = aux.size();
     }
     if (tab.size() > s.tables_cap) {
         if (s.d_tables) (void)hipFree(s.d_tables);
@@ -198,8 +213,7 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
         if ((e = hipMalloc((void **)&s.d_tables, tab.size() * 8)) != hipSuccess) return e;
         s.tables_cap = tab.size();
     }
-    if ((e = hipMemcpy(s.d_sorted_cpu, scpu.data(), sorted_elems * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMemcpy(s.d_sorted_mem, smem.data(), sorted_elems * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMemcpy(s.d_aux, aux.data(), aux.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(s.d_tables, tab.data(), tab.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if (!s.d_lab_meta && (e = hipMalloc((void **)&s.d_lab_meta, 72 * sizeof(uint32_t))) != hipSuccess) return e;
     {
@@ -211,26 +225,24 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
         if ((e = hipMemcpy(s.d_lab_meta, meta, sizeof meta, hipMemcpyHostToDevice)) != hipSuccess) return e;
     }
     s.h_tables = std::move(tab);
-    s.h_sorted_cpu = std::move(scpu);
-    s.h_sorted_mem = std::move(smem);
+    s.h_aux = std::move(aux);
     s.lay = l;
     s.built = true;
     return hipSuccess;
 }
 
-// ksched_update_nodes: `available` changed on some nodes of tile t -> rebuild that tile's fit rows and search
-// trees on the host image and re-upload just those (label and taint rows are untouched).
+// ksched_update_nodes: `available` changed on some nodes of tile t -> rebuild that tile's fit rows, search trees and
+// cnt tables on the host image and re-upload just those (label and taint rows are untouched).
 inline hipError_t indexed_update_tile(IndexedSnapshot &s, uint32_t t, const int64_t *cpu, const int64_t *mem) {
     const IndexedLayout &l = s.lay;
     const size_t tile_words = (size_t)l.rows * kTileWords;
     uint64_t *T = s.h_tables.data() + (size_t)t * tile_words;
-    int64_t *tc = s.h_sorted_cpu.data() + (size_t)t * kTileNodes, *tm = s.h_sorted_mem.data() + (size_t)t * kTileNodes;
-    index_tile_fit(l, t, cpu, mem, T, tc, tm);
+    uint64_t *aux = s.h_aux.data() + (size_t)t * kAuxWords;
+    index_tile_fit(l, t, cpu, mem, T, aux);
     hipError_t e;
-    const size_t fit_off = (size_t)l.row_cpu_hi * kTileWords, fit_words = (size_t)2 * (kFitHi + kFitLo) * kTileWords;
+    const size_t fit_off = (size_t)l.row_cpu * kTileWords, fit_words = (size_t)2 * kFitRows * kTileWords;
     if ((e = hipMemcpy(s.d_tables + (size_t)t * tile_words + fit_off, T + fit_off, fit_words * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMemcpy(s.d_sorted_cpu + (size_t)t * kTileNodes, tc, kTileNodes * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    return hipMemcpy(s.d_sorted_mem + (size_t)t * kTileNodes, tm, kTileNodes * 8, hipMemcpyHostToDevice);
+    return hipMemcpy(s.d_aux + (size_t)t * kAuxWords, aux, (size_t)kAuxWords * 8, hipMemcpyHostToDevice);
 }
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));

@@ -97,12 +97,15 @@ def audit_kernel(name: str, lines: list[str], meta: dict) -> list[str]:
     # reads are only allowed in the basic blocks that follow the counted wait up to the next load.
     first_load = min(i for i, _ in loads)
     wait_i = counted[0][0]
+    # everything before the header of the loop that holds the load site runs once, before any operand load exists:
+    # a register written there is simply reused later as a load destination
+    hdr = max((i for i, ln in enumerate(lines[:first_load]) if "Loop Header: Depth=1" in ln), default=0)
     for i, ln in enumerate(lines):
         t = ln.split(";")[0].strip()
         if not t or t.startswith(".") or t.endswith(":") or t.startswith("s_") or t.startswith("global_load_dword") and any(i == li for li, _ in loads):
             continue
         ops = t.split(None, 1)
-        if len(ops) < 2:
+        if len(ops) < 2 or i < hdr:
             continue
         used = regs_of(ops[1]) & dest
         if not used:
