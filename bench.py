@@ -112,13 +112,16 @@ def main():
     ap.add_argument("--packed", action="store_true",
                     help="mask rows packed at W words (default: rows pitched to ksched_mask_pitch(n) = W rounded up to 128 B)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (timing experiments; results invalid)")
+    ap.add_argument("--depth", type=int, default=1,
+                    help="steps in flight: the mask kernel of step i+1 overlaps the pick kernel and the all-gather of step i on separate "
+                         "HIP streams (double-buffered masks and bindings); 1 = strictly sequential steps on one stream")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
     from kube_scheduler_rs_reference_amd import Evaluator, _lib as L, synth
-    from kube_scheduler_rs_reference_amd.dist import ShardedScheduler
+    from kube_scheduler_rs_reference_amd.dist import PipelinedScheduler, ShardedScheduler
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -149,7 +152,8 @@ def main():
     if args.debug:
         ev.set_option(L.OPT_DEBUG, args.debug)
     ev.set_nodes(**c.node_columns())
-    sched = ShardedScheduler(P_total, dev)
+    pipelined = args.depth > 1 and not args.no_mask
+    sched = PipelinedScheduler(P_total, dev, depth=args.depth) if pipelined else ShardedScheduler(P_total, dev)
     lo, hi = sched.lo, sched.hi
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
     d_cpu, d_mem = t(c.req_cpu[lo:hi], np.int64), t(c.req_mem[lo:hi], np.int64)
@@ -157,11 +161,24 @@ def main():
     d_tol = t(c.pod_tol[lo:hi], np.int64) if taint else None
     d_smp = t(c.samples[lo:hi], np.int32) if pick == "sampled" else None
     W = ev.W
-    d_mask = None if args.no_mask else ev.alloc_mask(hi - lo, pitched=not args.packed)
+    n_masks = args.depth if pipelined else 1
+    d_masks = [None if args.no_mask else ev.alloc_mask(hi - lo, pitched=not args.packed) for _ in range(n_masks)]
+    d_mask = d_masks[0]
     pitch = int(d_mask.stride(0)) if d_mask is not None else W
+    pred_flags = flags & ~(L.PICK_SAMPLED | L.PICK_BESTFIT)
+    pick_flags = (flags & (L.PICK_SAMPLED | L.PICK_BESTFIT)) | (flags & L.FIT)
 
-    def local_eval(binding_out):
+    def local_eval(binding_out):  # sequential form: mask kernel + pick kernel on one stream, one library call
         ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=d_mask, out_binding=binding_out)
+
+    def mask_fn(slot):  # pipelined form: the same two kernels through two library calls on two streams
+        ev.eval_device(d_cpu, d_mem, d_sel, d_tol, None, pred_flags, out_feasible=d_masks[slot])
+
+    def pick_fn(slot, binding_out):
+        ev.pick_device(d_masks[slot], pick_flags, binding_out, req_mem_bytes=d_mem, samples=d_smp)
+
+    def one_step():
+        return sched.step(mask_fn, pick_fn) if pipelined else sched.step(local_eval)
 
     def sync():
         if world > 1:
@@ -169,15 +186,18 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        sched.step(local_eval)
+        last = one_step()
     sync()
     ev.set_timing(True)
     ev.kernel_time_ms()  # reset
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        bindings = sched.step(local_eval)
+        last = one_step()
+    if pipelined:
+        sched.drain()
     sync()
     elapsed = time.perf_counter() - t0
+    bindings = last.wait() if pipelined else last
     kern_ms, launches = ev.kernel_time_ms()
     ev.set_timing(False)
     if world > 1:
@@ -209,7 +229,8 @@ def main():
             "config": {"workload": desc, "pods_per_gpu": P_gpu, "pods_total": P_total, "nodes": N,
                        "predicates": "+".join(flag_names), "pick": pick, "mask_written": not args.no_mask,
                        "mask_row_pitch_words": pitch, "mask_words": W,
-                       "kernel": ev.last_kernel, "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
+                       "kernel": ev.last_kernel, "steps_in_flight": args.depth if pipelined else 1,
+                       "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
                        "allgather(int32 bindings)" if world > 1 else "single GPU",
                        "bound_fraction": bound_frac},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -13,7 +13,7 @@
  *   can_pod_fit            src/predicates.rs:20-43       KSCHED_FIT   bit of ksched_eval*
  *   does_node_selector_match  src/predicates.rs:45-61    KSCHED_SEL   bit of ksched_eval*
  *   check_node_validity    src/predicates.rs:63-77       feasible = fit AND sel (+ fit mask for the reason)
- *   select_node_for_pod    src/main.rs:49-71             KSCHED_PICK_SAMPLED (injected sample indices)
+ *   select_node_for_pod    src/main.rs:49-71             KSCHED_PICK_SAMPLED (injected sample indices), ksched_pick_device
  *   (extension E1, BASELINE.json config 5)               KSCHED_PICK_BESTFIT
  *   (extension E2, BASELINE.json config 5)               KSCHED_TAINT
  *
@@ -171,6 +171,18 @@ int ksched_eval_device_pitched(ksched_ctx *ctx, uint32_t p, const int64_t *req_c
                                uint32_t attempts, uint32_t flags, uint64_t *out_feasible, uint64_t *out_fit,
                                int32_t *out_binding, uint32_t mask_pitch_words, void *hip_stream);
 uint32_t ksched_mask_pitch(uint32_t n_nodes);
+
+/* The pick alone, from a feasibility mask already on the device (a previous ksched_eval_device* call): lets a caller
+ * run the mask kernel of batch i + 1 and the pick of batch i on different HIP streams (the two do not depend on each
+ * other; the mask of batch i must stay untouched until its pick has run).
+ *   flags        : exactly one of KSCHED_PICK_SAMPLED (select_node_for_pod, src/main.rs:51-71: `samples`, `attempts`)
+ *                  and KSCHED_PICK_BESTFIT (extension E1); KSCHED_FIT tells the best-fit pick that the mask includes
+ *                  the resource fit (then `req_mem_bytes` [p] is read to skip candidates that cannot fit)
+ *   feasible     : [p] rows, mask_pitch_words apart, as written by ksched_eval_device_pitched
+ * Results are identical to requesting the pick in the ksched_eval_device* call that produced the mask. */
+int ksched_pick_device(ksched_ctx *ctx, uint32_t p, const uint64_t *feasible, uint32_t mask_pitch_words,
+                       const int64_t *req_mem_bytes, const uint32_t *samples, uint32_t attempts, uint32_t flags,
+                       int32_t *out_binding, void *hip_stream);
 
 /* ---- reasons ------------------------------------------------------------------------------
  * Host helper: rebuild check_node_validity's result for one pair from the two masks, in the

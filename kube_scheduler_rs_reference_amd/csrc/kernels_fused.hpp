@@ -55,6 +55,11 @@
 #ifndef KSCHED_FUSED_THREADS
 #define KSCHED_FUSED_THREADS 1024
 #endif
+//   KSCHED_PROFILE       1 = diagnostics build (tools/trace_fused.py --profile): wave 0 of every block accumulates the core
+//                        cycles it spends in phase 2, in the operand wait and in phase 1, and leaves them in trace words 1..4
+#ifndef KSCHED_PROFILE
+#define KSCHED_PROFILE 0
+#endif
 
 namespace ksched {
 
@@ -65,7 +70,8 @@ constexpr uint32_t kFusedWaves = kFusedThreads / 64;
 struct FusedArgs {
     uint32_t W, pitch, tiles, rows, nkeys, ngroups;
     uint32_t row_zero, row_valid, row_cpu, row_mem, row_taint;
-    uint32_t lab_base[8], lab_max[8];  // first eight label keys; further keys go through lab_meta
+    uint32_t lab_off[8], lab_mx1[8];   // first eight label keys: byte offset of the row before id 1's, and lab_max + 1 (the id
+                                       // of the key's all-zero row); further keys go through lab_meta
     const uint32_t *lab_meta;          // device copy of IndexedLayout::lab_base[32], lab_max[32]
     const uint64_t *zero64;            // eight zero bytes in device memory
     uint32_t p, units, chunks, run;    // units = ceil(p / 8); run = (chunk, tile) pairs per XCD
@@ -156,8 +162,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rm) : "v"(g_pmem + pc) : "memory");
         }
         if (SEL) {
-            const uint32_t kl = a.nkeys - 1u;
-#define KSCHED_LOAD_SEL(K, DST) asm volatile("global_load_dword %0, %1, off" : "=v"(DST) : "v"(g_psel + (size_t)min((uint32_t)K, kl) * a.p + pc) : "memory")
+            // columns the snapshot does not have (K >= nkeys) read the zero word: "unconstrained" without a mask later
+#define KSCHED_LOAD_SEL(K, DST)                                                                                                   \
+    asm volatile("global_load_dword %0, %1, off"                                                                                  \
+                 : "=v"(DST)                                                                                                      \
+                 : "v"((uint32_t)K < a.nkeys ? g_psel + (size_t)K * a.p + pc : reinterpret_cast<const uint32_t *>(a.zero64)) \
+                 : "memory")
             KSCHED_LOAD_SEL(0, s0);
             KSCHED_LOAD_SEL(1, s1);
             KSCHED_LOAD_SEL(2, s2);
@@ -379,17 +389,18 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             // that costs a select per (key, slot) pair.
             const uint32_t rv2 = rv | (rv << 16);
             s_lab[lane] = make_uint4(rv2, rv2, rv2, rv2);
-            uint16_t *slots = reinterpret_cast<uint16_t *>(s_lab + lane);
+            uint16_t *const slots = reinterpret_cast<uint16_t *>(s_lab + lane);
+            uint16_t *slot = slots;  // next free slot of this pod's record
             const uint32_t sv[8] = {s0, s1, s2, s3, s4, s5, s6, s7};
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k) {
-                const uint32_t s = (k < a.nkeys) ? sv[k] : 0u;
+                const uint32_t s = sv[k];
                 if (s != 0u) {
-                    // value id s of key k -> its row; ids without a row (KSCHED_SEL_NEVER, unknown) -> the all-zero row
-                    slots[cnt] = (uint16_t)((s <= a.lab_max[k]) ? (a.lab_base[k] + s - 1u) * 128u : a.row_zero * 128u);
-                    ++cnt;
+                    // value id s of key k -> its row; ids no node carries (KSCHED_SEL_NEVER, unknown) clamp to the key's all-zero row
+                    *slot++ = (uint16_t)(min(s, a.lab_mx1[k]) * 128u + a.lab_off[k]);
                 }
             }
+            cnt = (uint32_t)(slot - slots);
             if (a.nkeys > 8u) {  // keys 9.. : any constraint there sends the pod down the overflow walk
                 const uint32_t pc = min(pod0 + lane, a.p - 1u);
                 for (uint32_t k = 8; k < a.nkeys; ++k) cnt += (g_psel[(size_t)k * a.p + pc] != 0u) ? 9u : 0u;
@@ -420,6 +431,19 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     uint32_t prev_u = 0, prev_nu = 0;
     uint64_t prev_over = 0;
     bool prev_extra = false;
+#if KSCHED_PROFILE
+    uint64_t prof_p2 = 0, prof_wait = 0, prof_p1 = 0, prof_rounds = 0, prof_t = 0;
+#define KSCHED_PROF(ACC)                                       \
+    do {                                                       \
+        const uint64_t now_ = __builtin_readcyclecounter();    \
+        ACC += now_ - prof_t;                                  \
+        prof_t = now_;                                         \
+    } while (0)
+#else
+#define KSCHED_PROF(ACC) \
+    do {                 \
+    } while (0)
+#endif
     while (true) {
         if (more) issue_ops(u * 8u + lane);
         if ((a.debug & 128u) && have_prev && !stamped4) stamp(1);  // experiment: after the 2nd round's operand loads were issued
@@ -442,6 +466,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         }
         if (have_prev) {
             // ============ phase 2 of the previous round: 8 lanes per pod, 2 words per lane ===========
+#if KSCHED_PROFILE
+            prof_t = __builtin_readcyclecounter();
+#endif
             const uint32_t pod0 = prev_u * 8u;
             rb_feas = uniform64(reinterpret_cast<uint64_t>(out_feas + (size_t)pod0 * a.pitch));
             if (WANT_FIT) rb_fit = uniform64(reinterpret_cast<uint64_t>(out_fit + (size_t)pod0 * a.pitch));
@@ -531,11 +558,18 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             stamped4 = true;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            KSCHED_PROF(prof_p2);
         }
         first = false;
         if (!more) break;
+#if KSCHED_PROFILE
+        prof_t = __builtin_readcyclecounter();
+        ++prof_rounds;
+#endif
         KSCHED_WAIT_OPS(kFastStores);  // operands of round u have landed; up to kFastStores younger stores may be in flight
+        KSCHED_PROF(prof_wait);
         prev_over = phase1(u * 8u);
+        KSCHED_PROF(prof_p1);
         prev_extra = extra_any;
         if (!have_prev) stamp(3);
         prev_u = u;
@@ -550,6 +584,15 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         __builtin_amdgcn_s_waitcnt(0);  // all counters to zero: this wave's stores have been acknowledged
         atomicMax((unsigned long long *)&a.trace[(size_t)b * 8u + 6u], (unsigned long long)wall_clock64());
     }
+#if KSCHED_PROFILE
+    if (tracer) {
+        a.trace[(size_t)b * 8u + 1u] = prof_p2;
+        a.trace[(size_t)b * 8u + 2u] = prof_wait;
+        a.trace[(size_t)b * 8u + 3u] = prof_p1;
+        a.trace[(size_t)b * 8u + 4u] = prof_rounds;
+    }
+#endif
+#undef KSCHED_PROF
     if (tracer) {
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -613,8 +656,8 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     a.row_mem = l.row_mem;
     a.row_taint = l.row_taint;
     for (int k = 0; k < 8; ++k) {
-        a.lab_base[k] = l.lab_base[k];
-        a.lab_max[k] = l.lab_max[k];
+        a.lab_off[k] = (l.lab_base[k] - 1u) * 128u;  // id s -> row lab_base + s - 1 (ids start at 1; keys without rows never match s != 0 below nkeys)
+        a.lab_mx1[k] = l.lab_max[k] + 1u;
     }
     a.lab_meta = s.d_lab_meta;
     a.zero64 = reinterpret_cast<const uint64_t *>(s.d_lab_meta + 64);

@@ -235,6 +235,20 @@ int run_direct(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pm
     return KSCHED_OK;
 }
 
+// the pick of select_node_for_pod (src/main.rs:51-71) / the best-fit extension, from a feasibility mask on the device
+int launch_pick(ksched_ctx *c, uint32_t p, const uint64_t *feas, uint32_t pitch, const int64_t *pmem, const uint32_t *samples,
+                uint32_t attempts, uint32_t flags, int32_t *out_binding, hipStream_t s) {
+    if (flags & KSCHED_PICK_SAMPLED) {
+        hipLaunchKernelGGL(k_pick_sampled, dim3((p + 255) / 256), dim3(256), 0, s, feas, samples, out_binding, p, c->n,
+                           pitch, attempts);
+    } else if (flags & KSCHED_PICK_BESTFIT) {
+        hipLaunchKernelGGL(k_pick_bestfit, dim3((p + 3) / 4), dim3(256), 0, s, feas, c->bf_order.ptr, c->bf_rank.ptr,
+                           c->bf_mem.ptr, pmem, out_binding, p, c->n, c->W, pitch, (flags & KSCHED_FIT) ? 1u : 0u);
+    }
+    HIPCHK(c, hipGetLastError());
+    return KSCHED_OK;
+}
+
 int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                    const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags,
                    uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, uint32_t pitch, hipStream_t s) {
@@ -289,15 +303,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     if (rc) return rc;
     if (c->opt_timing && kern != KSCHED_KERNEL_FUSED) HIPCHK(c, hipEventRecord(c->ev_pool[slot].b, s));
 
-    if (pick_s) {
-        hipLaunchKernelGGL(k_pick_sampled, dim3((p + 255) / 256), dim3(256), 0, s, feas, samples, out_binding, p, c->n,
-                           pitch, attempts);
-    } else if (pick_b) {
-        hipLaunchKernelGGL(k_pick_bestfit, dim3((p + 3) / 4), dim3(256), 0, s, feas, c->bf_order.ptr, c->bf_rank.ptr,
-                           c->bf_mem.ptr, pmem, out_binding, p, c->n, c->W, pitch, (flags & KSCHED_FIT) ? 1u : 0u);
-    }
-    HIPCHK(c, hipGetLastError());
-    return KSCHED_OK;
+    return launch_pick(c, p, feas, pitch, pmem, samples, attempts, flags, out_binding, s);
 }
 
 int check_eval_args(const ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *samples,
@@ -521,6 +527,27 @@ int ksched_eval_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int
 }
 
 uint32_t ksched_mask_pitch(uint32_t n_nodes) { return (ksched_mask_words(n_nodes) + 15u) & ~15u; }
+
+int ksched_pick_device(ksched_ctx *c, uint32_t p, const uint64_t *feasible, uint32_t mask_pitch_words, const int64_t *req_mem_bytes,
+                       const uint32_t *samples, uint32_t attempts, uint32_t flags, int32_t *out_binding, void *hip_stream) {
+    if (!c) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_nodes) return KSCHED_E_STATE;
+    const bool pick_s = flags & KSCHED_PICK_SAMPLED, pick_b = flags & KSCHED_PICK_BESTFIT;
+    if (pick_s == pick_b || (flags & ~(KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT | KSCHED_FIT | KSCHED_SEL | KSCHED_TAINT))) return KSCHED_E_INVAL;
+    if (!out_binding || (p > 0 && c->n > 0 && !feasible) || mask_pitch_words < c->W) return KSCHED_E_INVAL;
+    if (pick_s && (attempts == 0 || attempts > KSCHED_MAX_ATTEMPTS || (p > 0 && !samples))) return KSCHED_E_INVAL;
+    if (pick_b && (flags & KSCHED_FIT) && p > 0 && !req_mem_bytes) return KSCHED_E_INVAL;
+    if (p == 0) return KSCHED_OK;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (c->n == 0) {  // choose() on an empty store yields None on every attempt (src/main.rs:56,70)
+        HIPCHK(c, hipMemsetAsync(out_binding, 0xFF, (size_t)p * sizeof(int32_t), s));
+        return KSCHED_OK;
+    }
+    return launch_pick(c, p, feasible, mask_pitch_words, req_mem_bytes, samples, attempts, flags, out_binding, s);
+}
 
 int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                 const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, uint64_t *out_feas,

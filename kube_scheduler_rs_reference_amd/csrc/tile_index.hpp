@@ -22,8 +22,9 @@
 //              lane owning sub-tile s reads chunk s of row cnt[r][s].  cnt is a table of 1025
 //              8-byte entries per resource (one byte per sub-tile), read once per pod and tile.
 //   * sel   -- src/predicates.rs:45-61.  One bitmap row per (key, value id): nodes carrying that
-//              value.  A pod ANDs the rows of the keys it constrains; unconstrained keys read the
-//              all-valid row; KSCHED_SEL_NEVER / unknown ids hit the all-zero row.
+//              value, plus one all-zero row after the last id of every key.  A pod ANDs the rows of
+//              the keys it constrains; unconstrained keys read the all-valid row; ids no node
+//              carries (KSCHED_SEL_NEVER, unknown ids) clamp to the key's all-zero row.
 //   * taint -- (taints[n] & ~tol[p]) == 0.  Per 4-bit group g of taint bits and per tolerated
 //              subset s of that group: row {n : taints_g[n] subset of s}; a pod ANDs one row per
 //              group.
@@ -63,8 +64,8 @@ struct IndexedLayout {
     uint32_t row_zero, row_valid;
     uint32_t row_cpu, row_mem;          // first of the kFitRows rows {lr >= c} of each resource
     uint32_t row_taint;                 // + 16 * group + subset
-    uint32_t lab_base[kIdxMaxKeys];     // row of value id 1 of key k
-    uint32_t lab_max[kIdxMaxKeys];      // largest id with a row
+    uint32_t lab_base[kIdxMaxKeys];     // row of value id 1 of key k; row lab_base + lab_max is the key's all-zero row
+    uint32_t lab_max[kIdxMaxKeys];      // largest id some node carries
 };
 
 struct IndexedSnapshot {
@@ -162,13 +163,13 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
         uint32_t mx = 0;
         for (uint32_t i = 0; i < n; ++i) mx = std::max(mx, lab[(size_t)k * n + i]);
         l.lab_max[k] = mx;
-        label_rows += mx;
+        label_rows += mx + 1u;  // + the key's all-zero row (ids above mx clamp to it)
     }
     // all rows of a tile must fit in LDS next to the aux block and the per-pod records, and the named rows below 64 KiB
     if ((r + label_rows + 2u * kFitRows) * 128u + kLdsNonRowBytesMax > kLdsBudget || (r + label_rows) * 128u > 65536u) return hipSuccess;
     for (uint32_t k = 0; k < nkeys; ++k) {
         l.lab_base[k] = r;
-        r += l.lab_max[k];
+        r += l.lab_max[k] + 1u;
     }
     l.row_cpu = r; r += kFitRows;
     l.row_mem = r; r += kFitRows;

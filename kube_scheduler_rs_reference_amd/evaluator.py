@@ -210,6 +210,25 @@ class Evaluator:
             C.c_void_p(stream.cuda_stream))
         self._check(rc, "ksched_eval_device_pitched")
 
+    def pick_device(self, feasible, flags: int, out_binding, req_mem_bytes=None, samples=None, stream=None):
+        """The pick alone (ksched_pick_device) from a [p, W] device mask written by eval_device: torch CUDA tensors,
+        enqueued on `stream` (default: torch's current stream).  flags: PICK_SAMPLED (+ samples [p, attempts]) or
+        PICK_BESTFIT (+ FIT and req_mem_bytes when the mask includes the resource fit)."""
+        import torch
+        p, W = int(feasible.shape[0]), self.W
+        if not feasible.is_cuda or feasible.dim() != 2 or feasible.shape[1] != W or (W and feasible.stride(1) != 1):
+            raise ValueError(f"feasible must be a [p, {W}] CUDA mask with unit column stride")
+        pitch = int(feasible.stride(0)) if p > 1 else W  # a single row: any pitch >= W
+        if out_binding.dtype != torch.int32 or tuple(out_binding.shape) != (p,) or not out_binding.is_contiguous():
+            raise ValueError("out_binding must be a contiguous int32 [p] CUDA tensor")
+        attempts = int(samples.shape[1]) if (flags & L.PICK_SAMPLED and samples is not None) else 0
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        rc = self._lib.ksched_pick_device(self._h, p, ptr(feasible), pitch, ptr(req_mem_bytes), ptr(samples), attempts, flags,
+                                          ptr(out_binding), C.c_void_p(stream.cuda_stream))
+        self._check(rc, "ksched_pick_device")
+
     def alloc_mask(self, p: int, pitched: bool = True):
         """A [p, W] int64 mask tensor on this device.  pitched=True pads the row pitch to
         ksched_mask_pitch(n) words (cache-line aligned rows: the fast layout); the returned tensor

@@ -76,3 +76,67 @@ def test_shard_bounds_cover_rows_exactly_once():
                 seen += hi - lo
                 prev_hi = hi
             assert seen == P
+
+
+def _pipe_worker(rank, world, port, P, N, depth, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kube_scheduler_rs_reference_amd.dist import PipelinedScheduler
+        c = synth.make_cluster(P, N, n_keys=8, n_taints=0, seed=7)
+        sched = PipelinedScheduler(P, torch.device("cpu"), depth=depth)
+        lo, hi = sched.lo, sched.hi
+        flags = capi.FIT | capi.SEL | capi.PICK_SAMPLED
+        masks = [None] * depth
+        state = {"step": 0}
+
+        def samples_of(j):  # every step is a different batch: the draws rotate
+            return np.ascontiguousarray(np.roll(c.samples, j, axis=0))
+
+        def mask_fn(slot):  # stand-in for the device mask evaluation (test-only: the oracle)
+            masks[slot] = state["step"]
+
+        def pick_fn(slot, out):
+            j = masks[slot]
+            _, _, b = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, None, c.req_cpu[lo:hi], c.req_mem[lo:hi],
+                                        c.pod_sel[:, lo:hi], None, samples_of(j)[lo:hi], flags, want_mask=False, threads=1)
+            out.copy_(torch.from_numpy(b))
+
+        ok = True
+        pend = []
+        for j in range(steps):
+            state["step"] = j
+            pend.append((j, sched.step(mask_fn, pick_fn)))
+            if len(pend) >= depth:  # consume the oldest while newer steps are in flight: its slot is reused next
+                jj, pb = pend.pop(0)
+                got = pb.wait().clone().numpy()
+                _, _, want = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, None, c.req_cpu, c.req_mem, c.pod_sel, None,
+                                               samples_of(jj), flags, want_mask=False, threads=1)
+                ok = ok and bool(np.array_equal(got, want))
+        for jj, pb in pend:
+            got = pb.wait().clone().numpy()
+            _, _, want = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, None, c.req_cpu, c.req_mem, c.pod_sel, None,
+                                           samples_of(jj), flags, want_mask=False, threads=1)
+            ok = ok and bool(np.array_equal(got, want))
+        sched.drain()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,P,depth", [(2, 501, 2), (2, 64, 3), (3, 10, 2), (2, 1, 2)])
+def test_pipelined_allgather_matches_single_process(world, P, depth):
+    """PipelinedScheduler: `depth` steps in flight, asynchronous all-gather, slots reused -- every step's global
+    bindings equal the single-process result of THAT step's batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, P, 150, depth, 5, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -407,3 +407,70 @@ def test_update_nodes_matches_fresh_snapshot(evaluator, kernel, count):
         ev.update_nodes(np.array([c.N], np.uint32), np.zeros(1, np.int64), np.zeros(1, np.int64))
     assert e.value.code == _lib.E_INVAL
     ev.set_kernel("auto")
+
+
+@pytest.mark.parametrize("pick", [PICK_SAMPLED, PICK_BESTFIT])
+def test_pick_device_equals_fused_call(evaluator, pick):
+    """ksched_pick_device on a mask written by an earlier call == requesting the pick in that call == the oracle."""
+    import torch
+    ev = evaluator
+    c = synth.make_cluster(3000, 2600, n_keys=8, n_taints=16, seed=55)
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", ev.device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    cpu, mem, sel, tol, smp = t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.pod_tol, np.int64), t(c.samples, np.int32)
+    preds = FIT | SEL | TAINT
+    _, _, want = oracle_eval(c, preds | pick)
+    for pitched in (True, False):
+        mask = ev.alloc_mask(c.P, pitched=pitched)
+        ev.eval_device(cpu, mem, sel, tol, None, preds, out_feasible=mask)
+        b = torch.full((c.P,), -7, dtype=torch.int32, device=dev)
+        ev.pick_device(mask, pick | FIT, b, req_mem_bytes=mem, samples=smp if pick == PICK_SAMPLED else None)
+        torch.cuda.synchronize()
+        assert np.array_equal(b.cpu().numpy(), want)
+    with pytest.raises(KschedError) as e:  # both picks / no pick
+        ev.pick_device(mask, PICK_SAMPLED | PICK_BESTFIT, b, req_mem_bytes=mem, samples=smp)
+    assert e.value.code == _lib.E_INVAL
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_pipelined_steps_equal_sequential(evaluator, depth):
+    """PipelinedScheduler on the GPU: mask kernel of step i+1 on one stream, pick of step i on another, `depth`
+    slots.  Every step is a different batch (pods rotate); every step's bindings == the oracle for that batch."""
+    import torch
+    from kube_scheduler_rs_reference_amd.dist import PipelinedScheduler
+    ev = evaluator
+    c = synth.make_cluster(5000, 3000, n_keys=8, n_taints=0, seed=77)
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", ev.device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    steps = 6
+    rolled = [np.roll(np.arange(c.P), 37 * j) for j in range(steps)]
+    batches = [dict(cpu=t(c.req_cpu[r], np.int64), mem=t(c.req_mem[r], np.int64), sel=t(c.pod_sel[:, r], np.int32),
+                    smp=t(c.samples[r], np.int32)) for r in rolled]
+    torch.cuda.synchronize()
+    sched = PipelinedScheduler(c.P, dev, depth=depth)
+    masks = [ev.alloc_mask(c.P) for _ in range(depth)]
+    cur = {}
+
+    def mask_fn(slot):
+        cur[slot] = batches[state["j"]]
+        ev.eval_device(cur[slot]["cpu"], cur[slot]["mem"], cur[slot]["sel"], None, None, FIT | SEL, out_feasible=masks[slot])
+
+    def pick_fn(slot, out):
+        ev.pick_device(masks[slot], PICK_SAMPLED | FIT, out, req_mem_bytes=cur[slot]["mem"], samples=cur[slot]["smp"])
+
+    state = {"j": 0}
+    got = []
+    pend = []
+    for j in range(steps):
+        state["j"] = j
+        pend.append(sched.step(mask_fn, pick_fn))
+        if len(pend) >= depth:
+            got.append(pend.pop(0).wait().clone())
+    got += [p.wait().clone() for p in pend]
+    sched.drain()
+    torch.cuda.synchronize()
+    _, _, base = oracle_eval(c, FIT | SEL | PICK_SAMPLED)
+    for j in range(steps):
+        assert np.array_equal(got[j].cpu().numpy(), base[rolled[j]]), f"step {j}"

@@ -10,6 +10,7 @@ from bench import WORKLOADS
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="C3"); ap.add_argument("--pods", type=int, default=None)
+ap.add_argument("--profile", action="store_true", help="library built with -DKSCHED_PROFILE=1: trace words 1..4 are wave 0's cycle totals");
 ap.add_argument("--debug", type=int, default=0); ap.add_argument("--packed", action="store_true"); ap.add_argument("--nodes", type=int, default=None); ap.add_argument("--kill", type=int, default=0, help="make the last K nodes infeasible")
 a = ap.parse_args()
 cfg, P, N, flag_names, pick, desc = WORKLOADS[a.workload]
@@ -37,6 +38,17 @@ torch.cuda.synchronize()
 tr = ev.trace_read()
 live = tr[:, 0] > 0
 tr = tr[live]
+if a.profile:
+    p2, wt, p1, rounds = (tr[:, i].astype(np.float64) for i in (1, 2, 3, 4))
+    life = (tr[:, 6].astype(np.float64) - tr[:, 0].astype(np.float64)) * 0.01  # us, block entry -> drained
+    print(f"{a.workload} P={P} N={N} blocks={len(tr)}: wave 0 of every block, core cycles (s_memtime) -- medians")
+    r = np.maximum(rounds, 1)
+    print(f"  rounds per wave          {np.median(rounds):8.1f}")
+    print(f"  phase 2 / round          {np.median(p2 / r):8.0f} cycles   total {np.median(p2):9.0f}")
+    print(f"  operand wait / round     {np.median(wt / r):8.0f} cycles   total {np.median(wt):9.0f}")
+    print(f"  phase 1 / round          {np.median(p1 / r):8.0f} cycles   total {np.median(p1):9.0f}")
+    print(f"  block lifetime           {np.median(life):8.2f} us")
+    sys.exit(0)
 t0 = tr[:, 0].min()
 rel = (tr[:, :7].astype(np.int64) - np.int64(t0)) * 0.01  # us (100 MHz)
 names = ["entry", "staged_issue", "barrier", "phase1", "group0", "loop_end", "drained"]
