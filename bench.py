@@ -112,9 +112,13 @@ def main():
     ap.add_argument("--packed", action="store_true",
                     help="mask rows packed at W words (default: rows pitched to ksched_mask_pitch(n) = W rounded up to 128 B)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (timing experiments; results invalid)")
-    ap.add_argument("--depth", type=int, default=1,
-                    help="steps in flight: the mask kernel of step i+1 overlaps the pick kernel and the all-gather of step i on separate "
-                         "HIP streams (double-buffered masks and bindings); 1 = strictly sequential steps on one stream")
+    ap.add_argument("--depth", type=int, default=None,
+                    help="steps in flight (buffer slots).  Default: 1 on one GPU; 2 for N > 1, where the all-gather of step i is "
+                         "asynchronous and overlaps the kernels of step i+1 (double-buffered bindings)")
+    ap.add_argument("--two-stream", action="store_true",
+                    help="also run the mask kernel of step i+1 and the pick of step i on two HIP streams (ksched_pipe, needs --depth >= 2). "
+                         "Measured slower below ~100 us of kernel time per step (cross-stream waits cost more than the pick): "
+                         "profiles/r01_h1_ab_two_stream_pipeline.txt")
     args = ap.parse_args()
 
     import torch
@@ -152,8 +156,10 @@ def main():
     if args.debug:
         ev.set_option(L.OPT_DEBUG, args.debug)
     ev.set_nodes(**c.node_columns())
-    pipelined = args.depth > 1 and not args.no_mask
-    sched = PipelinedScheduler(P_total, dev, depth=args.depth) if pipelined else ShardedScheduler(P_total, dev)
+    depth = args.depth if args.depth else (2 if world > 1 else 1)
+    pipelined = depth > 1 and not args.no_mask
+    pipe = ev.pipe(depth) if (pipelined and args.two_stream) else None
+    sched = PipelinedScheduler(P_total, dev, depth=depth, pipe=pipe) if pipelined else ShardedScheduler(P_total, dev)
     lo, hi = sched.lo, sched.hi
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
     d_cpu, d_mem = t(c.req_cpu[lo:hi], np.int64), t(c.req_mem[lo:hi], np.int64)
@@ -161,24 +167,22 @@ def main():
     d_tol = t(c.pod_tol[lo:hi], np.int64) if taint else None
     d_smp = t(c.samples[lo:hi], np.int32) if pick == "sampled" else None
     W = ev.W
-    n_masks = args.depth if pipelined else 1
+    n_masks = depth if pipe is not None else 1
     d_masks = [None if args.no_mask else ev.alloc_mask(hi - lo, pitched=not args.packed) for _ in range(n_masks)]
     d_mask = d_masks[0]
     pitch = int(d_mask.stride(0)) if d_mask is not None else W
-    pred_flags = flags & ~(L.PICK_SAMPLED | L.PICK_BESTFIT)
-    pick_flags = (flags & (L.PICK_SAMPLED | L.PICK_BESTFIT)) | (flags & L.FIT)
 
     def local_eval(binding_out):  # sequential form: mask kernel + pick kernel on one stream, one library call
         ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=d_mask, out_binding=binding_out)
 
-    def mask_fn(slot):  # pipelined form: the same two kernels through two library calls on two streams
-        ev.eval_device(d_cpu, d_mem, d_sel, d_tol, None, pred_flags, out_feasible=d_masks[slot])
-
-    def pick_fn(slot, binding_out):
-        ev.pick_device(d_masks[slot], pick_flags, binding_out, req_mem_bytes=d_mem, samples=d_smp)
+    def run(slot, binding_out):  # pipelined form: bindings (and with --two-stream the masks) are per slot
+        if pipe is not None:  # ksched_pipe_submit puts the mask kernel and the pick on the pipe's two streams
+            pipe.submit(slot, d_cpu, d_mem, d_sel, d_tol, d_smp, flags, d_masks[slot], binding_out)
+        else:
+            ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=d_mask, out_binding=binding_out)
 
     def one_step():
-        return sched.step(mask_fn, pick_fn) if pipelined else sched.step(local_eval)
+        return sched.step(run) if pipelined else sched.step(local_eval)
 
     def sync():
         if world > 1:
@@ -229,7 +233,7 @@ def main():
             "config": {"workload": desc, "pods_per_gpu": P_gpu, "pods_total": P_total, "nodes": N,
                        "predicates": "+".join(flag_names), "pick": pick, "mask_written": not args.no_mask,
                        "mask_row_pitch_words": pitch, "mask_words": W,
-                       "kernel": ev.last_kernel, "steps_in_flight": args.depth if pipelined else 1,
+                       "kernel": ev.last_kernel, "steps_in_flight": depth if pipelined else 1, "two_stream": pipe is not None,
                        "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
                        "allgather(int32 bindings)" if world > 1 else "single GPU",
                        "bound_fraction": bound_frac},

@@ -184,6 +184,33 @@ int ksched_pick_device(ksched_ctx *ctx, uint32_t p, const uint64_t *feasible, ui
                        const int64_t *req_mem_bytes, const uint32_t *samples, uint32_t attempts, uint32_t flags,
                        int32_t *out_binding, void *hip_stream);
 
+/* ---- pipelined evaluation (throughput form) ------------------------------------------------
+ * Consecutive batches do not depend on each other, and within a batch the pick only needs the finished mask.  A
+ * ksched_pipe runs them software-pipelined on two internal HIP streams: the mask kernel of batch i + 1 on the
+ * "mask" stream while the pick of batch i (and whatever the caller enqueues behind it, e.g. the RCCL all-gather of
+ * the bindings) is still running on the "pick" stream.  `depth` slots; the caller owns the per-slot output buffers
+ * (device memory) and passes them to every submit, so the library retains nothing but streams and events.
+ *
+ *   ksched_pipe_submit(slot, ...)  enqueue one batch into `slot` (round-robin 0 .. depth-1):
+ *        mask stream : wait for the slot's previous pick -> mask kernel into `mask`
+ *        pick stream : wait for that mask kernel          -> pick into `binding`
+ *      `flags` must contain one KSCHED_PICK_* flag; predicates and pick mean what they mean in ksched_eval_device.
+ *      All input arrays are device pointers that must be complete before the call and stay untouched until the
+ *      slot's pick has run.  A caller that enqueues its own work on the pick stream behind the pick (reading
+ *      `binding`) thereby also delays the slot's next use correctly (the next pick of the slot is ordered after it).
+ *   ksched_pipe_wait(slot, stream)  make `hip_stream` wait for the slot's pick; stream == NULL blocks the host.
+ *   ksched_pipe_stream(which)       the internal hipStream_t: 0 = mask stream, 1 = pick stream.
+ * Results are identical to ksched_eval_device_pitched with the same arguments (tests/test_gpu_parity.py).
+ */
+typedef struct ksched_pipe ksched_pipe;
+int ksched_pipe_create(ksched_ctx *ctx, uint32_t depth, ksched_pipe **out);
+void ksched_pipe_destroy(ksched_pipe *pipe);
+int ksched_pipe_submit(ksched_pipe *pipe, uint32_t slot, uint32_t p, const int64_t *req_cpu_milli, const int64_t *req_mem_bytes,
+                       const uint32_t *sel_val_ids, const uint64_t *tolerations, const uint32_t *samples, uint32_t attempts,
+                       uint32_t flags, uint64_t *mask, uint32_t mask_pitch_words, int32_t *binding);
+int ksched_pipe_wait(ksched_pipe *pipe, uint32_t slot, void *hip_stream);
+void *ksched_pipe_stream(ksched_pipe *pipe, int which);
+
 /* ---- reasons ------------------------------------------------------------------------------
  * Host helper: rebuild check_node_validity's result for one pair from the two masks, in the
  * reference's order (fit first: src/predicates.rs:68-70, then selector: :72-74).

@@ -69,6 +69,11 @@ SYMBOLS = {
     "ksched_eval_device_pitched": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     "ksched_mask_pitch": (_u32, [_u32]),
     "ksched_pick_device": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp]),
+    "ksched_pipe_create": (C.c_int, [_vp, _u32, C.POINTER(_vp)]),
+    "ksched_pipe_destroy": (None, [_vp]),
+    "ksched_pipe_submit": (C.c_int, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _vp]),
+    "ksched_pipe_wait": (C.c_int, [_vp, _u32, _vp]),
+    "ksched_pipe_stream": (_vp, [_vp, C.c_int]),
     "ksched_reason": (C.c_int, [_vp, _vp, _u32, _u32]),
     "ksched_kernel_time_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "ksched_trace_read": (C.c_int, [_vp, _vp, C.c_uint32]),

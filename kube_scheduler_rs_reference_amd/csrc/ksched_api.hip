@@ -528,6 +528,93 @@ int ksched_eval_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int
 
 uint32_t ksched_mask_pitch(uint32_t n_nodes) { return (ksched_mask_words(n_nodes) + 15u) & ~15u; }
 
+struct ksched_pipe {
+    ksched_ctx *ctx = nullptr;
+    uint32_t depth = 0;
+    hipStream_t s_mask = nullptr, s_pick = nullptr;
+    std::vector<hipEvent_t> mask_done, pick_done;
+};
+
+int ksched_pipe_create(ksched_ctx *c, uint32_t depth, ksched_pipe **out) {
+    if (!c || !out || depth == 0 || depth > 16) return KSCHED_E_INVAL;
+    *out = nullptr;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    ksched_pipe *q = new (std::nothrow) ksched_pipe();
+    if (!q) return KSCHED_E_NOMEM;
+    q->ctx = c;
+    q->depth = depth;
+    bool ok = hipStreamCreateWithFlags(&q->s_mask, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&q->s_pick, hipStreamNonBlocking) == hipSuccess;
+    for (uint32_t i = 0; ok && i < 2 * depth; ++i) {
+        hipEvent_t e;
+        ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (ok) (i < depth ? q->mask_done : q->pick_done).push_back(e);
+    }
+    if (!ok) {
+        ksched_pipe_destroy(q);
+        return KSCHED_E_HIP;
+    }
+    *out = q;
+    return KSCHED_OK;
+}
+
+void ksched_pipe_destroy(ksched_pipe *q) {
+    if (!q) return;
+    {
+        DeviceGuard g(q->ctx->device);
+        if (q->s_mask) (void)hipStreamSynchronize(q->s_mask);
+        if (q->s_pick) (void)hipStreamSynchronize(q->s_pick);
+        for (auto e : q->mask_done) (void)hipEventDestroy(e);
+        for (auto e : q->pick_done) (void)hipEventDestroy(e);
+        if (q->s_mask) (void)hipStreamDestroy(q->s_mask);
+        if (q->s_pick) (void)hipStreamDestroy(q->s_pick);
+    }
+    delete q;
+}
+
+void *ksched_pipe_stream(ksched_pipe *q, int which) { return q ? (void *)(which == 0 ? q->s_mask : q->s_pick) : nullptr; }
+
+int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
+                       const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, uint64_t *mask,
+                       uint32_t mask_pitch_words, int32_t *binding) {
+    if (!q || slot >= q->depth) return KSCHED_E_INVAL;
+    ksched_ctx *c = q->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_nodes) return KSCHED_E_STATE;
+    const uint32_t pick = flags & (KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT);
+    if (!pick || (flags & KSCHED_WANT_FIT_MASK) || !mask) return KSCHED_E_INVAL;
+    int rc = check_eval_args(c, p, pcpu, pmem, samples, attempts, flags, mask, nullptr, binding);
+    if (rc) return rc;
+    if (mask_pitch_words < c->W) return KSCHED_E_INVAL;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    // mask stream: the slot's mask may be overwritten once the pick that read it has run
+    HIPCHK(c, hipStreamWaitEvent(q->s_mask, q->pick_done[slot], 0));
+    rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, nullptr, 0, flags & ~pick, mask, nullptr, nullptr, mask_pitch_words, q->s_mask);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(q->mask_done[slot], q->s_mask));
+    // pick stream: behind this slot's mask kernel (and, by stream order, behind everything the caller enqueued on the
+    // pick stream after the slot's previous pick)
+    HIPCHK(c, hipStreamWaitEvent(q->s_pick, q->mask_done[slot], 0));
+    if (p > 0) {
+        if (c->n == 0) HIPCHK(c, hipMemsetAsync(binding, 0xFF, (size_t)p * sizeof(int32_t), q->s_pick));
+        else if ((rc = launch_pick(c, p, mask, mask_pitch_words, pmem, samples, attempts, flags, binding, q->s_pick))) return rc;
+    }
+    HIPCHK(c, hipEventRecord(q->pick_done[slot], q->s_pick));
+    return KSCHED_OK;
+}
+
+int ksched_pipe_wait(ksched_pipe *q, uint32_t slot, void *hip_stream) {
+    if (!q || slot >= q->depth) return KSCHED_E_INVAL;
+    ksched_ctx *c = q->ctx;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    if (hip_stream) HIPCHK(c, hipStreamWaitEvent((hipStream_t)hip_stream, q->pick_done[slot], 0));
+    else HIPCHK(c, hipEventSynchronize(q->pick_done[slot]));
+    return KSCHED_OK;
+}
+
 int ksched_pick_device(ksched_ctx *c, uint32_t p, const uint64_t *feasible, uint32_t mask_pitch_words, const int64_t *req_mem_bytes,
                        const uint32_t *samples, uint32_t attempts, uint32_t flags, int32_t *out_binding, void *hip_stream) {
     if (!c) return KSCHED_E_INVAL;

@@ -11,10 +11,11 @@ produced them.
 callable (in the product: `Evaluator.eval_device` on this rank's GPU).
 
 `PipelinedScheduler` is the throughput form of the same thing: consecutive batches ("steps") are
-software-pipelined over two HIP streams with `depth` buffer slots -- the mask kernel of step i + 1
-runs while the pick kernel and the all-gather of step i are still in flight (they do not depend
-on each other; per slot, events order mask -> pick -> all-gather -> next use of the slot).  Every
-step's outputs are complete and identical to the sequential form.
+software-pipelined with `depth` buffer slots over the two HIP streams of a `ksched_pipe`
+(include/ksched.h) -- the mask kernel of step i + 1 runs while the pick kernel and the all-gather
+of step i are still in flight (they do not depend on each other; per slot, events and stream order
+give mask -> pick -> all-gather -> next use of the slot).  Every step's outputs are complete and
+identical to the sequential form.
 """
 from __future__ import annotations
 
@@ -73,77 +74,68 @@ class PendingBindings:
 
     def wait(self) -> torch.Tensor:
         s, k = self._s, self._slot
-        if s.world > 1:
+        if s._gather:
             if s._work[k] is not None:
                 s._work[k].wait()
             return s._gathered[k][: s.P]
-        if s._streams:
-            torch.cuda.current_stream(s.device).wait_event(s._pick_done[k])
+        if s.pipe is not None and s._used[k]:
+            s.pipe.wait(k)
         return s._local[k][: s.P]
 
 
 class PipelinedScheduler:
     """Row-sharded evaluation, pick and all-gather of consecutive batches, `depth` steps in flight.
 
-    step(mask_fn, pick_fn):
-        mask_fn(slot)                 enqueue this rank's mask evaluation into the caller's mask buffer `slot`
-        pick_fn(slot, binding_out)    enqueue the pick from that mask into binding_out[: n_local] (int32)
-    On a GPU the two run on two side streams; on the CPU (gloo tests) they run inline and only the all-gather is
-    asynchronous."""
+    step(run):  run(slot, binding_out) enqueues this rank's evaluation + pick of one batch into buffer slot `slot`,
+    filling binding_out[: n_local] (int32, -1 = no node).
+      * on a GPU, `pipe` is the evaluator's two-stream pipeline (Evaluator.pipe(depth)) and `run` calls
+        `pipe.submit(slot, ...)`: the mask kernel goes to the pipe's mask stream, the pick to its pick stream, and
+        the all-gather is enqueued (asynchronously) behind the pick on that same stream;
+      * without a pipe (CPU, gloo tests) `run` executes inline and only the all-gather is asynchronous."""
 
-    def __init__(self, P: int, device: torch.device, depth: int = 2, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, P: int, device: torch.device, depth: int = 2, group: Optional[dist.ProcessGroup] = None, pipe=None,
+                 gather_always: bool = False):
         if depth < 1:
             raise ValueError("depth >= 1")
-        self.P, self.device, self.depth, self.group = P, device, depth, group
+        if pipe is not None and pipe.depth != depth:
+            raise ValueError("pipe.depth != depth")
+        self.P, self.device, self.depth, self.group, self.pipe = P, device, depth, group, pipe
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.lo, self.hi, self.shard = shard_bounds(P, self.world, self.rank)
+        # gather_always: run the all-gather even in a one-rank group (exercises the RCCL path on a single GPU; tests)
+        self._gather = self.world > 1 or (gather_always and dist.is_initialized())
         self._local = [torch.full((self.shard,), -1, dtype=torch.int32, device=device) for _ in range(depth)]
-        self._gathered = [torch.full((self.shard * self.world,), -1, dtype=torch.int32, device=device) if self.world > 1 else None
+        self._gathered = [torch.full((self.shard * self.world,), -1, dtype=torch.int32, device=device) if self._gather else None
                           for _ in range(depth)]
         self._work = [None] * depth
-        self._streams = device.type == "cuda"
-        if self._streams:
-            self.s_mask, self.s_pick = torch.cuda.Stream(device), torch.cuda.Stream(device)
-            self._mask_done = [torch.cuda.Event() for _ in range(depth)]
-            self._pick_done = [torch.cuda.Event() for _ in range(depth)]
-            cur = torch.cuda.current_stream(device)
-            for e in self._mask_done + self._pick_done:  # "nothing pending" for the first use of every slot
-                e.record(cur)
+        self._used = [False] * depth
+        self._pick_stream = pipe.stream(1) if pipe is not None else None
         self._i = 0
 
     @property
     def n_local(self) -> int:
         return self.hi - self.lo
 
-    def step(self, mask_fn: Callable[[int], None], pick_fn: Callable[[int, torch.Tensor], None]) -> PendingBindings:
+    def step(self, run: Callable[[int, torch.Tensor], None]) -> PendingBindings:
         k = self._i % self.depth
         self._i += 1
         out = self._local[k][: self.n_local]
-        if self._streams:
-            cur = torch.cuda.current_stream(self.device)
-            self.s_mask.wait_stream(cur)                 # inputs prepared on the caller's stream
-            self.s_mask.wait_event(self._pick_done[k])   # the pick that read this slot's mask `depth` steps ago
-            with torch.cuda.stream(self.s_mask):
+        if self._pick_stream is not None and self._gather:
+            with torch.cuda.stream(self._pick_stream):
+                if self._work[k] is not None:  # the all-gather that read this slot's bindings `depth` steps ago:
+                    self._work[k].wait()       # the pick stream (hence this slot's next pick) is ordered after it
                 if self.n_local > 0:
-                    mask_fn(k)
-                self._mask_done[k].record(self.s_mask)
-            with torch.cuda.stream(self.s_pick):
-                self.s_pick.wait_event(self._mask_done[k])
-                if self._work[k] is not None:            # the all-gather that read this slot's bindings `depth` steps ago
-                    self._work[k].wait()
-                if self.n_local > 0:
-                    pick_fn(k, out)
-                self._pick_done[k].record(self.s_pick)
-                if self.world > 1:
-                    self._work[k] = dist.all_gather_into_tensor(self._gathered[k], self._local[k], group=self.group, async_op=True)
+                    run(k, out)
+                    self._used[k] = True
+                self._work[k] = dist.all_gather_into_tensor(self._gathered[k], self._local[k], group=self.group, async_op=True)
         else:
             if self._work[k] is not None:
                 self._work[k].wait()
             if self.n_local > 0:
-                mask_fn(k)
-                pick_fn(k, out)
-            if self.world > 1:
+                run(k, out)
+                self._used[k] = True
+            if self._gather:
                 self._work[k] = dist.all_gather_into_tensor(self._gathered[k], self._local[k], group=self.group, async_op=True)
         return PendingBindings(self, k)
 

@@ -229,6 +229,10 @@ class Evaluator:
                                           ptr(out_binding), C.c_void_p(stream.cuda_stream))
         self._check(rc, "ksched_pick_device")
 
+    def pipe(self, depth: int = 2) -> "Pipe":
+        """A `depth`-slot two-stream pipeline over this evaluator (ksched_pipe_*)."""
+        return Pipe(self, depth)
+
     def alloc_mask(self, p: int, pitched: bool = True):
         """A [p, W] int64 mask tensor on this device.  pitched=True pads the row pitch to
         ksched_mask_pitch(n) words (cache-line aligned rows: the fast layout); the returned tensor
@@ -244,6 +248,55 @@ class Evaluator:
         f = np.ascontiguousarray(feasible_row, dtype=np.uint64)
         r = None if fit_row is None else np.ascontiguousarray(fit_row, dtype=np.uint64)
         return self._lib.ksched_reason(_ptr(f), _ptr(r), int(node), int(flags))
+
+
+class Pipe:
+    """ksched_pipe: consecutive batches software-pipelined over two internal HIP streams (mask kernel of batch i + 1
+    overlaps the pick of batch i).  The caller owns the per-slot mask / binding tensors."""
+
+    def __init__(self, ev: "Evaluator", depth: int):
+        self.ev, self.depth = ev, depth
+        self._lib = ev._lib
+        h = C.c_void_p()
+        ev._check(self._lib.ksched_pipe_create(ev._h, depth, C.byref(h)), "ksched_pipe_create")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._lib.ksched_pipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    def stream(self, which: int):
+        """torch view of an internal stream: 0 = mask stream, 1 = pick stream."""
+        import torch
+        return torch.cuda.ExternalStream(int(self._lib.ksched_pipe_stream(self._h, which)), device=self.ev.device)
+
+    def submit(self, slot: int, req_cpu_milli, req_mem_bytes, sel_val_ids, tolerations, samples, flags: int, mask, binding):
+        """torch CUDA tensors (see Evaluator.eval_device); `mask` is a [p, W] (possibly pitched) view, `binding` int32 [p]."""
+        p, W = int(req_cpu_milli.shape[0]), self.ev.W
+        pitch = int(mask.stride(0)) if p > 1 else W
+        attempts = int(samples.shape[1]) if (flags & L.PICK_SAMPLED and samples is not None) else 0
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        rc = self._lib.ksched_pipe_submit(self._h, slot, p, ptr(req_cpu_milli), ptr(req_mem_bytes), ptr(sel_val_ids), ptr(tolerations),
+                                          ptr(samples), attempts, flags, ptr(mask), pitch, ptr(binding))
+        self.ev._check(rc, "ksched_pipe_submit")
+
+    def wait(self, slot: int, stream=None, host: bool = False):
+        """Order `stream` (default: torch's current stream) after the slot's pick; host=True blocks the host instead."""
+        import torch
+        if host:
+            sp = None
+        else:
+            sp = C.c_void_p((stream or torch.cuda.current_stream(self.ev.device)).cuda_stream or 0)
+            if not sp.value:  # the legacy default stream has handle 0 = "block the host" in the C ABI: use a host wait instead
+                sp = None
+        self.ev._check(self._lib.ksched_pipe_wait(self._h, slot, sp), "ksched_pipe_wait")
 
 
 # ---- pure helpers on masks (numpy; no predicate logic here) -----------------------------------------

@@ -88,17 +88,13 @@ def _pipe_worker(rank, world, port, P, N, depth, steps, q):
         sched = PipelinedScheduler(P, torch.device("cpu"), depth=depth)
         lo, hi = sched.lo, sched.hi
         flags = capi.FIT | capi.SEL | capi.PICK_SAMPLED
-        masks = [None] * depth
         state = {"step": 0}
 
         def samples_of(j):  # every step is a different batch: the draws rotate
             return np.ascontiguousarray(np.roll(c.samples, j, axis=0))
 
-        def mask_fn(slot):  # stand-in for the device mask evaluation (test-only: the oracle)
-            masks[slot] = state["step"]
-
-        def pick_fn(slot, out):
-            j = masks[slot]
+        def run(slot, out):  # stand-in for the device evaluation + pick (test-only: the oracle)
+            j = state["step"]
             _, _, b = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, None, c.req_cpu[lo:hi], c.req_mem[lo:hi],
                                         c.pod_sel[:, lo:hi], None, samples_of(j)[lo:hi], flags, want_mask=False, threads=1)
             out.copy_(torch.from_numpy(b))
@@ -107,7 +103,7 @@ def _pipe_worker(rank, world, port, P, N, depth, steps, q):
         pend = []
         for j in range(steps):
             state["step"] = j
-            pend.append((j, sched.step(mask_fn, pick_fn)))
+            pend.append((j, sched.step(run)))
             if len(pend) >= depth:  # consume the oldest while newer steps are in flight: its slot is reused next
                 jj, pb = pend.pop(0)
                 got = pb.wait().clone().numpy()

@@ -435,8 +435,8 @@ def test_pick_device_equals_fused_call(evaluator, pick):
 
 @pytest.mark.parametrize("depth", [2, 3])
 def test_pipelined_steps_equal_sequential(evaluator, depth):
-    """PipelinedScheduler on the GPU: mask kernel of step i+1 on one stream, pick of step i on another, `depth`
-    slots.  Every step is a different batch (pods rotate); every step's bindings == the oracle for that batch."""
+    """PipelinedScheduler over a ksched_pipe on the GPU: mask kernel of step i+1 on one stream, pick of step i on another,
+    `depth` slots.  Every step is a different batch (pods rotate); every step's bindings == the oracle for that batch."""
     import torch
     from kube_scheduler_rs_reference_amd.dist import PipelinedScheduler
     ev = evaluator
@@ -449,23 +449,20 @@ def test_pipelined_steps_equal_sequential(evaluator, depth):
     batches = [dict(cpu=t(c.req_cpu[r], np.int64), mem=t(c.req_mem[r], np.int64), sel=t(c.pod_sel[:, r], np.int32),
                     smp=t(c.samples[r], np.int32)) for r in rolled]
     torch.cuda.synchronize()
-    sched = PipelinedScheduler(c.P, dev, depth=depth)
+    pipe = ev.pipe(depth)
+    sched = PipelinedScheduler(c.P, dev, depth=depth, pipe=pipe)
     masks = [ev.alloc_mask(c.P) for _ in range(depth)]
-    cur = {}
 
-    def mask_fn(slot):
-        cur[slot] = batches[state["j"]]
-        ev.eval_device(cur[slot]["cpu"], cur[slot]["mem"], cur[slot]["sel"], None, None, FIT | SEL, out_feasible=masks[slot])
-
-    def pick_fn(slot, out):
-        ev.pick_device(masks[slot], PICK_SAMPLED | FIT, out, req_mem_bytes=cur[slot]["mem"], samples=cur[slot]["smp"])
+    def run(slot, out):
+        b = batches[state["j"]]
+        pipe.submit(slot, b["cpu"], b["mem"], b["sel"], None, b["smp"], FIT | SEL | PICK_SAMPLED, masks[slot], out)
 
     state = {"j": 0}
     got = []
     pend = []
     for j in range(steps):
         state["j"] = j
-        pend.append(sched.step(mask_fn, pick_fn))
+        pend.append(sched.step(run))
         if len(pend) >= depth:
             got.append(pend.pop(0).wait().clone())
     got += [p.wait().clone() for p in pend]
@@ -474,3 +471,62 @@ def test_pipelined_steps_equal_sequential(evaluator, depth):
     _, _, base = oracle_eval(c, FIT | SEL | PICK_SAMPLED)
     for j in range(steps):
         assert np.array_equal(got[j].cpu().numpy(), base[rolled[j]]), f"step {j}"
+    # the masks of the last `depth` steps are still in their slots and equal the oracle's
+    feas, _, _ = oracle_eval(c, FIT | SEL)
+    for j in range(steps - depth, steps):
+        assert np.array_equal(masks[j % depth].cpu().numpy().view(np.uint64), feas[rolled[j]]), f"mask of step {j}"
+    pipe.close()
+
+
+@pytest.mark.parametrize("two_stream", [False, True])
+def test_pipelined_allgather_over_rccl_one_rank(evaluator, two_stream):
+    """The N > 1 code path on the one GPU there is: a one-rank "nccl" (= RCCL) process group, asynchronous
+    all_gather_into_tensor behind the pick (on the pipe's pick stream when two_stream), slots reused over 6 steps."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from kube_scheduler_rs_reference_amd.dist import PipelinedScheduler
+    ev = evaluator
+    c = synth.make_cluster(4000, 2100, n_keys=8, n_taints=0, seed=91)
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", ev.device)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+        steps, depth = 6, 2
+        rolled = [np.roll(np.arange(c.P), 11 * j) for j in range(steps)]
+        batches = [dict(cpu=t(c.req_cpu[r], np.int64), mem=t(c.req_mem[r], np.int64), sel=t(c.pod_sel[:, r], np.int32),
+                        smp=t(c.samples[r], np.int32)) for r in rolled]
+        torch.cuda.synchronize()
+        pipe = ev.pipe(depth) if two_stream else None
+        sched = PipelinedScheduler(c.P, dev, depth=depth, pipe=pipe, gather_always=True)
+        masks = [ev.alloc_mask(c.P) for _ in range(depth)]
+        state = {"j": 0}
+
+        def run(slot, out):
+            b = batches[state["j"]]
+            if pipe is not None:
+                pipe.submit(slot, b["cpu"], b["mem"], b["sel"], None, b["smp"], FIT | SEL | PICK_SAMPLED, masks[slot], out)
+            else:
+                ev.eval_device(b["cpu"], b["mem"], b["sel"], None, b["smp"], FIT | SEL | PICK_SAMPLED, out_feasible=masks[0], out_binding=out)
+
+        got, pend = [], []
+        for j in range(steps):
+            state["j"] = j
+            pend.append(sched.step(run))
+            if len(pend) >= depth:
+                got.append(pend.pop(0).wait().clone())
+        got += [p.wait().clone() for p in pend]
+        sched.drain()
+        torch.cuda.synchronize()
+        _, _, base = oracle_eval(c, FIT | SEL | PICK_SAMPLED)
+        for j in range(steps):
+            assert np.array_equal(got[j].cpu().numpy(), base[rolled[j]]), f"step {j}"
+        if pipe is not None:
+            pipe.close()
+    finally:
+        dist.destroy_process_group()

@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/sessH_pytest.log 2>&1; tail -5 gpurun_out/sessH_pytest.log
-for depth in 1 2 3; do for wl in C3 C4s C5s C2; do timeout 300 python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline --depth $depth 2>&1 | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('depth=$depth $wl: value %.3e step %.1f us kernel %.2f us frac %.3f bound %.3f' % (d['value'], d['ms_per_step']*1e3, r['avg_kernel_us'], r['frac'], d['config']['bound_fraction']))"; done; done
+timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-400
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --depth 2 2>&1 | tail -1 | cut -c1-400
