@@ -90,6 +90,12 @@ extern "C" {
 #define KSCHED_OPT_TRACE 4
 #define KSCHED_TRACE_WORDS 8u /* uint64 words per block: t_entry, t_staged_issue, t_barrier, t_phase1, t_group0, t_loop_end, t_drained, xcc_id */
 
+/* KSCHED_OPT_PICK_FROM_MASK: 1 = KSCHED_PICK_SAMPLED reads the candidates' bits back from the feasibility mask (after
+ * the mask kernel); 0 (default) = it tests the drawn candidates directly from the pod and node columns, as the reference
+ * does (src/main.rs:53-66: draw, check_node_validity(pod, candidate)), before and independently of the mask kernel.  Same
+ * results either way; a bindings-only request (no output mask) then launches no mask kernel at all. */
+#define KSCHED_OPT_PICK_FROM_MASK 5
+
 typedef struct ksched_ctx ksched_ctx;
 
 /* ---- lifetime -------------------------------------------------------------------------- */

@@ -44,6 +44,7 @@ OPT_KERNEL = 1
 OPT_TIMING = 2
 OPT_DEBUG = 3
 OPT_TRACE = 4
+OPT_PICK_FROM_MASK = 5
 TRACE_WORDS = 8
 KERNEL_AUTO = 0
 KERNEL_DIRECT = 1

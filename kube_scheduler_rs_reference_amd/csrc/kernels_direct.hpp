@@ -178,6 +178,71 @@ __global__ __launch_bounds__(256) void k_pick_sampled(const uint64_t *__restrict
     binding[pod] = b;
 }
 
+// select_node_for_pod evaluated the reference's own way (src/main.rs:53-66): draw a candidate, run
+// check_node_validity(pod, candidate) on THAT pair, first Ok wins -- straight from the pod and node columns,
+// no mask involved, so this kernel neither waits for the mask kernel nor reads its 128-byte lines back
+// (the mask-reading pick above moves 500 k random sectors at C3; this one gathers from node columns that
+// stay in L2).  Same predicates, same arithmetic as k_eval_direct: req <= avail on signed i64
+// (src/predicates.rs:42), label id equality with 0 = absent / unconstrained (src/predicates.rs:45-61),
+// (taints & ~tolerations) == 0.  One lane per pod; ATT = attempts handled per pass (all candidates of a
+// pass are loaded together: two dependent memory round trips per pass).
+template <int ATT>
+__global__ __launch_bounds__(256) void k_select_sampled(const int64_t *__restrict__ g_ncpu, const int64_t *__restrict__ g_nmem,
+                                                         const uint32_t *__restrict__ g_nlab, const uint64_t *__restrict__ g_ntaint,
+                                                         const int64_t *__restrict__ g_pcpu, const int64_t *__restrict__ g_pmem,
+                                                         const uint32_t *__restrict__ g_psel, const uint64_t *__restrict__ g_ptol,
+                                                         const uint32_t *__restrict__ samples, int32_t *__restrict__ binding, uint32_t p,
+                                                         uint32_t n, uint32_t nkeys, uint32_t attempts, uint32_t do_fit,
+                                                         uint32_t do_taint) {
+    const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pod >= p) return;
+    const uint32_t *smp = samples + (size_t)pod * attempts;
+    const int64_t rc = do_fit ? g_pcpu[pod] : 0, rm = do_fit ? g_pmem[pod] : 0;
+    const uint64_t tol = (do_taint && g_ptol) ? g_ptol[pod] : 0ull;
+    // the pod's selector ids of the first eight keys in registers; further keys are re-read per candidate (rare)
+    uint32_t sel[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) sel[k] = (g_psel && k < nkeys) ? g_psel[(size_t)k * p + pod] : 0u;
+    int32_t b = -1;
+    for (uint32_t i0 = 0; i0 < attempts && b < 0; i0 += ATT) {
+        uint32_t s[ATT];
+        bool ok[ATT];
+#pragma unroll
+        for (int j = 0; j < ATT; ++j) {
+            s[j] = (i0 + j < attempts) ? smp[i0 + j] : 0xFFFFFFFFu;
+            ok[j] = s[j] < n;  // an index >= n is an infeasible draw (include/ksched.h)
+        }
+        int64_t ac[ATT], am[ATT];
+        uint64_t nt[ATT];
+        uint32_t nl[ATT][8];
+#pragma unroll
+        for (int j = 0; j < ATT; ++j) {
+            const uint32_t node = ok[j] ? s[j] : 0u;
+            ac[j] = do_fit ? g_ncpu[node] : 0;
+            am[j] = do_fit ? g_nmem[node] : 0;
+            nt[j] = (do_taint && g_ntaint) ? g_ntaint[node] : 0ull;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) nl[j][k] = (sel[k] != 0u) ? g_nlab[(size_t)k * n + node] : 0u;  // only constrained keys are read
+        }
+#pragma unroll
+        for (int j = 0; j < ATT; ++j) {
+            bool f = ok[j];
+            if (do_fit) f = f && rc <= ac[j] && rm <= am[j];
+            if (do_taint) f = f && (nt[j] & ~tol) == 0ull;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) f = f && (sel[k] == 0u || sel[k] == nl[j][k]);
+            if (f && nkeys > 8u) {
+                for (uint32_t k = 8; k < nkeys; ++k) {
+                    const uint32_t want = g_psel[(size_t)k * p + pod];
+                    if (want != 0u && want != g_nlab[(size_t)k * n + s[j]]) f = false;
+                }
+            }
+            if (b < 0 && f) b = (int32_t)s[j];  // first feasible draw wins (src/main.rs:61-65)
+        }
+    }
+    binding[pod] = b;
+}
+
 // Best fit (extension E1): argmin over feasible nodes of (avail_mem - req_mem, avail_cpu - req_cpu,
 // node index), lexicographic.  Both residuals are pod-independent shifts of the node's own
 // (avail_mem, avail_cpu), so the order of candidates is a property of the snapshot: bf_order

@@ -77,6 +77,7 @@ struct ksched_ctx {
     bool opt_timing = false;
     uint32_t opt_debug = 0;
     bool opt_trace = false;
+    bool opt_pick_from_mask = false;
     DevBuf<uint64_t> trace;
     uint32_t trace_blocks_last = 0;
     const char *last_kernel = "none";
@@ -249,6 +250,22 @@ int launch_pick(ksched_ctx *c, uint32_t p, const uint64_t *feas, uint32_t pitch,
     return KSCHED_OK;
 }
 
+// select_node_for_pod the reference's way: only the sampled candidates are tested, from the columns (k_select_sampled)
+int launch_select(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel, const uint64_t *ptol,
+                  const uint32_t *samples, uint32_t attempts, uint32_t flags, int32_t *out_binding, hipStream_t s) {
+    const bool sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
+    const bool taint = (flags & KSCHED_TAINT) && c->have_taints;
+    const dim3 grid((p + 255) / 256), block(256);
+#define KSCHED_SELECT_ARGS                                                                                                        \
+    c->ncpu.ptr, c->nmem.ptr, c->nlab.ptr, taint ? c->ntaint.ptr : nullptr, pcpu, pmem, sel ? psel : nullptr, ptol, samples, \
+        out_binding, p, c->n, sel ? c->nkeys : 0u, attempts, (flags & KSCHED_FIT) ? 1u : 0u, taint ? 1u : 0u
+    if (attempts <= 5) hipLaunchKernelGGL(k_select_sampled<5>, grid, block, 0, s, KSCHED_SELECT_ARGS);
+    else hipLaunchKernelGGL(k_select_sampled<8>, grid, block, 0, s, KSCHED_SELECT_ARGS);
+#undef KSCHED_SELECT_ARGS
+    HIPCHK(c, hipGetLastError());
+    return KSCHED_OK;
+}
+
 int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                    const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags,
                    uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, uint32_t pitch, hipStream_t s) {
@@ -260,8 +277,17 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         if ((pick_s || pick_b) && out_binding) HIPCHK(c, hipMemsetAsync(out_binding, 0xFF, (size_t)p * sizeof(int32_t), s));
         return KSCHED_OK;
     }
+    // The sampled pick tests only the drawn candidates, from the columns: it does not need the mask, so it goes
+    // first (nothing waits on a mask kernel) and a bindings-only request launches no mask kernel at all.
+    // KSCHED_OPT_PICK_FROM_MASK restores the mask-reading pick (same results; kept as a cross-check).
+    const bool select_direct = pick_s && !c->opt_pick_from_mask;
+    if (select_direct) {
+        int rcs = launch_select(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_binding, s);
+        if (rcs) return rcs;
+        if (!out_feas && !out_fit) return KSCHED_OK;
+    }
     uint64_t *feas = out_feas;
-    if (!feas && (pick_s || pick_b)) {
+    if (!feas) {  // the mask kernels always write the feasible mask: a pick that reads it, or a fit-mask-only request, gets a scratch one
         HIPCHK(c, c->scratch_mask.reserve((size_t)p * pitch));
         feas = c->scratch_mask.ptr;
     }
@@ -303,6 +329,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     if (rc) return rc;
     if (c->opt_timing && kern != KSCHED_KERNEL_FUSED) HIPCHK(c, hipEventRecord(c->ev_pool[slot].b, s));
 
+    if (select_direct || !(pick_s || pick_b)) return KSCHED_OK;
     return launch_pick(c, p, feas, pitch, pmem, samples, attempts, flags, out_binding, s);
 }
 
@@ -406,6 +433,9 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
             return KSCHED_OK;
         case KSCHED_OPT_TRACE:
             c->opt_trace = value != 0;
+            return KSCHED_OK;
+        case KSCHED_OPT_PICK_FROM_MASK:
+            c->opt_pick_from_mask = value != 0;
             return KSCHED_OK;
         default:
             return KSCHED_E_INVAL;
@@ -672,7 +702,9 @@ int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *p
     }
     uint64_t *d_feas = nullptr, *d_fit = nullptr;
     int32_t *d_bind = nullptr;
-    if (out_feas || pick) {
+    // a mask is needed when the caller wants it, or when the pick reads it (best fit; sampled only with KSCHED_OPT_PICK_FROM_MASK)
+    const bool pick_reads_mask = (flags & KSCHED_PICK_BESTFIT) || ((flags & KSCHED_PICK_SAMPLED) && c->opt_pick_from_mask);
+    if (out_feas || pick_reads_mask) {
         HIPCHK(c, c->feas.reserve((size_t)p * pitch));
         d_feas = c->feas.ptr;
     }

@@ -530,3 +530,37 @@ def test_pipelined_allgather_over_rccl_one_rank(evaluator, two_stream):
             pipe.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_sampled_pick_direct_equals_pick_from_mask(evaluator, kernel):
+    """KSCHED_PICK_SAMPLED two ways: candidates tested straight from the columns (default; the reference's own order of
+    work, src/main.rs:53-66) and candidates' bits read back from the mask (KSCHED_OPT_PICK_FROM_MASK) -- both == oracle,
+    with taints, > 8 label keys, out-of-range draws, more than 5 and more than 8 attempts, and bindings-only requests."""
+    ev = evaluator
+    ev.set_kernel(kernel)
+    rng = np.random.default_rng(17)
+    for (P, N, K, attempts) in [(2000, 1500, 8, 5), (700, 900, 13, 5), (500, 300, 8, 11), (300, 64, 3, 1), (64, 2000, 8, 8)]:
+        c = synth.make_cluster(P, N, n_keys=min(K, 8), n_taints=16, seed=P + K)
+        lab, sel = c.node_labels, c.pod_sel
+        if K > 8:  # extra keys beyond the generator's eight
+            lab = np.concatenate([lab, rng.integers(0, 3, size=(K - 8, N), dtype=np.uint32)])
+            sel = np.concatenate([sel, np.where(rng.random((K - 8, P)) < 0.2, rng.integers(1, 4, size=(K - 8, P)), 0).astype(np.uint32)])
+        samples = rng.integers(0, N + 3, size=(P, attempts), dtype=np.uint32)  # a few draws are out of range = infeasible
+        ev.set_nodes(c.avail_cpu, c.avail_mem, lab, c.node_taints)
+        flags = FIT | SEL | TAINT | PICK_SAMPLED
+        _, _, want = capi.eval_encoded(c.avail_cpu, c.avail_mem, lab, c.node_taints, c.req_cpu, c.req_mem, sel, c.pod_tol, samples, flags)
+        for from_mask in (0, 1):
+            ev.set_option(_lib.OPT_PICK_FROM_MASK, from_mask)
+            r = ev.eval(c.req_cpu, c.req_mem, sel, c.pod_tol, samples, flags)
+            assert np.array_equal(r.binding, want), (P, N, K, attempts, from_mask)
+            r2 = ev.eval(c.req_cpu, c.req_mem, sel, c.pod_tol, samples, flags, want_mask=False)  # bindings only
+            assert r2.feasible is None and np.array_equal(r2.binding, want)
+        # predicate subsets reach the select kernel too
+        ev.set_option(_lib.OPT_PICK_FROM_MASK, 0)
+        for sub in (FIT, SEL, TAINT, FIT | TAINT, 0):
+            _, _, w2 = capi.eval_encoded(c.avail_cpu, c.avail_mem, lab, c.node_taints, c.req_cpu, c.req_mem, sel, c.pod_tol, samples, sub | PICK_SAMPLED)
+            r = ev.eval(c.req_cpu, c.req_mem, sel, c.pod_tol, samples, sub | PICK_SAMPLED, want_mask=False)
+            assert np.array_equal(r.binding, w2), (P, N, K, attempts, sub)
+    ev.set_option(_lib.OPT_PICK_FROM_MASK, 0)
+    ev.set_kernel("auto")
