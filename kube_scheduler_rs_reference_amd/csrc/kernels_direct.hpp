@@ -185,62 +185,91 @@ __global__ __launch_bounds__(256) void k_pick_sampled(const uint64_t *__restrict
 // stay in L2).  Same predicates, same arithmetic as k_eval_direct: req <= avail on signed i64
 // (src/predicates.rs:42), label id equality with 0 = absent / unconstrained (src/predicates.rs:45-61),
 // (taints & ~tolerations) == 0.  One lane per pod; ATT = attempts handled per pass (all candidates of a
-// pass are loaded together: two dependent memory round trips per pass).
+// pass are loaded together: two dependent memory round trips per pass).  (Running this inside the fused
+// mask kernel's staging wait was tried: its ~50 registers per lane spill there and its scattered gathers
+// compete with the staging DMA for the texture-address unit -- the mask kernel grew by 10 us.)
+struct SelectArgs {
+    const int64_t *ncm;           // node columns interleaved: [n][2] = {avail_cpu, avail_mem} (one 16-byte gather per candidate)
+    const uint32_t *nlab;         // [nkeys][n]
+    const uint64_t *ntaint;       // [n] or nullptr
+    const int64_t *pcpu, *pmem;   // pod columns [p]
+    const uint32_t *psel;         // [nkeys][p] or nullptr
+    const uint64_t *ptol;         // [p] or nullptr
+    const uint32_t *samples;      // [p][attempts]
+    int32_t *binding;             // [p]
+    uint32_t p, n, nkeys, attempts, do_fit, do_taint;
+};
+
 template <int ATT>
-__global__ __launch_bounds__(256) void k_select_sampled(const int64_t *__restrict__ g_ncpu, const int64_t *__restrict__ g_nmem,
-                                                         const uint32_t *__restrict__ g_nlab, const uint64_t *__restrict__ g_ntaint,
-                                                         const int64_t *__restrict__ g_pcpu, const int64_t *__restrict__ g_pmem,
-                                                         const uint32_t *__restrict__ g_psel, const uint64_t *__restrict__ g_ptol,
-                                                         const uint32_t *__restrict__ samples, int32_t *__restrict__ binding, uint32_t p,
-                                                         uint32_t n, uint32_t nkeys, uint32_t attempts, uint32_t do_fit,
-                                                         uint32_t do_taint) {
-    const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pod >= p) return;
-    const uint32_t *smp = samples + (size_t)pod * attempts;
-    const int64_t rc = do_fit ? g_pcpu[pod] : 0, rm = do_fit ? g_pmem[pod] : 0;
-    const uint64_t tol = (do_taint && g_ptol) ? g_ptol[pod] : 0ull;
+__device__ __forceinline__ int32_t select_one_pod(const SelectArgs &a, uint32_t pod) {
+    // the arrays are global memory: say so (pointers that arrive in a by-value struct are generic to the compiler, and the
+    // fused kernel, which also juggles LDS pointers, would emit flat loads with aperture checks)
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+#define KSCHED_G(T, P) ((const __attribute__((address_space(1))) T *)(P))
+    struct {
+        const __attribute__((address_space(1))) i64x2 *ncm;
+        const __attribute__((address_space(1))) uint32_t *nlab, *psel, *samples;
+        const __attribute__((address_space(1))) uint64_t *ntaint, *ptol;
+        const __attribute__((address_space(1))) int64_t *pcpu, *pmem;
+        uint32_t p, n, nkeys, attempts, do_fit, do_taint;
+    } q = {KSCHED_G(i64x2, a.ncm), KSCHED_G(uint32_t, a.nlab), KSCHED_G(uint32_t, a.psel), KSCHED_G(uint32_t, a.samples),
+           KSCHED_G(uint64_t, a.ntaint), KSCHED_G(uint64_t, a.ptol), KSCHED_G(int64_t, a.pcpu), KSCHED_G(int64_t, a.pmem),
+           a.p, a.n, a.nkeys, a.attempts, a.do_fit, a.do_taint};
+#undef KSCHED_G
+    const __attribute__((address_space(1))) uint32_t *smp = q.samples + (size_t)pod * q.attempts;
+    const int64_t rc = q.do_fit ? q.pcpu[pod] : 0, rm = q.do_fit ? q.pmem[pod] : 0;
+    const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
     // the pod's selector ids of the first eight keys in registers; further keys are re-read per candidate (rare)
     uint32_t sel[8];
 #pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) sel[k] = (g_psel && k < nkeys) ? g_psel[(size_t)k * p + pod] : 0u;
+    for (uint32_t k = 0; k < 8; ++k) sel[k] = (q.psel && k < q.nkeys) ? q.psel[(size_t)k * q.p + pod] : 0u;
     int32_t b = -1;
-    for (uint32_t i0 = 0; i0 < attempts && b < 0; i0 += ATT) {
+    for (uint32_t i0 = 0; i0 < q.attempts && b < 0; i0 += ATT) {
         uint32_t s[ATT];
         bool ok[ATT];
 #pragma unroll
         for (int j = 0; j < ATT; ++j) {
-            s[j] = (i0 + j < attempts) ? smp[i0 + j] : 0xFFFFFFFFu;
-            ok[j] = s[j] < n;  // an index >= n is an infeasible draw (include/ksched.h)
+            s[j] = (i0 + j < q.attempts) ? smp[i0 + j] : 0xFFFFFFFFu;
+            ok[j] = s[j] < q.n;  // an index >= n is an infeasible draw (include/ksched.h)
         }
-        int64_t ac[ATT], am[ATT];
+        // Scattered gathers cost one cache-line request per distinct line: the fit columns come interleaved (one
+        // 16-byte gather instead of two), and the lanes that do not constrain a key all read the SAME word (one line)
+        // instead of being masked off -- the compiler would otherwise turn the masked load into an unconditional
+        // scattered one.
+        i64x2 acm[ATT];
         uint64_t nt[ATT];
         uint32_t nl[ATT][8];
 #pragma unroll
         for (int j = 0; j < ATT; ++j) {
             const uint32_t node = ok[j] ? s[j] : 0u;
-            ac[j] = do_fit ? g_ncpu[node] : 0;
-            am[j] = do_fit ? g_nmem[node] : 0;
-            nt[j] = (do_taint && g_ntaint) ? g_ntaint[node] : 0ull;
+            acm[j] = q.do_fit ? q.ncm[node] : i64x2{0, 0};
+            nt[j] = (q.do_taint && q.ntaint) ? q.ntaint[node] : 0ull;
 #pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) nl[j][k] = (sel[k] != 0u) ? g_nlab[(size_t)k * n + node] : 0u;  // only constrained keys are read
+            for (uint32_t k = 0; k < 8; ++k) nl[j][k] = (k < q.nkeys) ? q.nlab[(sel[k] != 0u) ? (size_t)k * q.n + node : (size_t)0] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < ATT; ++j) {
             bool f = ok[j];
-            if (do_fit) f = f && rc <= ac[j] && rm <= am[j];
-            if (do_taint) f = f && (nt[j] & ~tol) == 0ull;
+            if (q.do_fit) f = f && rc <= acm[j].x && rm <= acm[j].y;
+            if (q.do_taint) f = f && (nt[j] & ~tol) == 0ull;
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k) f = f && (sel[k] == 0u || sel[k] == nl[j][k]);
-            if (f && nkeys > 8u) {
-                for (uint32_t k = 8; k < nkeys; ++k) {
-                    const uint32_t want = g_psel[(size_t)k * p + pod];
-                    if (want != 0u && want != g_nlab[(size_t)k * n + s[j]]) f = false;
+            if (f && q.nkeys > 8u) {
+                for (uint32_t k = 8; k < q.nkeys; ++k) {
+                    const uint32_t want = q.psel[(size_t)k * q.p + pod];
+                    if (want != 0u && want != q.nlab[(size_t)k * q.n + s[j]]) f = false;
                 }
             }
             if (b < 0 && f) b = (int32_t)s[j];  // first feasible draw wins (src/main.rs:61-65)
         }
     }
-    binding[pod] = b;
+    return b;
+}
+
+template <int ATT>
+__global__ __launch_bounds__(256) void k_select_sampled(const SelectArgs q) {
+    const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pod < q.p) q.binding[pod] = select_one_pod<ATT>(q, pod);
 }
 
 // Best fit (extension E1): argmin over feasible nodes of (avail_mem - req_mem, avail_cpu - req_cpu,

@@ -57,6 +57,7 @@ struct ksched_ctx {
     uint32_t n = 0, nkeys = 0, W = 0;
     bool have_taints = false;
     DevBuf<int64_t> ncpu, nmem;
+    DevBuf<int64_t> ncm;  // {avail_cpu, avail_mem} interleaved per node (k_select_sampled: one 16-byte gather per candidate)
     DevBuf<uint32_t> nlab;
     DevBuf<uint64_t> ntaint;
     DevBuf<uint32_t> bf_order, bf_rank;
@@ -250,18 +251,36 @@ int launch_pick(ksched_ctx *c, uint32_t p, const uint64_t *feas, uint32_t pitch,
     return KSCHED_OK;
 }
 
+SelectArgs make_select_args(const ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
+                            const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, int32_t *out_binding) {
+    const bool sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
+    const bool taint = (flags & KSCHED_TAINT) && c->have_taints;
+    SelectArgs q{};
+    q.ncm = c->ncm.ptr;
+    q.nlab = c->nlab.ptr;
+    q.ntaint = taint ? c->ntaint.ptr : nullptr;
+    q.pcpu = pcpu;
+    q.pmem = pmem;
+    q.psel = sel ? psel : nullptr;
+    q.ptol = ptol;
+    q.samples = samples;
+    q.binding = out_binding;
+    q.p = p;
+    q.n = c->n;
+    q.nkeys = sel ? c->nkeys : 0u;
+    q.attempts = attempts;
+    q.do_fit = (flags & KSCHED_FIT) ? 1u : 0u;
+    q.do_taint = taint ? 1u : 0u;
+    return q;
+}
+
 // select_node_for_pod the reference's way: only the sampled candidates are tested, from the columns (k_select_sampled)
 int launch_select(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel, const uint64_t *ptol,
                   const uint32_t *samples, uint32_t attempts, uint32_t flags, int32_t *out_binding, hipStream_t s) {
-    const bool sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
-    const bool taint = (flags & KSCHED_TAINT) && c->have_taints;
+    const SelectArgs q = make_select_args(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_binding);
     const dim3 grid((p + 255) / 256), block(256);
-#define KSCHED_SELECT_ARGS                                                                                                        \
-    c->ncpu.ptr, c->nmem.ptr, c->nlab.ptr, taint ? c->ntaint.ptr : nullptr, pcpu, pmem, sel ? psel : nullptr, ptol, samples, \
-        out_binding, p, c->n, sel ? c->nkeys : 0u, attempts, (flags & KSCHED_FIT) ? 1u : 0u, taint ? 1u : 0u
-    if (attempts <= 5) hipLaunchKernelGGL(k_select_sampled<5>, grid, block, 0, s, KSCHED_SELECT_ARGS);
-    else hipLaunchKernelGGL(k_select_sampled<8>, grid, block, 0, s, KSCHED_SELECT_ARGS);
-#undef KSCHED_SELECT_ARGS
+    if (attempts <= 5) hipLaunchKernelGGL(k_select_sampled<5>, grid, block, 0, s, q);
+    else hipLaunchKernelGGL(k_select_sampled<8>, grid, block, 0, s, q);
     HIPCHK(c, hipGetLastError());
     return KSCHED_OK;
 }
@@ -397,7 +416,7 @@ void ksched_destroy(ksched_ctx *c) {
     {
         DeviceGuard g(c->device);
         (void)hipDeviceSynchronize();
-        c->ncpu.release(); c->nmem.release(); c->nlab.release(); c->ntaint.release();
+        c->ncpu.release(); c->nmem.release(); c->ncm.release(); c->nlab.release(); c->ntaint.release();
         c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release();
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
         c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release();
@@ -437,6 +456,7 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
         case KSCHED_OPT_PICK_FROM_MASK:
             c->opt_pick_from_mask = value != 0;
             return KSCHED_OK;
+
         default:
             return KSCHED_E_INVAL;
     }
@@ -463,6 +483,7 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     c->have_taints = taints != nullptr;
     HIPCHK(c, c->ncpu.reserve(n));
     HIPCHK(c, c->nmem.reserve(n));
+    HIPCHK(c, c->ncm.reserve((size_t)n * 2));
     HIPCHK(c, c->nlab.reserve((size_t)n * n_keys));
     HIPCHK(c, c->ntaint.reserve(n));
     HIPCHK(c, c->bf_order.reserve(n));
@@ -476,6 +497,14 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
         if (taints) HIPCHK(c, hipMemcpy(c->ntaint.ptr, taints, (size_t)n * 8, hipMemcpyHostToDevice));
         c->h_cpu.assign(cpu, cpu + n);
         c->h_mem.assign(mem, mem + n);
+        {
+            std::vector<int64_t> cm((size_t)n * 2);
+            for (uint32_t i = 0; i < n; ++i) {
+                cm[2 * (size_t)i] = cpu[i];
+                cm[2 * (size_t)i + 1] = mem[i];
+            }
+            HIPCHK(c, hipMemcpy(c->ncm.ptr, cm.data(), cm.size() * 8, hipMemcpyHostToDevice));
+        }
         rc_bf = upload_bestfit_order(c);
     } else {
         c->h_cpu.clear();
@@ -515,12 +544,20 @@ int ksched_update_nodes(ksched_ctx *c, uint32_t count, const uint32_t *node_inde
             const uint32_t n = node_index[i];
             HIPCHK(c, hipMemcpy(c->ncpu.ptr + n, &c->h_cpu[n], 8, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(c->nmem.ptr + n, &c->h_mem[n], 8, hipMemcpyHostToDevice));
+            const int64_t pair[2] = {c->h_cpu[n], c->h_mem[n]};
+            HIPCHK(c, hipMemcpy(c->ncm.ptr + 2 * (size_t)n, pair, 16, hipMemcpyHostToDevice));
         }
     } else {
         for (uint32_t t : tiles) {
             const size_t lo = (size_t)t * kTileNodes, len = std::min<size_t>(kTileNodes, c->n - lo);
             HIPCHK(c, hipMemcpy(c->ncpu.ptr + lo, c->h_cpu.data() + lo, len * 8, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(c->nmem.ptr + lo, c->h_mem.data() + lo, len * 8, hipMemcpyHostToDevice));
+            std::vector<int64_t> cm(len * 2);
+            for (size_t i = 0; i < len; ++i) {
+                cm[2 * i] = c->h_cpu[lo + i];
+                cm[2 * i + 1] = c->h_mem[lo + i];
+            }
+            HIPCHK(c, hipMemcpy(c->ncm.ptr + 2 * lo, cm.data(), cm.size() * 8, hipMemcpyHostToDevice));
         }
     }
     int rc = upload_bestfit_order(c);

@@ -550,10 +550,12 @@ def test_sampled_pick_direct_equals_pick_from_mask(evaluator, kernel):
         ev.set_nodes(c.avail_cpu, c.avail_mem, lab, c.node_taints)
         flags = FIT | SEL | TAINT | PICK_SAMPLED
         _, _, want = capi.eval_encoded(c.avail_cpu, c.avail_mem, lab, c.node_taints, c.req_cpu, c.req_mem, sel, c.pod_tol, samples, flags)
-        for from_mask in (0, 1):
+        for from_mask in (0, 1):  # candidates tested from the columns / candidates' bits read back from the mask
             ev.set_option(_lib.OPT_PICK_FROM_MASK, from_mask)
             r = ev.eval(c.req_cpu, c.req_mem, sel, c.pod_tol, samples, flags)
             assert np.array_equal(r.binding, want), (P, N, K, attempts, from_mask)
+            feas, _, _ = capi.eval_encoded(c.avail_cpu, c.avail_mem, lab, c.node_taints, c.req_cpu, c.req_mem, sel, c.pod_tol, None, FIT | SEL | TAINT)
+            assert np.array_equal(r.feasible, feas)
             r2 = ev.eval(c.req_cpu, c.req_mem, sel, c.pod_tol, samples, flags, want_mask=False)  # bindings only
             assert r2.feasible is None and np.array_equal(r2.binding, want)
         # predicate subsets reach the select kernel too
