@@ -93,7 +93,10 @@ extern "C" {
 /* KSCHED_OPT_PICK_FROM_MASK: 1 = KSCHED_PICK_SAMPLED reads the candidates' bits back from the feasibility mask (after
  * the mask kernel); 0 (default) = it tests the drawn candidates directly from the pod and node columns, as the reference
  * does (src/main.rs:53-66: draw, check_node_validity(pod, candidate)), before and independently of the mask kernel.  Same
- * results either way; a bindings-only request (no output mask) then launches no mask kernel at all. */
+ * results either way; a bindings-only request (no output mask) then launches no mask kernel at all.
+ * KSCHED_PICK_BESTFIT likewise: 0 (default) = candidates are tested in best-fit order from node columns kept in that
+ * order, the mask row is only scanned for pods whose best node sits deep in the order; 1 = every candidate's bit is
+ * looked up in the mask. */
 #define KSCHED_OPT_PICK_FROM_MASK 5
 
 typedef struct ksched_ctx ksched_ctx;

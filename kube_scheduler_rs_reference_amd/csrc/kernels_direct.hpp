@@ -344,4 +344,162 @@ __global__ __launch_bounds__(256) void k_pick_bestfit(const uint64_t *__restrict
     if (lane == 0) binding[pod] = (best == 0xFFFFFFFFu) ? -1 : (int32_t)bf_order[best];
 }
 
+// Best fit from bitmaps in best-fit order (the fused kernel's idea applied to the pick): the node bitmaps a pod ANDs --
+// one row per (label key, value), one per (taint group, tolerated subset), the all-valid row -- are kept a second time
+// with the nodes in bf_order, as whole rows of Wbf = ceil(n / 64) words.  The pod's candidates at or after `start` (the
+// first position whose memory can hold the pod) that pass selector and taints are then the set bits of the AND of a few
+// rows, 64 words = 4096 candidates per wave round with coalesced loads.  The cpu test uses 257 threshold rows in the
+// same order, row[t] = {i : cpurank[i] >= t * q} (cpurank = position in ascending cpu order, q = ceil(n / 256)): with
+// r = #nodes whose cpu is below the request, row[ceil(r / q)] holds only nodes that fit and row[floor(r / q)] all that
+// do, so only candidates in the difference (at most q nodes of the whole snapshot) are tested individually.  The first
+// set bit of the lowest word wins.  No mask is read: like the sampled pick, this runs before and independently of
+// the mask kernel, and a bindings-only request launches no mask kernel.
+struct BestfitRowsArgs {
+    const uint64_t *rows;          // [rows][Wbf] bitmaps over bf_order positions
+    const uint32_t *lab_meta;      // lab_base[32], lab_max[32] (row numbers shared with the tile index)
+    const int64_t *cpu_sorted;     // [n] ascending avail_cpu
+    const int64_t *bf_mem, *bf_cpu;  // node columns in best-fit order
+    const int64_t *mem_s1, *mem_s2, *cpu_s1, *cpu_s2;  // sample arrays of bf_mem / cpu_sorted (wave_lower_bound_sampled), or nullptr
+    const uint32_t *bf_order;
+    const int64_t *pcpu, *pmem;
+    const uint32_t *psel;          // [nkeys][p] or nullptr
+    const uint64_t *ptol;          // [p] or nullptr
+    int32_t *binding;
+    uint32_t p, n, Wbf, nkeys, ngroups, row_valid, row_zero, row_taint, row_cpu0, q, do_fit, do_taint;
+    uint32_t lab_base8[8], lab_max8[8];  // the first eight keys' row numbers as arguments (no dependent load)
+};
+
+// first i in [0, n) with arr[i] >= key (n if none), by the whole wave: 64-ary search, three rounds for n <= 262144
+__device__ __forceinline__ uint32_t wave_lower_bound(const int64_t *__restrict__ arr, uint32_t n, int64_t key, uint32_t lane) {
+    uint32_t lo = 0, len = n;  // the answer lies in [lo, lo + len]
+    while (len > 0) {
+        const uint32_t step = (len + 63u) / 64u;
+        const uint32_t end = lo + len;
+        const uint32_t seg = lo + lane * step;  // lane's segment [seg, min(seg + step, end))
+        bool less = false;
+        if (seg < end) less = arr[min(seg + step, end) - 1u] < key;  // last element of the segment
+        const uint32_t nseg = (len + step - 1u) / step;
+        const uint32_t c = (uint32_t)__popcll(__ballot(less));  // segments entirely below key (a prefix)
+        lo += c * step;
+        len = (c >= nseg) ? 0u : (min(lo + step, end) - lo - 1u);
+        if (c >= nseg) lo = end;
+    }
+    return lo;
+}
+
+// The same lower bound with two sample arrays: s1[j] = last element of block j of 64, s2[j] = last element of block j of
+// 4096.  A plain 64-ary step reads 64 far-apart cache lines to use 8 bytes of each (125 k pods x 2 searches x ~120 lines
+// was most of the best-fit pick's time at the C5 shard); with the samples every round reads 64 CONSECUTIVE entries:
+// three rounds, ~9 lines per search.  n <= 64^3.
+__device__ __forceinline__ uint32_t wave_lower_bound_sampled(const int64_t *__restrict__ arr, const int64_t *__restrict__ s1,
+                                                             const int64_t *__restrict__ s2, uint32_t n, int64_t key, uint32_t lane) {
+    const uint32_t n1 = (n + 63u) / 64u, n2 = (n + 4095u) / 4096u;  // entries of s1, s2
+    // blocks of 4096 entirely below the key (a prefix, since arr is sorted)
+    const uint32_t cA = (uint32_t)__popcll(__ballot(lane < n2 && s2[lane] < key));
+    if (cA >= n2) return n;
+    // within that block: its (up to) 64 blocks of 64
+    const uint32_t j1 = cA * 64u + lane;
+    const uint32_t cB = (uint32_t)__popcll(__ballot(j1 < n1 && s1[j1] < key));
+    const uint32_t b1 = cA * 64u + cB;  // < n1: block cA is not entirely below the key
+    const uint32_t i = b1 * 64u + lane;
+    const uint32_t cC = (uint32_t)__popcll(__ballot(i < n && arr[i] < key));
+    return b1 * 64u + cC;
+}
+
+// two lower bounds at once (the rounds of the two searches are independent of each other: issue their loads together)
+__device__ __forceinline__ void wave_lower_bound_sampled2(const int64_t *__restrict__ a0, const int64_t *__restrict__ a0s1,
+                                                          const int64_t *__restrict__ a0s2, int64_t key0, const int64_t *__restrict__ a1,
+                                                          const int64_t *__restrict__ a1s1, const int64_t *__restrict__ a1s2, int64_t key1,
+                                                          uint32_t n, uint32_t lane, uint32_t &out0, uint32_t &out1) {
+    const uint32_t n1 = (n + 63u) / 64u, n2 = (n + 4095u) / 4096u;
+    const int64_t v0 = (lane < n2) ? a0s2[lane] : 0, v1 = (lane < n2) ? a1s2[lane] : 0;
+    const uint32_t cA0 = (uint32_t)__popcll(__ballot(lane < n2 && v0 < key0)), cA1 = (uint32_t)__popcll(__ballot(lane < n2 && v1 < key1));
+    // a search that has run off the end keeps reading block 0 (harmless) and is fixed up at the end
+    const uint32_t bA0 = (cA0 >= n2) ? 0u : cA0, bA1 = (cA1 >= n2) ? 0u : cA1;
+    const uint32_t j0 = bA0 * 64u + lane, j1 = bA1 * 64u + lane;
+    const int64_t w0 = (j0 < n1) ? a0s1[j0] : 0, w1 = (j1 < n1) ? a1s1[j1] : 0;
+    const uint32_t cB0 = (uint32_t)__popcll(__ballot(j0 < n1 && w0 < key0)), cB1 = (uint32_t)__popcll(__ballot(j1 < n1 && w1 < key1));
+    const uint32_t b0 = bA0 * 64u + cB0, b1 = bA1 * 64u + cB1;
+    const uint32_t i0 = b0 * 64u + lane, i1 = b1 * 64u + lane;
+    const int64_t x0 = (i0 < n) ? a0[i0] : 0, x1 = (i1 < n) ? a1[i1] : 0;
+    const uint32_t cC0 = (uint32_t)__popcll(__ballot(i0 < n && x0 < key0)), cC1 = (uint32_t)__popcll(__ballot(i1 < n && x1 < key1));
+    out0 = (cA0 >= n2) ? n : b0 * 64u + cC0;
+    out1 = (cA1 >= n2) ? n : b1 * 64u + cC1;
+}
+
+__global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs q) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pod = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pod >= q.p) return;
+    // Everything that depends only on the pod is loaded up front, together (the chain of dependent memory round trips
+    // is what this kernel's time is made of: operands -> three search rounds -> rows -> winner's node id).
+    const int64_t req_c = q.do_fit ? q.pcpu[pod] : 0, req_m = q.do_fit ? q.pmem[pod] : 0;
+    const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
+    uint32_t sel[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) sel[k] = (q.psel && k < q.nkeys) ? q.psel[(size_t)k * q.p + pod] : 0u;  // wave-uniform
+    uint32_t start = 0, r_hi = q.row_valid, r_lo = q.row_valid;
+    if (q.do_fit) {
+        uint32_t r;  // #nodes with cpu < request
+        if (q.mem_s1) {
+            wave_lower_bound_sampled2(q.bf_mem, q.mem_s1, q.mem_s2, req_m, q.cpu_sorted, q.cpu_s1, q.cpu_s2, req_c, q.n, lane, start, r);
+        } else {
+            start = wave_lower_bound(q.bf_mem, q.n, req_m, lane);
+            r = wave_lower_bound(q.cpu_sorted, q.n, req_c, lane);
+        }
+        r_hi = q.row_cpu0 + (r + q.q - 1u) / q.q;  // only nodes that fit
+        r_lo = q.row_cpu0 + r / q.q;               // every node that fits
+    }
+    if (start >= q.n) {
+        if (lane == 0) q.binding[pod] = -1;
+        return;
+    }
+    // the rows this pod ANDs (wave-uniform): selector keys, taint groups; row numbers of the first eight keys from the arguments
+    uint32_t lrow[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) lrow[k] = (sel[k] <= q.lab_max8[k]) ? q.lab_base8[k] + sel[k] - 1u : q.row_zero;
+    const uint32_t w_first = start >> 6;
+    for (uint32_t wb = w_first; wb < q.Wbf; wb += 64u) {
+        const uint32_t w = wb + lane;
+        const bool in = w < q.Wbf;
+        const uint32_t wc = in ? w : 0u;
+        // all row words of the round are loaded together, unconditionally (one round trip)
+        uint64_t base = q.rows[(size_t)q.row_valid * q.Wbf + wc];
+        const uint64_t hi = q.rows[(size_t)r_hi * q.Wbf + wc], lo = q.rows[(size_t)r_lo * q.Wbf + wc];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+            if (sel[k] != 0u) base &= q.rows[(size_t)lrow[k] * q.Wbf + wc];
+        for (uint32_t k = 8; k < q.nkeys; ++k) {
+            const uint32_t s = q.psel[(size_t)k * q.p + pod];
+            if (s != 0u) base &= q.rows[(size_t)((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero) * q.Wbf + wc];
+        }
+        if (q.do_taint)
+            for (uint32_t g = 0; g < q.ngroups; ++g)
+                base &= q.rows[(size_t)(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * q.Wbf + wc];
+        if (!in) base = 0;
+        if (w == w_first) base &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
+        const uint64_t sure = q.do_fit ? (base & hi) : base;
+        const uint64_t maybe = q.do_fit ? (base & lo & ~hi) : 0ull;
+        // this lane's first feasible position (rarely more than one trip: `maybe` holds < 1/256 of the nodes)
+        uint32_t found = 0xFFFFFFFFu;
+        uint64_t cand = sure | maybe;
+        while (cand) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(cand);
+            const uint32_t i = w * 64u + b;
+            if (((sure >> b) & 1ull) || req_c <= q.bf_cpu[i]) {
+                found = i;
+                break;
+            }
+            cand &= cand - 1ull;
+        }
+        const uint64_t hit = __ballot(found != 0xFFFFFFFFu);
+        if (hit) {  // lanes hold ascending words: the lowest lane with a hit holds the best-fit node
+            const uint32_t first = (uint32_t)__shfl((int)found, __builtin_ctzll(hit), 64);
+            if (lane == 0) q.binding[pod] = (int32_t)q.bf_order[first];
+            return;
+        }
+    }
+    if (lane == 0) q.binding[pod] = -1;
+}
+
 }  // namespace ksched

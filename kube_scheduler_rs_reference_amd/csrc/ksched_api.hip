@@ -61,7 +61,15 @@ struct ksched_ctx {
     DevBuf<uint32_t> nlab;
     DevBuf<uint64_t> ntaint;
     DevBuf<uint32_t> bf_order, bf_rank;
-    DevBuf<int64_t> bf_mem;
+    DevBuf<int64_t> bf_mem, bf_cpu;  // node columns once more, in best-fit order
+    DevBuf<int64_t> cpu_sorted;      // ascending avail_cpu (rank of a cpu request)
+    DevBuf<int64_t> bf_samples;      // sample arrays of bf_mem and cpu_sorted: [mem s1][mem s2][cpu s1][cpu s2]
+    uint32_t bf_n1 = 0, bf_n2 = 0;
+    DevBuf<uint64_t> bf_rows;        // [rows][Wbf] bitmaps over best-fit positions (k_pick_bestfit_rows); built with the tile index
+    bool bf_rows_built = false;
+    uint32_t bf_row_cpu0 = 0, bf_q = 1;
+    std::vector<uint32_t> h_lab;     // host images of the label and taint columns (re-permuted when the order changes)
+    std::vector<uint64_t> h_taint;
     IndexedSnapshot idx;  // per-tile bitmap index (tile_index.hpp)
     std::vector<int64_t> h_cpu, h_mem;  // host image of `available` (ksched_update_nodes patches single rows)
 
@@ -140,14 +148,98 @@ int upload_bestfit_order(ksched_ctx *c) {
         if (cpu[x] != cpu[y]) return cpu[x] < cpu[y];
         return x < y;
     });
-    std::vector<int64_t> bfmem(n);
+    std::vector<int64_t> bfmem(n), bfcpu(n);
     for (uint32_t i = 0; i < n; ++i) {
         rank[order[i]] = i;
         bfmem[i] = mem[order[i]];
+        bfcpu[i] = cpu[order[i]];
     }
     HIPCHK(c, hipMemcpy(c->bf_mem.ptr, bfmem.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->bf_cpu.ptr, bfcpu.data(), (size_t)n * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->bf_order.ptr, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->bf_rank.ptr, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    return KSCHED_OK;
+}
+
+// Bitmaps over best-fit positions for k_pick_bestfit_rows: the tile index's named rows (valid, taint groups, label
+// values: same row numbers) with the nodes in bf_order, followed by 257 cpu threshold rows.  Rebuilt whenever the order
+// changes (ksched_set_nodes, ksched_update_nodes): O(n * (keys + 16 * taint groups)) bit operations on the host.
+int upload_bestfit_rows(ksched_ctx *c) {
+    c->bf_rows_built = false;
+    if (!c->idx.built || c->n == 0) return KSCHED_OK;
+    const IndexedLayout &l = c->idx.lay;
+    const uint32_t n = c->n, Wbf = (n + 63u) / 64u;
+    const uint32_t named = l.row_cpu;  // rows [0, named): zero, valid, taint rows, label rows
+    const uint32_t levels = 256u, q = (n + levels - 1u) / levels;
+    const uint32_t rows = named + levels + 1u;
+    std::vector<uint32_t> order(n);
+    {
+        const int64_t *cpu = c->h_cpu.data(), *mem = c->h_mem.data();
+        std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            if (mem[x] != mem[y]) return mem[x] < mem[y];
+            if (cpu[x] != cpu[y]) return cpu[x] < cpu[y];
+            return x < y;
+        });
+    }
+    std::vector<uint64_t> R((size_t)rows * Wbf, 0ull);
+    auto setbit = [&](uint32_t row, uint32_t i) { R[(size_t)row * Wbf + (i >> 6)] |= 1ull << (i & 63u); };
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t node = order[i];
+        setbit(l.row_valid, i);
+        for (uint32_t k = 0; k < c->nkeys; ++k) {
+            const uint32_t id = c->h_lab[(size_t)k * n + node];
+            if (id) setbit(l.lab_base[k] + id - 1u, i);
+        }
+        if (c->have_taints)
+            for (uint32_t g = 0; g < l.ngroups; ++g) {
+                const uint32_t tg = (uint32_t)((c->h_taint[node] >> (4u * g)) & 15ull);
+                for (uint32_t sub = 0; sub < 16; ++sub)
+                    if ((tg & ~sub) == 0) setbit(l.row_taint + 16u * g + sub, i);
+            }
+    }
+    if (!c->have_taints)  // no node has a taint: every (group, subset) row is the all-valid row
+        for (uint32_t r = l.row_taint; r < l.row_taint + 16u * l.ngroups; ++r)
+            std::copy(R.begin() + (size_t)l.row_valid * Wbf, R.begin() + (size_t)(l.row_valid + 1) * Wbf, R.begin() + (size_t)r * Wbf);
+    // cpu threshold rows: cpurank = position in ascending (cpu, node) order; row[t] = {i : cpurank >= t * q}
+    std::vector<uint32_t> by_cpu(n), pos_of(n);
+    std::iota(by_cpu.begin(), by_cpu.end(), 0u);
+    std::stable_sort(by_cpu.begin(), by_cpu.end(), [&](uint32_t x, uint32_t y) { return c->h_cpu[x] < c->h_cpu[y]; });
+    std::vector<int64_t> sorted(n);
+    std::vector<uint32_t> bfpos(n);
+    for (uint32_t i = 0; i < n; ++i) bfpos[order[i]] = i;
+    for (uint32_t rnk = 0; rnk < n; ++rnk) {
+        sorted[rnk] = c->h_cpu[by_cpu[rnk]];
+        pos_of[rnk] = bfpos[by_cpu[rnk]];
+    }
+    // from the top down: row[levels] = {rank >= levels * q} (empty: levels * q >= n), row[t] = row[t + 1] | {ranks in [t q, (t + 1) q)}
+    for (int t = (int)levels; t >= 0; --t) {
+        uint64_t *row = R.data() + (size_t)(named + (uint32_t)t) * Wbf;
+        if ((uint32_t)t < levels) std::copy(row + Wbf, row + 2 * (size_t)Wbf, row);
+        const uint64_t lo = std::min<uint64_t>(n, (uint64_t)t * q), hi = ((uint32_t)t == levels) ? n : std::min<uint64_t>(n, (uint64_t)(t + 1) * q);
+        for (uint64_t rnk = lo; rnk < hi; ++rnk) setbit(named + (uint32_t)t, pos_of[rnk]);
+    }
+    // sample arrays for the three-round searches: last element of every block of 64 / of 4096
+    {
+        const uint32_t n1 = (n + 63u) / 64u, n2 = (n + 4095u) / 4096u;
+        std::vector<int64_t> smp(2 * (size_t)(n1 + n2));
+        for (int which = 0; which < 2; ++which) {
+            int64_t *s1 = smp.data() + (size_t)which * (n1 + n2), *s2 = s1 + n1;
+            auto at = [&](uint32_t i) { return which == 0 ? c->h_mem[order[i]] : sorted[i]; };
+            for (uint32_t j = 0; j < n1; ++j) s1[j] = at(std::min(n, (j + 1u) * 64u) - 1u);
+            for (uint32_t j = 0; j < n2; ++j) s2[j] = at(std::min<uint64_t>(n, (uint64_t)(j + 1u) * 4096u) - 1u);
+        }
+        HIPCHK(c, c->bf_samples.reserve(smp.size()));
+        HIPCHK(c, hipMemcpy(c->bf_samples.ptr, smp.data(), smp.size() * 8, hipMemcpyHostToDevice));
+        c->bf_n1 = n1;
+        c->bf_n2 = n2;
+    }
+    HIPCHK(c, c->bf_rows.reserve(R.size()));
+    HIPCHK(c, hipMemcpy(c->bf_rows.ptr, R.data(), R.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->cpu_sorted.ptr, sorted.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    c->bf_row_cpu0 = named;
+    c->bf_q = q;
+    c->bf_rows_built = true;
     return KSCHED_OK;
 }
 
@@ -305,6 +397,49 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         if (rcs) return rcs;
         if (!out_feas && !out_fit) return KSCHED_OK;
     }
+    // The best-fit pick likewise: from bitmaps kept in best-fit order (k_pick_bestfit_rows), no mask involved.
+    const bool bestfit_rows = pick_b && !c->opt_pick_from_mask && c->bf_rows_built;
+    if (bestfit_rows) {
+        const IndexedLayout &l = c->idx.lay;
+        BestfitRowsArgs q{};
+        const bool sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
+        q.rows = c->bf_rows.ptr;
+        q.lab_meta = c->idx.d_lab_meta;
+        q.cpu_sorted = c->cpu_sorted.ptr;
+        q.bf_mem = c->bf_mem.ptr;
+        q.bf_cpu = c->bf_cpu.ptr;
+        q.bf_order = c->bf_order.ptr;
+        if (c->n <= 64u * 64u * 64u) {  // three rounds of 64 cover the array
+            q.mem_s1 = c->bf_samples.ptr;
+            q.mem_s2 = q.mem_s1 + c->bf_n1;
+            q.cpu_s1 = q.mem_s2 + c->bf_n2;
+            q.cpu_s2 = q.cpu_s1 + c->bf_n1;
+        }
+        q.pcpu = pcpu;
+        q.pmem = pmem;
+        q.psel = sel ? psel : nullptr;
+        q.ptol = ptol;
+        q.binding = out_binding;
+        q.p = p;
+        q.n = c->n;
+        q.Wbf = c->W;
+        q.nkeys = sel ? c->nkeys : 0u;
+        q.ngroups = l.ngroups;
+        q.row_valid = l.row_valid;
+        q.row_zero = l.row_zero;
+        q.row_taint = l.row_taint;
+        q.row_cpu0 = c->bf_row_cpu0;
+        q.q = c->bf_q;
+        q.do_fit = (flags & KSCHED_FIT) ? 1u : 0u;
+        q.do_taint = ((flags & KSCHED_TAINT) && c->have_taints) ? 1u : 0u;
+        for (int k = 0; k < 8; ++k) {
+            q.lab_base8[k] = l.lab_base[k];
+            q.lab_max8[k] = l.lab_max[k];
+        }
+        hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q);
+        HIPCHK(c, hipGetLastError());
+        if (!out_feas && !out_fit) return KSCHED_OK;
+    }
     uint64_t *feas = out_feas;
     if (!feas) {  // the mask kernels always write the feasible mask: a pick that reads it, or a fit-mask-only request, gets a scratch one
         HIPCHK(c, c->scratch_mask.reserve((size_t)p * pitch));
@@ -348,7 +483,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     if (rc) return rc;
     if (c->opt_timing && kern != KSCHED_KERNEL_FUSED) HIPCHK(c, hipEventRecord(c->ev_pool[slot].b, s));
 
-    if (select_direct || !(pick_s || pick_b)) return KSCHED_OK;
+    if (select_direct || bestfit_rows || !(pick_s || pick_b)) return KSCHED_OK;
     return launch_pick(c, p, feas, pitch, pmem, samples, attempts, flags, out_binding, s);
 }
 
@@ -417,7 +552,7 @@ void ksched_destroy(ksched_ctx *c) {
         DeviceGuard g(c->device);
         (void)hipDeviceSynchronize();
         c->ncpu.release(); c->nmem.release(); c->ncm.release(); c->nlab.release(); c->ntaint.release();
-        c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release();
+        c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release(); c->bf_cpu.release(); c->cpu_sorted.release(); c->bf_rows.release(); c->bf_samples.release();
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
         c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release();
         c->scratch_mask.release(); c->trace.release();
@@ -489,6 +624,8 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     HIPCHK(c, c->bf_order.reserve(n));
     HIPCHK(c, c->bf_rank.reserve(n));
     HIPCHK(c, c->bf_mem.reserve(n));
+    HIPCHK(c, c->bf_cpu.reserve(n));
+    HIPCHK(c, c->cpu_sorted.reserve(n));
     int rc_bf = KSCHED_OK;
     if (n > 0) {
         HIPCHK(c, hipMemcpy(c->ncpu.ptr, cpu, (size_t)n * 8, hipMemcpyHostToDevice));
@@ -497,6 +634,10 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
         if (taints) HIPCHK(c, hipMemcpy(c->ntaint.ptr, taints, (size_t)n * 8, hipMemcpyHostToDevice));
         c->h_cpu.assign(cpu, cpu + n);
         c->h_mem.assign(mem, mem + n);
+        if (n_keys) c->h_lab.assign(lab, lab + (size_t)n * n_keys);
+        else c->h_lab.clear();
+        if (taints) c->h_taint.assign(taints, taints + n);
+        else c->h_taint.clear();
         {
             std::vector<int64_t> cm((size_t)n * 2);
             for (uint32_t i = 0; i < n; ++i) {
@@ -513,6 +654,7 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     if (rc_bf) return rc_bf;
     hipError_t e = indexed_build(c->idx, n, cpu, mem, lab, n_keys, taints);
     if (e != hipSuccess) return fail_hip(c, e, "indexed_build");
+    if (int rcr = upload_bestfit_rows(c)) return rcr;
     c->have_nodes = true;
     return KSCHED_OK;
 }
@@ -567,7 +709,7 @@ int ksched_update_nodes(ksched_ctx *c, uint32_t count, const uint32_t *node_inde
             hipError_t e = indexed_update_tile(c->idx, t, c->h_cpu.data(), c->h_mem.data());
             if (e != hipSuccess) return fail_hip(c, e, "indexed_update_tile");
         }
-    return KSCHED_OK;
+    return upload_bestfit_rows(c);
 }
 
 int ksched_eval_device_pitched(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
@@ -740,7 +882,8 @@ int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *p
     uint64_t *d_feas = nullptr, *d_fit = nullptr;
     int32_t *d_bind = nullptr;
     // a mask is needed when the caller wants it, or when the pick reads it (best fit; sampled only with KSCHED_OPT_PICK_FROM_MASK)
-    const bool pick_reads_mask = (flags & KSCHED_PICK_BESTFIT) || ((flags & KSCHED_PICK_SAMPLED) && c->opt_pick_from_mask);
+    const bool pick_reads_mask = (flags & (KSCHED_PICK_BESTFIT | KSCHED_PICK_SAMPLED)) &&
+                                 (c->opt_pick_from_mask || ((flags & KSCHED_PICK_BESTFIT) && !c->bf_rows_built));
     if (out_feas || pick_reads_mask) {
         HIPCHK(c, c->feas.reserve((size_t)p * pitch));
         d_feas = c->feas.ptr;

@@ -566,3 +566,40 @@ def test_sampled_pick_direct_equals_pick_from_mask(evaluator, kernel):
             assert np.array_equal(r.binding, w2), (P, N, K, attempts, sub)
     ev.set_option(_lib.OPT_PICK_FROM_MASK, 0)
     ev.set_kernel("auto")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_bestfit_direct_equals_bestfit_from_mask(evaluator, kernel):
+    """KSCHED_PICK_BESTFIT two ways: first set bit of the AND of bitmaps kept in best-fit order (default, no mask read) and
+    every candidate's bit looked up in the mask (KSCHED_OPT_PICK_FROM_MASK) -- both == oracle; with taints, > 8 label keys, predicate subsets, rows whose only feasible nodes sit beyond the direct window,
+    and after ksched_update_nodes (the order changes)."""
+    ev = evaluator
+    ev.set_kernel(kernel)
+    rng = np.random.default_rng(23)
+    for (P, N, K) in [(1500, 6000, 8), (600, 2500, 12), (200, 100, 3), (64, 1, 8)]:
+        c = synth.make_cluster(P, N, n_keys=min(K, 8), n_taints=16, seed=3 * P + K)
+        lab, sel = c.node_labels, c.pod_sel
+        if K > 8:
+            lab = np.concatenate([lab, rng.integers(0, 3, size=(K - 8, N), dtype=np.uint32)])
+            sel = np.concatenate([sel, np.where(rng.random((K - 8, P)) < 0.2, rng.integers(1, 4, size=(K - 8, P)), 0).astype(np.uint32)])
+        cpu, mem = c.avail_cpu.copy(), c.avail_mem.copy()
+        req_cpu = c.req_cpu.copy()
+        req_cpu[::7] = np.sort(cpu)[-max(1, N // 400)]  # these pods fit only the few largest nodes: deep in the best-fit order
+        ev.set_nodes(cpu, mem, lab, c.node_taints)
+        for step in range(2):
+            for flags in (FIT | SEL | TAINT, FIT, SEL | TAINT, FIT | SEL):
+                _, _, want = capi.eval_encoded(cpu, mem, lab, c.node_taints, req_cpu, c.req_mem, sel, c.pod_tol, None, flags | PICK_BESTFIT)
+                for from_mask in (0, 1):
+                    ev.set_option(_lib.OPT_PICK_FROM_MASK, from_mask)
+                    r = ev.eval(req_cpu, c.req_mem, sel, c.pod_tol, None, flags | PICK_BESTFIT)
+                    assert np.array_equal(r.binding, want), (P, N, K, flags, from_mask, step)
+                    r = ev.eval(req_cpu, c.req_mem, sel, c.pod_tol, None, flags | PICK_BESTFIT, want_mask=False)  # bindings only
+                    assert np.array_equal(r.binding, want), (P, N, K, flags, from_mask, step, "no mask")
+            # a few nodes change: the best-fit order and the columns kept in that order are rebuilt
+            idx = rng.choice(N, size=min(N, 9), replace=False).astype(np.uint32)
+            cpu[idx] = rng.integers(0, 200_000, size=idx.size)
+            mem[idx] = rng.integers(0, 1 << 38, size=idx.size)
+            ev.set_option(_lib.OPT_PICK_FROM_MASK, 0)
+            ev.update_nodes(idx, cpu[idx], mem[idx])
+    ev.set_option(_lib.OPT_PICK_FROM_MASK, 0)
+    ev.set_kernel("auto")
