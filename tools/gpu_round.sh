@@ -3,7 +3,7 @@
 #   steps (default: all): test bench prof pmc lines trace smoke
 # Everything lands under gpurun_out/<tag>/ ; tools/collect_profiles.py copies the summaries into profiles/.
 TAG=${1:-r}; shift
-STEPS=${@:-"test bench prof pmc lines trace smoke"}
+STEPS=${@:-"test bench prof pmc lines trace smoke host"}
 REPO=$PWD; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 stamp() { echo "[$(date +%H:%M:%S)] $*"; }
@@ -78,6 +78,10 @@ except Exception as e:
     print("$wl debug=$bits: FAILED", e)
 PY
   done; done
+fi
+if has host; then
+  stamp "host-side cost of the snapshot calls"
+  timeout 300 python tools/host_costs.py > $OUT/host_costs.txt 2>&1; cat $OUT/host_costs.txt
 fi
 if has trace; then
   stamp "fused kernel phase trace (C3)"
