@@ -113,12 +113,14 @@ def main():
                     help="mask rows packed at W words (default: rows pitched to ksched_mask_pitch(n) = W rounded up to 128 B)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (timing experiments; results invalid)")
     ap.add_argument("--depth", type=int, default=None,
-                    help="steps in flight (buffer slots).  Default: 1 on one GPU; 2 for N > 1, where the all-gather of step i is "
-                         "asynchronous and overlaps the kernels of step i+1 (double-buffered bindings)")
+                    help="steps in flight (buffer slots).  Default: 1 on one GPU (strictly sequential steps on one stream); 2 for N > 1, "
+                         "where the all-gather of step i is asynchronous and overlaps the kernels of step i+1 (double-buffered bindings)")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="attach HIP events to every N-th mask kernel launch of the timed steps (roofline.avg_kernel_us is their mean)")
     ap.add_argument("--two-stream", action="store_true",
-                    help="also run the mask kernel of step i+1 and the pick of step i on two HIP streams (ksched_pipe, needs --depth >= 2). "
-                         "Measured slower below ~100 us of kernel time per step (cross-stream waits cost more than the pick): "
-                         "profiles/r01_h1_ab_two_stream_pipeline.txt")
+                    help="with --depth >= 2: mask kernels on one HIP stream, pick kernels (+ all-gather) on another (ksched_pipe).  The picks "
+                         "do not read the mask, so the two streams need no ordering between them: +25 %% evals/s at C3, but the mask kernel "
+                         "then shares the chip with pick kernels (its own duration grows; profiles/r01_h4_ab_streams.txt)")
     args = ap.parse_args()
 
     import torch
@@ -175,9 +177,13 @@ def main():
     def local_eval(binding_out):  # sequential form: mask kernel + pick kernel on one stream, one library call
         ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=d_mask, out_binding=binding_out)
 
-    def run(slot, binding_out):  # pipelined form: bindings (and with --two-stream the masks) are per slot
-        if pipe is not None:  # ksched_pipe_submit puts the mask kernel and the pick on the pipe's two streams
-            pipe.submit(slot, d_cpu, d_mem, d_sel, d_tol, d_smp, flags, d_masks[slot], binding_out)
+    submit = None
+    if pipe is not None:  # pre-marshalled ksched_pipe_submit: the mask kernel goes to the pipe's mask stream, the pick to its pick stream
+        submit = pipe.bind(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, d_masks, [sched._local[k][: hi - lo] for k in range(depth)])
+
+    def run(slot, binding_out):  # pipelined form: bindings and masks are per slot
+        if submit is not None:
+            submit(slot)
         else:
             ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=d_mask, out_binding=binding_out)
 
@@ -192,7 +198,7 @@ def main():
     for _ in range(args.warmup):
         last = one_step()
     sync()
-    ev.set_timing(True)
+    ev.set_timing(True, every=args.time_every)  # HIP events on every N-th mask kernel dispatch (they cost launch gap: sample)
     ev.kernel_time_ms()  # reset
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -81,7 +81,8 @@ extern "C" {
 #define KSCHED_KERNEL_AUTO 0
 #define KSCHED_KERNEL_DIRECT 1  /* lanes = nodes, compare-is-ballot; always applicable */
 #define KSCHED_KERNEL_FUSED 3   /* LDS-resident per-tile bitmap index, one launch: rank search + row AND + store (default when applicable) */
-/* KSCHED_OPT_TIMING: 1 = bracket the mask kernel with hipEvents (adds two event records per call) */
+/* KSCHED_OPT_TIMING: N > 0 = every N-th mask kernel launch carries hipEvents on its dispatch (1 = every launch; the events
+ * cost ~1.5 us of launch gap each, so a throughput measurement samples with N > 1); 0 = off */
 #define KSCHED_OPT_TIMING 2
 /* KSCHED_OPT_DEBUG: ablation bits for kernel timing experiments (tools/); any non-zero value makes results invalid */
 #define KSCHED_OPT_DEBUG 3
@@ -201,8 +202,11 @@ int ksched_pick_device(ksched_ctx *ctx, uint32_t p, const uint64_t *feasible, ui
  * (device memory) and passes them to every submit, so the library retains nothing but streams and events.
  *
  *   ksched_pipe_submit(slot, ...)  enqueue one batch into `slot` (round-robin 0 .. depth-1):
- *        mask stream : wait for the slot's previous pick -> mask kernel into `mask`
- *        pick stream : wait for that mask kernel          -> pick into `binding`
+ *        mask stream : mask kernel into `mask`
+ *        pick stream : pick into `binding`
+ *      By default the picks do not read the mask (KSCHED_OPT_PICK_FROM_MASK), so the two streams are not ordered
+ *      against each other at all: each is in order by itself.  With a mask-reading pick the pick waits for its mask
+ *      kernel and the slot's next mask kernel for that pick (events).
  *      `flags` must contain one KSCHED_PICK_* flag; predicates and pick mean what they mean in ksched_eval_device.
  *      All input arrays are device pointers that must be complete before the call and stay untouched until the
  *      slot's pick has run.  A caller that enqueues its own work on the pick stream behind the pick (reading

@@ -83,7 +83,8 @@ struct ksched_ctx {
 
     // options
     int opt_kernel = KSCHED_KERNEL_AUTO;
-    bool opt_timing = false;
+    uint32_t opt_timing = 0;       // 0 off, N: every N-th mask launch carries events
+    uint64_t timing_seq = 0;
     uint32_t opt_debug = 0;
     bool opt_trace = false;
     bool opt_pick_from_mask = false;
@@ -459,7 +460,8 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         return KSCHED_E_UNSUPPORTED;
     }
     size_t slot = 0;
-    if (c->opt_timing) {
+    const bool timed = c->opt_timing && (c->timing_seq++ % c->opt_timing) == 0;
+    if (timed) {
         int trc = timing_slot(c, &slot);
         if (trc) return trc;
         if (kern != KSCHED_KERNEL_FUSED) HIPCHK(c, hipEventRecord(c->ev_pool[slot].a, s));
@@ -472,7 +474,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
             HIPCHK(c, hipMemsetAsync(c->trace.ptr, 0, (size_t)kTraceBlocks * KSCHED_TRACE_WORDS * 8, s));
         }
         hipError_t e = run_fused(c->idx, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, pitch, s, c->opt_debug,
-                                 c->opt_timing ? c->ev_pool[slot].a : nullptr, c->opt_timing ? c->ev_pool[slot].b : nullptr,
+                                 timed ? c->ev_pool[slot].a : nullptr, timed ? c->ev_pool[slot].b : nullptr,
                                  c->opt_trace ? c->trace.ptr : nullptr, kTraceBlocks);
         if (e != hipSuccess) return fail_hip(c, e, "run_fused");
         c->last_kernel = "fused";
@@ -481,7 +483,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         rc = run_direct(c, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, pitch, s);
     }
     if (rc) return rc;
-    if (c->opt_timing && kern != KSCHED_KERNEL_FUSED) HIPCHK(c, hipEventRecord(c->ev_pool[slot].b, s));
+    if (timed && kern != KSCHED_KERNEL_FUSED) HIPCHK(c, hipEventRecord(c->ev_pool[slot].b, s));
 
     if (select_direct || bestfit_rows || !(pick_s || pick_b)) return KSCHED_OK;
     return launch_pick(c, p, feas, pitch, pmem, samples, attempts, flags, out_binding, s);
@@ -580,7 +582,9 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
             c->opt_kernel = (int)value;
             return KSCHED_OK;
         case KSCHED_OPT_TIMING:
-            c->opt_timing = value != 0;
+            if (value < 0 || value > 1000000) return KSCHED_E_INVAL;
+            c->opt_timing = (uint32_t)value;
+            c->timing_seq = 0;
             return KSCHED_OK;
         case KSCHED_OPT_DEBUG:
             c->opt_debug = (uint32_t)value;
@@ -798,17 +802,24 @@ int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t 
     if (mask_pitch_words < c->W) return KSCHED_E_INVAL;
     DeviceGuard g(c->device);
     if (!g.ok) return KSCHED_E_HIP;
-    // mask stream: the slot's mask may be overwritten once the pick that read it has run
-    HIPCHK(c, hipStreamWaitEvent(q->s_mask, q->pick_done[slot], 0));
+    // Does the pick read the mask?  By default it does not (sampled: the drawn candidates are tested from the columns;
+    // best fit: bitmaps kept in best-fit order), so the two streams need no ordering at all: each is in order by itself
+    // (mask kernels of successive batches on one, picks on the other), which also covers the reuse of a slot's buffers.
+    const bool pick_reads_mask = c->opt_pick_from_mask || ((pick & KSCHED_PICK_BESTFIT) && !c->bf_rows_built);
+    if (pick_reads_mask) HIPCHK(c, hipStreamWaitEvent(q->s_mask, q->pick_done[slot], 0));  // the slot's mask may be overwritten once its pick has run
     rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, nullptr, 0, flags & ~pick, mask, nullptr, nullptr, mask_pitch_words, q->s_mask);
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(q->mask_done[slot], q->s_mask));
-    // pick stream: behind this slot's mask kernel (and, by stream order, behind everything the caller enqueued on the
-    // pick stream after the slot's previous pick)
-    HIPCHK(c, hipStreamWaitEvent(q->s_pick, q->mask_done[slot], 0));
-    if (p > 0) {
-        if (c->n == 0) HIPCHK(c, hipMemsetAsync(binding, 0xFF, (size_t)p * sizeof(int32_t), q->s_pick));
-        else if ((rc = launch_pick(c, p, mask, mask_pitch_words, pmem, samples, attempts, flags, binding, q->s_pick))) return rc;
+    if (pick_reads_mask) {
+        HIPCHK(c, hipEventRecord(q->mask_done[slot], q->s_mask));
+        HIPCHK(c, hipStreamWaitEvent(q->s_pick, q->mask_done[slot], 0));
+        if (p > 0) {
+            if (c->n == 0) HIPCHK(c, hipMemsetAsync(binding, 0xFF, (size_t)p * sizeof(int32_t), q->s_pick));
+            else if ((rc = launch_pick(c, p, mask, mask_pitch_words, pmem, samples, attempts, flags, binding, q->s_pick))) return rc;
+        }
+    } else {
+        // bindings-only evaluation on the pick stream: launches the pick kernel alone
+        rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, nullptr, nullptr, binding, mask_pitch_words, q->s_pick);
+        if (rc) return rc;
     }
     HIPCHK(c, hipEventRecord(q->pick_done[slot], q->s_pick));
     return KSCHED_OK;

@@ -79,8 +79,9 @@ class Evaluator:
     def set_kernel(self, name: str):
         self.set_option(L.OPT_KERNEL, {"auto": L.KERNEL_AUTO, "direct": L.KERNEL_DIRECT, "fused": L.KERNEL_FUSED}[name])
 
-    def set_timing(self, on: bool):
-        self.set_option(L.OPT_TIMING, 1 if on else 0)
+    def set_timing(self, on, every: int = 1):
+        """Events on every `every`-th mask kernel launch (0 / False = off)."""
+        self.set_option(L.OPT_TIMING, int(every) if on else 0)
 
     def kernel_time_ms(self):
         ms = C.c_double(0)
@@ -286,6 +287,24 @@ class Pipe:
         rc = self._lib.ksched_pipe_submit(self._h, slot, p, ptr(req_cpu_milli), ptr(req_mem_bytes), ptr(sel_val_ids), ptr(tolerations),
                                           ptr(samples), attempts, flags, ptr(mask), pitch, ptr(binding))
         self.ev._check(rc, "ksched_pipe_submit")
+
+    def bind(self, req_cpu_milli, req_mem_bytes, sel_val_ids, tolerations, samples, flags: int, masks, bindings):
+        """Pre-marshal a batch whose inputs stay in place (steady-state loops): returns submit(slot) for slot-indexed `masks` /
+        `bindings` lists.  Saves the per-call tensor -> pointer conversions (the host would otherwise bound the step rate)."""
+        p, W = int(req_cpu_milli.shape[0]), self.ev.W
+        attempts = int(samples.shape[1]) if (flags & L.PICK_SAMPLED and samples is not None) else 0
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        fixed = (ptr(req_cpu_milli), ptr(req_mem_bytes), ptr(sel_val_ids), ptr(tolerations), ptr(samples), attempts, flags)
+        per_slot = [(ptr(m), int(m.stride(0)) if p > 1 else W, ptr(b)) for m, b in zip(masks, bindings)]
+        keep = (req_cpu_milli, req_mem_bytes, sel_val_ids, tolerations, samples, list(masks), list(bindings))  # keep the tensors alive
+        fn, h, check = self._lib.ksched_pipe_submit, self._h, self.ev._check
+
+        def submit(slot: int, _keep=keep):
+            m, pitch, b = per_slot[slot]
+            rc = fn(h, slot, p, *fixed, m, pitch, b)
+            if rc:
+                check(rc, "ksched_pipe_submit")
+        return submit
 
     def wait(self, slot: int, stream=None, host: bool = False):
         """Order `stream` (default: torch's current stream) after the slot's pick; host=True blocks the host instead."""
