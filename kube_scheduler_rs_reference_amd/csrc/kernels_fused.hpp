@@ -560,23 +560,26 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             __builtin_amdgcn_wave_barrier();
             KSCHED_PROF(prof_p2);
         }
-        first = false;
-        if (!more) break;
+        const bool had_more = more;
+        if (more) {
 #if KSCHED_PROFILE
-        prof_t = __builtin_readcyclecounter();
-        ++prof_rounds;
+            prof_t = __builtin_readcyclecounter();
+            ++prof_rounds;
 #endif
-        KSCHED_WAIT_OPS(kFastStores);  // operands of round u have landed; up to kFastStores younger stores may be in flight
-        KSCHED_PROF(prof_wait);
-        prev_over = phase1(u * 8u);
-        KSCHED_PROF(prof_p1);
-        prev_extra = extra_any;
-        if (!have_prev) stamp(3);
-        prev_u = u;
-        prev_nu = min(8u, u_hi - u);
-        have_prev = true;
-        u += 8u;
-        more = u < u_hi;
+            KSCHED_WAIT_OPS(kFastStores);  // operands of round u have landed; up to kFastStores younger stores may be in flight
+            KSCHED_PROF(prof_wait);
+            prev_over = phase1(u * 8u);
+            KSCHED_PROF(prof_p1);
+            prev_extra = extra_any;
+            if (!have_prev) stamp(3);
+            prev_u = u;
+            prev_nu = min(8u, u_hi - u);
+            have_prev = true;
+            u += 8u;
+            more = u < u_hi;
+        }
+        first = false;
+        if (!had_more) break;
     }
 #undef KSCHED_WAIT_OPS
     if (a.trace && lane == 0) {  // every wave: latest loop end / drain of the block
