@@ -117,6 +117,9 @@ def main():
                          "where the all-gather of step i is asynchronous and overlaps the kernels of step i+1 (double-buffered bindings)")
     ap.add_argument("--time-every", type=int, default=4,
                     help="attach HIP events to every N-th mask kernel launch of the timed steps (roofline.avg_kernel_us is their mean)")
+    ap.add_argument("--gather-every", type=int, default=None,
+                    help="N > 1: one all-gather per this many steps (their bindings share a buffer).  Default 4: an RCCL call costs tens "
+                         "of microseconds of host and launch time whatever its size -- the same order as a step's kernels")
     ap.add_argument("--two-stream", action="store_true",
                     help="with --depth >= 2: mask kernels on one HIP stream, pick kernels (+ all-gather) on another (ksched_pipe).  The picks "
                          "do not read the mask, so the two streams need no ordering between them: +25 %% evals/s at C3, but the mask kernel "
@@ -140,8 +143,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # KSCHED_BENCH_FORCE_DIST=1 (self-test): run the N > 1 code path -- RCCL process group, asynchronous all-gather of the
+    # bindings, barrier, MAX all-reduce of the elapsed time -- in a one-rank group on the one GPU there is
+    multi = world > 1 or bool(os.environ.get("KSCHED_BENCH_FORCE_DIST"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg, P_gpu, N, flag_names, pick, desc = WORKLOADS[args.workload]
@@ -158,10 +165,12 @@ def main():
     if args.debug:
         ev.set_option(L.OPT_DEBUG, args.debug)
     ev.set_nodes(**c.node_columns())
-    depth = args.depth if args.depth else (2 if world > 1 else 1)
+    depth = args.depth if args.depth else (2 if multi else 1)
     pipelined = depth > 1 and not args.no_mask
     pipe = ev.pipe(depth) if (pipelined and args.two_stream) else None
-    sched = PipelinedScheduler(P_total, dev, depth=depth, pipe=pipe) if pipelined else ShardedScheduler(P_total, dev)
+    gather_every = 1 if (pipe is not None or not multi) else max(1, args.gather_every or 4)
+    sched = (PipelinedScheduler(P_total, dev, depth=depth, pipe=pipe, gather_always=multi, gather_every=gather_every) if pipelined
+             else ShardedScheduler(P_total, dev))
     lo, hi = sched.lo, sched.hi
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
     d_cpu, d_mem = t(c.req_cpu[lo:hi], np.int64), t(c.req_mem[lo:hi], np.int64)
@@ -191,7 +200,7 @@ def main():
         return sched.step(run) if pipelined else sched.step(local_eval)
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -210,7 +219,7 @@ def main():
     bindings = last.wait() if pipelined else last
     kern_ms, launches = ev.kernel_time_ms()
     ev.set_timing(False)
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -240,6 +249,7 @@ def main():
                        "predicates": "+".join(flag_names), "pick": pick, "mask_written": not args.no_mask,
                        "mask_row_pitch_words": pitch, "mask_words": W,
                        "kernel": ev.last_kernel, "steps_in_flight": depth if pipelined else 1, "two_stream": pipe is not None,
+                       "steps_per_allgather": gather_every if (pipelined and multi) else (1 if multi else None),
                        "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
                        "allgather(int32 bindings)" if world > 1 else "single GPU",
                        "bound_fraction": bound_frac},
@@ -254,11 +264,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(c, flag_names)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     ev.close()
+    if rank == 0:
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer until exit: push it out first
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)  # the ONE line, last
 
 
 if __name__ == "__main__":

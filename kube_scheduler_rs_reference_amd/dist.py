@@ -66,80 +66,105 @@ class ShardedScheduler:
 
 class PendingBindings:
     """Result of PipelinedScheduler.step: `.wait()` orders the current stream (CPU: the host) after the step's pick
-    and all-gather and returns the global bindings [P] (a view of the slot's buffer, valid until the slot is reused,
-    i.e. for `depth - 1` further steps)."""
+    and all-gather and returns the global bindings [P] (valid until the step's buffer slot is reused, i.e. for
+    `(depth - 1) * gather_every` further steps)."""
 
-    def __init__(self, sched: "PipelinedScheduler", slot: int):
-        self._s, self._slot = sched, slot
+    def __init__(self, sched: "PipelinedScheduler", slot: int, sub: int):
+        self._s, self._slot, self._sub = sched, slot, sub
 
     def wait(self) -> torch.Tensor:
-        s, k = self._s, self._slot
+        s, k, g = self._s, self._slot, self._sub
         if s._gather:
+            if s._fill[k] > 0 and s._cur == k:  # the step's group has not been gathered yet: do it now, short
+                s._flush(k)
             if s._work[k] is not None:
                 s._work[k].wait()
-            return s._gathered[k][: s.P]
+            # gathered[k] is [world][gather_every][shard]: this step's rows of every rank
+            return s._gathered[k].view(s.world, s.gather_every, s.shard)[:, g].reshape(-1)[: s.P]
         if s.pipe is not None and s._used[k]:
             s.pipe.wait(k)
-        return s._local[k][: s.P]
+        return s._local[k].view(s.gather_every, s.shard)[g][: s.P]
 
 
 class PipelinedScheduler:
-    """Row-sharded evaluation, pick and all-gather of consecutive batches, `depth` steps in flight.
+    """Row-sharded evaluation, pick and all-gather of consecutive batches, `depth` buffer slots in flight.
 
-    step(run):  run(slot, binding_out) enqueues this rank's evaluation + pick of one batch into buffer slot `slot`,
-    filling binding_out[: n_local] (int32, -1 = no node).
-      * on a GPU, `pipe` is the evaluator's two-stream pipeline (Evaluator.pipe(depth)) and `run` calls
-        `pipe.submit(slot, ...)`: the mask kernel goes to the pipe's mask stream, the pick to its pick stream, and
-        the all-gather is enqueued (asynchronously) behind the pick on that same stream;
-      * without a pipe (CPU, gloo tests) `run` executes inline and only the all-gather is asynchronous."""
+    step(run):  run(slot, binding_out) enqueues this rank's evaluation + pick of one batch, filling
+    binding_out[: n_local] (int32, -1 = no node).
+      * on a GPU with `pipe` (Evaluator.pipe(depth), only with gather_every == 1) `run` calls `pipe.submit(slot, ...)`:
+        the mask kernel goes to the pipe's mask stream, the pick to its pick stream, and the all-gather is enqueued
+        (asynchronously) behind the pick on that same stream;
+      * without a pipe `run` enqueues on the current stream (CPU, gloo tests: executes inline) and only the
+        all-gather is asynchronous.
+    gather_every = G > 1: the bindings of G consecutive steps share one buffer and ONE all-gather (fewer, larger
+    collectives: an RCCL call costs tens of microseconds of host and launch time whatever its size, the same order as
+    a step's kernels).  A step's result is then available once its group has been gathered (`wait()` flushes a partial
+    group)."""
 
     def __init__(self, P: int, device: torch.device, depth: int = 2, group: Optional[dist.ProcessGroup] = None, pipe=None,
-                 gather_always: bool = False):
-        if depth < 1:
-            raise ValueError("depth >= 1")
-        if pipe is not None and pipe.depth != depth:
-            raise ValueError("pipe.depth != depth")
-        self.P, self.device, self.depth, self.group, self.pipe = P, device, depth, group, pipe
+                 gather_always: bool = False, gather_every: int = 1):
+        if depth < 1 or gather_every < 1:
+            raise ValueError("depth >= 1, gather_every >= 1")
+        if pipe is not None and (pipe.depth != depth or gather_every != 1):
+            raise ValueError("a pipe needs pipe.depth == depth and gather_every == 1")
+        self.P, self.device, self.depth, self.group, self.pipe, self.gather_every = P, device, depth, group, pipe, gather_every
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.lo, self.hi, self.shard = shard_bounds(P, self.world, self.rank)
         # gather_always: run the all-gather even in a one-rank group (exercises the RCCL path on a single GPU; tests)
         self._gather = self.world > 1 or (gather_always and dist.is_initialized())
-        self._local = [torch.full((self.shard,), -1, dtype=torch.int32, device=device) for _ in range(depth)]
-        self._gathered = [torch.full((self.shard * self.world,), -1, dtype=torch.int32, device=device) if self._gather else None
+        G = gather_every
+        self._local = [torch.full((G * self.shard,), -1, dtype=torch.int32, device=device) for _ in range(depth)]
+        self._gathered = [torch.full((G * self.shard * self.world,), -1, dtype=torch.int32, device=device) if self._gather else None
                           for _ in range(depth)]
         self._work = [None] * depth
         self._used = [False] * depth
+        self._fill = [0] * depth   # steps written into the slot since its last gather
+        self._cur = 0              # slot being filled
         self._pick_stream = pipe.stream(1) if pipe is not None else None
-        self._i = 0
 
     @property
     def n_local(self) -> int:
         return self.hi - self.lo
 
+    def _flush(self, k: int) -> None:
+        """Issue the (asynchronous) all-gather of slot k's group and move on to the next slot."""
+        if self._gather and self._fill[k] > 0:
+            if self._pick_stream is not None:
+                with torch.cuda.stream(self._pick_stream):
+                    self._work[k] = dist.all_gather_into_tensor(self._gathered[k], self._local[k], group=self.group, async_op=True)
+            else:
+                self._work[k] = dist.all_gather_into_tensor(self._gathered[k], self._local[k], group=self.group, async_op=True)
+        self._fill[k] = 0
+        self._cur = (k + 1) % self.depth
+
     def step(self, run: Callable[[int, torch.Tensor], None]) -> PendingBindings:
-        k = self._i % self.depth
-        self._i += 1
-        out = self._local[k][: self.n_local]
-        if self._pick_stream is not None and self._gather:
-            with torch.cuda.stream(self._pick_stream):
-                if self._work[k] is not None:  # the all-gather that read this slot's bindings `depth` steps ago:
-                    self._work[k].wait()       # the pick stream (hence this slot's next pick) is ordered after it
-                if self.n_local > 0:
-                    run(k, out)
-                    self._used[k] = True
-                self._work[k] = dist.all_gather_into_tensor(self._gathered[k], self._local[k], group=self.group, async_op=True)
-        else:
-            if self._work[k] is not None:
+        k, g = self._cur, self._fill[self._cur]
+        if g == 0 and self._work[k] is not None:
+            # first step into a reused slot: the all-gather that read its bindings must be done before they are overwritten
+            if self._pick_stream is not None:
+                with torch.cuda.stream(self._pick_stream):
+                    self._work[k].wait()
+            else:
                 self._work[k].wait()
-            if self.n_local > 0:
-                run(k, out)
-                self._used[k] = True
-            if self._gather:
-                self._work[k] = dist.all_gather_into_tensor(self._gathered[k], self._local[k], group=self.group, async_op=True)
-        return PendingBindings(self, k)
+            self._work[k] = None
+        out = self._local[k][g * self.shard: g * self.shard + self.n_local]
+        if self.n_local > 0:
+            run(k, out)
+            self._used[k] = True
+        self._fill[k] = g + 1
+        pending = PendingBindings(self, k, g)
+        if self._fill[k] == self.gather_every:
+            self._flush(k)
+        return pending
 
     def drain(self) -> None:
-        """Order the current stream (CPU: the host) after everything in flight."""
+        """Gather what is still ungathered and order the current stream (CPU: the host) after everything in flight."""
+        if self._fill[self._cur] > 0:
+            self._flush(self._cur)
         for k in range(self.depth):
-            PendingBindings(self, k).wait()
+            if self._gather:
+                if self._work[k] is not None:
+                    self._work[k].wait()
+            elif self.pipe is not None and self._used[k]:
+                self.pipe.wait(k)

@@ -78,14 +78,14 @@ def test_shard_bounds_cover_rows_exactly_once():
             assert seen == P
 
 
-def _pipe_worker(rank, world, port, P, N, depth, steps, q):
+def _pipe_worker(rank, world, port, P, N, depth, steps, q, gather_every=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from kube_scheduler_rs_reference_amd.dist import PipelinedScheduler
         c = synth.make_cluster(P, N, n_keys=8, n_taints=0, seed=7)
-        sched = PipelinedScheduler(P, torch.device("cpu"), depth=depth)
+        sched = PipelinedScheduler(P, torch.device("cpu"), depth=depth, gather_every=gather_every)
         lo, hi = sched.lo, sched.hi
         flags = capi.FIT | capi.SEL | capi.PICK_SAMPLED
         state = {"step": 0}
@@ -104,7 +104,7 @@ def _pipe_worker(rank, world, port, P, N, depth, steps, q):
         for j in range(steps):
             state["step"] = j
             pend.append((j, sched.step(run)))
-            if len(pend) >= depth:  # consume the oldest while newer steps are in flight: its slot is reused next
+            if len(pend) >= max(1, (depth - 1) * gather_every):  # consume the oldest while newer steps are in flight (its slot is reused soon)
                 jj, pb = pend.pop(0)
                 got = pb.wait().clone().numpy()
                 _, _, want = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, None, c.req_cpu, c.req_mem, c.pod_sel, None,
@@ -121,14 +121,14 @@ def _pipe_worker(rank, world, port, P, N, depth, steps, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,P,depth", [(2, 501, 2), (2, 64, 3), (3, 10, 2), (2, 1, 2)])
-def test_pipelined_allgather_matches_single_process(world, P, depth):
-    """PipelinedScheduler: `depth` steps in flight, asynchronous all-gather, slots reused -- every step's global
-    bindings equal the single-process result of THAT step's batch."""
+@pytest.mark.parametrize("world,P,depth,every", [(2, 501, 2, 1), (2, 64, 3, 1), (3, 10, 2, 1), (2, 1, 2, 1), (2, 301, 2, 3), (3, 77, 2, 4), (2, 50, 1, 2)])
+def test_pipelined_allgather_matches_single_process(world, P, depth, every):
+    """PipelinedScheduler: `depth` slots in flight, asynchronous all-gather (one per `every` steps), slots reused, partial last
+    group -- every step's global bindings equal the single-process result of THAT step's batch."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, P, 150, depth, 5, q)) for r in range(world)]
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, P, 150, depth, 7, q, every)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]

@@ -478,8 +478,8 @@ def test_pipelined_steps_equal_sequential(evaluator, depth):
     pipe.close()
 
 
-@pytest.mark.parametrize("two_stream", [False, True])
-def test_pipelined_allgather_over_rccl_one_rank(evaluator, two_stream):
+@pytest.mark.parametrize("two_stream,every", [(False, 1), (True, 1), (False, 3)])
+def test_pipelined_allgather_over_rccl_one_rank(evaluator, two_stream, every):
     """The N > 1 code path on the one GPU there is: a one-rank "nccl" (= RCCL) process group, asynchronous
     all_gather_into_tensor behind the pick (on the pipe's pick stream when two_stream), slots reused over 6 steps."""
     import socket
@@ -503,7 +503,7 @@ def test_pipelined_allgather_over_rccl_one_rank(evaluator, two_stream):
                         smp=t(c.samples[r], np.int32)) for r in rolled]
         torch.cuda.synchronize()
         pipe = ev.pipe(depth) if two_stream else None
-        sched = PipelinedScheduler(c.P, dev, depth=depth, pipe=pipe, gather_always=True)
+        sched = PipelinedScheduler(c.P, dev, depth=depth, pipe=pipe, gather_always=True, gather_every=every)
         masks = [ev.alloc_mask(c.P) for _ in range(depth)]
         state = {"j": 0}
 
@@ -518,7 +518,7 @@ def test_pipelined_allgather_over_rccl_one_rank(evaluator, two_stream):
         for j in range(steps):
             state["j"] = j
             pend.append(sched.step(run))
-            if len(pend) >= depth:
+            if len(pend) >= (depth - 1) * every + 1:
                 got.append(pend.pop(0).wait().clone())
         got += [p.wait().clone() for p in pend]
         sched.drain()
