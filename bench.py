@@ -183,8 +183,17 @@ def main():
     d_mask = d_masks[0]
     pitch = int(d_mask.stride(0)) if d_mask is not None else W
 
-    def local_eval(binding_out):  # sequential form: mask kernel + pick kernel on one stream, one library call
-        ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=d_mask, out_binding=binding_out)
+    # sequential form: pick kernel + mask kernel on one stream, one (pre-marshalled) library call per step
+    if pipelined:  # one binding buffer per (slot, step of the slot's gather group)
+        slot_outs = {(k, g): sched._local[k][g * sched.shard: g * sched.shard + (hi - lo)] for k in range(depth) for g in range(gather_every)}
+    else:
+        slot_outs = {(0, 0): sched.local[: hi - lo]}
+    keys = sorted(slot_outs)
+    bound = ev.bind_eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=d_mask, out_bindings=[slot_outs[k] for k in keys])
+    index_of = {slot_outs[k].data_ptr(): i for i, k in enumerate(keys)}
+
+    def local_eval(binding_out):
+        bound(index_of[binding_out.data_ptr()])
 
     submit = None
     if pipe is not None:  # pre-marshalled ksched_pipe_submit: the mask kernel goes to the pipe's mask stream, the pick to its pick stream
@@ -194,7 +203,7 @@ def main():
         if submit is not None:
             submit(slot)
         else:
-            ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=d_mask, out_binding=binding_out)
+            bound(index_of[binding_out.data_ptr()])
 
     def one_step():
         return sched.step(run) if pipelined else sched.step(local_eval)
