@@ -68,6 +68,7 @@ struct ksched_ctx {
     DevBuf<uint64_t> bf_rows;        // [rows][Wbf] bitmaps over best-fit positions (k_pick_bestfit_rows); built with the tile index
     bool bf_rows_built = false;
     uint32_t bf_row_cpu0 = 0, bf_q = 1;
+    std::vector<uint32_t> h_order;   // bf_order on the host (upload_bestfit_order -> upload_bestfit_rows)
     std::vector<uint32_t> h_lab;     // host images of the label and taint columns (re-permuted when the order changes)
     std::vector<uint64_t> h_taint;
     IndexedSnapshot idx;  // per-tile bitmap index (tile_index.hpp)
@@ -159,6 +160,7 @@ int upload_bestfit_order(ksched_ctx *c) {
     HIPCHK(c, hipMemcpy(c->bf_cpu.ptr, bfcpu.data(), (size_t)n * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->bf_order.ptr, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->bf_rank.ptr, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    c->h_order = std::move(order);
     return KSCHED_OK;
 }
 
@@ -173,16 +175,7 @@ int upload_bestfit_rows(ksched_ctx *c) {
     const uint32_t named = l.row_cpu;  // rows [0, named): zero, valid, taint rows, label rows
     const uint32_t levels = 256u, q = (n + levels - 1u) / levels;
     const uint32_t rows = named + levels + 1u;
-    std::vector<uint32_t> order(n);
-    {
-        const int64_t *cpu = c->h_cpu.data(), *mem = c->h_mem.data();
-        std::iota(order.begin(), order.end(), 0u);
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            if (mem[x] != mem[y]) return mem[x] < mem[y];
-            if (cpu[x] != cpu[y]) return cpu[x] < cpu[y];
-            return x < y;
-        });
-    }
+    const std::vector<uint32_t> &order = c->h_order;  // the best-fit order just made by upload_bestfit_order
     std::vector<uint64_t> R((size_t)rows * Wbf, 0ull);
     auto setbit = [&](uint32_t row, uint32_t i) { R[(size_t)row * Wbf + (i >> 6)] |= 1ull << (i & 63u); };
     for (uint32_t i = 0; i < n; ++i) {
