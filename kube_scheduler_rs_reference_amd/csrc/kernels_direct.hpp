@@ -410,9 +410,12 @@ __device__ __forceinline__ uint32_t wave_lower_bound_sampled(const int64_t *__re
 __device__ __forceinline__ void wave_lower_bound_sampled2(const int64_t *__restrict__ a0, const int64_t *__restrict__ a0s1,
                                                           const int64_t *__restrict__ a0s2, int64_t key0, const int64_t *__restrict__ a1,
                                                           const int64_t *__restrict__ a1s1, const int64_t *__restrict__ a1s2, int64_t key1,
-                                                          uint32_t n, uint32_t lane, uint32_t &out0, uint32_t &out1) {
+                                                          uint32_t n, uint32_t lane, int64_t v0, int64_t v1, uint32_t &out0, uint32_t &out1) {
+    // v0, v1: this lane's entries of the two top-level sample arrays (a0s2[lane], a1s2[lane]); they do not depend on the keys,
+    // so the caller loads them together with the keys (one dependent round trip less)
     const uint32_t n1 = (n + 63u) / 64u, n2 = (n + 4095u) / 4096u;
-    const int64_t v0 = (lane < n2) ? a0s2[lane] : 0, v1 = (lane < n2) ? a1s2[lane] : 0;
+    (void)a0s2;
+    (void)a1s2;
     const uint32_t cA0 = (uint32_t)__popcll(__ballot(lane < n2 && v0 < key0)), cA1 = (uint32_t)__popcll(__ballot(lane < n2 && v1 < key1));
     // a search that has run off the end keeps reading block 0 (harmless) and is fixed up at the end
     const uint32_t bA0 = (cA0 >= n2) ? 0u : cA0, bA1 = (cA1 >= n2) ? 0u : cA1;
@@ -427,12 +430,13 @@ __device__ __forceinline__ void wave_lower_bound_sampled2(const int64_t *__restr
     out1 = (cA1 >= n2) ? n : b1 * 64u + cC1;
 }
 
-__global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs q) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t pod = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (pod >= q.p) return;
+// one pod, by the whole wave; returns the chosen node (every lane holds the same value)
+__device__ __forceinline__ int32_t bestfit_rows_one_pod(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane) {
     // Everything that depends only on the pod is loaded up front, together (the chain of dependent memory round trips
-    // is what this kernel's time is made of: operands -> three search rounds -> rows -> winner's node id).
+    // is what this kernel's time is made of: operands -> two more search rounds -> rows -> winner's node id).
+    const uint32_t n2 = (q.n + 4095u) / 4096u;
+    const bool sampled = q.do_fit && q.mem_s1 != nullptr;
+    const int64_t top_m = (sampled && lane < n2) ? q.mem_s2[lane] : 0, top_c = (sampled && lane < n2) ? q.cpu_s2[lane] : 0;
     const int64_t req_c = q.do_fit ? q.pcpu[pod] : 0, req_m = q.do_fit ? q.pmem[pod] : 0;
     const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
     uint32_t sel[8];
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
     if (q.do_fit) {
         uint32_t r;  // #nodes with cpu < request
         if (q.mem_s1) {
-            wave_lower_bound_sampled2(q.bf_mem, q.mem_s1, q.mem_s2, req_m, q.cpu_sorted, q.cpu_s1, q.cpu_s2, req_c, q.n, lane, start, r);
+            wave_lower_bound_sampled2(q.bf_mem, q.mem_s1, q.mem_s2, req_m, q.cpu_sorted, q.cpu_s1, q.cpu_s2, req_c, q.n, lane, top_m, top_c, start, r);
         } else {
             start = wave_lower_bound(q.bf_mem, q.n, req_m, lane);
             r = wave_lower_bound(q.cpu_sorted, q.n, req_c, lane);
@@ -450,10 +454,7 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
         r_hi = q.row_cpu0 + (r + q.q - 1u) / q.q;  // only nodes that fit
         r_lo = q.row_cpu0 + r / q.q;               // every node that fits
     }
-    if (start >= q.n) {
-        if (lane == 0) q.binding[pod] = -1;
-        return;
-    }
+    if (start >= q.n) return -1;
     // the rows this pod ANDs (wave-uniform): selector keys, taint groups; row numbers of the first eight keys from the arguments
     uint32_t lrow[8];
 #pragma unroll
@@ -495,11 +496,22 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
         const uint64_t hit = __ballot(found != 0xFFFFFFFFu);
         if (hit) {  // lanes hold ascending words: the lowest lane with a hit holds the best-fit node
             const uint32_t first = (uint32_t)__shfl((int)found, __builtin_ctzll(hit), 64);
-            if (lane == 0) q.binding[pod] = (int32_t)q.bf_order[first];
-            return;
+            return (int32_t)q.bf_order[first];
         }
     }
-    if (lane == 0) q.binding[pod] = -1;
+    return -1;
+}
+
+// One wave per pod, one launch slot per pod.  (A persistent grid of 8192 waves walking the pods was measured slower,
+// 210 us against 147 us at the C5 shard: the kernel is bound by instruction issue -- ~280 scalar and ~240 vector
+// instructions per pod, mostly address arithmetic and wave-uniform control flow, rocprofv3 SQ counters -- not by wave
+// launches or memory latency, and the short-lived waves balance better.)
+__global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs q) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pod = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pod >= q.p) return;
+    const int32_t b = bestfit_rows_one_pod(q, pod, lane);
+    if (lane == 0) q.binding[pod] = b;
 }
 
 }  // namespace ksched
