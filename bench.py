@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--two-stream", action="store_true",
                     help="with --depth >= 2: mask kernels on one HIP stream, pick kernels (+ all-gather) on another (ksched_pipe).  The picks "
                          "do not read the mask, so the two streams need no ordering between them: +25 %% evals/s at C3, but the mask kernel "
-                         "then shares the chip with pick kernels (its own duration grows; profiles/r01_h4_ab_streams.txt)")
+                         "then shares the chip with pick kernels (its own duration grows; profiles/r01_h5_ab_streams.txt)")
     args = ap.parse_args()
 
     import torch
