@@ -113,8 +113,8 @@ def main():
                     help="mask rows packed at W words (default: rows pitched to ksched_mask_pitch(n) = W rounded up to 128 B)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (timing experiments; results invalid)")
     ap.add_argument("--depth", type=int, default=None,
-                    help="steps in flight (buffer slots).  Default: 1 on one GPU (strictly sequential steps on one stream); 2 for N > 1, "
-                         "where the all-gather of step i is asynchronous and overlaps the kernels of step i+1 (double-buffered bindings)")
+                    help="buffer slots in flight (bindings, and masks with two streams).  Default: 1 on one GPU (strictly sequential steps "
+                         "on one stream); 2 for N > 1, where the all-gather is asynchronous and overlaps the kernels of the following steps")
     ap.add_argument("--time-every", type=int, default=4,
                     help="attach HIP events to every N-th mask kernel launch of the timed steps (roofline.avg_kernel_us is their mean)")
     ap.add_argument("--gather-every", type=int, default=None,
@@ -122,8 +122,9 @@ def main():
                          "of microseconds of host and launch time whatever its size -- the same order as a step's kernels")
     ap.add_argument("--two-stream", action="store_true",
                     help="with --depth >= 2: mask kernels on one HIP stream, pick kernels (+ all-gather) on another (ksched_pipe).  The picks "
-                         "do not read the mask, so the two streams need no ordering between them: +25 %% evals/s at C3, but the mask kernel "
-                         "then shares the chip with pick kernels (its own duration grows; profiles/r01_h5_ab_streams.txt)")
+                         "do not read the mask, so the two streams need no ordering between them: +25 %% evals/s at C3 and in the N > 1 path; "
+                         "the mask kernel then shares the chip with pick kernels and its own duration grows by 6-10 %%, which is why the "
+                         "default keeps one stream and a clean per-kernel roofline number (profiles/r01_h5_ab_streams.txt)")
     args = ap.parse_args()
 
     import torch
@@ -167,8 +168,8 @@ def main():
     ev.set_nodes(**c.node_columns())
     depth = args.depth if args.depth else (2 if multi else 1)
     pipelined = depth > 1 and not args.no_mask
-    pipe = ev.pipe(depth) if (pipelined and args.two_stream) else None
-    gather_every = 1 if (pipe is not None or not multi) else max(1, args.gather_every or 4)
+    gather_every = max(1, args.gather_every or 4) if (multi and pipelined) else 1
+    pipe = ev.pipe(depth * gather_every) if (pipelined and args.two_stream) else None
     sched = (PipelinedScheduler(P_total, dev, depth=depth, pipe=pipe, gather_always=multi, gather_every=gather_every) if pipelined
              else ShardedScheduler(P_total, dev))
     lo, hi = sched.lo, sched.hi
@@ -178,7 +179,7 @@ def main():
     d_tol = t(c.pod_tol[lo:hi], np.int64) if taint else None
     d_smp = t(c.samples[lo:hi], np.int32) if pick == "sampled" else None
     W = ev.W
-    n_masks = depth if pipe is not None else 1
+    n_masks = depth * gather_every if pipe is not None else 1
     d_masks = [None if args.no_mask else ev.alloc_mask(hi - lo, pitched=not args.packed) for _ in range(n_masks)]
     d_mask = d_masks[0]
     pitch = int(d_mask.stride(0)) if d_mask is not None else W
@@ -197,7 +198,7 @@ def main():
 
     submit = None
     if pipe is not None:  # pre-marshalled ksched_pipe_submit: the mask kernel goes to the pipe's mask stream, the pick to its pick stream
-        submit = pipe.bind(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, d_masks, [sched._local[k][: hi - lo] for k in range(depth)])
+        submit = pipe.bind(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, d_masks, [slot_outs[k] for k in keys])  # pipe slot = k * gather_every + g
 
     def run(slot, binding_out):  # pipelined form: bindings and masks are per slot
         if submit is not None:

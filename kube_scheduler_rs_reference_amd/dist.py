@@ -82,7 +82,7 @@ class PendingBindings:
             # gathered[k] is [world][gather_every][shard]: this step's rows of every rank
             return s._gathered[k].view(s.world, s.gather_every, s.shard)[:, g].reshape(-1)[: s.P]
         if s.pipe is not None and s._used[k]:
-            s.pipe.wait(k)
+            s.pipe.wait(k * s.gather_every + g)
         return s._local[k].view(s.gather_every, s.shard)[g][: s.P]
 
 
@@ -91,9 +91,10 @@ class PipelinedScheduler:
 
     step(run):  run(slot, binding_out) enqueues this rank's evaluation + pick of one batch, filling
     binding_out[: n_local] (int32, -1 = no node).
-      * on a GPU with `pipe` (Evaluator.pipe(depth), only with gather_every == 1) `run` calls `pipe.submit(slot, ...)`:
-        the mask kernel goes to the pipe's mask stream, the pick to its pick stream, and the all-gather is enqueued
-        (asynchronously) behind the pick on that same stream;
+      * on a GPU with `pipe` (Evaluator.pipe(depth * gather_every)) `run(slot, ...)` gets the pipe slot of the step
+        (`slot = buffer slot * gather_every + position in the gather group`) and calls `pipe.submit(slot, ...)`: the
+        mask kernel goes to the pipe's mask stream, the pick to its pick stream, and the all-gather is enqueued
+        (asynchronously) behind the group's last pick on that same stream;
       * without a pipe `run` enqueues on the current stream (CPU, gloo tests: executes inline) and only the
         all-gather is asynchronous.
     gather_every = G > 1: the bindings of G consecutive steps share one buffer and ONE all-gather (fewer, larger
@@ -105,8 +106,8 @@ class PipelinedScheduler:
                  gather_always: bool = False, gather_every: int = 1):
         if depth < 1 or gather_every < 1:
             raise ValueError("depth >= 1, gather_every >= 1")
-        if pipe is not None and (pipe.depth != depth or gather_every != 1):
-            raise ValueError("a pipe needs pipe.depth == depth and gather_every == 1")
+        if pipe is not None and pipe.depth != depth * gather_every:
+            raise ValueError("a pipe needs pipe.depth == depth * gather_every (one pipe slot per step in flight)")
         self.P, self.device, self.depth, self.group, self.pipe, self.gather_every = P, device, depth, group, pipe, gather_every
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -150,7 +151,7 @@ class PipelinedScheduler:
             self._work[k] = None
         out = self._local[k][g * self.shard: g * self.shard + self.n_local]
         if self.n_local > 0:
-            run(k, out)
+            run(k * self.gather_every + g if self.pipe is not None else k, out)
             self._used[k] = True
         self._fill[k] = g + 1
         pending = PendingBindings(self, k, g)
@@ -167,4 +168,5 @@ class PipelinedScheduler:
                 if self._work[k] is not None:
                     self._work[k].wait()
             elif self.pipe is not None and self._used[k]:
-                self.pipe.wait(k)
+                for g in range(self.gather_every):
+                    self.pipe.wait(k * self.gather_every + g)

@@ -478,7 +478,7 @@ def test_pipelined_steps_equal_sequential(evaluator, depth):
     pipe.close()
 
 
-@pytest.mark.parametrize("two_stream,every", [(False, 1), (True, 1), (False, 3)])
+@pytest.mark.parametrize("two_stream,every", [(False, 1), (True, 1), (False, 3), (True, 3)])
 def test_pipelined_allgather_over_rccl_one_rank(evaluator, two_stream, every):
     """The N > 1 code path on the one GPU there is: a one-rank "nccl" (= RCCL) process group, asynchronous
     all_gather_into_tensor behind the pick (on the pipe's pick stream when two_stream), slots reused over 6 steps."""
@@ -502,9 +502,9 @@ def test_pipelined_allgather_over_rccl_one_rank(evaluator, two_stream, every):
         batches = [dict(cpu=t(c.req_cpu[r], np.int64), mem=t(c.req_mem[r], np.int64), sel=t(c.pod_sel[:, r], np.int32),
                         smp=t(c.samples[r], np.int32)) for r in rolled]
         torch.cuda.synchronize()
-        pipe = ev.pipe(depth) if two_stream else None
+        pipe = ev.pipe(depth * every) if two_stream else None  # one pipe slot per step in flight
         sched = PipelinedScheduler(c.P, dev, depth=depth, pipe=pipe, gather_always=True, gather_every=every)
-        masks = [ev.alloc_mask(c.P) for _ in range(depth)]
+        masks = [ev.alloc_mask(c.P) for _ in range(depth * every)]
         state = {"j": 0}
 
         def run(slot, out):
