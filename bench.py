@@ -186,7 +186,7 @@ def main():
 
     # sequential form: pick kernel + mask kernel on one stream, one (pre-marshalled) library call per step
     if pipelined:  # one binding buffer per (slot, step of the slot's gather group)
-        slot_outs = {(k, g): sched._local[k][g * sched.shard: g * sched.shard + (hi - lo)] for k in range(depth) for g in range(gather_every)}
+        slot_outs = {(k, g): sched.binding_buffer(k, g) for k in range(depth) for g in range(gather_every)}
     else:
         slot_outs = {(0, 0): sched.local[: hi - lo]}
     keys = sorted(slot_outs)

@@ -128,6 +128,11 @@ class PipelinedScheduler:
     def n_local(self) -> int:
         return self.hi - self.lo
 
+    def binding_buffer(self, k: int, g: int = 0) -> torch.Tensor:
+        """The int32 [n_local] buffer that step `g` of buffer slot `k`'s gather group writes (for callers that pre-marshal their
+        launches: the same tensor `run` receives)."""
+        return self._local[k][g * self.shard: g * self.shard + self.n_local]
+
     def _flush(self, k: int) -> None:
         """Issue the (asynchronous) all-gather of slot k's group and move on to the next slot."""
         if self._gather and self._fill[k] > 0:
@@ -149,7 +154,7 @@ class PipelinedScheduler:
             else:
                 self._work[k].wait()
             self._work[k] = None
-        out = self._local[k][g * self.shard: g * self.shard + self.n_local]
+        out = self.binding_buffer(k, g)
         if self.n_local > 0:
             run(k * self.gather_every + g if self.pipe is not None else k, out)
             self._used[k] = True
