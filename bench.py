@@ -15,7 +15,9 @@ Workloads (per GPU; weak scaling: rank r evaluates its own P pods against the re
     C5s 125k pods x 50k nodes, fit + sel + taints, best fit configs[4] = 8 of these (1M x 50k)
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant (mask) kernel: algorithmic bytes
-per launch / its HIP-event duration measured live on the launch stream inside the timed steps.
+per launch / its mean HIP-event duration, measured live in this run on the launch stream: events on
+every mask kernel dispatch of a post-pass of --kernel-samples further steps right after the timed
+region (events cost launch gap, so the timed steps carry none).
 `cpu_baseline` is the oracle (CPU restatement, kind "port") timed on this box's host cores on a
 bounded sample of the same workload; it is a reported baseline, never the thing measured above.
 """
@@ -102,8 +104,8 @@ def cpu_baseline(c, flags_names, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "fused"])
     ap.add_argument("--pods", type=int, default=None, help="override pods per GPU")
@@ -115,8 +117,13 @@ def main():
     ap.add_argument("--depth", type=int, default=None,
                     help="buffer slots in flight (bindings, and masks with two streams).  Default: 1 on one GPU (strictly sequential steps "
                          "on one stream); 2 for N > 1, where the all-gather is asynchronous and overlaps the kernels of the following steps")
-    ap.add_argument("--time-every", type=int, default=4,
-                    help="attach HIP events to every N-th mask kernel launch of the timed steps (roofline.avg_kernel_us is their mean)")
+    ap.add_argument("--ramp-ms", type=float, default=60.0,
+                    help="after the W warm-up steps keep stepping (untimed) until this many ms have passed: the GPU's clocks ramp over "
+                         "tens of milliseconds, and a 5-step warm-up of 26 us steps ends long before that")
+    ap.add_argument("--kernel-samples", type=int, default=64,
+                    help="post-pass after the timed region: this many further steps with HIP events on EVERY mask kernel dispatch "
+                         "(roofline.avg_kernel_us = their mean; min / median reported).  Events cost launch gap, not kernel time, so "
+                         "they are kept out of the timed steps")
     ap.add_argument("--gather-every", type=int, default=None,
                     help="N > 1: one all-gather per this many steps (their bindings share a buffer).  Default 4: an RCCL call costs tens "
                          "of microseconds of host and launch time whatever its size -- the same order as a step's kernels")
@@ -216,9 +223,27 @@ def main():
 
     for _ in range(args.warmup):
         last = one_step()
+    # clock ramp (untimed, part of the warm-up): step until about --ramp-ms have passed.  The step count is agreed across ranks
+    # (MAX) so that every rank issues the same collectives.
+    def burst(k):
+        t_b = time.perf_counter()
+        for _ in range(k):
+            one_step()
+        if pipelined:
+            sched.drain()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t_b
+    t16 = burst(16)
+    more = int(min(50_000, max(0.0, args.ramp_ms * 1e-3 - t16) / max(t16 / 16, 1e-7)))
+    if multi:
+        mt = torch.tensor([more], dtype=torch.int64, device=dev)
+        dist.all_reduce(mt, op=dist.ReduceOp.MAX)
+        more = int(mt.item())
+    if more:
+        burst(more)
+    ramp_steps = 16 + more
     sync()
-    ev.set_timing(True, every=args.time_every)  # HIP events on every N-th mask kernel dispatch (they cost launch gap: sample)
-    ev.kernel_time_ms()  # reset
+    # ---- the timed region: exactly K steps, no events inside -------------------------------------------------------
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = one_step()
@@ -226,15 +251,25 @@ def main():
         sched.drain()
     sync()
     elapsed = time.perf_counter() - t0
-    bindings = last.wait() if pipelined else last
-    kern_ms, launches = ev.kernel_time_ms()
-    ev.set_timing(False)
+    bindings = (last.wait() if pipelined else last).clone()
     if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # ---- post-pass: the same steps with HIP events on every mask kernel dispatch (per-kernel roofline number) ----------
+    ev.set_timing(True, every=1)
+    ev.kernel_time_ms()  # reset
+    for _ in range(max(1, args.kernel_samples)):
+        one_step()
+    if pipelined:
+        sched.drain()
+    sync()
+    samples_us = np.sort(ev.kernel_time_samples(max(1, args.kernel_samples) * 2) * 1e3)
+    ev.set_timing(False)
+    launches = int(samples_us.shape[0])
+    kern_ms = float(samples_us.sum()) * 1e-3
 
-    # sanity inside the bench: bindings of the last step agree with a spot check of the mask
+    # sanity inside the bench: the fraction of pods the last timed step bound (a degenerate workload would show 0 or 1)
     bound_frac = float((bindings >= 0).float().mean().item())
 
     if rank == 0:
@@ -243,12 +278,17 @@ def main():
         avg_kernel_s = (kern_ms / max(launches, 1)) * 1e-3
         alg = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint)
         achieved = alg / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-        traffic = None
+        # HBM traffic per launch comes from SEPARATE rocprofv3 --pmc passes (tools/gpu_pmc.sh -> tools/pmc_traffic.py), not from
+        # this run: the counters cannot be collected inside a timing run.  The file names the session it was measured in.
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                rec = json.load(open(tpath)).get(f"{args.workload}:{ev.last_kernel}")
+                doc = json.load(open(tpath))
+                rec = doc.get(f"{args.workload}:{ev.last_kernel}")
                 traffic = rec["hbm_bytes_per_launch"] if rec else None
+                if rec:
+                    traffic_source = f"profiles/pmc_traffic.json ({doc.get('_session', 'session unnamed')}): separate rocprofv3 --pmc passes, not this run"
             except Exception:
                 traffic = None
         out = {
@@ -264,10 +304,14 @@ def main():
                        "allgather(int32 bindings)" if world > 1 else "single GPU",
                        "bound_fraction": bound_frac},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                          "kernel": f"mask kernel ({ev.last_kernel})", "algorithmic_bytes_per_launch": alg,
-                         "avg_kernel_us": avg_kernel_s * 1e6, "launches_timed": int(launches),
+                         "avg_kernel_us": avg_kernel_s * 1e6, "median_kernel_us": float(np.median(samples_us)) if launches else None,
+                         "min_kernel_us": float(samples_us[0]) if launches else None, "max_kernel_us": float(samples_us[-1]) if launches else None,
+                         "launches_timed": int(launches),
+                         "timing": f"HIP events on every mask kernel dispatch of a post-pass of {launches} steps after the timed region "
+                                   f"(clock ramp {ramp_steps} untimed steps >= {args.ramp_ms:.0f} ms before it)",
                          "mask_kernel_evals_per_s": (hi - lo) * N / avg_kernel_s if avg_kernel_s > 0 else 0.0},
         }
         if world == 1 and not args.no_cpu_baseline:

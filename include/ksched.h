@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define KSCHED_ABI_VERSION 1u
+#define KSCHED_ABI_VERSION 2u
 
 /* at most this many label-key columns per batch */
 #define KSCHED_MAX_KEYS 32u
@@ -231,12 +231,26 @@ void *ksched_pipe_stream(ksched_pipe *pipe, int which);
  */
 int ksched_reason(const uint64_t *feasible_row, const uint64_t *fit_row, uint32_t node, uint32_t flags);
 
+/* Per-pair reasons, decided on the device: check_node_validity's result (src/predicates.rs:63-77) for `count` listed
+ * (pod, node) pairs of an encoded batch -- what the reference logs at WARN for every rejected candidate
+ * (src/main.rs:62).  Order: resources (:68-70), then selector (:72-74), then the taint extension.  Two masks cannot
+ * tell a selector failure from a taint failure when both predicates are active (ksched_reason then answers
+ * NODE_SELECTOR_MISMATCH); this entry point re-checks the listed pairs from the columns and can.
+ *   pod columns as in ksched_eval (host pointers, [p]); pair_pod[i] < p, pair_node[i] < ksched_num_nodes
+ *   flags : subset of KSCHED_FIT | KSCHED_SEL | KSCHED_TAINT;  out_reason[i] = KSCHED_REASON_* */
+int ksched_explain(ksched_ctx *ctx, uint32_t p, const int64_t *req_cpu_milli, const int64_t *req_mem_bytes,
+                   const uint32_t *sel_val_ids, const uint64_t *tolerations, uint32_t count, const uint32_t *pair_pod,
+                   const uint32_t *pair_node, uint32_t flags, int32_t *out_reason);
+
 /* ---- measurement --------------------------------------------------------------------------
  * With KSCHED_OPT_TIMING = 1 every ksched_eval* brackets its mask kernel with hipEvents on the
  * launch stream.  ksched_kernel_time_ms synchronises those events and returns the accumulated
  * kernel milliseconds and launch count since the last reset (both reset by the call).
  */
 int ksched_kernel_time_ms(ksched_ctx *ctx, double *total_ms, uint64_t *launches);
+/* The same measurement launch by launch: writes the duration (ms) of up to `cap` timed mask kernel launches since the
+ * last reset, in launch order, returns how many were written (<0 on error) and resets like ksched_kernel_time_ms. */
+int ksched_kernel_time_samples(ksched_ctx *ctx, double *out_ms, uint32_t cap);
 /* Diagnostics: copy out the trace of the last fused launch (KSCHED_OPT_TRACE = 1): up to max_blocks records of
  * KSCHED_TRACE_WORDS uint64 (100 MHz timestamps); returns the number of blocks of that launch, <0 on error. */
 int ksched_trace_read(ksched_ctx *ctx, uint64_t *out, uint32_t max_blocks);

@@ -14,7 +14,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KSCHED_LIB") or os.path.join(_PKG_DIR, "libksched_hip.so")
 
 # --- constants mirrored from include/ksched.h --------------------------------------------------
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_KEYS = 32
 MAX_ATTEMPTS = 64
 SEL_NEVER = 0xFFFFFFFF
@@ -77,6 +77,8 @@ SYMBOLS = {
     "ksched_pipe_stream": (_vp, [_vp, C.c_int]),
     "ksched_reason": (C.c_int, [_vp, _vp, _u32, _u32]),
     "ksched_kernel_time_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "ksched_kernel_time_samples": (C.c_int, [_vp, _vp, _u32]),
+    "ksched_explain": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _vp]),
     "ksched_trace_read": (C.c_int, [_vp, _vp, C.c_uint32]),
     "ksched_last_kernel": (C.c_char_p, [_vp]),
 }

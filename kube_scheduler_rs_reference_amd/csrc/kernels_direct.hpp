@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/ksched.h"
+
 // clang (ROCm 7.2) exposes no __builtin_amdgcn_writelane; bind the LLVM intrinsic by name.
 // v_writelane_b32: lane `lane` of the result takes the wave-uniform `val`, the others keep `old`.
 extern "C" __device__ uint32_t ksched_writelane_u32(uint32_t val, uint32_t lane, uint32_t old) __asm(
@@ -270,6 +272,41 @@ template <int ATT>
 __global__ __launch_bounds__(256) void k_select_sampled(const SelectArgs q) {
     const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
     if (pod < q.p) q.binding[pod] = select_one_pod<ATT>(q, pod);
+}
+
+// check_node_validity for a list of (pod, node) pairs, with the REASON: what the reference logs at WARN for every rejected
+// candidate (src/main.rs:62 prints the InvalidNodeReason of src/predicates.rs:63-77).  Order: resources first
+// (src/predicates.rs:68-70), then the selector (:72-74), then the taint extension (E2).  One lane per pair, straight from
+// the columns (same compares as k_select_sampled).  Unlike two masks, this tells selector and taint failures apart.
+struct ExplainArgs {
+    const int64_t *ncm;           // [n][2] = {avail_cpu, avail_mem}
+    const uint32_t *nlab;         // [nkeys][n]
+    const uint64_t *ntaint;       // [n] or nullptr
+    const int64_t *pcpu, *pmem;   // [p]
+    const uint32_t *psel;         // [nkeys][p] or nullptr
+    const uint64_t *ptol;         // [p] or nullptr
+    const uint32_t *pair_pod, *pair_node;  // [count]
+    int32_t *reason;              // [count]: KSCHED_REASON_*
+    uint32_t count, p, n, nkeys, do_fit, do_taint;
+};
+
+__global__ __launch_bounds__(256) void k_explain_pairs(const ExplainArgs q) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.count) return;
+    const uint32_t pod = q.pair_pod[i], node = q.pair_node[i];
+    int32_t r = KSCHED_REASON_OK;
+    if (q.do_fit && !(q.pcpu[pod] <= q.ncm[2 * (size_t)node] && q.pmem[pod] <= q.ncm[2 * (size_t)node + 1])) {
+        r = KSCHED_REASON_NOT_ENOUGH_RESOURCES;  // src/predicates.rs:42,68-70
+    } else {
+        if (q.psel)
+            for (uint32_t k = 0; k < q.nkeys; ++k) {  // src/predicates.rs:48-57
+                const uint32_t want = q.psel[(size_t)k * q.p + pod];
+                if (want != 0u && want != q.nlab[(size_t)k * q.n + node]) r = KSCHED_REASON_NODE_SELECTOR_MISMATCH;
+            }
+        if (r == KSCHED_REASON_OK && q.do_taint && q.ntaint && (q.ntaint[node] & ~(q.ptol ? q.ptol[pod] : 0ull)) != 0ull)
+            r = KSCHED_REASON_TAINT_NOT_TOLERATED;
+    }
+    q.reason[i] = r;
 }
 
 // Best fit (extension E1): argmin over feasible nodes of (avail_mem - req_mem, avail_cpu - req_cpu,

@@ -79,6 +79,8 @@ struct ksched_ctx {
     DevBuf<uint32_t> psel, psamples;
     DevBuf<uint64_t> ptol, feas, fit;
     DevBuf<int32_t> binding;
+    DevBuf<uint32_t> xpairs;  // ksched_explain: [pair_pod][pair_node]
+    DevBuf<int32_t> xreason;
     // scratch mask when a pick is requested without an output mask
     DevBuf<uint64_t> scratch_mask;
 
@@ -549,7 +551,7 @@ void ksched_destroy(ksched_ctx *c) {
         c->ncpu.release(); c->nmem.release(); c->ncm.release(); c->nlab.release(); c->ntaint.release();
         c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release(); c->bf_cpu.release(); c->cpu_sorted.release(); c->bf_rows.release(); c->bf_samples.release();
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
-        c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release();
+        c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release(); c->xpairs.release(); c->xreason.release();
         c->scratch_mask.release(); c->trace.release();
         indexed_release(c->idx);
         for (auto &ep : c->ev_pool) {
@@ -925,6 +927,65 @@ int ksched_reason(const uint64_t *feasible_row, const uint64_t *fit_row, uint32_
     return KSCHED_REASON_NODE_SELECTOR_MISMATCH;
 }
 
+int ksched_explain(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel, const uint64_t *ptol,
+                   uint32_t count, const uint32_t *pair_pod, const uint32_t *pair_node, uint32_t flags, int32_t *out_reason) {
+    if (!c) return KSCHED_E_INVAL;
+    if (flags & ~(KSCHED_FIT | KSCHED_SEL | KSCHED_TAINT)) return KSCHED_E_INVAL;
+    if (count > 0 && (!pair_pod || !pair_node || !out_reason)) return KSCHED_E_INVAL;
+    if (count > 0 && (flags & KSCHED_FIT) && (!pcpu || !pmem)) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_nodes) return KSCHED_E_STATE;
+    for (uint32_t i = 0; i < count; ++i)
+        if (pair_pod[i] >= p || pair_node[i] >= c->n) return KSCHED_E_INVAL;
+    if (count == 0) return KSCHED_OK;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    hipStream_t s = c->stream;
+    const bool use_fit = flags & KSCHED_FIT;
+    const bool use_sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
+    const bool use_taint = (flags & KSCHED_TAINT) && c->have_taints;
+    if (use_fit) {
+        HIPCHK(c, c->pcpu.reserve(p));
+        HIPCHK(c, c->pmem.reserve(p));
+        HIPCHK(c, hipMemcpyAsync(c->pcpu.ptr, pcpu, (size_t)p * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->pmem.ptr, pmem, (size_t)p * 8, hipMemcpyHostToDevice, s));
+    }
+    if (use_sel) {
+        HIPCHK(c, c->psel.reserve((size_t)p * c->nkeys));
+        HIPCHK(c, hipMemcpyAsync(c->psel.ptr, psel, (size_t)p * c->nkeys * 4, hipMemcpyHostToDevice, s));
+    }
+    if (use_taint && ptol) {
+        HIPCHK(c, c->ptol.reserve(p));
+        HIPCHK(c, hipMemcpyAsync(c->ptol.ptr, ptol, (size_t)p * 8, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, c->xpairs.reserve((size_t)count * 2));
+    HIPCHK(c, c->xreason.reserve(count));
+    HIPCHK(c, hipMemcpyAsync(c->xpairs.ptr, pair_pod, (size_t)count * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->xpairs.ptr + count, pair_node, (size_t)count * 4, hipMemcpyHostToDevice, s));
+    ExplainArgs q{};
+    q.ncm = c->ncm.ptr;
+    q.nlab = c->nlab.ptr;
+    q.ntaint = use_taint ? c->ntaint.ptr : nullptr;
+    q.pcpu = c->pcpu.ptr;
+    q.pmem = c->pmem.ptr;
+    q.psel = use_sel ? c->psel.ptr : nullptr;
+    q.ptol = (use_taint && ptol) ? c->ptol.ptr : nullptr;
+    q.pair_pod = c->xpairs.ptr;
+    q.pair_node = c->xpairs.ptr + count;
+    q.reason = c->xreason.ptr;
+    q.count = count;
+    q.p = p;
+    q.n = c->n;
+    q.nkeys = use_sel ? c->nkeys : 0u;
+    q.do_fit = use_fit ? 1u : 0u;
+    q.do_taint = use_taint ? 1u : 0u;
+    hipLaunchKernelGGL(k_explain_pairs, dim3((count + 255u) / 256u), dim3(256), 0, s, q);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out_reason, c->xreason.ptr, (size_t)count * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return KSCHED_OK;
+}
+
 int ksched_trace_read(ksched_ctx *c, uint64_t *out, uint32_t max_blocks) {
     if (!c || !out) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -951,6 +1012,21 @@ int ksched_kernel_time_ms(ksched_ctx *c, double *total_ms, uint64_t *launches) {
     if (launches) *launches = c->ev_used;
     c->ev_used = 0;
     return KSCHED_OK;
+}
+
+int ksched_kernel_time_samples(ksched_ctx *c, double *out_ms, uint32_t cap) {
+    if (!c || (cap > 0 && !out_ms)) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    const size_t n = std::min<size_t>(c->ev_used, cap);
+    for (size_t i = 0; i < n; ++i) {
+        HIPCHK(c, hipEventSynchronize(c->ev_pool[i].b));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b));
+        out_ms[i] = ms;
+    }
+    c->ev_used = 0;
+    return (int)n;
 }
 
 }  // extern "C"

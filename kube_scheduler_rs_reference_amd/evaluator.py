@@ -89,6 +89,14 @@ class Evaluator:
         self._check(self._lib.ksched_kernel_time_ms(self._h, C.byref(ms), C.byref(cnt)), "ksched_kernel_time_ms")
         return ms.value, cnt.value
 
+    def kernel_time_samples(self, cap: int = 4096) -> np.ndarray:
+        """Per-launch durations (ms) of the timed mask kernel launches since the last reset, in launch order."""
+        out = np.zeros((cap,), dtype=np.float64)
+        n = self._lib.ksched_kernel_time_samples(self._h, out.ctypes.data_as(C.c_void_p), cap)
+        if n < 0:
+            self._check(n, "ksched_kernel_time_samples")
+        return out[:n]
+
     def trace_read(self, max_blocks: int = 8192) -> np.ndarray:
         """Diagnostics: per-block phase timestamps of the last fused launch (set_option(OPT_TRACE, 1) first)."""
         out = np.zeros((max_blocks, L.TRACE_WORDS), dtype=np.uint64)
@@ -199,6 +207,8 @@ class Evaluator:
         u64 = (torch.int64, torch.uint64)
         u32 = (torch.int32, torch.uint32)
         attempts = int(samples.shape[1]) if (flags & L.PICK_SAMPLED and samples is not None) else 0
+        if flags & L.PICK_SAMPLED and (samples is None or samples.dim() != 2 or samples.shape[0] != p or attempts == 0):
+            raise ValueError(f"samples must be a [{p}, attempts] tensor with KSCHED_PICK_SAMPLED")  # a wrong shape would be an out-of-bounds device read
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
         pf, pitch = mask_ptr(out_feasible, None)
@@ -284,6 +294,23 @@ class Evaluator:
         return buf[:, :W]
 
     # -- reasons -------------------------------------------------------------------------------------
+    def explain(self, req_cpu_milli, req_mem_bytes, sel_val_ids, tolerations, pair_pod, pair_node, flags: int) -> np.ndarray:
+        """ksched_explain: REASON_* of check_node_validity for the listed (pod, node) pairs, decided on the device."""
+        cpu = _np(req_cpu_milli, np.int64, "req_cpu_milli")
+        mem = _np(req_mem_bytes, np.int64, "req_mem_bytes")
+        p = cpu.shape[0]
+        sel = _np(sel_val_ids, np.uint32, "sel_val_ids")
+        if sel is not None and sel.shape != (self.n_keys, p):
+            raise ValueError(f"sel_val_ids must be [{self.n_keys}][{p}]")
+        tol = _np(tolerations, np.uint64, "tolerations")
+        pp, pn = _np(pair_pod, np.uint32, "pair_pod"), _np(pair_node, np.uint32, "pair_node")
+        if pp.ndim != 1 or pp.shape != pn.shape:
+            raise ValueError("pair_pod, pair_node must be 1-D of one length")
+        out = np.empty((pp.shape[0],), dtype=np.int32)
+        rc = self._lib.ksched_explain(self._h, p, _ptr(cpu), _ptr(mem), _ptr(sel), _ptr(tol), pp.shape[0], _ptr(pp), _ptr(pn), flags, _ptr(out))
+        self._check(rc, "ksched_explain")
+        return out
+
     def reason(self, feasible_row: np.ndarray, fit_row: Optional[np.ndarray], node: int, flags: int) -> int:
         f = np.ascontiguousarray(feasible_row, dtype=np.uint64)
         r = None if fit_row is None else np.ascontiguousarray(fit_row, dtype=np.uint64)
