@@ -279,6 +279,36 @@ def test_reasons_rebuilt_from_masks(evaluator):
     assert seen == {0, 1, 2}
 
 
+def test_explain_separates_selector_from_taint(evaluator):
+    """ksched_explain: per-pair reasons decided on the device, in the reference's order (resources, src/predicates.rs:68-70;
+    selector, :72-74) then the taint extension -- and, unlike two masks, it tells selector and taint failures apart."""
+    ev = evaluator
+    c = synth.make_cluster(700, 900, n_keys=8, n_taints=16, seed=0xE8)
+    ev.set_kernel("auto")
+    ev.set_nodes(**c.node_columns())
+    pc = c.pod_columns()
+    # three single-predicate oracle masks give the expected reason of every pair
+    fit, _, _ = oracle_eval(c, FIT, samples=False)
+    sel, _, _ = oracle_eval(c, SEL, samples=False)
+    tnt, _, _ = oracle_eval(c, TAINT, samples=False)
+    bits = lambda m: unpack_mask(m, c.N)  # noqa: E731
+    bf, bs, bt = bits(fit), bits(sel), bits(tnt)
+    want = np.where(~bf, _lib.REASON_NOT_ENOUGH_RESOURCES,
+                    np.where(~bs, _lib.REASON_NODE_SELECTOR_MISMATCH, np.where(~bt, _lib.REASON_TAINT_NOT_TOLERATED, _lib.REASON_OK)))
+    rng = np.random.default_rng(5)
+    pp = rng.integers(0, c.P, 20000).astype(np.uint32)
+    pn = rng.integers(0, c.N, 20000).astype(np.uint32)
+    got = ev.explain(pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], pc["tolerations"], pp, pn, FIT | SEL | TAINT)
+    assert np.array_equal(got, want[pp, pn])
+    assert {1, 2, 3, 0} <= set(np.unique(got).tolist()), "the sample must exercise every reason"
+    # predicate subsets: a predicate that is not selected never produces its reason
+    got = ev.explain(pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], pc["tolerations"], pp, pn, SEL | TAINT)
+    want2 = np.where(~bs, _lib.REASON_NODE_SELECTOR_MISMATCH, np.where(~bt, _lib.REASON_TAINT_NOT_TOLERATED, _lib.REASON_OK))
+    assert np.array_equal(got, want2[pp, pn])
+    with pytest.raises(KschedError):
+        ev.explain(pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], pc["tolerations"], [c.P], [0], FIT)  # pod out of range
+
+
 def test_snapshot_replacement(evaluator):
     """set_nodes twice: the second snapshot fully replaces the first (different N and keys)."""
     ev = evaluator

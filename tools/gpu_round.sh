@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session that produces the round's evidence set.  usage: bash tools/gpu_round.sh <tag> [steps...]
-#   steps (default: all): test bench prof pmc lines trace smoke
+#   steps (default: all but probe): probe test bench prof pmc lines trace smoke host
 # Everything lands under gpurun_out/<tag>/ ; tools/collect_profiles.py copies the summaries into profiles/.
 TAG=${1:-r}; shift
 STEPS=${@:-"test bench prof pmc lines trace smoke host"}
@@ -8,6 +8,12 @@ REPO=$PWD; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 stamp() { echo "[$(date +%H:%M:%S)] $*"; }
 
+if has probe; then
+  stamp "toolchain probe (BASELINE.md section 4 asks whether the reference's own toolchain exists on the GPU box)"
+  { for t in cargo rustc rustup go javac node gcc g++ hipcc python3; do printf "%-8s " $t; (command -v $t >/dev/null && ($t --version 2>&1 | head -1)) || echo MISSING; done
+    echo "nproc $(nproc)"; ls -d ~/.cargo ~/.rustup 2>&1 | head -2; rocminfo 2>/dev/null | grep -m2 -E "gfx|Marketing"; } > $OUT/toolchain_probe.txt 2>&1
+  cat $OUT/toolchain_probe.txt
+fi
 if has test; then
   stamp "pytest -m gpu"
   timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
