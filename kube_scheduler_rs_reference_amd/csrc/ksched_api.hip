@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -132,9 +133,14 @@ struct DeviceGuard {
 
 int timing_slot(ksched_ctx *c, size_t *slot) {
     if (c->ev_used == c->ev_pool.size()) {
+        // Timing-only events: without the system-scope fence a default event performs when it is recorded (a cache
+        // write-back / invalidate around the very kernel being measured: +2 us at C3 and a cold L2 for its tables).
+        // KSCHED_TIMING_EVENT_FLAGS overrides the flags (A/B of that effect, tools/).
+        unsigned flags = hipEventDisableSystemFence;
+        if (const char *e = getenv("KSCHED_TIMING_EVENT_FLAGS")) flags = (unsigned)strtoul(e, nullptr, 0);
         ksched_ctx::EvPair ep;
-        HIPCHK(c, hipEventCreate(&ep.a));
-        HIPCHK(c, hipEventCreate(&ep.b));
+        HIPCHK(c, hipEventCreateWithFlags(&ep.a, flags));
+        HIPCHK(c, hipEventCreateWithFlags(&ep.b, flags));
         c->ev_pool.push_back(ep);
     }
     *slot = c->ev_used++;
