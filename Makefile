@@ -41,7 +41,7 @@ $(LIB_HOST): $(HOST_SRCS) $(HOST_HDRS) $(LIB_HIP)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRCS) -L$(PKG) -lksched_hip -Wl,-rpath,'$$ORIGIN' -lpthread
 # C++ tests of the host mirror (tests/cpp/host_tests.cpp; driven by tests/test_host_mirror.py)
 $(HOST_TEST): tests/cpp/host_tests.cpp $(LIB_HOST) $(HOST_HDRS)
-	$(CXX) $(CXXFLAGS) -o $@ tests/cpp/host_tests.cpp -L$(PKG) -lksched_host -lksched_hip -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lpthread
+	$(CXX) $(CXXFLAGS) -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o $@ tests/cpp/host_tests.cpp -L$(PKG) -lksched_host -lksched_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -Wl,-rpath,/opt/rocm/lib -lpthread
 
 oracle: $(LIB_ORA)
 $(LIB_ORA): oracle/oracle.c oracle/oracle.h

@@ -106,7 +106,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: C3 on one GPU (configs[2], the largest single-GPU configuration); C4s for N > 1 (8 GPUs x C4s == configs[3], "
+                         "1M pods x 10k nodes)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "fused"])
     ap.add_argument("--pods", type=int, default=None, help="override pods per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,6 +129,10 @@ def main():
     ap.add_argument("--gather-every", type=int, default=None,
                     help="N > 1: one all-gather per this many steps (their bindings share a buffer).  Default 4: an RCCL call costs tens "
                          "of microseconds of host and launch time whatever its size -- the same order as a step's kernels")
+    ap.add_argument("--torch-gather", action="store_true",
+                    help="N > 1: all-gather with torch.distributed.all_gather_into_tensor instead of the C ABI's communicator "
+                         "(ksched_allgather_bindings); A/B only, the default is the ABI")
+    ap.add_argument("--one-stream", action="store_true", help="N > 1: keep pick, all-gather (side stream) and mask kernel off the two-stream pipe")
     ap.add_argument("--two-stream", action="store_true",
                     help="with --depth >= 2: mask kernels on one HIP stream, pick kernels (+ all-gather) on another (ksched_pipe).  The picks "
                          "do not read the mask, so the two streams need no ordering between them: +25 %% evals/s at C3 and in the N > 1 path; "
@@ -138,7 +144,7 @@ def main():
     import torch.distributed as dist
 
     from kube_scheduler_rs_reference_amd import Evaluator, _lib as L, synth
-    from kube_scheduler_rs_reference_amd.dist import PipelinedScheduler, ShardedScheduler
+    from kube_scheduler_rs_reference_amd.dist import AbiComm, PipelinedScheduler, ShardedScheduler, shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -159,6 +165,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload is None:
+        args.workload = "C4s" if world > 1 else "C3"
     cfg, P_gpu, N, flag_names, pick, desc = WORKLOADS[args.workload]
     if args.pods:
         P_gpu = args.pods
@@ -175,46 +183,71 @@ def main():
     ev.set_nodes(**c.node_columns())
     depth = args.depth if args.depth else (2 if multi else 1)
     pipelined = depth > 1 and not args.no_mask
-    gather_every = max(1, args.gather_every or 4) if (multi and pipelined) else 1
-    pipe = ev.pipe(depth * gather_every) if (pipelined and args.two_stream) else None
-    sched = (PipelinedScheduler(P_total, dev, depth=depth, pipe=pipe, gather_always=multi, gather_every=gather_every) if pipelined
-             else ShardedScheduler(P_total, dev))
-    lo, hi = sched.lo, sched.hi
+    # N > 1: ONE all-gather per batch by default -- what north_star describes ("an RCCL allgather of the resulting bindings").
+    # --gather-every G batches the bindings of G steps into one collective; the default run also times G = 4 and reports it
+    # next to the primary number (config.allgather_every_4).
+    gather_every = max(1, args.gather_every or 1) if (multi and pipelined) else 1
+    if multi and pipelined and not args.one_stream:
+        # N > 1 default: ksched_pipe -- mask kernels on one stream; pick -> all-gather -> pick -> ... on the other.  The gather is
+        # ordered behind its pick by the stream itself (no event per step) and overlaps the next batches' mask kernels.
+        args.two_stream = True
+    comm = AbiComm(ev) if (multi and not args.torch_gather) else None  # ksched_comm_create: the C ABI's RCCL communicator
+    lo, hi, _ = shard_bounds(P_total, world, rank)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
     d_cpu, d_mem = t(c.req_cpu[lo:hi], np.int64), t(c.req_mem[lo:hi], np.int64)
     d_sel = t(c.pod_sel[:, lo:hi], np.int32) if c.n_keys else None
     d_tol = t(c.pod_tol[lo:hi], np.int64) if taint else None
     d_smp = t(c.samples[lo:hi], np.int32) if pick == "sampled" else None
     W = ev.W
-    n_masks = depth * gather_every if pipe is not None else 1
-    d_masks = [None if args.no_mask else ev.alloc_mask(hi - lo, pitched=not args.packed) for _ in range(n_masks)]
-    d_mask = d_masks[0]
+
+    class Loop:
+        """One configuration of the step loop: scheduler (sharding + gather), buffers, pre-marshalled launches."""
+
+        def __init__(self, G):
+            self.G = G
+            self.pipe = ev.pipe(depth * G) if (pipelined and args.two_stream) else None
+            self.sched = (PipelinedScheduler(P_total, dev, depth=depth, pipe=self.pipe, gather_always=multi, gather_every=G, comm=comm)
+                          if pipelined else ShardedScheduler(P_total, dev, comm=comm))
+            sched = self.sched
+            n_masks = depth * G if self.pipe is not None else 1
+            self.masks = [None if args.no_mask else ev.alloc_mask(hi - lo, pitched=not args.packed) for _ in range(n_masks)]
+            if pipelined:  # one binding buffer per (slot, step of the slot's gather group)
+                slot_outs = {(k, g): sched.binding_buffer(k, g) for k in range(depth) for g in range(G)}
+            else:
+                slot_outs = {(0, 0): sched.local[: hi - lo]}
+            keys = sorted(slot_outs)
+            # sequential form: pick kernel + mask kernel on one stream, one (pre-marshalled) library call per step
+            bound = ev.bind_eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=self.masks[0], out_bindings=[slot_outs[k] for k in keys])
+            index_of = {slot_outs[k].data_ptr(): i for i, k in enumerate(keys)}
+            submit = None
+            if self.pipe is not None:  # pre-marshalled ksched_pipe_submit: mask kernel -> the pipe's mask stream, pick -> its pick stream
+                submit = self.pipe.bind(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, self.masks, [slot_outs[k] for k in keys])  # pipe slot = k * G + g
+
+            def local_eval(binding_out):
+                bound(index_of[binding_out.data_ptr()])
+
+            def run(slot, binding_out):  # pipelined form: bindings and masks are per slot
+                if submit is not None:
+                    submit(slot)
+                else:
+                    bound(index_of[binding_out.data_ptr()])
+            self.step = (lambda: sched.step(run)) if pipelined else (lambda: sched.step(local_eval))
+
+        def drain(self):
+            if pipelined:
+                self.sched.drain()
+
+        def close(self):
+            if self.pipe is not None:
+                self.pipe.close()
+
+    loop = Loop(gather_every)
+    sched, pipe = loop.sched, loop.pipe
+    d_mask = loop.masks[0]
     pitch = int(d_mask.stride(0)) if d_mask is not None else W
 
-    # sequential form: pick kernel + mask kernel on one stream, one (pre-marshalled) library call per step
-    if pipelined:  # one binding buffer per (slot, step of the slot's gather group)
-        slot_outs = {(k, g): sched.binding_buffer(k, g) for k in range(depth) for g in range(gather_every)}
-    else:
-        slot_outs = {(0, 0): sched.local[: hi - lo]}
-    keys = sorted(slot_outs)
-    bound = ev.bind_eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=d_mask, out_bindings=[slot_outs[k] for k in keys])
-    index_of = {slot_outs[k].data_ptr(): i for i, k in enumerate(keys)}
-
-    def local_eval(binding_out):
-        bound(index_of[binding_out.data_ptr()])
-
-    submit = None
-    if pipe is not None:  # pre-marshalled ksched_pipe_submit: the mask kernel goes to the pipe's mask stream, the pick to its pick stream
-        submit = pipe.bind(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, d_masks, [slot_outs[k] for k in keys])  # pipe slot = k * gather_every + g
-
-    def run(slot, binding_out):  # pipelined form: bindings and masks are per slot
-        if submit is not None:
-            submit(slot)
-        else:
-            bound(index_of[binding_out.data_ptr()])
-
     def one_step():
-        return sched.step(run) if pipelined else sched.step(local_eval)
+        return loop.step()
 
     def sync():
         if multi:
@@ -273,6 +306,26 @@ def main():
     ev.set_timing(False)
     launches = int(samples_us.shape[0])
     kern_ms = float(samples_us.sum()) * 1e-3
+    # ---- N > 1, second number: the same K steps with ONE all-gather per 4 steps (fewer, larger collectives) ------------
+    alt = None
+    if multi and pipelined and args.gather_every is None:
+        loop.drain()
+        loop_alt = Loop(4)
+        for _ in range(32):
+            loop_alt.step()
+        loop_alt.drain()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            loop_alt.step()
+        loop_alt.drain()
+        sync()
+        e_alt = time.perf_counter() - t1
+        tt = torch.tensor([e_alt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        e_alt = float(tt.item())
+        alt = {"value": float(P_total) * N * args.steps / e_alt, "ms_per_step": e_alt / args.steps * 1e3, "steps": args.steps}
+        loop_alt.close()
 
     # sanity inside the bench: the fraction of pods the last timed step bound (a degenerate workload would show 0 or 1)
     bound_frac = float((bindings >= 0).float().mean().item())
@@ -305,6 +358,8 @@ def main():
                        "mask_row_pitch_words": pitch, "mask_words": W,
                        "kernel": ev.last_kernel, "steps_in_flight": depth if pipelined else 1, "two_stream": pipe is not None,
                        "steps_per_allgather": gather_every if (pipelined and multi) else (1 if multi else None),
+                       "allgather": (("torch.distributed.all_gather_into_tensor" if args.torch_gather else "ksched_allgather_bindings (C ABI, ncclAllGather on the pick's stream)") if multi else None),
+                       "allgather_every_4": alt,
                        "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
                        "allgather(int32 bindings)" if world > 1 else "single GPU",
                        "bound_fraction": bound_frac},
@@ -326,6 +381,9 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    loop.close()
+    if comm is not None:
+        comm.close()
     ev.close()
     if rank == 0:
         import ctypes

@@ -61,6 +61,7 @@ extern "C" {
 #define KSCHED_E_NOMEM (-4)       /* host or device allocation failed */
 #define KSCHED_E_STATE (-5)       /* ksched_set_nodes has not been called */
 #define KSCHED_E_UNSUPPORTED (-6) /* request outside what this build supports */
+#define KSCHED_E_RCCL (-7)        /* RCCL unavailable or a collective call failed; see ksched_comm_last_error */
 
 /* predicate / output selection flags for ksched_eval* */
 #define KSCHED_FIT 0x01u           /* resource fit: req <= available on cpu AND memory */
@@ -241,6 +242,39 @@ int ksched_reason(const uint64_t *feasible_row, const uint64_t *fit_row, uint32_
 int ksched_explain(ksched_ctx *ctx, uint32_t p, const int64_t *req_cpu_milli, const int64_t *req_mem_bytes,
                    const uint32_t *sel_val_ids, const uint64_t *tolerations, uint32_t count, const uint32_t *pair_pod,
                    const uint32_t *pair_node, uint32_t flags, int32_t *out_reason);
+
+/* ---- multi-GPU: all-gather of the (pod -> node) bindings over RCCL / xGMI --------------------
+ * The pod batch row-shards over the GPUs of one node (north_star): rank r evaluates pod rows
+ * [r * shard, (r + 1) * shard) with its own ksched_ctx against the replicated node snapshot, and ONE all-gather of the
+ * int32 bindings (4 B per pod) gives every rank the whole table.  Masks stay on the GPU that produced them.  The
+ * reference has no exchange step at all (one process, src/main.rs:127-152); this replaces nothing, it is what makes
+ * the batched path span 8 GPUs.
+ *
+ * Two ways to build the communicator:
+ *   one process per GPU : rank 0 calls ksched_comm_unique_id and hands the 128 bytes to the other ranks out of band
+ *                         (env, file, TCP store); every rank calls ksched_comm_create(ctx, id, rank, nranks)
+ *                         (ncclCommInitRank on the ctx's device; collective: all ranks must call it).
+ *   one process, n GPUs : ksched_comm_create_local(ctxs, n, comms) (ncclCommInitAll): comms[i] belongs to ctxs[i].
+ * ksched_allgather_bindings enqueues ncclAllGather(int32) on `hip_stream` and returns without syncing:
+ *   gathered[r * count_per_rank + i] = rank r's local[i].  Device pointers; every rank passes the same count (pad the
+ *   last shard with -1).  Enqueue it on the stream the pick was launched on and no host sync or event is needed.
+ * With one process driving n devices the n calls of one collective must be issued together:
+ * ksched_allgather_bindings_local wraps them in ncclGroupStart/End (local[i], gathered[i], hip_streams[i] belong to comms[i]).
+ * RCCL is loaded on first use (dlopen "librccl.so.1"); a process that never calls these never loads it.
+ */
+#define KSCHED_COMM_ID_BYTES 128u
+typedef struct ksched_comm ksched_comm;
+int ksched_comm_unique_id(uint8_t *id /* [KSCHED_COMM_ID_BYTES] */);
+int ksched_comm_create(ksched_ctx *ctx, const uint8_t *id, int rank, int nranks, ksched_comm **out);
+int ksched_comm_create_local(ksched_ctx *const *ctxs, int n, ksched_comm **out /* [n] */);
+void ksched_comm_destroy(ksched_comm *comm);
+int ksched_comm_rank(const ksched_comm *comm);
+int ksched_comm_size(const ksched_comm *comm);
+int ksched_allgather_bindings(ksched_comm *comm, const int32_t *local, int32_t *gathered, uint32_t count_per_rank, void *hip_stream);
+int ksched_allgather_bindings_local(ksched_comm *const *comms, int n, const int32_t *const *local, int32_t *const *gathered,
+                                    uint32_t count_per_rank, void *const *hip_streams);
+/* text of the calling thread's last RCCL failure (empty string if none) */
+const char *ksched_comm_last_error(void);
 
 /* ---- measurement --------------------------------------------------------------------------
  * With KSCHED_OPT_TIMING = 1 every ksched_eval* brackets its mask kernel with hipEvents on the

@@ -26,6 +26,8 @@ E_HIP = -3
 E_NOMEM = -4
 E_STATE = -5
 E_UNSUPPORTED = -6
+E_RCCL = -7
+COMM_ID_BYTES = 128
 
 FIT = 0x01
 SEL = 0x02
@@ -76,6 +78,15 @@ SYMBOLS = {
     "ksched_pipe_wait": (C.c_int, [_vp, _u32, _vp]),
     "ksched_pipe_stream": (_vp, [_vp, C.c_int]),
     "ksched_reason": (C.c_int, [_vp, _vp, _u32, _u32]),
+    "ksched_comm_unique_id": (C.c_int, [_vp]),
+    "ksched_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "ksched_comm_create_local": (C.c_int, [_vp, C.c_int, _vp]),
+    "ksched_comm_destroy": (None, [_vp]),
+    "ksched_comm_rank": (C.c_int, [_vp]),
+    "ksched_comm_size": (C.c_int, [_vp]),
+    "ksched_allgather_bindings": (C.c_int, [_vp, _vp, _vp, _u32, _vp]),
+    "ksched_allgather_bindings_local": (C.c_int, [_vp, C.c_int, _vp, _vp, _u32, _vp]),
+    "ksched_comm_last_error": (C.c_char_p, []),
     "ksched_kernel_time_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "ksched_kernel_time_samples": (C.c_int, [_vp, _vp, _u32]),
     "ksched_explain": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _vp]),

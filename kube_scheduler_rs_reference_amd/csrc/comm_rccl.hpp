@@ -1,0 +1,66 @@
+// comm_rccl.hpp -- the one exchange step of the path, behind the C ABI: an RCCL all-gather of the int32 (pod -> node)
+// bindings over xGMI (pod rows shard contiguously over the GPUs of one node, the node snapshot is
+// replicated, masks stay where they were produced; 4 B per pod are exchanged).
+//
+// RCCL is resolved at run time (dlopen of librccl.so.1), not at link time: the evaluator itself has no use for it, a
+// single-GPU caller never loads it, and inside a process that already carries an RCCL (e.g. PyTorch's bundled
+// librccl.so.1) the same library instance is reused instead of a second copy being mapped next to it.  The header is
+// only used for its types and prototypes.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+#include <string>
+
+namespace ksched {
+
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+    std::string error;
+};
+
+inline RcclApi &rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) {
+            api.error = std::string("cannot load librccl.so.1: ") + dlerror();
+            return;
+        }
+        bool all = true;
+        auto sym = [&](const char *name) -> void * {
+            void *p = dlsym(h, name);
+            if (!p) {
+                all = false;
+                api.error = std::string("librccl lacks ") + name;
+            }
+            return p;
+        };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        api.ok = all;
+    });
+    return api;
+}
+
+}  // namespace ksched

@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "comm_rccl.hpp"
 #include "kernels_direct.hpp"
 #include "kernels_fused.hpp"
 #include "tile_index.hpp"
@@ -527,6 +528,7 @@ const char *ksched_strerror(int code) {
         case KSCHED_E_NOMEM: return "out of memory";
         case KSCHED_E_STATE: return "ksched_set_nodes has not been called";
         case KSCHED_E_UNSUPPORTED: return "unsupported request";
+        case KSCHED_E_RCCL: return "RCCL error (see ksched_comm_last_error)";
         default: return "unknown error";
     }
 }
@@ -990,6 +992,143 @@ int ksched_explain(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     HIPCHK(c, hipMemcpyAsync(out_reason, c->xreason.ptr, (size_t)count * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     return KSCHED_OK;
+}
+
+// ---- multi-GPU: RCCL all-gather of the bindings (comm_rccl.hpp) --------------------------------------------------
+
+struct ksched_comm {
+    ncclComm_t comm = nullptr;
+    int device = 0, rank = 0, nranks = 1;
+};
+
+namespace {
+thread_local std::string g_comm_error;
+
+int comm_fail(const char *what, ncclResult_t r) {
+    RcclApi &api = rccl_api();
+    g_comm_error = std::string(what) + ": " + ((api.ok && api.GetErrorString) ? api.GetErrorString(r) : "RCCL unavailable");
+    return KSCHED_E_RCCL;
+}
+int comm_unavailable() {
+    g_comm_error = rccl_api().error;
+    return KSCHED_E_RCCL;
+}
+}  // namespace
+
+const char *ksched_comm_last_error(void) { return g_comm_error.c_str(); }
+
+int ksched_comm_unique_id(uint8_t *id) {
+    if (!id) return KSCHED_E_INVAL;
+    RcclApi &api = rccl_api();
+    if (!api.ok) return comm_unavailable();
+    static_assert(sizeof(ncclUniqueId) == KSCHED_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    ncclResult_t r = api.GetUniqueId(&u);
+    if (r != ncclSuccess) return comm_fail("ncclGetUniqueId", r);
+    memcpy(id, &u, sizeof u);
+    return KSCHED_OK;
+}
+
+int ksched_comm_create(ksched_ctx *c, const uint8_t *id, int rank, int nranks, ksched_comm **out) {
+    if (!c || !id || !out || nranks <= 0 || rank < 0 || rank >= nranks) return KSCHED_E_INVAL;
+    *out = nullptr;
+    RcclApi &api = rccl_api();
+    if (!api.ok) return comm_unavailable();
+    DeviceGuard g(c->device);  // ncclCommInitRank binds the communicator to the current device
+    if (!g.ok) return KSCHED_E_HIP;
+    ksched_comm *q = new (std::nothrow) ksched_comm();
+    if (!q) return KSCHED_E_NOMEM;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclResult_t r = api.CommInitRank(&q->comm, nranks, u, rank);
+    if (r != ncclSuccess) {
+        delete q;
+        return comm_fail("ncclCommInitRank", r);
+    }
+    q->device = c->device;
+    q->rank = rank;
+    q->nranks = nranks;
+    *out = q;
+    return KSCHED_OK;
+}
+
+int ksched_comm_create_local(ksched_ctx *const *ctxs, int n, ksched_comm **out) {
+    if (!ctxs || !out || n <= 0 || n > 64) return KSCHED_E_INVAL;
+    for (int i = 0; i < n; ++i) {
+        out[i] = nullptr;
+        if (!ctxs[i]) return KSCHED_E_INVAL;
+    }
+    RcclApi &api = rccl_api();
+    if (!api.ok) return comm_unavailable();
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+    std::vector<ncclComm_t> comms(n, nullptr);
+    ncclResult_t r = api.CommInitAll(comms.data(), n, devs.data());
+    if (r != ncclSuccess) return comm_fail("ncclCommInitAll", r);
+    for (int i = 0; i < n; ++i) {
+        ksched_comm *q = new (std::nothrow) ksched_comm();
+        if (!q) {
+            for (int j = 0; j < n; ++j) {
+                if (j < i) delete out[j];
+                out[j] = nullptr;
+                (void)api.CommDestroy(comms[j]);
+            }
+            return KSCHED_E_NOMEM;
+        }
+        q->comm = comms[i];
+        q->device = devs[i];
+        q->rank = i;
+        q->nranks = n;
+        out[i] = q;
+    }
+    return KSCHED_OK;
+}
+
+void ksched_comm_destroy(ksched_comm *q) {
+    if (!q) return;
+    RcclApi &api = rccl_api();
+    if (api.ok && q->comm) {
+        DeviceGuard g(q->device);
+        (void)api.CommDestroy(q->comm);
+    }
+    delete q;
+}
+
+int ksched_comm_rank(const ksched_comm *q) { return q ? q->rank : -1; }
+int ksched_comm_size(const ksched_comm *q) { return q ? q->nranks : 0; }
+
+int ksched_allgather_bindings(ksched_comm *q, const int32_t *local, int32_t *gathered, uint32_t count_per_rank, void *hip_stream) {
+    if (!q || !q->comm) return KSCHED_E_INVAL;
+    if (count_per_rank > 0 && (!local || !gathered)) return KSCHED_E_INVAL;
+    if (count_per_rank == 0) return KSCHED_OK;
+    RcclApi &api = rccl_api();
+    if (!api.ok) return comm_unavailable();
+    DeviceGuard g(q->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    ncclResult_t r = api.AllGather(local, gathered, count_per_rank, ncclInt32, q->comm, (hipStream_t)hip_stream);
+    return r == ncclSuccess ? KSCHED_OK : comm_fail("ncclAllGather", r);
+}
+
+int ksched_allgather_bindings_local(ksched_comm *const *comms, int n, const int32_t *const *local, int32_t *const *gathered,
+                                    uint32_t count_per_rank, void *const *hip_streams) {
+    if (!comms || n <= 0 || !local || !gathered) return KSCHED_E_INVAL;
+    for (int i = 0; i < n; ++i)
+        if (!comms[i] || !comms[i]->comm || (count_per_rank > 0 && (!local[i] || !gathered[i]))) return KSCHED_E_INVAL;
+    if (count_per_rank == 0) return KSCHED_OK;
+    RcclApi &api = rccl_api();
+    if (!api.ok) return comm_unavailable();
+    // one process drives every device: the per-device calls of one collective must be fused in a group
+    ncclResult_t r = api.GroupStart();
+    if (r != ncclSuccess) return comm_fail("ncclGroupStart", r);
+    ncclResult_t first = ncclSuccess;
+    for (int i = 0; i < n; ++i) {
+        DeviceGuard g(comms[i]->device);
+        r = api.AllGather(local[i], gathered[i], count_per_rank, ncclInt32, comms[i]->comm, hip_streams ? (hipStream_t)hip_streams[i] : nullptr);
+        if (r != ncclSuccess && first == ncclSuccess) first = r;
+    }
+    r = api.GroupEnd();
+    if (first != ncclSuccess) return comm_fail("ncclAllGather", first);
+    return r == ncclSuccess ? KSCHED_OK : comm_fail("ncclGroupEnd", r);
 }
 
 int ksched_trace_read(ksched_ctx *c, uint64_t *out, uint32_t max_blocks) {

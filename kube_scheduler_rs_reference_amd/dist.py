@@ -1,9 +1,14 @@
 """Multi-GPU: pod rows shard across ranks, node snapshot is replicated, bindings are all-gathered.
 
-One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the
-CPU tests).  Pods are independent given the node snapshot, so the only
+One process per GPU.  Pods are independent given the node snapshot, so the only
 exchange step is one all-gather of the int32 bindings (4 B per pod); masks stay on the GPU that
 produced them.
+
+The data path of that exchange is the C ABI's own RCCL communicator (`AbiComm` = ksched_comm_create +
+ksched_allgather_bindings, include/ksched.h: ncclAllGather enqueued on the pick's stream), the same entry points a
+Rust or C++ host binds.  `torch.distributed` is only the launcher-side control plane here (rank / world size, handing
+the 128-byte RCCL unique id to the other ranks, the bench's barrier); without a GPU (the world-size-2/3 "gloo" tests of
+the sharding arithmetic) the gather falls back to torch's collective, which is test plumbing, not the product path.
 
     rank r owns pod rows [r * shard, min(P, (r + 1) * shard)),  shard = ceil(P / world)
 
@@ -26,6 +31,82 @@ import torch
 import torch.distributed as dist
 
 
+class _EventWork:
+    """`.wait()` orders the current stream after a recorded event (the stream-ordered equivalent of a torch Work)."""
+
+    def __init__(self, event):
+        self._event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self._event)
+
+
+class _StreamWork:
+    """`.wait()` orders the current stream after everything enqueued on `stream` so far; nothing is recorded per step (the
+    gather was enqueued on `stream` behind the pick, so the stream's own order is the only synchronisation needed until
+    someone on another stream wants the result)."""
+
+    def __init__(self, stream):
+        self._stream = stream
+
+    def wait(self):
+        cur = torch.cuda.current_stream(self._stream.device)
+        if cur.cuda_stream != self._stream.cuda_stream:
+            cur.wait_stream(self._stream)
+
+
+class AbiComm:
+    """RCCL communicator behind the C ABI (ksched_comm_*), one process per GPU.
+
+    Rank 0 draws the unique id (ksched_comm_unique_id) and the launcher's process group -- any backend -- carries its 128
+    bytes to the other ranks; ksched_comm_create is then collective over all ranks.  all_gather() enqueues
+    ksched_allgather_bindings on a HIP stream and returns: no host sync, no torch collective on the data path."""
+
+    def __init__(self, evaluator, group: Optional[dist.ProcessGroup] = None):
+        import ctypes as C
+        from . import _lib as L
+        self._lib, self._ev = evaluator._lib, evaluator
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        ident = (C.c_uint8 * L.COMM_ID_BYTES)()
+        if self.rank == 0:
+            self._check(self._lib.ksched_comm_unique_id(C.cast(ident, C.c_void_p)), "ksched_comm_unique_id")
+        if self.world > 1:
+            box = [bytes(ident) if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (C.c_uint8 * L.COMM_ID_BYTES).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        self._check(self._lib.ksched_comm_create(evaluator._h, C.cast(ident, C.c_void_p), self.rank, self.world, C.byref(h)), "ksched_comm_create")
+        self._h = h
+
+    def _check(self, rc: int, where: str):
+        if rc != 0:
+            from . import _lib as L
+            raise L.KschedError(rc, where, self._lib.ksched_comm_last_error().decode())
+
+    def all_gather(self, gathered: torch.Tensor, local: torch.Tensor, stream=None) -> None:
+        """gathered[r * len(local) + i] = rank r's local[i] (int32 CUDA tensors), enqueued on `stream` (default: current)."""
+        import ctypes as C
+        if local.dtype != torch.int32 or gathered.dtype != torch.int32 or not local.is_contiguous() or not gathered.is_contiguous():
+            raise ValueError("bindings must be contiguous int32 CUDA tensors")
+        if gathered.numel() != local.numel() * self.world:
+            raise ValueError("gathered must hold world * len(local) entries")
+        stream = stream or torch.cuda.current_stream(local.device)
+        self._check(self._lib.ksched_allgather_bindings(self._h, C.c_void_p(local.data_ptr()), C.c_void_p(gathered.data_ptr()),
+                                                        local.numel(), C.c_void_p(stream.cuda_stream)), "ksched_allgather_bindings")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ksched_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def shard_bounds(P: int, world: int, rank: int) -> Tuple[int, int, int]:
     """-> (lo, hi, shard) for contiguous row sharding; the last ranks may own fewer (or zero) rows."""
     shard = (P + world - 1) // world if world > 0 else P
@@ -40,6 +121,7 @@ class ShardedScheduler:
     P: int                                   # global number of pods
     device: torch.device
     group: Optional[dist.ProcessGroup] = None
+    comm: Optional[AbiComm] = None           # the C ABI's RCCL communicator (GPU); None = torch collective (CPU / gloo tests)
 
     def __post_init__(self):
         self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
@@ -58,8 +140,11 @@ class ShardedScheduler:
         rank's rows, enqueued on the current stream.  Returns the global bindings [P] (a view)."""
         if self.n_local > 0:
             local_eval(self.local[: self.n_local])
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
+        if self.world > 1 or self.comm is not None:
+            if self.comm is not None:
+                self.comm.all_gather(self.gathered, self.local)  # ksched_allgather_bindings on the current stream
+            else:
+                dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
             return self.gathered[: self.P]
         return self.local[: self.P]
 
@@ -103,17 +188,18 @@ class PipelinedScheduler:
     group)."""
 
     def __init__(self, P: int, device: torch.device, depth: int = 2, group: Optional[dist.ProcessGroup] = None, pipe=None,
-                 gather_always: bool = False, gather_every: int = 1):
+                 gather_always: bool = False, gather_every: int = 1, comm: Optional[AbiComm] = None):
         if depth < 1 or gather_every < 1:
             raise ValueError("depth >= 1, gather_every >= 1")
         if pipe is not None and pipe.depth != depth * gather_every:
             raise ValueError("a pipe needs pipe.depth == depth * gather_every (one pipe slot per step in flight)")
         self.P, self.device, self.depth, self.group, self.pipe, self.gather_every = P, device, depth, group, pipe, gather_every
+        self.comm = comm  # the C ABI's communicator: the gather is ksched_allgather_bindings, stream-ordered behind the pick
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.lo, self.hi, self.shard = shard_bounds(P, self.world, self.rank)
         # gather_always: run the all-gather even in a one-rank group (exercises the RCCL path on a single GPU; tests)
-        self._gather = self.world > 1 or (gather_always and dist.is_initialized())
+        self._gather = self.world > 1 or (gather_always and (dist.is_initialized() or comm is not None))
         G = gather_every
         self._local = [torch.full((G * self.shard,), -1, dtype=torch.int32, device=device) for _ in range(depth)]
         self._gathered = [torch.full((G * self.shard * self.world,), -1, dtype=torch.int32, device=device) if self._gather else None
@@ -123,6 +209,10 @@ class PipelinedScheduler:
         self._fill = [0] * depth   # steps written into the slot since its last gather
         self._cur = 0              # slot being filled
         self._pick_stream = pipe.stream(1) if pipe is not None else None
+        # single-stream form with the ABI communicator: the gather runs on a side stream behind an event, like torch's async_op
+        self._side = torch.cuda.Stream(device=device) if (comm is not None and pipe is None) else None
+        self._ready = [torch.cuda.Event() for _ in range(depth)] if self._side is not None else None  # reused: no event creation per step
+        self._done = [torch.cuda.Event() for _ in range(depth)] if self._side is not None else None
 
     @property
     def n_local(self) -> int:
@@ -136,7 +226,17 @@ class PipelinedScheduler:
     def _flush(self, k: int) -> None:
         """Issue the (asynchronous) all-gather of slot k's group and move on to the next slot."""
         if self._gather and self._fill[k] > 0:
-            if self._pick_stream is not None:
+            if self.comm is not None:
+                if self._pick_stream is not None:  # stream-ordered behind the group's last pick: no event, nothing to wait for
+                    self.comm.all_gather(self._gathered[k], self._local[k], stream=self._pick_stream)
+                    self._work[k] = _StreamWork(self._pick_stream)
+                else:
+                    self._ready[k].record(torch.cuda.current_stream(self.device))
+                    self._side.wait_event(self._ready[k])
+                    self.comm.all_gather(self._gathered[k], self._local[k], stream=self._side)
+                    self._done[k].record(self._side)
+                    self._work[k] = _EventWork(self._done[k])
+            elif self._pick_stream is not None:
                 with torch.cuda.stream(self._pick_stream):
                     self._work[k] = dist.all_gather_into_tensor(self._gathered[k], self._local[k], group=self.group, async_op=True)
             else:

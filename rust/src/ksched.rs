@@ -1,0 +1,403 @@
+// src/ksched.rs -- safe layer over the C ABI (ksched_sys.rs): evaluator handle, exact quantity encoding, the node
+// snapshot (canonical order + label dictionaries) and the batched evaluation.  This is the Rust twin of the C++ host
+// mirror in the ksched repository (kube_scheduler_rs_reference_amd/host/{quantity,encoder,predicates}.cpp): same
+// encoding rules, same error behaviour, so the parity tests of both read the same.
+//
+// Encoding rules (include/ksched.h "Conventions"):
+//   * quantities -> exact i64: CPU in milli-cores, memory in bytes.  The text is parsed with the Kubernetes quantity
+//     grammar into exact nano-units (i128); a value that is not a whole number of milli-cores / bytes, or leaves i64, is
+//     an error (the reference would have compared it in decimal; the device compares integers).
+//   * available[n] = allocatable[n] - sum(total requests of every pod whose spec.nodeName == n)   (src/predicates.rs:27-38),
+//     signed: it may be negative.
+//   * nodes in canonical order = ascending metadata.name; column index == mask bit.
+//   * label values -> dense dictionary ids per key (1..), 0 = key absent on the node; a selector value that no node
+//     carries -> KSCHED_SEL_NEVER.  Exact interning, never a hash.
+#![allow(dead_code)]
+use std::collections::{BTreeMap, BTreeSet};
+use std::ffi::CStr;
+use std::sync::Arc;
+
+use k8s_openapi::api::core::v1 as corev1;
+
+use crate::ksched_sys as sys;
+
+#[derive(Debug, Clone)]
+pub struct KschedError {
+    pub code: i32,
+    pub message: String,
+}
+
+impl std::fmt::Display for KschedError {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        return write!(f, "ksched error {}: {}", self.code, self.message);
+    }
+}
+
+fn strerror(code: i32) -> String {
+    let p = unsafe { sys::ksched_strerror(code) };
+    if p.is_null() {
+        return String::new();
+    }
+    return unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned();
+}
+
+/// One `ksched_ctx` = one GPU.  The handle is internally serialised by a mutex (include/ksched.h), so it may be shared
+/// between reconcile tasks; FFI calls block, so async callers wrap them in `tokio::task::spawn_blocking`.
+pub struct Evaluator(*mut sys::ksched_ctx);
+unsafe impl Send for Evaluator {}
+unsafe impl Sync for Evaluator {}
+
+impl Evaluator {
+    pub fn new(device: i32) -> Result<Evaluator, KschedError> {
+        if unsafe { sys::ksched_abi_version() } != sys::KSCHED_ABI_VERSION {
+            return Err(KschedError { code: sys::KSCHED_E_UNSUPPORTED, message: "libksched_hip.so ABI version differs from ksched_sys.rs".into() });
+        }
+        let mut h: *mut sys::ksched_ctx = std::ptr::null_mut();
+        let rc = unsafe { sys::ksched_create(&mut h, device) };
+        if rc != sys::KSCHED_OK {
+            // KSCHED_E_NODEVICE: there is no CPU fallback by design
+            return Err(KschedError { code: rc, message: strerror(rc) });
+        }
+        return Ok(Evaluator(h));
+    }
+
+    pub fn raw(&self) -> *mut sys::ksched_ctx {
+        return self.0;
+    }
+
+    fn check(&self, rc: i32, what: &str) -> Result<(), KschedError> {
+        if rc == sys::KSCHED_OK {
+            return Ok(());
+        }
+        let detail = unsafe { CStr::from_ptr(sys::ksched_last_error(self.0)) }.to_string_lossy().into_owned();
+        return Err(KschedError { code: rc, message: format!("{}: {} ({})", what, strerror(rc), detail) });
+    }
+}
+
+impl Drop for Evaluator {
+    fn drop(&mut self) {
+        unsafe { sys::ksched_destroy(self.0) }
+    }
+}
+
+// ---- quantities -------------------------------------------------------------------------------------------------
+
+/// Kubernetes resource.Quantity text -> exact nano-units.  Grammar: sign? digits ('.' digits)? suffix with suffix one of
+/// "" n u m k M G T P E | Ki Mi Gi Ti Pi Ei | e<exp> E<exp>.  Err where the reference's `.expect(..)` would panic
+/// (src/util.rs:65,68; src/predicates.rs:29,31) or where the value is finer than one nano-unit / out of range.
+pub fn parse_quantity_nanos(text: &str) -> Result<i128, String> {
+    let bad = |why: &str| format!("invalid quantity '{}': {}", text, why);
+    let b = text.as_bytes();
+    let mut i = 0usize;
+    let mut neg = false;
+    if i < b.len() && (b[i] == b'+' || b[i] == b'-') {
+        neg = b[i] == b'-';
+        i += 1;
+    }
+    let mut mant: i128 = 0;
+    let mut digits = 0u32;
+    let mut frac = 0i32;
+    let mut in_frac = false;
+    loop {
+        if i < b.len() && b[i].is_ascii_digit() {
+            mant = mant.checked_mul(10).and_then(|m| m.checked_add((b[i] - b'0') as i128)).ok_or_else(|| bad("mantissa too large"))?;
+            digits += 1;
+            if in_frac {
+                frac += 1;
+            }
+            i += 1;
+        } else if i < b.len() && b[i] == b'.' && !in_frac {
+            in_frac = true;
+            i += 1;
+        } else {
+            break;
+        }
+    }
+    if digits == 0 {
+        return Err(bad("no digits"));
+    }
+    let suf = &text[i..];
+    let sb = suf.as_bytes();
+    let mut exp10: i32 = 0;
+    let mut shift: u32 = 0;
+    if sb.is_empty() {
+    } else if (sb[0] == b'e' || sb[0] == b'E') && sb.len() > 1 && (sb[1].is_ascii_digit() || sb[1] == b'+' || sb[1] == b'-') {
+        let mut j = 1usize;
+        let mut eneg = false;
+        if sb[j] == b'+' || sb[j] == b'-' {
+            eneg = sb[j] == b'-';
+            j += 1;
+        }
+        if j >= sb.len() {
+            return Err(bad("empty exponent"));
+        }
+        let mut ev: i32 = 0;
+        while j < sb.len() {
+            if !sb[j].is_ascii_digit() {
+                return Err(bad("bad exponent"));
+            }
+            ev = ev * 10 + (sb[j] - b'0') as i32;
+            if ev > 100 {
+                return Err(bad("exponent too large"));
+            }
+            j += 1;
+        }
+        exp10 = if eneg { -ev } else { ev };
+    } else if sb.len() == 2 && sb[1] == b'i' {
+        shift = match sb[0] {
+            b'K' => 10,
+            b'M' => 20,
+            b'G' => 30,
+            b'T' => 40,
+            b'P' => 50,
+            b'E' => 60,
+            _ => return Err(bad("unknown binary suffix")),
+        };
+    } else if sb.len() == 1 {
+        exp10 = match sb[0] {
+            b'n' => -9,
+            b'u' => -6,
+            b'm' => -3,
+            b'k' => 3,
+            b'M' => 6,
+            b'G' => 9,
+            b'T' => 12,
+            b'P' => 15,
+            b'E' => 18,
+            _ => return Err(bad("unknown suffix")),
+        };
+    } else {
+        return Err(bad("unknown suffix"));
+    }
+    let mut v = mant;
+    if shift != 0 {
+        v = v.checked_mul(1i128 << shift).ok_or_else(|| bad("out of range"))?;
+    }
+    let mut scale = 9 + exp10 - frac;
+    while scale > 0 {
+        v = v.checked_mul(10).ok_or_else(|| bad("out of range"))?;
+        scale -= 1;
+    }
+    while scale < 0 {
+        if v % 10 != 0 {
+            return Err(bad("finer than one nano-unit"));
+        }
+        v /= 10;
+        scale += 1;
+    }
+    return Ok(if neg { -v } else { v });
+}
+
+fn nanos_to_i64(nanos: i128, per_unit: i128, what: &str) -> Result<i64, String> {
+    if nanos % per_unit != 0 {
+        return Err(format!("quantity is not a whole number of {}", what));
+    }
+    return i64::try_from(nanos / per_unit).map_err(|_| format!("{} overflow i64", what));
+}
+
+/// total_pod_resources (src/util.rs:54-75) in exact nano-units: spec.containers only, requests only.
+pub fn total_pod_resources_nanos(pod: &corev1::Pod) -> Result<(i128, i128), String> {
+    let (mut cpu, mut mem) = (0i128, 0i128);
+    if let Some(spec) = &pod.spec {
+        for c in &spec.containers {
+            if let corev1::Container { resources: Some(corev1::ResourceRequirements { requests: Some(requests), .. }), .. } = c {
+                if let Some(q) = requests.get("cpu") {
+                    cpu += parse_quantity_nanos(&q.0).map_err(|e| format!("invalid pod spec: cpu request: {}", e))?;
+                }
+                if let Some(q) = requests.get("memory") {
+                    mem += parse_quantity_nanos(&q.0).map_err(|e| format!("invalid pod spec: memory request: {}", e))?;
+                }
+            }
+        }
+    }
+    return Ok((cpu, mem));
+}
+
+// ---- snapshot -----------------------------------------------------------------------------------------------------
+
+/// Encoded pod batch = the arguments of ksched_eval.
+pub struct PodColumns {
+    pub p: u32,
+    pub n_keys: u32,
+    pub req_cpu_milli: Vec<i64>,
+    pub req_mem_bytes: Vec<i64>,
+    pub sel_val_ids: Vec<u32>, // [n_keys][p]
+}
+
+/// Device-resident snapshot of the node store + bound pods, and the dictionaries that encode pods against it.
+pub struct Snapshot {
+    pub names: Vec<String>,           // canonical order
+    pub store_index: Vec<usize>,      // canonical index -> position in the slice given to build()
+    pub avail_cpu_milli: Vec<i64>,
+    pub avail_mem_bytes: Vec<i64>,
+    pub keys: Vec<String>,            // label column k <-> key
+    value_ids: Vec<BTreeMap<String, u32>>,
+    labels: Vec<Option<BTreeMap<String, String>>>, // canonical order
+    label_val_ids: Vec<u32>,          // [n_keys][n]
+}
+
+impl Snapshot {
+    /// `nodes` in any order (the reflector store's), `all_pods` = every pod of the cluster (one LIST for the whole batch
+    /// instead of one per evaluation, src/predicates.rs:34).  Err where the reference panics: allocatable lacking cpu or
+    /// memory (src/predicates.rs:29-31), unparsable quantities.
+    pub fn build(nodes: &[Arc<corev1::Node>], all_pods: &[corev1::Pod]) -> Result<Snapshot, String> {
+        let n = nodes.len();
+        let mut order: Vec<usize> = (0..n).collect();
+        let name_of = |i: usize| nodes[i].metadata.name.clone().unwrap_or_default();
+        order.sort_by(|&a, &b| name_of(a).cmp(&name_of(b)).then(a.cmp(&b)));
+        let names: Vec<String> = order.iter().map(|&i| name_of(i)).collect();
+        // requests of the bound pods, summed per node name (every phase counts: no phase filter in the reference)
+        let mut used: BTreeMap<&str, (i128, i128)> = BTreeMap::new();
+        for p in all_pods {
+            if let Some(corev1::PodSpec { node_name: Some(nn), .. }) = &p.spec {
+                let (c, m) = total_pod_resources_nanos(p)?;
+                let e = used.entry(nn.as_str()).or_insert((0, 0));
+                e.0 += c;
+                e.1 += m;
+            }
+        }
+        let mut avail_cpu_milli = Vec::with_capacity(n);
+        let mut avail_mem_bytes = Vec::with_capacity(n);
+        let mut labels = Vec::with_capacity(n);
+        for (ci, &si) in order.iter().enumerate() {
+            let node = &nodes[si];
+            let (mut cpu, mut mem) = (0i128, 0i128); // PodResources::new(): "0", "0" (src/util.rs:22-29)
+            if let Some(corev1::NodeStatus { allocatable: Some(allocatable), .. }) = &node.status {
+                let c = allocatable.get("cpu").ok_or_else(|| format!("node {}: allocatable lacks cpu (reference panics, src/predicates.rs:29)", names[ci]))?;
+                let m = allocatable.get("memory").ok_or_else(|| format!("node {}: allocatable lacks memory (src/predicates.rs:30-31)", names[ci]))?;
+                cpu = parse_quantity_nanos(&c.0).map_err(|e| format!("invalid node spec: allocatable cpu: {}", e))?;
+                mem = parse_quantity_nanos(&m.0).map_err(|e| format!("invalid node spec: allocatable memory: {}", e))?;
+            }
+            if let Some((uc, um)) = used.get(names[ci].as_str()) {
+                cpu -= uc;
+                mem -= um;
+            }
+            avail_cpu_milli.push(nanos_to_i64(cpu, 1_000_000, "milli-cores")?);
+            avail_mem_bytes.push(nanos_to_i64(mem, 1_000_000_000, "bytes")?);
+            labels.push(node.metadata.labels.clone());
+        }
+        return Ok(Snapshot { names, store_index: order, avail_cpu_milli, avail_mem_bytes, keys: Vec::new(), value_ids: Vec::new(), labels, label_val_ids: Vec::new() });
+    }
+
+    pub fn n(&self) -> u32 {
+        return self.names.len() as u32;
+    }
+
+    /// (Re)build the label columns for exactly `keys` (the selector keys the current batch uses: the key set is per batch,
+    /// so a long-running scheduler never accumulates columns).
+    fn encode_labels(&mut self, keys: &BTreeSet<String>) -> Result<(), String> {
+        if keys.len() > sys::KSCHED_MAX_KEYS as usize {
+            return Err(format!("{} distinct nodeSelector keys in one batch (limit {}): split the batch", keys.len(), sys::KSCHED_MAX_KEYS));
+        }
+        let n = self.names.len();
+        self.keys = keys.iter().cloned().collect();
+        self.value_ids = vec![BTreeMap::new(); self.keys.len()];
+        self.label_val_ids = vec![0u32; self.keys.len() * n];
+        for (k, key) in self.keys.iter().enumerate() {
+            for i in 0..n {
+                if let Some(Some(v)) = self.labels[i].as_ref().map(|l| l.get(key)) {
+                    let next = self.value_ids[k].len() as u32 + 1;
+                    let id = *self.value_ids[k].entry(v.clone()).or_insert(next);
+                    self.label_val_ids[k * n + i] = id; // "" is a value like any other: a non-zero id
+                }
+            }
+        }
+        return Ok(());
+    }
+
+    /// Encode `pods` against this snapshot and upload the snapshot's columns for the batch's selector keys.
+    pub fn encode_and_upload(&mut self, ev: &Evaluator, pods: &[&corev1::Pod]) -> Result<PodColumns, String> {
+        let mut keys = BTreeSet::new();
+        for p in pods {
+            if let Some(corev1::PodSpec { node_selector: Some(sel), .. }) = &p.spec {
+                for k in sel.keys() {
+                    keys.insert(k.clone());
+                }
+            }
+        }
+        self.encode_labels(&keys)?;
+        let n = self.n();
+        let n_keys = self.keys.len() as u32;
+        let rc = unsafe {
+            sys::ksched_set_nodes(
+                ev.raw(), n, self.avail_cpu_milli.as_ptr(), self.avail_mem_bytes.as_ptr(),
+                if n_keys > 0 { self.label_val_ids.as_ptr() } else { std::ptr::null() }, n_keys, std::ptr::null(),
+            )
+        };
+        ev.check(rc, "ksched_set_nodes").map_err(|e| e.to_string())?;
+        let p = pods.len();
+        let mut cols = PodColumns { p: p as u32, n_keys, req_cpu_milli: vec![0; p], req_mem_bytes: vec![0; p], sel_val_ids: vec![0u32; self.keys.len() * p] };
+        for (i, pod) in pods.iter().enumerate() {
+            let (c, m) = total_pod_resources_nanos(pod)?; // src/predicates.rs:40
+            cols.req_cpu_milli[i] = nanos_to_i64(c, 1_000_000, "milli-cores")?;
+            cols.req_mem_bytes[i] = nanos_to_i64(m, 1_000_000_000, "bytes")?;
+            if let Some(corev1::PodSpec { node_selector: Some(sel), .. }) = &pod.spec {
+                for (k, v) in sel.iter() { // src/predicates.rs:48-53
+                    let col = self.keys.iter().position(|x| x == k).expect("key was interned above");
+                    cols.sel_val_ids[col * p + i] = match self.value_ids[col].get(v) {
+                        Some(id) => *id,
+                        None => sys::KSCHED_SEL_NEVER,
+                    };
+                }
+            }
+        }
+        return Ok(cols);
+    }
+}
+
+/// Both masks (+ optional bindings) of one batch, pod-major, node bit = canonical index.
+pub struct BatchValidity {
+    pub p: u32,
+    pub n: u32,
+    pub words: u32,
+    pub feasible: Vec<u64>,
+    pub fit: Vec<u64>,
+    pub binding: Vec<i32>,
+}
+
+impl BatchValidity {
+    pub fn is_valid(&self, pod: u32, node: u32) -> bool {
+        return (self.feasible[(pod * self.words + (node >> 6)) as usize] >> (node & 63)) & 1 == 1;
+    }
+    /// check_node_validity's result for the pair in the reference's order: fit first (src/predicates.rs:68-70).
+    pub fn reason(&self, pod: u32, node: u32) -> i32 {
+        let o = (pod * self.words) as usize;
+        return unsafe { sys::ksched_reason(self.feasible[o..].as_ptr(), self.fit[o..].as_ptr(), node, sys::KSCHED_FIT | sys::KSCHED_SEL) };
+    }
+}
+
+/// check_node_validity (src/predicates.rs:63-77) for every (pod, node) pair in ONE device call, optionally with the
+/// sampled pick of select_node_for_pod (src/main.rs:51-71): `samples` = [p][attempts] canonical node indices.
+pub fn eval_batch(ev: &Evaluator, snap: &mut Snapshot, pods: &[&corev1::Pod], samples: Option<(&[u32], u32)>) -> Result<BatchValidity, String> {
+    let cols = snap.encode_and_upload(ev, pods)?;
+    let n = snap.n();
+    let words = unsafe { sys::ksched_mask_words(n) };
+    let mut out = BatchValidity { p: cols.p, n, words, feasible: vec![0u64; (cols.p * words) as usize], fit: vec![0u64; (cols.p * words) as usize], binding: Vec::new() };
+    if cols.p == 0 || n == 0 {
+        if samples.is_some() {
+            out.binding = vec![-1; cols.p as usize]; // choose() on an empty store: None on every attempt (src/main.rs:56,70)
+        }
+        return Ok(out);
+    }
+    let mut flags = sys::KSCHED_FIT | sys::KSCHED_SEL | sys::KSCHED_WANT_FIT_MASK;
+    let (smp_ptr, attempts) = match samples {
+        Some((s, a)) => {
+            if s.len() != (cols.p * a) as usize {
+                return Err("samples must hold p * attempts indices".into());
+            }
+            flags |= sys::KSCHED_PICK_SAMPLED;
+            out.binding = vec![-1; cols.p as usize];
+            (s.as_ptr(), a)
+        },
+        None => (std::ptr::null(), 0),
+    };
+    let rc = unsafe {
+        sys::ksched_eval(
+            ev.raw(), cols.p, cols.req_cpu_milli.as_ptr(), cols.req_mem_bytes.as_ptr(),
+            if cols.n_keys > 0 { cols.sel_val_ids.as_ptr() } else { std::ptr::null() }, std::ptr::null(), smp_ptr, attempts, flags,
+            out.feasible.as_mut_ptr(), out.fit.as_mut_ptr(), if out.binding.is_empty() { std::ptr::null_mut() } else { out.binding.as_mut_ptr() },
+        )
+    };
+    ev.check(rc, "ksched_eval").map_err(|e| e.to_string())?;
+    return Ok(out);
+}

@@ -1,0 +1,129 @@
+// src/ksched_sys.rs -- mechanical binding of include/ksched.h (ABI version 2): one `extern "C"` item per symbol the
+// header declares, same order.  Nothing here allocates or panics.  tests/test_abi_symbols.py (in the ksched repository)
+// checks this list against the header and the shared library's exports.
+#![allow(non_camel_case_types, dead_code)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct ksched_ctx {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct ksched_pipe {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct ksched_comm {
+    _private: [u8; 0],
+}
+
+pub const KSCHED_ABI_VERSION: u32 = 2;
+pub const KSCHED_MAX_KEYS: u32 = 32;
+pub const KSCHED_MAX_ATTEMPTS: u32 = 64;
+pub const KSCHED_SEL_NEVER: u32 = 0xFFFF_FFFF;
+pub const KSCHED_COMM_ID_BYTES: u32 = 128;
+
+pub const KSCHED_OK: c_int = 0;
+pub const KSCHED_E_INVAL: c_int = -1;
+pub const KSCHED_E_NODEVICE: c_int = -2;
+pub const KSCHED_E_HIP: c_int = -3;
+pub const KSCHED_E_NOMEM: c_int = -4;
+pub const KSCHED_E_STATE: c_int = -5;
+pub const KSCHED_E_UNSUPPORTED: c_int = -6;
+pub const KSCHED_E_RCCL: c_int = -7;
+
+pub const KSCHED_FIT: u32 = 0x01;
+pub const KSCHED_SEL: u32 = 0x02;
+pub const KSCHED_TAINT: u32 = 0x04;
+pub const KSCHED_PICK_SAMPLED: u32 = 0x08;
+pub const KSCHED_PICK_BESTFIT: u32 = 0x10;
+pub const KSCHED_WANT_FIT_MASK: u32 = 0x20;
+
+pub const KSCHED_REASON_OK: c_int = 0;
+pub const KSCHED_REASON_NOT_ENOUGH_RESOURCES: c_int = 1; // InvalidNodeReason::NotEnoughResources   (src/predicates.rs:16)
+pub const KSCHED_REASON_NODE_SELECTOR_MISMATCH: c_int = 2; // InvalidNodeReason::NodeSelectorMismatch (src/predicates.rs:17)
+pub const KSCHED_REASON_TAINT_NOT_TOLERATED: c_int = 3; // extension E2 only
+
+pub const KSCHED_OPT_KERNEL: c_int = 1;
+pub const KSCHED_OPT_TIMING: c_int = 2;
+pub const KSCHED_OPT_DEBUG: c_int = 3;
+pub const KSCHED_OPT_TRACE: c_int = 4;
+pub const KSCHED_OPT_PICK_FROM_MASK: c_int = 5;
+
+extern "C" {
+    // ---- lifetime
+    pub fn ksched_create(out: *mut *mut ksched_ctx, device_id: c_int) -> c_int;
+    pub fn ksched_destroy(ctx: *mut ksched_ctx);
+    pub fn ksched_abi_version() -> u32;
+    pub fn ksched_strerror(code: c_int) -> *const c_char;
+    pub fn ksched_last_error(ctx: *const ksched_ctx) -> *const c_char;
+    pub fn ksched_mask_words(n_nodes: u32) -> u32;
+    pub fn ksched_set_option(ctx: *mut ksched_ctx, option: c_int, value: i64) -> c_int;
+    // ---- node snapshot
+    pub fn ksched_set_nodes(
+        ctx: *mut ksched_ctx, n: u32, avail_cpu_milli: *const i64, avail_mem_bytes: *const i64, label_val_ids: *const u32,
+        n_keys: u32, taints: *const u64,
+    ) -> c_int;
+    pub fn ksched_update_nodes(
+        ctx: *mut ksched_ctx, count: u32, node_index: *const u32, avail_cpu_milli: *const i64, avail_mem_bytes: *const i64,
+    ) -> c_int;
+    pub fn ksched_num_nodes(ctx: *const ksched_ctx) -> u32;
+    pub fn ksched_num_keys(ctx: *const ksched_ctx) -> u32;
+    // ---- evaluation
+    pub fn ksched_eval(
+        ctx: *mut ksched_ctx, p: u32, req_cpu_milli: *const i64, req_mem_bytes: *const i64, sel_val_ids: *const u32,
+        tolerations: *const u64, samples: *const u32, attempts: u32, flags: u32, out_feasible: *mut u64, out_fit: *mut u64,
+        out_binding: *mut i32,
+    ) -> c_int;
+    pub fn ksched_eval_device(
+        ctx: *mut ksched_ctx, p: u32, req_cpu_milli: *const i64, req_mem_bytes: *const i64, sel_val_ids: *const u32,
+        tolerations: *const u64, samples: *const u32, attempts: u32, flags: u32, out_feasible: *mut u64, out_fit: *mut u64,
+        out_binding: *mut i32, hip_stream: *mut c_void,
+    ) -> c_int;
+    pub fn ksched_eval_device_pitched(
+        ctx: *mut ksched_ctx, p: u32, req_cpu_milli: *const i64, req_mem_bytes: *const i64, sel_val_ids: *const u32,
+        tolerations: *const u64, samples: *const u32, attempts: u32, flags: u32, out_feasible: *mut u64, out_fit: *mut u64,
+        out_binding: *mut i32, mask_pitch_words: u32, hip_stream: *mut c_void,
+    ) -> c_int;
+    pub fn ksched_mask_pitch(n_nodes: u32) -> u32;
+    pub fn ksched_pick_device(
+        ctx: *mut ksched_ctx, p: u32, feasible: *const u64, mask_pitch_words: u32, req_mem_bytes: *const i64,
+        samples: *const u32, attempts: u32, flags: u32, out_binding: *mut i32, hip_stream: *mut c_void,
+    ) -> c_int;
+    // ---- pipelined evaluation
+    pub fn ksched_pipe_create(ctx: *mut ksched_ctx, depth: u32, out: *mut *mut ksched_pipe) -> c_int;
+    pub fn ksched_pipe_destroy(pipe: *mut ksched_pipe);
+    pub fn ksched_pipe_submit(
+        pipe: *mut ksched_pipe, slot: u32, p: u32, req_cpu_milli: *const i64, req_mem_bytes: *const i64,
+        sel_val_ids: *const u32, tolerations: *const u64, samples: *const u32, attempts: u32, flags: u32, mask: *mut u64,
+        mask_pitch_words: u32, binding: *mut i32,
+    ) -> c_int;
+    pub fn ksched_pipe_wait(pipe: *mut ksched_pipe, slot: u32, hip_stream: *mut c_void) -> c_int;
+    pub fn ksched_pipe_stream(pipe: *mut ksched_pipe, which: c_int) -> *mut c_void;
+    // ---- reasons
+    pub fn ksched_reason(feasible_row: *const u64, fit_row: *const u64, node: u32, flags: u32) -> c_int;
+    pub fn ksched_explain(
+        ctx: *mut ksched_ctx, p: u32, req_cpu_milli: *const i64, req_mem_bytes: *const i64, sel_val_ids: *const u32,
+        tolerations: *const u64, count: u32, pair_pod: *const u32, pair_node: *const u32, flags: u32, out_reason: *mut i32,
+    ) -> c_int;
+    // ---- multi-GPU: RCCL all-gather of the (pod -> node) bindings
+    pub fn ksched_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn ksched_comm_create(ctx: *mut ksched_ctx, id: *const u8, rank: c_int, nranks: c_int, out: *mut *mut ksched_comm) -> c_int;
+    pub fn ksched_comm_create_local(ctxs: *const *mut ksched_ctx, n: c_int, out: *mut *mut ksched_comm) -> c_int;
+    pub fn ksched_comm_destroy(comm: *mut ksched_comm);
+    pub fn ksched_comm_rank(comm: *const ksched_comm) -> c_int;
+    pub fn ksched_comm_size(comm: *const ksched_comm) -> c_int;
+    pub fn ksched_allgather_bindings(
+        comm: *mut ksched_comm, local: *const i32, gathered: *mut i32, count_per_rank: u32, hip_stream: *mut c_void,
+    ) -> c_int;
+    pub fn ksched_allgather_bindings_local(
+        comms: *const *mut ksched_comm, n: c_int, local: *const *const i32, gathered: *const *mut i32, count_per_rank: u32,
+        hip_streams: *const *mut c_void,
+    ) -> c_int;
+    pub fn ksched_comm_last_error() -> *const c_char;
+    // ---- measurement / diagnostics
+    pub fn ksched_kernel_time_ms(ctx: *mut ksched_ctx, total_ms: *mut f64, launches: *mut u64) -> c_int;
+    pub fn ksched_kernel_time_samples(ctx: *mut ksched_ctx, out_ms: *mut f64, cap: u32) -> c_int;
+    pub fn ksched_trace_read(ctx: *mut ksched_ctx, out: *mut u64, max_blocks: u32) -> c_int;
+    pub fn ksched_last_kernel(ctx: *const ksched_ctx) -> *const c_char;
+}

@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>  // device buffers / streams for the *_device entry points of the C ABI (tests only)
+
 #include "../../kube_scheduler_rs_reference_amd/host/encoder.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/predicates.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/scheduler.hpp"
@@ -605,12 +607,90 @@ static void gpu_tests() {
     });
 }
 
+// The exchange step behind the C ABI (include/ksched.h "multi-GPU"): bindings produced by ksched_eval_device on a stream are
+// all-gathered by ksched_allgather_bindings on the SAME stream -- no host sync, no torch.  One rank is what one GPU allows; both
+// communicator constructors are exercised (one process per GPU: unique id + ksched_comm_create; one process, n devices:
+// ksched_comm_create_local + the grouped all-gather).
+static void comm_tests() {
+    run("RCCL all-gather of the bindings through the C ABI (one rank): ksched_comm_create / _create_local", [] {
+        const uint32_t n = 300, p = 1000, attempts = ATTEMPTS;
+        std::vector<int64_t> ncpu(n), nmem(n), pcpu(p), pmem(p);
+        std::vector<uint32_t> samples((size_t)p * attempts);
+        SplitMixChooser rng(11);
+        for (uint32_t i = 0; i < n; ++i) {
+            ncpu[i] = 500 + (int64_t)*rng.choose(8000);
+            nmem[i] = (int64_t)1 << (20 + *rng.choose(14));
+        }
+        for (uint32_t i = 0; i < p; ++i) {
+            pcpu[i] = 100 + (int64_t)*rng.choose(6000);
+            pmem[i] = (int64_t)1 << (18 + *rng.choose(14));
+            for (uint32_t t = 0; t < attempts; ++t) samples[(size_t)i * attempts + t] = (uint32_t)*rng.choose(n);
+        }
+        ksched_ctx *c = nullptr;
+        CHECK(ksched_create(&c, 0) == KSCHED_OK);
+        CHECK(ksched_set_nodes(c, n, ncpu.data(), nmem.data(), nullptr, 0, nullptr) == KSCHED_OK);
+        std::vector<int32_t> want(p);
+        CHECK(ksched_eval(c, p, pcpu.data(), pmem.data(), nullptr, nullptr, samples.data(), attempts, KSCHED_FIT | KSCHED_PICK_SAMPLED, nullptr,
+                          nullptr, want.data()) == KSCHED_OK);
+        int bound = 0;
+        for (int32_t b : want) bound += b >= 0;
+        CHECK(bound > 50 && bound < (int)p);  // a non-degenerate batch
+        int64_t *d_pcpu = nullptr, *d_pmem = nullptr;
+        uint32_t *d_smp = nullptr;
+        int32_t *d_local = nullptr, *d_all = nullptr;
+        hipStream_t s = nullptr;
+        CHECK(hipMalloc((void **)&d_pcpu, p * 8) == hipSuccess && hipMalloc((void **)&d_pmem, p * 8) == hipSuccess);
+        CHECK(hipMalloc((void **)&d_smp, samples.size() * 4) == hipSuccess);
+        CHECK(hipMalloc((void **)&d_local, p * 4) == hipSuccess && hipMalloc((void **)&d_all, p * 4) == hipSuccess);
+        CHECK(hipStreamCreate(&s) == hipSuccess);
+        CHECK(hipMemcpy(d_pcpu, pcpu.data(), p * 8, hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(hipMemcpy(d_pmem, pmem.data(), p * 8, hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(hipMemcpy(d_smp, samples.data(), samples.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
+        auto run_once = [&](const std::function<int()> &gather) {
+            CHECK(hipMemsetAsync(d_local, 0x7F, p * 4, s) == hipSuccess);
+            CHECK(hipMemsetAsync(d_all, 0x7F, p * 4, s) == hipSuccess);
+            CHECK(ksched_eval_device(c, p, d_pcpu, d_pmem, nullptr, nullptr, d_smp, attempts, KSCHED_FIT | KSCHED_PICK_SAMPLED, nullptr, nullptr,
+                                     d_local, s) == KSCHED_OK);
+            const int rc = gather();  // enqueued behind the pick on the same stream
+            if (rc != KSCHED_OK) std::printf("    gather failed: %s / %s\n", ksched_strerror(rc), ksched_comm_last_error());
+            CHECK(rc == KSCHED_OK);
+            std::vector<int32_t> got(p);
+            CHECK(hipMemcpyAsync(got.data(), d_all, p * 4, hipMemcpyDeviceToHost, s) == hipSuccess);
+            CHECK(hipStreamSynchronize(s) == hipSuccess);
+            CHECK(got == want);
+        };
+        // one process per GPU
+        uint8_t id[KSCHED_COMM_ID_BYTES];
+        ksched_comm *q = nullptr;
+        CHECK(ksched_comm_unique_id(id) == KSCHED_OK);
+        CHECK(ksched_comm_create(c, id, 0, 1, &q) == KSCHED_OK);
+        CHECK(ksched_comm_rank(q) == 0 && ksched_comm_size(q) == 1);
+        run_once([&] { return ksched_allgather_bindings(q, d_local, d_all, p, s); });
+        CHECK(ksched_allgather_bindings(q, nullptr, d_all, p, s) == KSCHED_E_INVAL);
+        CHECK(ksched_comm_create(c, id, 1, 1, &q) == KSCHED_E_INVAL);  // rank out of range (q untouched on failure? no: it is reset)
+        ksched_comm_destroy(q);
+        // one process, n devices (n = 1 here)
+        ksched_comm *qs[1] = {nullptr};
+        ksched_ctx *ctxs[1] = {c};
+        CHECK(ksched_comm_create_local(ctxs, 1, qs) == KSCHED_OK);
+        const int32_t *locals[1] = {d_local};
+        int32_t *alls[1] = {d_all};
+        void *streams[1] = {s};
+        run_once([&] { return ksched_allgather_bindings_local(qs, 1, locals, alls, p, streams); });
+        ksched_comm_destroy(qs[0]);
+        (void)hipFree(d_pcpu); (void)hipFree(d_pmem); (void)hipFree(d_smp); (void)hipFree(d_local); (void)hipFree(d_all);
+        (void)hipStreamDestroy(s);
+        ksched_destroy(c);
+    });
+}
+
 int main(int argc, char **argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (mode == "cpu") cpu_tests();
     else if (mode == "gpu") gpu_tests();
+    else if (mode == "comm") comm_tests();
     else {
-        std::printf("usage: host_tests cpu|gpu\n");
+        std::printf("usage: host_tests cpu|gpu|comm\n");
         return 2;
     }
     std::printf("%d test(s), %d failed check(s)\n", g_run, g_fail);

@@ -6,8 +6,20 @@ Python restatement (oracle/oracle_ref.py: Fractions on Kubernetes-shaped dicts, 
 evaluation at a time) on seeded synthetic clusters, and stored next to the encoded columns of the
 same clusters.  They pin (a) the oracle's C restatements and (b) the HIP path against drift.
 
+Next to every <name>.npz the same cluster is exported as Kubernetes JSON objects, <name>_objects.json
+({"pods", "nodes", "bound", "samples"}): the input a maintainer with cargo feeds to the REFERENCE's own predicates
+(rust/src/predicates/parity_dump.rs, one command: rust/pin_parity.sh) to produce tests/golden/ref_<name>.json, which
+tests/test_reference_fixtures.py then compares with these fixtures -- that is what pins resource-fit to the reference.
+
+Two further object-only cases have no encoded columns:
+  binsuffix_60x40   memory spelled with Ki / Mi (believed exact in kube_quantity 0.6.1)
+  hazard_gi_24x10   Gi / Ti / exponent / fractional spellings at exact-fit boundaries: OUTSIDE the parity domain D; the
+                    expected masks follow true Kubernetes semantics (exact powers of 1024).  A reference run that
+                    differs here documents kube_quantity's suspected f32 scale conversion, it does not fail parity.
+
     python tests/golden/make_golden.py
 """
+import json
 import os
 import sys
 
@@ -29,10 +41,68 @@ CASES = {
 }
 
 
+def hex_rows(mask):
+    return [[f"{int(w):016x}" for w in row] for row in mask]
+
+
+def dump_objects(name, pods, nodes, bound, samples, domain):
+    doc = {"name": name, "domain": domain, "p": len(pods), "n": len(nodes), "attempts": R.ATTEMPTS,
+           "note": "nodes are in canonical order (ascending metadata.name); mask bit n of a pod row = node n",
+           "pods": pods, "nodes": nodes, "bound": bound, "samples": [[int(x) for x in r] for r in samples]}
+    with open(os.path.join(HERE, name + "_objects.json"), "w") as f:
+        json.dump(doc, f, separators=(",", ":"), sort_keys=True)
+        f.write("\n")
+
+
+def dump_expected(name, pods, nodes, bound, samples, use_taint):
+    """Object-only cases: expected masks as hex words (what ref_<name>.json holds for the reference side)."""
+    P, N = len(pods), len(nodes)
+    feas, fit = R.eval_matrix(pods, nodes, bound, use_taint=use_taint)
+    sel, _ = R.eval_matrix(pods, nodes, bound, use_fit=False)
+    pk = lambda m: pack_mask(np.array(m, dtype=bool).reshape(P, N))  # noqa: E731
+    picks = [(-1 if (b := R.select_node_for_pod(p, nodes, bound, [int(s) for s in samples[i]])) is None else b) for i, p in enumerate(pods)]
+    doc = {"name": name, "p": P, "n": N, "fit": hex_rows(pk(fit)), "sel": hex_rows(pk(sel)),
+           "feasible_fit_and_sel": hex_rows(pk(fit) & pk(sel)), "sampled": picks,
+           "source": "oracle/oracle_ref.py (exact Fractions, true Kubernetes quantity semantics)"}
+    with open(os.path.join(HERE, name + "_expected.json"), "w") as f:
+        json.dump(doc, f, separators=(",", ":"), sort_keys=True)
+        f.write("\n")
+
+
+def hazard_case():
+    """Hand-built: quantities OUTSIDE the canonical domain D at exact-fit boundaries."""
+    GI = 1 << 30
+    allocs = [("4", "1Gi"), ("8", "8Gi"), ("7500m", "16Gi"), ("0.5", "1.5Gi"), ("2", "1Ti"), ("16", "64Gi"),
+              ("1e1", "1e10"), ("32", "34359738368"), ("3", "3G"), ("64", "0.5Ti")]
+    nodes = [{"metadata": {"name": f"hz-node-{i:02d}", "labels": {"zone": "a" if i % 2 else "b"}},
+              "status": {"allocatable": {"cpu": c, "memory": m}}} for i, (c, m) in enumerate(allocs)]
+    reqs = [("1", str(GI)), ("1", str(GI + 1)), ("1", "1Gi"), ("1", "1024Mi"), ("1", "1048576Ki"), ("500m", "1.5Gi"),
+            ("0.5", "1610612736"), ("0.5", "1610612737"), ("2", "8Gi"), ("2", str(8 * GI)), ("2", str(8 * GI + 1)),
+            ("7500m", "16Gi"), ("7501m", "16Gi"), ("7.5", str(16 * GI)), ("1", "1Ti"), ("1", str(1 << 40)), ("1", str((1 << 40) + 1)),
+            ("10", "1e10"), ("10", "10G"), ("10", "10000000001"), ("3", "3G"), ("3", "3000000000"), ("3", "2.9Gi"), ("1", "512Gi")]
+    pods = [{"metadata": {"name": f"hz-pod-{i:02d}", "namespace": "hz"},
+             "spec": {"containers": [{"name": "c", "resources": {"requests": {"cpu": c, "memory": m}}}]}}
+            for i, (c, m) in enumerate(reqs)]
+    pods[3]["spec"]["nodeSelector"] = {"zone": "a"}
+    bound = [{"metadata": {"name": "hz-bound-0", "namespace": "hz"},
+              "spec": {"nodeName": "hz-node-05", "containers": [{"name": "c", "resources": {"requests": {"cpu": "1", "memory": "32Gi"}}}]}}]
+    samples = np.array([[(i * 7 + t * 3) % len(nodes) for t in range(R.ATTEMPTS)] for i in range(len(pods))], dtype=np.uint32)
+    return pods, nodes, bound, samples
+
+
 def main():
+    # object-only cases
+    c = synth.make_cluster(P=60, N=40, n_keys=8, n_taints=0, seed=0x5EED0303, binary_suffixes=True)
+    pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()
+    dump_objects("binsuffix_60x40", pods, nodes, bound, c.samples, "D + Ki/Mi memory spellings (believed exact)")
+    dump_expected("binsuffix_60x40", pods, nodes, bound, c.samples, use_taint=False)
+    pods, nodes, bound, samples = hazard_case()
+    dump_objects("hazard_gi_24x10", pods, nodes, bound, samples, "OUTSIDE D: Gi/Ti/exponent/fractional spellings (hazard list, SURVEY.md 8c)")
+    dump_expected("hazard_gi_24x10", pods, nodes, bound, samples, use_taint=False)
     for name, kw in CASES.items():
         c = synth.make_cluster(**kw)
         pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()
+        dump_objects(name, pods, nodes, bound, c.samples, "D (SURVEY.md section 8c): cpu '<n>' / '<n>m', memory plain integer bytes")
         use_taint = kw["n_taints"] > 0
         feas, fit = R.eval_matrix(pods, nodes, bound, use_taint=use_taint)
         feas = pack_mask(np.array(feas, dtype=bool).reshape(c.P, c.N))

@@ -562,6 +562,62 @@ def test_pipelined_allgather_over_rccl_one_rank(evaluator, two_stream, every):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("two_stream,every", [(False, 1), (True, 1), (True, 3), (False, 2)])
+def test_pipelined_allgather_through_the_c_abi_one_rank(evaluator, two_stream, every):
+    """The N > 1 data path with the C ABI's own RCCL communicator (AbiComm = ksched_comm_create + ksched_allgather_bindings):
+    no torch.distributed process group exists in this test at all.  Slots reused over 7 steps, gather groups of 1 / 2 / 3."""
+    import torch
+    from kube_scheduler_rs_reference_amd.dist import AbiComm, PipelinedScheduler, ShardedScheduler
+    ev = evaluator
+    c = synth.make_cluster(4000, 2100, n_keys=8, n_taints=0, seed=92)
+    ev.set_kernel("auto")
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", ev.device)
+    comm = AbiComm(ev)
+    assert (comm.rank, comm.world) == (0, 1)
+    try:
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+        steps, depth = 7, 2
+        rolled = [np.roll(np.arange(c.P), 13 * j) for j in range(steps)]
+        batches = [dict(cpu=t(c.req_cpu[r], np.int64), mem=t(c.req_mem[r], np.int64), sel=t(c.pod_sel[:, r], np.int32),
+                        smp=t(c.samples[r], np.int32)) for r in rolled]
+        torch.cuda.synchronize()
+        pipe = ev.pipe(depth * every) if two_stream else None
+        sched = PipelinedScheduler(c.P, dev, depth=depth, pipe=pipe, gather_always=True, gather_every=every, comm=comm)
+        masks = [ev.alloc_mask(c.P) for _ in range(depth * every)]
+        state = {"j": 0}
+
+        def run(slot, out):
+            b = batches[state["j"]]
+            if pipe is not None:
+                pipe.submit(slot, b["cpu"], b["mem"], b["sel"], None, b["smp"], FIT | SEL | PICK_SAMPLED, masks[slot], out)
+            else:
+                ev.eval_device(b["cpu"], b["mem"], b["sel"], None, b["smp"], FIT | SEL | PICK_SAMPLED, out_feasible=masks[0], out_binding=out)
+
+        got, pend = [], []
+        for j in range(steps):
+            state["j"] = j
+            pend.append(sched.step(run))
+            if len(pend) >= (depth - 1) * every + 1:
+                got.append(pend.pop(0).wait().clone())
+        got += [p.wait().clone() for p in pend]
+        sched.drain()
+        torch.cuda.synchronize()
+        _, _, base = oracle_eval(c, FIT | SEL | PICK_SAMPLED)
+        for j in range(steps):
+            assert np.array_equal(got[j].cpu().numpy(), base[rolled[j]]), f"step {j}"
+        # the sequential form through the same communicator
+        seq = ShardedScheduler(c.P, dev, comm=comm)
+        b = batches[0]
+        out = seq.step(lambda o: ev.eval_device(b["cpu"], b["mem"], b["sel"], None, b["smp"], FIT | SEL | PICK_SAMPLED, out_feasible=masks[0], out_binding=o))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), base[rolled[0]])
+        if pipe is not None:
+            pipe.close()
+    finally:
+        comm.close()
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_sampled_pick_direct_equals_pick_from_mask(evaluator, kernel):
     """KSCHED_PICK_SAMPLED two ways: candidates tested straight from the columns (default; the reference's own order of

@@ -36,3 +36,11 @@ def test_host_mirror_gpu():
     out = _run("gpu")
     assert "test_does_node_selector_match_true (KAT-S3)" in out
     assert out.count("ok  ") >= 9
+
+
+@pytest.mark.gpu
+def test_rccl_allgather_through_the_c_abi():
+    """ksched_comm_* / ksched_allgather_bindings from C++ (no torch in the process): one-rank RCCL communicator, the gather
+    enqueued behind ksched_eval_device's pick on the same HIP stream."""
+    out = _run("comm")
+    assert "ok  " in out and "RCCL all-gather" in out
