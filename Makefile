@@ -24,6 +24,7 @@ LIB_ORA  := oracle/liboracle.so
 HOST_SRCS := $(wildcard $(HOST)/*.cpp)
 HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/ksched.h
 HOST_TEST := tests/cpp/host_tests
+OBJ_TOOL := tests/cpp/objects_eval
 INDEX_TEST := tests/cpp/index_tests
 
 .PHONY: all lib host oracle clean
@@ -33,7 +34,7 @@ lib: $(LIB_HIP)
 $(LIB_HIP): $(CSRC)/ksched_api.hip $(wildcard $(CSRC)/*.hpp) include/ksched.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ksched_api.hip
 
-host: $(LIB_HOST) $(HOST_TEST) $(INDEX_TEST)
+host: $(LIB_HOST) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL)
 # host-only check of the bitmap index arithmetic (no GPU, no HIP runtime call): tests/test_index_host.py runs it
 $(INDEX_TEST): tests/cpp/index_tests.cpp $(CSRC)/tile_index.hpp
 	$(CXX) -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -o $@ tests/cpp/index_tests.cpp
@@ -43,9 +44,13 @@ $(LIB_HOST): $(HOST_SRCS) $(HOST_HDRS) $(LIB_HIP)
 $(HOST_TEST): tests/cpp/host_tests.cpp $(LIB_HOST) $(HOST_HDRS)
 	$(CXX) $(CXXFLAGS) -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o $@ tests/cpp/host_tests.cpp -L$(PKG) -lksched_host -lksched_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -Wl,-rpath,/opt/rocm/lib -lpthread
 
+# objects JSON -> host encoder -> device, printed for the Python parity tests (tests/test_gpu_objects.py)
+$(OBJ_TOOL): tests/cpp/objects_eval.cpp tests/cpp/json_min.hpp $(LIB_HOST) $(HOST_HDRS)
+	$(CXX) $(CXXFLAGS) -o $@ tests/cpp/objects_eval.cpp -L$(PKG) -lksched_host -lksched_hip -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lpthread
+
 oracle: $(LIB_ORA)
 $(LIB_ORA): oracle/oracle.c oracle/oracle.h
 	$(CC) $(CFLAGS) -shared -o $@ oracle/oracle.c
 
 clean:
-	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA) $(HOST_TEST) $(INDEX_TEST)
+	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL)

@@ -22,7 +22,8 @@ import numpy as np
 
 GOLDEN = np.uint64(0x9E3779B97F4A7C15)
 SEL_NEVER = 0xFFFFFFFF
-KEY_CARDINALITY = (2, 3, 4, 8, 16, 32, 64, 128)
+KEY_CARDINALITY = (2, 3, 4, 8, 16, 32, 64, 128,  # keys k0..k7
+                   3, 5, 2, 7, 4, 9, 6, 11)       # keys k8..k15 (clusters with more than eight label keys; tests)
 NODE_CORES = (4, 8, 16, 32, 64, 96, 128)
 GIB_PER_CORE = (2, 4, 8)
 MIB = 1 << 20
@@ -199,7 +200,7 @@ def make_cluster(P: int, N: int, n_keys: int = 8, n_taints: int = 0, seed: int =
                  binary_suffixes: bool = False) -> Cluster:
     """Build the cluster of SURVEY.md section 8d for P pending pods and N nodes."""
     if not (0 <= n_keys <= len(KEY_CARDINALITY)):
-        raise ValueError("n_keys must be 0..8")
+        raise ValueError("n_keys must be 0..16")
     if not (0 <= n_taints <= 64):
         raise ValueError("n_taints must be 0..64")
     c = Cluster(seed=seed, P=P, N=N, n_keys=n_keys, n_taints=n_taints, attempts=attempts, binary_suffixes=binary_suffixes)

@@ -238,3 +238,118 @@ def eval_matrix(pods: Sequence[dict], nodes: Sequence[dict], all_pods: Sequence[
         feas.append(frow)
         fits.append(rrow)
     return feas, fits
+
+
+# ---- the callers either side of the pick ---------------------------------------
+class SplitMixChooser:
+    """The injected stand-in for `SliceRandom::choose(&mut thread_rng())` (src/main.rs:56): a SplitMix64 stream, the same
+    one the host mirror's SplitMixChooser and the generator use.  choose(n) -> index in [0, n) or None for an empty slice."""
+    M = (1 << 64) - 1
+
+    def __init__(self, seed: int):
+        self.state = seed & self.M
+
+    def choose(self, n: int) -> Optional[int]:
+        if n == 0:
+            return None
+        self.state = (self.state + 0x9E3779B97F4A7C15) & self.M
+        z = self.state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & self.M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & self.M
+        z ^= z >> 31
+        return z % n
+
+
+def is_pod_bound(pod: dict) -> bool:
+    """src/util.rs:38-45"""
+    spec = pod.get("spec")
+    return spec is not None and spec.get("nodeName") is not None
+
+
+def _draws(chooser, n_store: int, attempts: int) -> List[Optional[int]]:
+    return [chooser.choose(n_store) for _ in range(attempts)]
+
+
+def _select_with_draws(pod: dict, store: Sequence[dict], all_pods: Sequence[dict], draws: Sequence[Optional[int]]) -> Optional[int]:
+    """src/main.rs:51-71 on the store's own ordering: first drawn candidate whose check_node_validity is Ok(())."""
+    for s in draws:  # :53
+        if s is None:  # :56 empty store
+            continue
+        candidate = store[s]  # :57
+        if check_node_validity(pod, candidate, list_pods_on_node(all_pods, node_name(candidate))) is None:  # :61
+            return s  # :64-65
+    return None  # :70
+
+
+def _post(outcomes, i, pod, node, sink_state):
+    """src/main.rs:94-108: the binding POST; sink_state = [calls, fail_every, posted]."""
+    sink_state[0] += 1
+    if sink_state[1] and sink_state[0] % sink_state[1] == 0:
+        outcomes[i] = {"ok": False, "error": "create-binding-failed", "bound_to": None}  # :105-108
+        return False
+    md = pod.get("metadata") or {}
+    sink_state[2].append((f"{md.get('namespace')}/{md.get('name')}", node_name(node)))
+    outcomes[i] = {"ok": True, "error": None, "bound_to": node_name(node)}  # :119
+    return True
+
+
+def reconcile_batch(pods: Sequence[dict], store: Sequence[dict], all_pods: Sequence[dict], chooser, fail_every: int = 0,
+                    attempts: int = ATTEMPTS):
+    """The batching reconciler (8f n2) as a legal execution of the reference: every pending pod is reconciled
+    (src/main.rs:73-120) against the SAME API-server state -- the reference has no assume/reserve step (:78-119), so
+    reconciles racing on one state all see it unchanged.  Bound pods return Ok at once (:74-76).  Each pending pod, in batch
+    order, takes ATTEMPTS draws from the chooser (all of them: the draws after its first success cannot change its outcome);
+    the POSTs then go out in batch order.  -> (outcomes, posted)"""
+    outcomes = [None] * len(pods)
+    pending = [i for i, p in enumerate(pods) if not is_pod_bound(p)]
+    for i in range(len(pods)):
+        if i not in pending:
+            outcomes[i] = {"ok": True, "error": None, "bound_to": None}  # :74-76
+    picks = [_select_with_draws(pods[i], store, all_pods, _draws(chooser, len(store), attempts)) for i in pending]
+    sink = [0, fail_every, []]
+    for i, s in zip(pending, picks):
+        if s is None:
+            outcomes[i] = {"ok": False, "error": "no-node-found", "bound_to": None}  # :116-118
+        else:
+            _post(outcomes, i, pods[i], store[s], sink)
+    return outcomes, sink[2]
+
+
+def reconcile_batch_sequential(pods: Sequence[dict], store: Sequence[dict], all_pods: Sequence[dict], chooser, fail_every: int = 0,
+                               max_rounds: int = 64, attempts: int = ATTEMPTS):
+    """In-batch capacity accounting (8f n3; NOT reference behaviour -- builder-defined): rounds.  In a round
+    every still-pending pod is picked against the state at the START of the round (fresh ATTEMPTS draws each); per node only the
+    first pod of the round (batch order) is accepted and POSTed, its requests then count against the node (it joins the pods
+    the LIST returns); later pods that drew the same node go to the next round.  A pod with no feasible draw gets NoNodeFound;
+    so do pods still colliding after max_rounds.  -> (outcomes, posted, rounds, conflicts, final list of bound pods)"""
+    outcomes = [None] * len(pods)
+    pending = []
+    for i, p in enumerate(pods):
+        if is_pod_bound(p):
+            outcomes[i] = {"ok": True, "error": None, "bound_to": None}
+        else:
+            pending.append(i)
+    state = list(all_pods)
+    sink = [0, fail_every, []]
+    rounds = conflicts = 0
+    while pending and rounds < max_rounds:
+        rounds += 1
+        picks = [_select_with_draws(pods[i], store, state, _draws(chooser, len(store), attempts)) for i in pending]
+        taken, nxt, landed = set(), [], []
+        for i, s in zip(pending, picks):
+            if s is None:
+                outcomes[i] = {"ok": False, "error": "no-node-found", "bound_to": None}
+            elif s in taken:
+                conflicts += 1
+                nxt.append(i)
+            elif _post(outcomes, i, pods[i], store[s], sink):
+                taken.add(s)
+                p = dict(pods[i])
+                p["spec"] = dict(p.get("spec") or {})
+                p["spec"]["nodeName"] = node_name(store[s])
+                landed.append(p)
+        state += landed
+        pending = nxt
+    for i in pending:
+        outcomes[i] = {"ok": False, "error": "no-node-found", "bound_to": None}
+    return outcomes, sink[2], rounds, conflicts, state

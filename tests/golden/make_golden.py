@@ -79,7 +79,7 @@ def hazard_case():
     reqs = [("1", str(GI)), ("1", str(GI + 1)), ("1", "1Gi"), ("1", "1024Mi"), ("1", "1048576Ki"), ("500m", "1.5Gi"),
             ("0.5", "1610612736"), ("0.5", "1610612737"), ("2", "8Gi"), ("2", str(8 * GI)), ("2", str(8 * GI + 1)),
             ("7500m", "16Gi"), ("7501m", "16Gi"), ("7.5", str(16 * GI)), ("1", "1Ti"), ("1", str(1 << 40)), ("1", str((1 << 40) + 1)),
-            ("10", "1e10"), ("10", "10G"), ("10", "10000000001"), ("3", "3G"), ("3", "3000000000"), ("3", "2.9Gi"), ("1", "512Gi")]
+            ("10", "1e10"), ("10", "10G"), ("10", "10000000001"), ("3", "3G"), ("3", "3000000000"), ("3", "2.5Gi"), ("1", "512Gi")]
     pods = [{"metadata": {"name": f"hz-pod-{i:02d}", "namespace": "hz"},
              "spec": {"containers": [{"name": "c", "resources": {"requests": {"cpu": c, "memory": m}}}]}}
             for i, (c, m) in enumerate(reqs)]

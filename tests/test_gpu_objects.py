@@ -1,0 +1,133 @@
+"""The PRODUCT's object -> column path on whole clusters, against the independent object-level oracle.
+
+tests/cpp/objects_eval (C++: tests/cpp/objects_eval.cpp) loads Kubernetes JSON objects, runs them through the host mirror --
+host/quantity.cpp (quantity strings -> exact i64), host/encoder.cpp (canonical order, `available` from the LISTs, label
+interning, taint bits), host/predicates.cpp / host/scheduler.cpp -- and the device (ksched_set_nodes, ksched_eval), and
+prints what came back.  The expectation is oracle/oracle_ref.py: a different parser (regex + Fraction), dict lookups, one
+per-pair evaluation at a time.  (oracle.c's parser mirrors the host's structure, so it is NOT the independent side here.)
+
+  * masks: the five golden object sets + a 2000 x 500 cluster with Ki/Mi spellings, 12 label keys (> 8: the kernel's overflow walk)
+    and 16 taints  (row a3 of SURVEY.md section 8);
+  * reconcile_batch == the oracle's restatement of the batched reference execution (row f-n2);
+  * reconcile_batch_sequential == the oracle's restatement of the round-based accounting (row f-n3), including the snapshot the
+    device is left with (incremental ksched_update_nodes == re-LIST).
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from kube_scheduler_rs_reference_amd import pack_mask, synth
+from oracle import oracle_ref as R
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+TOOL = os.path.join(ROOT, "tests", "cpp", "objects_eval")
+
+
+def tool(*args):
+    if os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.check_call(["make", "-C", ROOT, "-s", "host"])
+    r = subprocess.run([TOOL, *map(str, args)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout)
+
+
+def unhex(rows, W):
+    return np.array([[int(w, 16) for w in r] for r in rows], dtype=np.uint64).reshape(len(rows), W)
+
+
+def write_objects(path, pods, nodes, bound):
+    with open(path, "w") as f:
+        json.dump({"name": "tmp", "pods": pods, "nodes": nodes, "bound": bound, "samples": []}, f)
+
+
+def expect_masks(pods, nodes, bound, use_taint, cache):
+    P, N = len(pods), len(nodes)
+    feas, fit = R.eval_matrix(pods, nodes, bound, use_taint=use_taint, cache=cache)
+    return pack_mask(np.array(feas, dtype=bool).reshape(P, N)), pack_mask(np.array(fit, dtype=bool).reshape(P, N))
+
+
+@pytest.mark.parametrize("name,taints", [("c1_100x20", False), ("ragged_70x130_taints", True), ("one_node_33x1", True),
+                                         ("binsuffix_60x40", False), ("hazard_gi_24x10", False)])
+def test_golden_objects_through_the_host_encoder(name, taints):
+    path = os.path.join(GOLD, name + "_objects.json")
+    doc = json.load(open(path))
+    got = tool("masks", path, *(["taints"] if taints else []))
+    W = (doc["n"] + 63) // 64
+    feas, fit = expect_masks(doc["pods"], doc["nodes"], doc["bound"], taints, cache=False)  # every pair re-parsed, as the reference does
+    assert got["names"] == [n["metadata"]["name"] for n in doc["nodes"]], "canonical order = ascending node name"
+    assert np.array_equal(unhex(got["fit"], W), fit)
+    assert np.array_equal(unhex(got["feasible"], W), feas)
+    assert got["list_calls"] == doc["n"], "one LIST per node per batch (not per evaluation, src/predicates.rs:34)"
+
+
+def test_cluster_2000x500_binary_suffixes_12_keys_taints(tmp_path):
+    c = synth.make_cluster(P=2000, N=500, n_keys=12, n_taints=16, seed=0x0B1EC7, binary_suffixes=True)
+    pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()
+    assert max(len((p["spec"].get("nodeSelector") or {})) for p in pods) > 4
+    path = tmp_path / "objs.json"
+    write_objects(path, pods, nodes, bound)
+    got = tool("masks", path, "taints")
+    W = (c.N + 63) // 64
+    feas, fit = expect_masks(pods, nodes, bound, True, cache=True)
+    assert np.array_equal(unhex(got["fit"], W), fit)
+    assert np.array_equal(unhex(got["feasible"], W), feas)
+    dens = np.unpackbits(feas.view(np.uint8)).sum() / (c.P * c.N)
+    assert 0.02 < dens < 0.9
+
+
+def small_cluster(seed, P=60, N=12, tight=False):
+    c = synth.make_cluster(P=P, N=N, n_keys=4, n_taints=0, seed=seed, binary_suffixes=True)
+    pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()
+    pods[3]["spec"]["nodeName"] = nodes[0]["metadata"]["name"]  # an already-bound pod in the batch: skipped (src/main.rs:74-76)
+    if tight:  # every node fits about two of these pods: the plain batch over-commits, the sequential one must not
+        for n in nodes:
+            n["status"]["allocatable"] = {"cpu": "2", "memory": "4Gi"}
+        bound = []
+        for p in pods:
+            for cont in p["spec"]["containers"]:
+                if "resources" in cont and cont["resources"].get("requests"):
+                    cont["resources"]["requests"] = {"cpu": "400m", "memory": "512Mi"}
+            p["spec"].pop("nodeSelector", None)
+    return pods, nodes, bound
+
+
+@pytest.mark.parametrize("seed,fail_every", [(1, 0), (2, 0), (3, 5)])
+def test_reconcile_batch_equals_oracle_restatement(tmp_path, seed, fail_every):
+    pods, nodes, bound = small_cluster(0xBA7C00 + seed)
+    path = tmp_path / "objs.json"
+    write_objects(path, pods, nodes, bound)
+    got = tool("batch", path, 1000 + seed, fail_every)
+    store = list(reversed(nodes))  # the tool hands the store over in reversed canonical order
+    want, posted = R.reconcile_batch(pods, store, bound, R.SplitMixChooser(1000 + seed), fail_every=fail_every)
+    assert [(o["ok"], o["error"], o["bound_to"]) for o in got["outcomes"]] == [(o["ok"], o["error"], o["bound_to"]) for o in want]
+    assert [tuple(x) for x in got["posted"]] == posted
+    kinds = {o["error"] for o in want}
+    assert None in kinds and "no-node-found" in kinds and (not fail_every or "create-binding-failed" in kinds)
+    assert all(o["action"] == ("await_change" if o["ok"] else "requeue_300s") for o in got["outcomes"])  # error_policy, src/main.rs:122-125
+
+
+@pytest.mark.parametrize("seed,fail_every,tight", [(1, 0, True), (2, 4, True), (3, 0, False)])
+def test_reconcile_batch_sequential_equals_oracle_restatement(tmp_path, seed, fail_every, tight):
+    pods, nodes, bound = small_cluster(0x5E0000 + seed, P=48, N=10, tight=tight)
+    path = tmp_path / "objs.json"
+    write_objects(path, pods, nodes, bound)
+    got = tool("sequential", path, 2000 + seed, fail_every)
+    store = list(reversed(nodes))
+    want, posted, rounds, conflicts, state = R.reconcile_batch_sequential(pods, store, bound, R.SplitMixChooser(2000 + seed), fail_every=fail_every)
+    assert [(o["ok"], o["error"], o["bound_to"]) for o in got["outcomes"]] == [(o["ok"], o["error"], o["bound_to"]) for o in want]
+    assert [tuple(x) for x in got["posted"]] == posted
+    assert (got["rounds"], got["conflicts"]) == (rounds, conflicts)
+    if tight:
+        assert rounds > 1 and conflicts > 0, "the case must exercise the deferral"
+    # the snapshot the device was left with == allocatable - LIST over the final state (exact), and nothing is over-committed
+    for j, node in enumerate(nodes):
+        av = R.available_of(node, state)
+        assert got["avail_cpu_milli"][j] == av.cpu * 1000 and got["avail_mem_bytes"][j] == av.memory
+        if tight:
+            assert av.cpu >= 0 and av.memory >= 0
