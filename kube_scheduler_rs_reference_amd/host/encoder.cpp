@@ -52,7 +52,8 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
     c.taints.assign(n, 0);
     node_labels_.assign(n, {});
     node_has_labels_.assign(n, false);
-    taint_ids_.clear();
+    node_taints_raw_.assign(n, {});
+    any_counted_taint_ = false;
     for (uint32_t i = 0; i < n; ++i) {
         const corev1::Node &node = nodes[order[i]];
         c.names[i] = corev1::name_any(node.metadata);
@@ -94,20 +95,43 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
         if (node.spec && node.spec->taints) {
             for (const auto &t : *node.spec->taints) {
                 if (t.effect != "NoSchedule" && t.effect != "NoExecute") continue;  // PreferNoSchedule never filters
-                TaintId id{t.key, t.value.value_or(""), t.effect};
-                auto it = taint_ids_.find(id);
-                if (it == taint_ids_.end()) {
-                    if (taint_ids_.size() >= 64) throw EncodeError("more than 64 distinct taints in one snapshot");
-                    it = taint_ids_.emplace(id, (uint32_t)taint_ids_.size()).first;
-                }
-                c.taints[i] |= 1ull << it->second;
+                node_taints_raw_[i].emplace_back(t.key, t.value.value_or(""), t.effect);
+                any_counted_taint_ = true;
             }
         }
     }
     c.keys = cols_.keys;  // keep the label columns that were in use
     cols_ = std::move(c);
+    if (taints_enabled_) intern_taints();  // the extension stays on across rebuilds once a caller has asked for it
     encode_labels();
     upload();
+}
+
+// Extension E2: (key, value, effect) triples -> bit positions, at most 64 per snapshot.
+void Snapshot::intern_taints() {
+    taint_ids_.clear();
+    std::fill(cols_.taints.begin(), cols_.taints.end(), 0ull);
+    for (uint32_t i = 0; i < cols_.n; ++i)
+        for (const TaintId &id : node_taints_raw_[i]) {
+            auto it = taint_ids_.find(id);
+            if (it == taint_ids_.end()) {
+                if (taint_ids_.size() >= 64) {
+                    taint_ids_.clear();
+                    std::fill(cols_.taints.begin(), cols_.taints.end(), 0ull);
+                    taints_enabled_ = false;
+                    throw EncodeError("taint extension: more than 64 distinct NoSchedule/NoExecute taints in one snapshot");
+                }
+                it = taint_ids_.emplace(id, (uint32_t)taint_ids_.size()).first;
+            }
+            cols_.taints[i] |= 1ull << it->second;
+        }
+}
+
+void Snapshot::enable_taints() {
+    if (taints_enabled_) return;
+    taints_enabled_ = true;
+    intern_taints();
+    if (!taint_ids_.empty()) upload();
 }
 
 void Snapshot::encode_labels() {
@@ -132,7 +156,7 @@ void Snapshot::upload() {
     if (!dev_) return;  // encode-only snapshot (host tests of the wire-format step)
     dev_->check(ksched_set_nodes(dev_->handle(), cols_.n, cols_.avail_cpu_milli.data(), cols_.avail_mem_bytes.data(),
                                  cols_.n_keys ? cols_.label_val_ids.data() : nullptr, cols_.n_keys,
-                                 taint_ids_.empty() ? nullptr : cols_.taints.data()),
+                                 (taints_enabled_ && !taint_ids_.empty()) ? cols_.taints.data() : nullptr),
                 "ksched_set_nodes");
 }
 
@@ -180,20 +204,26 @@ size_t Snapshot::apply_pod_events(const std::vector<std::pair<const corev1::Pod 
 bool Snapshot::apply_bound_pod(const corev1::Pod &pod) { return apply_pod_events({{&pod, true}}) == 1; }
 bool Snapshot::apply_deleted_pod(const corev1::Pod &pod) { return apply_pod_events({{&pod, false}}) == 1; }
 
+void Snapshot::selector_keys(const corev1::Pod &pod, std::set<std::string> &into) {
+    if (pod.spec && pod.spec->node_selector)
+        for (const auto &kv : *pod.spec->node_selector) into.insert(kv.first);
+}
+
 void Snapshot::ensure_keys(const std::set<std::string> &keys) {
-    bool grew = false;
-    for (const auto &k : keys) {
-        if (std::find(cols_.keys.begin(), cols_.keys.end(), k) == cols_.keys.end()) {
-            if (cols_.keys.size() >= KSCHED_MAX_KEYS)
-                throw EncodeError("more than KSCHED_MAX_KEYS distinct nodeSelector keys in use; split the batch");
-            cols_.keys.push_back(k);
-            grew = true;
-        }
+    if (keys.size() > KSCHED_MAX_KEYS)
+        throw EncodeError("one batch uses more than KSCHED_MAX_KEYS distinct nodeSelector keys (check_node_validity_batch splits such batches)");
+    std::vector<std::string> missing;
+    for (const auto &k : keys)
+        if (std::find(cols_.keys.begin(), cols_.keys.end(), k) == cols_.keys.end()) missing.push_back(k);
+    if (missing.empty()) return;
+    if (cols_.keys.size() + missing.size() > KSCHED_MAX_KEYS) {
+        // evict: keep only what this batch uses (columns are a working set; the dictionaries are rebuilt from the node labels)
+        cols_.keys.assign(keys.begin(), keys.end());
+    } else {
+        cols_.keys.insert(cols_.keys.end(), missing.begin(), missing.end());
     }
-    if (grew) {
-        encode_labels();
-        upload();
-    }
+    encode_labels();
+    upload();
 }
 
 int Snapshot::index_of(const std::string &node_name) const {
@@ -204,9 +234,7 @@ int Snapshot::index_of(const std::string &node_name) const {
 
 PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
     std::set<std::string> keys;
-    for (const auto *p : pods)
-        if (p->spec && p->spec->node_selector)
-            for (const auto &kv : *p->spec->node_selector) keys.insert(kv.first);
+    for (const auto *p : pods) selector_keys(*p, keys);
     ensure_keys(keys);
 
     PodColumns pc;
@@ -232,7 +260,7 @@ PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
                 pc.sel_val_ids[(size_t)col * pc.p + i] = (it == value_ids_[col].end()) ? KSCHED_SEL_NEVER : it->second;
             }
         }
-        if (pod.spec && pod.spec->tolerations) {
+        if (taints_enabled_ && pod.spec && pod.spec->tolerations) {
             for (const auto &[id, bit] : taint_ids_)
                 for (const auto &t : *pod.spec->tolerations)
                     if (toleration_matches(t, id)) {

@@ -85,8 +85,19 @@ public:
     // Many events, one device update.  second = true: bound, false: deleted.  Returns how many were applied.
     size_t apply_pod_events(const std::vector<std::pair<const corev1::Pod *, bool>> &events);
 
-    // Make sure every label key in `keys` has a column (re-uploads the label columns if not).
+    // Make sure every label key in `keys` (the selector keys of ONE batch) has a column; re-uploads the label columns when the
+    // column set changes.  Columns are a per-batch working set, not a lifetime dictionary: when adding the batch's keys would
+    // exceed KSCHED_MAX_KEYS, the columns no pod of this batch uses are evicted.  Throws EncodeError only when one batch alone
+    // uses more than KSCHED_MAX_KEYS distinct keys (check_node_validity_batch splits such a batch before it gets here).
     void ensure_keys(const std::set<std::string> &keys);
+    // The selector keys of a pod (for callers that split batches by key budget).
+    static void selector_keys(const corev1::Pod &pod, std::set<std::string> &into);
+
+    // Extension E2 is opt-in: taints are interned to bit positions only when a caller asks for the taint predicate.  The
+    // reference has no taint predicate, so a cluster with any number of distinct taints must schedule normally on the parity
+    // path (FIT | SEL); only enable_taints() can fail with "more than 64 distinct taints".
+    void enable_taints();
+    bool taints_enabled() const { return taints_enabled_; }
 
     // Encode pods against this snapshot's dictionaries.  Adds columns for selector keys that
     // have none yet (ensure_keys).  A selector value no node carries becomes KSCHED_SEL_NEVER.
@@ -99,7 +110,7 @@ public:
     uint32_t canonical_index(uint32_t store) const { return canonical_of_store_[store]; }
     uint32_t n() const { return cols_.n; }
     uint32_t mask_words() const { return ksched_mask_words(cols_.n); }
-    bool has_taints() const { return !taint_ids_.empty(); }
+    bool has_taints() const { return any_counted_taint_; }  // some node carries a NoSchedule / NoExecute taint
     DeviceEvaluator &device();
     const std::map<TaintId, uint32_t> &taint_ids() const { return taint_ids_; }
     uint64_t generation() const { return generation_; }
@@ -114,7 +125,10 @@ private:
     std::vector<corev1::StringMap> node_labels_;            // canonical order; empty map when labels is None
     std::vector<bool> node_has_labels_;
     std::vector<std::map<std::string, uint32_t>> value_ids_;  // per column: value string -> id (1..)
-    std::map<TaintId, uint32_t> taint_ids_;                 // NoSchedule / NoExecute taints -> bit
+    std::map<TaintId, uint32_t> taint_ids_;                 // NoSchedule / NoExecute taints -> bit (filled by enable_taints)
+    std::vector<std::vector<TaintId>> node_taints_raw_;     // canonical order: the node's counted taints, un-interned
+    bool any_counted_taint_ = false, taints_enabled_ = false;
+    void intern_taints();
     uint64_t generation_ = 0;
 };
 

@@ -2,6 +2,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <set>
 
 namespace ksched_host {
 namespace predicates {
@@ -90,13 +91,31 @@ uint64_t BatchValidity::feasible_count(uint32_t pod) const {
     return c;
 }
 
+namespace {
+
+// One device call for pods [lo, hi) of the batch, written into rows [lo, hi) of `out`.
+void eval_range(Snapshot &snap, const std::vector<const corev1::Pod *> &pods, size_t lo, size_t hi, uint32_t pick,
+                const std::vector<uint32_t> *samples, uint32_t attempts, BatchValidity &out) {
+    const std::vector<const corev1::Pod *> part(pods.begin() + (std::ptrdiff_t)lo, pods.begin() + (std::ptrdiff_t)hi);
+    PodColumns pc = snap.encode_pods(part);
+    DeviceEvaluator &dev = snap.device();
+    dev.check(ksched_eval(dev.handle(), pc.p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(),
+                          pc.n_keys ? pc.sel_val_ids.data() : nullptr, (out.flags & KSCHED_TAINT) ? pc.tolerations.data() : nullptr,
+                          (pick & KSCHED_PICK_SAMPLED) ? samples->data() + lo * attempts : nullptr, attempts,
+                          out.flags | KSCHED_WANT_FIT_MASK | pick, out.feasible.data() + lo * out.W, out.fit.data() + lo * out.W,
+                          pick ? out.binding.data() + lo : nullptr),
+              "ksched_eval");
+}
+
+}  // namespace
+
 BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, bool taints, uint32_t pick_flags,
                                         const std::vector<uint32_t> *samples, uint32_t attempts) {
     if (!ctx.snapshot) ctx.refresh_snapshot();
     Snapshot &snap = *ctx.snapshot;
-    PodColumns pc = snap.encode_pods(pods);
+    if (taints && snap.has_taints()) snap.enable_taints();  // extension E2 is opt-in: interning happens (and can fail) only here
     BatchValidity out;
-    out.p = pc.p;
+    out.p = (uint32_t)pods.size();
     out.n = snap.n();
     out.W = snap.mask_words();
     out.flags = KSCHED_FIT | KSCHED_SEL | ((taints && snap.has_taints()) ? KSCHED_TAINT : 0u);
@@ -107,13 +126,27 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
     if (out.p == 0 || out.n == 0) return out;  // no pods, or an empty store: nothing is feasible
     if ((pick & KSCHED_PICK_SAMPLED) && (!samples || samples->size() != (size_t)out.p * attempts))
         throw EncodeError("check_node_validity_batch: samples must hold p * attempts indices");
-    DeviceEvaluator &dev = snap.device();
-    dev.check(ksched_eval(dev.handle(), pc.p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(),
-                          pc.n_keys ? pc.sel_val_ids.data() : nullptr, (out.flags & KSCHED_TAINT) ? pc.tolerations.data() : nullptr,
-                          (pick & KSCHED_PICK_SAMPLED) ? samples->data() : nullptr, attempts,
-                          out.flags | KSCHED_WANT_FIT_MASK | pick, out.feasible.data(), out.fit.data(),
-                          pick ? out.binding.data() : nullptr),
-              "ksched_eval");
+    // The device takes at most KSCHED_MAX_KEYS label columns per call.  The reference has no limit on selector keys, so a batch
+    // that uses more distinct keys is evaluated in consecutive pod ranges, each within the budget (a new range re-uploads the
+    // label columns it needs).  Only a single pod with more than KSCHED_MAX_KEYS selector keys is refused.
+    size_t lo = 0;
+    std::set<std::string> keys;
+    for (size_t i = 0; i < pods.size(); ++i) {
+        std::set<std::string> mine;
+        Snapshot::selector_keys(*pods[i], mine);
+        if (mine.size() > KSCHED_MAX_KEYS)
+            throw EncodeError("pod " + full_name(pods[i]->metadata) + ": more than KSCHED_MAX_KEYS nodeSelector keys on one pod");
+        std::set<std::string> merged = keys;
+        merged.insert(mine.begin(), mine.end());
+        if (merged.size() > KSCHED_MAX_KEYS) {
+            eval_range(snap, pods, lo, i, pick, samples, attempts, out);
+            lo = i;
+            keys = mine;
+        } else {
+            keys.swap(merged);
+        }
+    }
+    eval_range(snap, pods, lo, pods.size(), pick, samples, attempts, out);
     return out;
 }
 

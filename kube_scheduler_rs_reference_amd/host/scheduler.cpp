@@ -130,9 +130,24 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
         where.push_back(i);
     }
     const BatchSelection sel = select_nodes_for_pods(pending, ctx, chooser);
+    std::vector<corev1::Pod> landed;  // copies carrying spec.nodeName, for the snapshot update
     for (size_t j = 0; j < pending.size(); ++j) {
         const int32_t idx = sel.node_store_index[j];
         out[where[j]] = bind(*pending[j], idx >= 0 ? &ctx.node_store[(size_t)idx] : nullptr, sink);
+        if (out[where[j]].ok && out[where[j]].bound_to) {
+            corev1::Pod p = *pending[j];
+            if (!p.spec) p.spec = corev1::PodSpec{};
+            p.spec->node_name = *out[where[j]].bound_to;
+            landed.push_back(std::move(p));
+        }
+    }
+    // The whole batch was evaluated against ONE snapshot (the reference's racing reconciles all see the same API-server state).
+    // The bindings it created then count against their nodes for the NEXT batch -- the reference gets that from re-LISTing on
+    // every evaluation (src/predicates.rs:34-38); here the snapshot is patched in one device update.
+    if (ctx.snapshot && !landed.empty()) {
+        std::vector<std::pair<const corev1::Pod *, bool>> events;
+        for (const auto &p : landed) events.emplace_back(&p, true);
+        ctx.snapshot->apply_pod_events(events);
     }
     return out;
 }

@@ -220,7 +220,9 @@ static void cpu_tests() {
         CHECK(c.avail_cpu_milli[2] == 0 && c.avail_mem_bytes[2] == 0);  // no status: 0/0 (D-R5)
         CHECK(lister.list_calls == 3);                                   // one LIST per node
         CHECK(snap.store_index(0) == 1 && snap.canonical_index(0) == 1 && snap.index_of("node-c") == 2 && snap.index_of("nope") == -1);
-        CHECK(c.taints[1] == 1ull && c.taints[0] == 0ull);               // PreferNoSchedule never filters
+        CHECK(c.taints[1] == 0ull && snap.has_taints() && !snap.taints_enabled());  // extension E2 is opt-in: nothing interned yet
+        snap.enable_taints();
+        CHECK(snap.columns().taints[1] == 1ull && snap.columns().taints[0] == 0ull);  // PreferNoSchedule never filters
         // label columns appear when a pod asks for the key
         corev1::Pod p1 = test_pod("zone", "z1"), p2 = test_pod("disk", ""), p3 = test_pod("zone", "nowhere"), p4 = test_pod();
         corev1::Toleration tol;
@@ -241,6 +243,50 @@ static void cpu_tests() {
         CHECK(pc.sel_val_ids[kz * 4 + 2] == KSCHED_SEL_NEVER);
         CHECK(pc.sel_val_ids[kz * 4 + 3] == 0 && pc.sel_val_ids[kd * 4 + 3] == 0);
         CHECK(pc.tolerations[3] == 1ull && pc.tolerations[0] == 0ull);
+        // more than 64 distinct taints (e.g. per-node dedicated=<name>): the parity path (no taint predicate in the reference) is
+        // unaffected; only asking for the extension fails, and it leaves the snapshot usable
+        {
+            std::vector<corev1::Node> many;
+            for (int i = 0; i < 70; ++i) {
+                many.push_back(node_with("t" + std::to_string(100 + i), "1", "1"));
+                corev1::NodeSpec sp;
+                sp.taints = std::vector<corev1::Taint>{{"dedicated", std::string("n") + std::to_string(i), "NoSchedule"}};
+                many.back().spec = sp;
+            }
+            Snapshot s3(Snapshot::kEncodeOnly);
+            s3.rebuild(many, nullptr);  // does not throw
+            CHECK(s3.has_taints());
+            corev1::Pod q = test_pod();
+            CHECK(s3.encode_pods({&q}).p == 1);
+            CHECK_THROWS(s3.enable_taints());
+            CHECK(!s3.taints_enabled());
+            CHECK(s3.encode_pods({&q}).tolerations[0] == 0ull);
+        }
+        // label columns are a per-batch working set: a scheduler that has seen more than KSCHED_MAX_KEYS keys over its lifetime
+        // keeps encoding (unused columns are evicted); only ONE batch using more than the limit is refused here (the batched
+        // entry point splits such a batch)
+        {
+            Snapshot s4(Snapshot::kEncodeOnly);
+            s4.rebuild(nodes, nullptr);
+            for (int k = 0; k < 40; ++k) {
+                corev1::Pod q = test_pod(("key" + std::to_string(k)).c_str(), "v");
+                PodColumns one = s4.encode_pods({&q});
+                CHECK(one.n_keys <= KSCHED_MAX_KEYS && one.n_keys >= 1);
+            }
+            CHECK(s4.columns().keys.size() <= KSCHED_MAX_KEYS);
+            corev1::Pod z = test_pod("zone", "z1");
+            PodColumns pz = s4.encode_pods({&z});
+            const auto &ks = s4.columns().keys;
+            const uint32_t col = (uint32_t)(std::find(ks.begin(), ks.end(), "zone") - ks.begin());
+            CHECK(col < pz.n_keys && pz.sel_val_ids[col] != 0 && pz.sel_val_ids[col] != KSCHED_SEL_NEVER);
+            std::vector<corev1::Pod> wide(40);
+            std::vector<const corev1::Pod *> wp;
+            for (int k = 0; k < 40; ++k) {
+                wide[k] = test_pod(("wide" + std::to_string(k)).c_str(), "v");
+                wp.push_back(&wide[k]);
+            }
+            CHECK_THROWS(s4.encode_pods(wp));
+        }
         // allocatable present but lacking memory: the reference panics (src/predicates.rs:29-31)
         std::vector<corev1::Node> badn = {node_with("x", "1", nullptr)};
         Snapshot s2(Snapshot::kEncodeOnly);

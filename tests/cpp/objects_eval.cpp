@@ -204,13 +204,29 @@ int main(int argc, char **argv) {
                 const auto out = reconcile_batch_sequential(pp, ctx, chooser, sink, 64, &st);
                 print_outcomes(out, sink);
                 std::printf(",\"rounds\":%u,\"conflicts\":%u", st.rounds, st.conflicts);
-                // the snapshot after the batch: available per canonical node (what the next batch would be evaluated against)
+            }
+            {  // the snapshot after the batch: available per canonical node (what the next batch is evaluated against)
                 const NodeColumns &c = ctx.snapshot->columns();
                 std::printf(",\"avail_cpu_milli\":[");
                 for (uint32_t i = 0; i < c.n; ++i) std::printf("%s%lld", i ? "," : "", (long long)c.avail_cpu_milli[i]);
                 std::printf("],\"avail_mem_bytes\":[");
                 for (uint32_t i = 0; i < c.n; ++i) std::printf("%s%lld", i ? "," : "", (long long)c.avail_mem_bytes[i]);
                 std::printf("]");
+                // and the device agrees with those columns: a second evaluation of the same pods == a fresh re-LIST snapshot
+                Context fresh;
+                auto l2 = std::make_shared<StaticPodLister>();
+                l2->pods = bound;
+                for (const auto &pr : sink.posted)
+                    for (const auto &p : pods)
+                        if (full_name(p.metadata) == pr.first) {
+                            corev1::Pod q = p;
+                            q.spec->node_name = pr.second;
+                            l2->pods.push_back(q);
+                        }
+                fresh.client = l2;
+                fresh.node_store = ctx.node_store;
+                const predicates::BatchValidity a = predicates::check_node_validity_batch(pp, ctx), b = predicates::check_node_validity_batch(pp, fresh);
+                std::printf(",\"incremental_equals_relist\":%s", (a.feasible == b.feasible && a.fit == b.fit) ? "true" : "false");
             }
             std::printf("}\n");
             return 0;

@@ -81,6 +81,31 @@ def test_cluster_2000x500_binary_suffixes_12_keys_taints(tmp_path):
     assert 0.02 < dens < 0.9
 
 
+def test_more_than_32_selector_keys_in_one_batch(tmp_path):
+    """The device takes 32 label columns per call; the reference has no such limit (src/predicates.rs:45-61 walks any map).
+    A batch whose pods use 45 distinct keys is evaluated in pod ranges, each within the budget -- same masks."""
+    c = synth.make_cluster(P=90, N=70, n_keys=4, n_taints=0, seed=0x4B45)
+    pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()
+    for i, n in enumerate(nodes):
+        n["metadata"].setdefault("labels", {})
+        for k in range(45):
+            if (i + k) % 3:
+                n["metadata"]["labels"][f"extra{k:02d}"] = f"v{(i * 7 + k) % 2}"
+    for i, p in enumerate(pods):
+        sel = p["spec"].setdefault("nodeSelector", {})
+        sel[f"extra{i % 45:02d}"] = f"v{i % 2}"
+        if i % 5 == 0:
+            sel[f"extra{(i + 11) % 45:02d}"] = "v0"
+    path = tmp_path / "objs.json"
+    write_objects(path, pods, nodes, bound)
+    got = tool("masks", path)
+    W = (c.N + 63) // 64
+    feas, fit = expect_masks(pods, nodes, bound, False, cache=True)
+    assert np.array_equal(unhex(got["fit"], W), fit)
+    assert np.array_equal(unhex(got["feasible"], W), feas)
+    assert 0 < np.unpackbits(feas.view(np.uint8)).sum() < np.unpackbits(fit.view(np.uint8)).sum()
+
+
 def small_cluster(seed, P=60, N=12, tight=False):
     c = synth.make_cluster(P=P, N=N, n_keys=4, n_taints=0, seed=seed, binary_suffixes=True)
     pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()
@@ -110,6 +135,17 @@ def test_reconcile_batch_equals_oracle_restatement(tmp_path, seed, fail_every):
     kinds = {o["error"] for o in want}
     assert None in kinds and "no-node-found" in kinds and (not fail_every or "create-binding-failed" in kinds)
     assert all(o["action"] == ("await_change" if o["ok"] else "requeue_300s") for o in got["outcomes"])  # error_policy, src/main.rs:122-125
+    # after the batch its own bindings count against their nodes (the reference re-LISTs per evaluation, src/predicates.rs:34-38)
+    by_name = {f"{p['metadata']['namespace']}/{p['metadata']['name']}": p for p in pods}
+    state = list(bound)
+    for pod_name, node in posted:
+        q = json.loads(json.dumps(by_name[pod_name]))
+        q["spec"]["nodeName"] = node
+        state.append(q)
+    for j, node in enumerate(nodes):
+        av = R.available_of(node, state)
+        assert got["avail_cpu_milli"][j] == av.cpu * 1000 and got["avail_mem_bytes"][j] == av.memory
+    assert got["incremental_equals_relist"] is True
 
 
 @pytest.mark.parametrize("seed,fail_every,tight", [(1, 0, True), (2, 4, True), (3, 0, False)])
@@ -125,6 +161,7 @@ def test_reconcile_batch_sequential_equals_oracle_restatement(tmp_path, seed, fa
     assert (got["rounds"], got["conflicts"]) == (rounds, conflicts)
     if tight:
         assert rounds > 1 and conflicts > 0, "the case must exercise the deferral"
+    assert got["incremental_equals_relist"] is True
     # the snapshot the device was left with == allocatable - LIST over the final state (exact), and nothing is over-committed
     for j, node in enumerate(nodes):
         av = R.available_of(node, state)
