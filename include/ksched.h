@@ -100,6 +100,9 @@ extern "C" {
  * order, the mask row is only scanned for pods whose best node sits deep in the order; 1 = every candidate's bit is
  * looked up in the mask. */
 #define KSCHED_OPT_PICK_FROM_MASK 5
+/* KSCHED_OPT_INDEX_BUILD: how ksched_set_nodes fills the per-tile bitmap index: 0 (default) = HIP kernels from the columns in
+ * HBM; 1 = the host code that specifies it (csrc/tile_index.hpp), uploaded.  Same tables bit for bit (ksched_index_checksum). */
+#define KSCHED_OPT_INDEX_BUILD 6
 
 typedef struct ksched_ctx ksched_ctx;
 
@@ -121,7 +124,9 @@ int ksched_set_option(ksched_ctx *ctx, int option, int64_t value);
 /* ---- node snapshot ----------------------------------------------------------------------
  * Replaces, for a whole batch, what can_pod_fit recomputes per evaluation
  * (src/predicates.rs:27-38): available[n] = allocatable[n] - sum(requests of pods bound to n).
- * Host pointers; the library copies and builds its device-side columns and indexes.
+ * Host pointers; the library copies them (they may be reused when the call returns) and builds its device-side indexes with
+ * HIP kernels on the ctx's stream; the call does not wait for the device.  Evaluations already enqueued keep reading the
+ * previous snapshot; evaluations enqueued afterwards (on any stream) are ordered behind the build by events.
  *   avail_cpu_milli, avail_mem_bytes : [n] signed
  *   label_val_ids : [n_keys][n] or NULL when n_keys == 0; ids must be < KSCHED_SEL_NEVER
  *   taints        : [n] bit set of (interned) taints, or NULL = no taints
@@ -133,11 +138,20 @@ int ksched_set_nodes(ksched_ctx *ctx, uint32_t n, const int64_t *avail_cpu_milli
  * bound to or removed from them (src/predicates.rs:36-38 subtracts every pod the LIST returns; here the caller
  * keeps that sum current from watch events instead of re-LISTing).  node_index[i] is a canonical node index
  * (< ksched_num_nodes); the two value arrays hold the node's NEW available cpu / memory.  Labels and taints are
- * not touched (use ksched_set_nodes when the node set or its labels change).  Only the affected 1024-node tiles
- * of the library's indexes are rebuilt.  Waits for evaluations already enqueued on this ctx's device.
+ * not touched (use ksched_set_nodes when the node set or its labels change).  A node listed twice takes its last values.
+ * Cost: the new values are scattered into the columns and the fit part (rows, search trees, cnt tables) of the touched
+ * 1024-node tiles is rebuilt by one kernel on the ctx's stream; updates of up to 16 nodes travel in kernel arguments (no
+ * copy).  The best-fit order is only marked stale: the next KSCHED_PICK_BESTFIT request rebuilds it.  The host does not wait:
+ * evaluations already enqueued on any stream this ctx has seen read the snapshot as it was, later ones the new one (events).
+ * If a HIP call fails midway the snapshot is invalidated (KSCHED_E_STATE until the next ksched_set_nodes).
  */
 int ksched_update_nodes(ksched_ctx *ctx, uint32_t count, const uint32_t *node_index, const int64_t *avail_cpu_milli,
                         const int64_t *avail_mem_bytes);
+
+/* The ctx remembers every stream a *_device evaluation was enqueued on (that is how snapshot changes are ordered against
+ * them without a device-wide wait).  A caller that DESTROYS such a stream while the ctx lives must say so first; streams that
+ * outlive the ctx (e.g. a framework's pooled streams) need nothing.  ksched_pipe_destroy does this for the pipe's streams. */
+int ksched_forget_stream(ksched_ctx *ctx, void *hip_stream);
 
 /* number of nodes / keys of the current snapshot (0 before ksched_set_nodes) */
 uint32_t ksched_num_nodes(const ksched_ctx *ctx);
@@ -288,6 +302,10 @@ int ksched_kernel_time_samples(ksched_ctx *ctx, double *out_ms, uint32_t cap);
 /* Diagnostics: copy out the trace of the last fused launch (KSCHED_OPT_TRACE = 1): up to max_blocks records of
  * KSCHED_TRACE_WORDS uint64 (100 MHz timestamps); returns the number of blocks of that launch, <0 on error. */
 int ksched_trace_read(ksched_ctx *ctx, uint64_t *out, uint32_t max_blocks);
+/* Diagnostics: 64-bit checksums of the per-tile bitmap index as it is on the device right now (out[0]: bitmap rows, out[1]:
+ * search trees + cnt tables; both 0 when the snapshot has no index).  Waits for pending snapshot work.  Lets tests show that
+ * the device-built index, the host-specified one (KSCHED_OPT_INDEX_BUILD) and an incrementally updated one are the same bits. */
+int ksched_index_checksum(ksched_ctx *ctx, uint64_t *out /* [2] */);
 /* name of the mask kernel variant the last ksched_eval* used ("direct", "indexed", ...) */
 const char *ksched_last_kernel(const ksched_ctx *ctx);
 

@@ -47,6 +47,7 @@ OPT_TIMING = 2
 OPT_DEBUG = 3
 OPT_TRACE = 4
 OPT_PICK_FROM_MASK = 5
+OPT_INDEX_BUILD = 6
 TRACE_WORDS = 8
 KERNEL_AUTO = 0
 KERNEL_DIRECT = 1
@@ -65,6 +66,7 @@ SYMBOLS = {
     "ksched_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
     "ksched_set_nodes": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _u32, _vp]),
     "ksched_update_nodes": (C.c_int, [_vp, _u32, _vp, _vp, _vp]),
+    "ksched_forget_stream": (C.c_int, [_vp, _vp]),
     "ksched_num_nodes": (_u32, [_vp]),
     "ksched_num_keys": (_u32, [_vp]),
     "ksched_eval": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
@@ -90,6 +92,7 @@ SYMBOLS = {
     "ksched_kernel_time_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "ksched_kernel_time_samples": (C.c_int, [_vp, _vp, _u32]),
     "ksched_explain": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _vp]),
+    "ksched_index_checksum": (C.c_int, [_vp, _vp]),
     "ksched_trace_read": (C.c_int, [_vp, _vp, C.c_uint32]),
     "ksched_last_kernel": (C.c_char_p, [_vp]),
 }

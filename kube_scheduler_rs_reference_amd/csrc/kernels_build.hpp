@@ -1,0 +1,318 @@
+// kernels_build.hpp -- the snapshot builder on the device (the hot half): the per-tile bitmap index
+// of tile_index.hpp and the best-fit structures, built by HIP kernels from the node columns already resident in HBM.
+//
+// The reference recomputes `available` per evaluation (src/predicates.rs:21-38); here a snapshot precedes every batch, so
+// after the mask kernel (26 us per 100k-pod batch) the snapshot build is what a real batch loop waits for.  On the host it cost
+// 2.7-17.9 ms per ksched_set_nodes and 0.7-7.2 ms per ksched_update_nodes (profiles/r01_h5_host_costs_snapshot_calls.txt); these
+// kernels make it a few launches.  tile_index.hpp's host functions (index_tile_fit, eytzinger_from_sorted) remain the SPEC: the
+// device build must produce bit-identical tables (tests/test_gpu_index_build.py compares checksums and results).
+//
+//   k_build_tile_fit    grid (tiles | dirty tiles, 2 resources) x 1024 threads: thread = node of the tile.
+//                         sort  = bitonic network over LDS on (value, node) pairs: the tile's positions
+//                         tree  = Eytzinger image of the sorted values                                (search tree of phase 1)
+//                         cnt[r]= per-sub-tile counts of nodes with pos < r, one byte each = exclusive prefix sum over positions
+//                         lr    = rank of the node inside its 128-node sub-tile = its sub-tile's byte of that prefix
+//                         rows  = {n : lr[n] >= c}, c = 0..128: one wave ballot per (row, word)
+//   k_build_tile_named  grid tiles x 1024: valid row, taint subset rows (ballots), label (key, value) rows (LDS atomic OR)
+//   k_patch_nodes       ksched_update_nodes: scatter the new `available` values into the columns
+//   k_bf_*              best-fit order and its row bitmaps (built lazily, on the first PICK_BESTFIT after a change)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tile_index.hpp"
+
+namespace ksched {
+
+struct BuildFitArgs {
+    const int64_t *ncpu, *nmem;  // node columns [n]
+    uint64_t *tables, *aux;      // IndexedSnapshot::d_tables, d_aux
+    const uint32_t *tile_list;   // tiles to (re)build, or nullptr = tile blockIdx.x
+    uint32_t n, rows, row_cpu;   // layout: rows per tile, first fit row of cpu (memory's follow kFitRows later)
+};
+
+__global__ __launch_bounds__(1024) void k_build_tile_fit(const BuildFitArgs a) {
+    __shared__ int64_t s_key[kTileNodes];  // bitonic network: value; afterwards the sorted values (position order)
+    __shared__ uint16_t s_idx[kTileNodes];  // ... node of the element; afterwards s_lr: local rank by node
+    __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_rows[kFitRows * kTileWords];
+    const uint32_t tile = a.tile_list ? a.tile_list[blockIdx.x] : blockIdx.x;
+    const uint32_t res = blockIdx.y;
+    const int64_t *col = res == 0 ? a.ncpu : a.nmem;
+    const uint32_t base = tile * kTileNodes;
+    const uint32_t m = min((uint32_t)kTileNodes, a.n - base);
+    const uint32_t i = threadIdx.x, lane = i & 63u, wave = i >> 6;
+    // Sort the tile's (value, node) pairs ascending -- ties by node index, so the order is total and the positions are a
+    // permutation (tile_index.hpp).  Padding (node >= m) carries INT64_MAX and the largest indices: it sorts last.
+    // Bitonic network over LDS, one element per thread: 55 compare-exchange stages; the 45 stages whose partners sit in the same
+    // wave need no block barrier (LDS operations of a wave execute in order).  (Ranking by counting -- 1024 broadcast compares per
+    // thread -- was measured at 54 us per tile: 8k VALU instructions per thread on one CU; this is ~1k.)
+    int64_t kv = (i < m) ? col[base + i] : INT64_MAX;
+    uint32_t ki = i;
+    s_key[i] = kv;
+    s_idx[i] = (uint16_t)ki;
+    __syncthreads();
+    for (uint32_t k = 2; k <= (uint32_t)kTileNodes; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64u) __syncthreads();  // the partner's wave has finished the previous stage
+            const uint32_t p = i ^ j;
+            const int64_t pv = s_key[p];
+            const uint32_t pi = s_idx[p];
+            const bool ascending = (i & k) == 0u, lower = (i & j) == 0u;
+            const bool p_less = pv < kv || (pv == kv && pi < ki);
+            const bool take = (lower == ascending) ? p_less : !p_less;  // the lower slot of an ascending pair keeps the smaller element
+            // reads of this stage before its writes, writes before the next stage's reads: block barriers when the partner is in
+            // another wave, wavefront-scope fences (ordering for the compiler; the hardware runs a wave's LDS operations in order)
+            // when it is a lane of this one
+            if (j >= 64u) {
+                __syncthreads();
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (take) {
+                kv = pv;
+                ki = pi;
+                s_key[i] = kv;
+                s_idx[i] = (uint16_t)ki;
+            }
+            // (no block barrier here: the next stage either starts with one, or its partners are lanes of this wave)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // thread i now holds the element at POSITION i: value kv, node ki; s_key is the sorted column
+    __syncthreads();
+    uint64_t *aux = a.aux + (size_t)tile * kAuxWords;
+    // search tree (eytzinger_from_sorted): slot k of level L = floor(log2 k), j = k - 2^L holds sorted[(2j + 1) * 2^(9 - L) - 1]
+    {
+        int64_t t;
+        if (i == 0) {
+            t = s_key[kTileNodes - 1];
+        } else {
+            const uint32_t L = 31u - (uint32_t)__builtin_clz(i), j = i - (1u << L);
+            t = s_key[((2u * j + 1u) << (9u - L)) - 1u];
+        }
+        reinterpret_cast<int64_t *>(aux)[(size_t)res * kAuxTreeWords + i] = t;
+    }
+    // cnt[r] = per-sub-tile counts of nodes at positions < r, one byte each = exclusive prefix sum, over positions, of what each
+    // position adds (bytes never carry: a sub-tile holds at most 128 nodes).  The same prefix gives the local rank of the node at
+    // position r: the number of nodes of ITS sub-tile at earlier positions.
+    {
+        const bool live = ki < m;
+        const uint32_t sub = ki / kSubNodes;
+        const uint64_t x = live ? (1ull << (8u * sub)) : 0ull;
+        uint64_t incl = x;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), d, 64);
+            if (lane >= d) incl += ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();  // also: every thread has read its tree entry from s_key / s_idx is no longer needed as the network's
+        uint64_t before = 0, total = 0;
+        for (uint32_t w = 0; w < 16; ++w) {
+            const uint64_t t = s_wave[w];
+            before += (w < wave) ? t : 0ull;
+            total += t;
+        }
+        const uint64_t excl = before + incl - x;
+        uint64_t *cnt = aux + 2u * kAuxTreeWords + (size_t)res * kCntEntries;
+        cnt[i] = excl;
+        if (i < (uint32_t)kCntEntries - (uint32_t)kTileNodes) cnt[kTileNodes + i] = total;  // r = 1024, 1025
+        s_idx[ki] = (uint16_t)((excl >> (8u * sub)) & 0xFFull);  // local rank, by node (every node appears at exactly one position)
+    }
+    __syncthreads();
+    // rows {lr >= c}: thread i is node i again; wave w owns word w of every row
+    {
+        const bool live = i < m;
+        const uint32_t lr = s_idx[i];
+        for (uint32_t c = 0; c < (uint32_t)kFitRows; ++c) {
+            const uint64_t word = __ballot(live && lr >= c);
+            if (lane == 0) s_rows[c * kTileWords + wave] = word;
+        }
+    }
+    __syncthreads();
+    uint64_t *T = a.tables + ((size_t)tile * a.rows + a.row_cpu + (size_t)res * kFitRows) * kTileWords;
+    for (uint32_t k = i; k < (uint32_t)kFitRows * kTileWords; k += 1024u) T[k] = s_rows[k];
+}
+
+struct BuildNamedArgs {
+    const uint32_t *nlab;      // [nkeys][n]
+    const uint64_t *ntaint;    // [n] or nullptr
+    uint64_t *tables;
+    const uint32_t *lab_meta;  // lab_base[32] (kLabList = the key has no rows), lab_max[32]
+    uint32_t n, rows, nkeys, ngroups, row_valid, row_taint, named_rows;  // named_rows = row_cpu: rows [0, named_rows) are built here
+};
+
+constexpr uint32_t kLabList = 0xFFFFFFFFu;  // lab_base value of a key kept as a sorted list instead of bitmap rows
+
+// dynamic LDS: named_rows * 128 bytes
+__global__ __launch_bounds__(1024) void k_build_tile_named(const BuildNamedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_named[];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t base = tile * kTileNodes;
+    const uint32_t m = min((uint32_t)kTileNodes, a.n - base);
+    const uint32_t i = threadIdx.x, lane = i & 63u, wave = i >> 6;
+    const bool live = i < m;
+    const uint32_t total = a.named_rows * kTileWords;
+    for (uint32_t k = i; k < total; k += 1024u) s_named[k] = 0ull;
+    __syncthreads();
+    {
+        const uint64_t word = __ballot(live);
+        if (lane == 0) s_named[a.row_valid * kTileWords + wave] = word;
+    }
+    if (a.ngroups) {  // row (g, s) = nodes whose taint bits of group g are a subset of s
+        const uint64_t t = (live && a.ntaint) ? a.ntaint[base + i] : 0ull;
+        for (uint32_t g = 0; g < a.ngroups; ++g) {
+            const uint32_t tg = (uint32_t)((t >> (4u * g)) & 15ull);
+            for (uint32_t sset = 0; sset < 16; ++sset) {
+                const uint64_t word = __ballot(live && (tg & ~sset) == 0u);
+                if (lane == 0) s_named[(a.row_taint + 16u * g + sset) * kTileWords + wave] = word;
+            }
+        }
+    }
+    for (uint32_t k = 0; k < a.nkeys; ++k) {
+        const uint32_t lb = a.lab_meta[k];
+        if (lb == kLabList) continue;
+        const uint32_t id = live ? a.nlab[(size_t)k * a.n + base + i] : 0u;
+        if (id) atomicOr((unsigned long long *)&s_named[(size_t)(lb + id - 1u) * kTileWords + wave], 1ull << lane);
+    }
+    __syncthreads();
+    uint64_t *T = a.tables + (size_t)tile * a.rows * kTileWords;
+    for (uint32_t k = i; k < total; k += 1024u) T[k] = s_named[k];
+}
+
+// ---- ksched_update_nodes ------------------------------------------------------------------------------------------------
+constexpr uint32_t kPatchInline = 16;  // updates of up to this many nodes travel in the kernel arguments (no copy, no staging)
+struct PatchArgs {
+    int64_t *ncpu, *nmem, *ncm;  // columns; ncm = [n][2] interleaved
+    const uint32_t *idx;         // device arrays for count > kPatchInline, else nullptr
+    const int64_t *cpu, *mem;
+    uint32_t count;
+    uint32_t idx_in[kPatchInline];
+    int64_t cpu_in[kPatchInline], mem_in[kPatchInline];
+};
+__global__ __launch_bounds__(256) void k_patch_nodes(const PatchArgs a) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.count) return;
+    uint32_t node;
+    int64_t c, m;
+    if (a.idx) {
+        node = a.idx[t];
+        c = a.cpu[t];
+        m = a.mem[t];
+    } else {
+        node = a.idx_in[t];
+        c = a.cpu_in[t];
+        m = a.mem_in[t];
+    }
+    a.ncpu[node] = c;
+    a.nmem[node] = m;
+    a.ncm[2 * (size_t)node] = c;
+    a.ncm[2 * (size_t)node + 1] = m;
+}
+
+struct TileListArgs {
+    uint32_t *out;
+    uint32_t count;
+    uint32_t tiles[kPatchInline];
+};
+__global__ void k_write_tile_list(const TileListArgs a) {
+    if (threadIdx.x < a.count) a.out[threadIdx.x] = a.tiles[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_interleave_cm(const int64_t *__restrict__ cpu, const int64_t *__restrict__ mem, int64_t *__restrict__ cm, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        cm[2 * (size_t)i] = cpu[i];
+        cm[2 * (size_t)i + 1] = mem[i];
+    }
+}
+
+// ---- best-fit structures, after the two device sorts ------------------------------------------------------
+// by_cpu[r]   : node with cpu rank r (ascending (cpu, node))           -- sort 1
+// bf_order[i] : node at best-fit position i (ascending (mem, cpu, node)) -- sort 2 (stable, by mem, of by_cpu)
+struct BfGatherArgs {
+    const int64_t *ncpu, *nmem;
+    const uint32_t *bf_order, *by_cpu;
+    uint32_t *bf_rank, *cpurank;  // bf_rank[node] = position, cpurank[node] = cpu rank
+    int64_t *bf_mem, *bf_cpu, *cpu_sorted;
+    int64_t *samples;  // [mem s1 (n1)][mem s2 (n2)][cpu s1][cpu s2]: last element of every block of 64 / 4096
+    uint32_t n, n1, n2;
+};
+__global__ __launch_bounds__(256) void k_bf_gather(const BfGatherArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t node = a.bf_order[i], cn = a.by_cpu[i];
+    a.bf_rank[node] = i;
+    a.cpurank[cn] = i;
+    const int64_t bm = a.nmem[node], cs = a.ncpu[cn];
+    a.bf_mem[i] = bm;
+    a.bf_cpu[i] = a.ncpu[node];
+    a.cpu_sorted[i] = cs;
+    const bool last = i + 1u == a.n;
+    if ((i & 63u) == 63u || last) {
+        a.samples[i >> 6] = bm;
+        a.samples[(size_t)a.n1 + a.n2 + (i >> 6)] = cs;
+    }
+    if ((i & 4095u) == 4095u || last) {
+        a.samples[(size_t)a.n1 + (i >> 12)] = bm;
+        a.samples[(size_t)2 * a.n1 + a.n2 + (i >> 12)] = cs;
+    }
+}
+
+struct BfRowsArgs {
+    const uint32_t *nlab;
+    const uint64_t *ntaint;       // nullptr: every taint row is the all-valid row
+    const uint32_t *bf_order, *cpurank;
+    const uint32_t *lab_meta;
+    uint64_t *rows;               // [rows][Wbf], zero-filled before the launch
+    uint32_t n, Wbf, nkeys, ngroups, row_valid, row_taint, row_cpu0, q, levels;
+};
+// one wave per 64 best-fit positions (one word of every row)
+__global__ __launch_bounds__(256) void k_bf_rows(const BfRowsArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= a.Wbf) return;
+    const uint32_t i = w * 64u + lane;
+    const bool live = i < a.n;
+    const uint32_t node = live ? a.bf_order[i] : 0u;
+    {
+        const uint64_t word = __ballot(live);
+        if (lane == 0) a.rows[(size_t)a.row_valid * a.Wbf + w] = word;
+    }
+    for (uint32_t k = 0; k < a.nkeys; ++k) {
+        const uint32_t id = live ? a.nlab[(size_t)k * a.n + node] : 0u;
+        // lanes of one wave own one word of each row: combine per distinct id with a ballot-free OR (atomics on distinct
+        // words are rare collisions only inside the wave)
+        if (id) atomicOr((unsigned long long *)&a.rows[(size_t)(a.lab_meta[k] + id - 1u) * a.Wbf + w], 1ull << lane);
+    }
+    if (a.ngroups) {
+        const uint64_t t = (live && a.ntaint) ? a.ntaint[node] : 0ull;
+        for (uint32_t g = 0; g < a.ngroups; ++g) {
+            const uint32_t tg = (uint32_t)((t >> (4u * g)) & 15ull);
+            for (uint32_t sset = 0; sset < 16; ++sset) {
+                const uint64_t word = __ballot(live && (tg & ~sset) == 0u);
+                if (lane == 0) a.rows[(size_t)(a.row_taint + 16u * g + sset) * a.Wbf + w] = word;
+            }
+        }
+    }
+    // cpu threshold rows: row[t] = {i : cpurank >= t * q}, t = 0..levels
+    const uint32_t cr = live ? a.cpurank[node] : 0u;
+    for (uint32_t t = 0; t <= a.levels; ++t) {
+        const uint64_t word = __ballot(live && (uint64_t)cr >= (uint64_t)t * a.q);
+        if (lane == 0) a.rows[(size_t)(a.row_cpu0 + t) * a.Wbf + w] = word;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_iota(uint32_t *out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+__global__ __launch_bounds__(256) void k_gather_i64(const int64_t *__restrict__ src, const uint32_t *__restrict__ idx, int64_t *__restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+
+}  // namespace ksched

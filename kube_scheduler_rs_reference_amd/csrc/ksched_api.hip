@@ -17,7 +17,10 @@
 #include <string>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>
+
 #include "comm_rccl.hpp"
+#include "kernels_build.hpp"
 #include "kernels_direct.hpp"
 #include "kernels_fused.hpp"
 #include "tile_index.hpp"
@@ -70,11 +73,30 @@ struct ksched_ctx {
     DevBuf<uint64_t> bf_rows;        // [rows][Wbf] bitmaps over best-fit positions (k_pick_bestfit_rows); built with the tile index
     bool bf_rows_built = false;
     uint32_t bf_row_cpu0 = 0, bf_q = 1;
-    std::vector<uint32_t> h_order;   // bf_order on the host (upload_bestfit_order -> upload_bestfit_rows)
-    std::vector<uint32_t> h_lab;     // host images of the label and taint columns (re-permuted when the order changes)
-    std::vector<uint64_t> h_taint;
-    IndexedSnapshot idx;  // per-tile bitmap index (tile_index.hpp)
-    std::vector<int64_t> h_cpu, h_mem;  // host image of `available` (ksched_update_nodes patches single rows)
+    // the best-fit structures are built lazily, by the first PICK_BESTFIT request after the snapshot changed
+    bool bf_dirty = true;
+    DevBuf<uint32_t> by_cpu, cpurank, iota;
+    DevBuf<int64_t> sort_keys;
+    DevBuf<uint8_t> sort_tmp;
+    IndexedSnapshot idx;  // per-tile bitmap index (tile_index.hpp), built on the device (kernels_build.hpp)
+    std::string index_reason;  // why the snapshot has no bitmap index (the fused kernel is then not applicable)
+    // host -> device staging for the snapshot calls: pinned, so the copies are asynchronous on the ctx's stream
+    uint8_t *h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    hipEvent_t ev_stage = nullptr;  // the last copy out of h_stage
+    DevBuf<uint8_t> d_stage;
+    // Ordering between the snapshot (built / patched on `stream`) and evaluations on the caller's streams, without a device
+    // synchronize: every stream an evaluation was enqueued on is remembered with an event; a snapshot change first makes
+    // `stream` wait for what those streams hold (evaluations already enqueued read the snapshot as it was), and an evaluation
+    // enqueued afterwards makes its stream wait for the change (ev_build).
+    struct UserStream {
+        hipStream_t s;
+        hipEvent_t ev;
+        uint64_t gen;  // snapshot generation this stream has waited for
+    };
+    std::vector<UserStream> user_streams;
+    hipEvent_t ev_build = nullptr;
+    uint64_t build_gen = 0;
 
     // scratch for the host-pointer path
     DevBuf<int64_t> pcpu, pmem;
@@ -93,6 +115,7 @@ struct ksched_ctx {
     uint32_t opt_debug = 0;
     bool opt_trace = false;
     bool opt_pick_from_mask = false;
+    int opt_index_build = 0;  // KSCHED_OPT_INDEX_BUILD: 0 = device kernels (default), 1 = host spec (tile_index.hpp)
     DevBuf<uint64_t> trace;
     uint32_t trace_blocks_last = 0;
     const char *last_kernel = "none";
@@ -148,102 +171,206 @@ int timing_slot(ksched_ctx *c, size_t *slot) {
     return KSCHED_OK;
 }
 
-// best-fit candidate order of the snapshot: ascending (avail_mem, avail_cpu, node)
-int upload_bestfit_order(ksched_ctx *c) {
-    const uint32_t n = c->n;
-    const int64_t *cpu = c->h_cpu.data(), *mem = c->h_mem.data();
-    std::vector<uint32_t> order(n), rank(n);
-    std::iota(order.begin(), order.end(), 0u);
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        if (mem[x] != mem[y]) return mem[x] < mem[y];
-        if (cpu[x] != cpu[y]) return cpu[x] < cpu[y];
-        return x < y;
-    });
-    std::vector<int64_t> bfmem(n), bfcpu(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        rank[order[i]] = i;
-        bfmem[i] = mem[order[i]];
-        bfcpu[i] = cpu[order[i]];
+// ---- stream ordering (see ksched_ctx::user_streams) ---------------------------------------------------------------
+
+// remember `s` as a stream evaluations are enqueued on; make it wait for the latest snapshot change if it has not yet
+int stream_enter(ksched_ctx *c, hipStream_t s) {
+    if (s == c->stream) return KSCHED_OK;  // the snapshot is built on this very stream: in order by itself
+    ksched_ctx::UserStream *u = nullptr;
+    for (auto &x : c->user_streams)
+        if (x.s == s) u = &x;
+    if (!u) {
+        ksched_ctx::UserStream n{s, nullptr, 0};
+        HIPCHK(c, hipEventCreateWithFlags(&n.ev, hipEventDisableTiming));
+        c->user_streams.push_back(n);
+        u = &c->user_streams.back();
     }
-    HIPCHK(c, hipMemcpy(c->bf_mem.ptr, bfmem.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->bf_cpu.ptr, bfcpu.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->bf_order.ptr, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->bf_rank.ptr, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    c->h_order = std::move(order);
+    if (u->gen != c->build_gen) {
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_build, 0));
+        u->gen = c->build_gen;
+    }
     return KSCHED_OK;
 }
 
-// Bitmaps over best-fit positions for k_pick_bestfit_rows: the tile index's named rows (valid, taint groups, label
-// values: same row numbers) with the nodes in bf_order, followed by 257 cpu threshold rows.  Rebuilt whenever the order
-// changes (ksched_set_nodes, ksched_update_nodes): O(n * (keys + 16 * taint groups)) bit operations on the host.
-int upload_bestfit_rows(ksched_ctx *c) {
-    c->bf_rows_built = false;
-    if (!c->idx.built || c->n == 0) return KSCHED_OK;
-    const IndexedLayout &l = c->idx.lay;
-    const uint32_t n = c->n, Wbf = (n + 63u) / 64u;
-    const uint32_t named = l.row_cpu;  // rows [0, named): zero, valid, taint rows, label rows
-    const uint32_t levels = 256u, q = (n + levels - 1u) / levels;
-    const uint32_t rows = named + levels + 1u;
-    const std::vector<uint32_t> &order = c->h_order;  // the best-fit order just made by upload_bestfit_order
-    std::vector<uint64_t> R((size_t)rows * Wbf, 0ull);
-    auto setbit = [&](uint32_t row, uint32_t i) { R[(size_t)row * Wbf + (i >> 6)] |= 1ull << (i & 63u); };
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t node = order[i];
-        setbit(l.row_valid, i);
-        for (uint32_t k = 0; k < c->nkeys; ++k) {
-            const uint32_t id = c->h_lab[(size_t)k * n + node];
-            if (id) setbit(l.lab_base[k] + id - 1u, i);
+void stream_forget(ksched_ctx *c, hipStream_t s) {
+    for (size_t i = 0; i < c->user_streams.size(); ++i)
+        if (c->user_streams[i].s == s) {
+            (void)hipEventDestroy(c->user_streams[i].ev);
+            c->user_streams.erase(c->user_streams.begin() + (std::ptrdiff_t)i);
+            return;
         }
-        if (c->have_taints)
-            for (uint32_t g = 0; g < l.ngroups; ++g) {
-                const uint32_t tg = (uint32_t)((c->h_taint[node] >> (4u * g)) & 15ull);
-                for (uint32_t sub = 0; sub < 16; ++sub)
-                    if ((tg & ~sub) == 0) setbit(l.row_taint + 16u * g + sub, i);
-            }
-    }
-    if (!c->have_taints)  // no node has a taint: every (group, subset) row is the all-valid row
-        for (uint32_t r = l.row_taint; r < l.row_taint + 16u * l.ngroups; ++r)
-            std::copy(R.begin() + (size_t)l.row_valid * Wbf, R.begin() + (size_t)(l.row_valid + 1) * Wbf, R.begin() + (size_t)r * Wbf);
-    // cpu threshold rows: cpurank = position in ascending (cpu, node) order; row[t] = {i : cpurank >= t * q}
-    std::vector<uint32_t> by_cpu(n), pos_of(n);
-    std::iota(by_cpu.begin(), by_cpu.end(), 0u);
-    std::stable_sort(by_cpu.begin(), by_cpu.end(), [&](uint32_t x, uint32_t y) { return c->h_cpu[x] < c->h_cpu[y]; });
-    std::vector<int64_t> sorted(n);
-    std::vector<uint32_t> bfpos(n);
-    for (uint32_t i = 0; i < n; ++i) bfpos[order[i]] = i;
-    for (uint32_t rnk = 0; rnk < n; ++rnk) {
-        sorted[rnk] = c->h_cpu[by_cpu[rnk]];
-        pos_of[rnk] = bfpos[by_cpu[rnk]];
-    }
-    // from the top down: row[levels] = {rank >= levels * q} (empty: levels * q >= n), row[t] = row[t + 1] | {ranks in [t q, (t + 1) q)}
-    for (int t = (int)levels; t >= 0; --t) {
-        uint64_t *row = R.data() + (size_t)(named + (uint32_t)t) * Wbf;
-        if ((uint32_t)t < levels) std::copy(row + Wbf, row + 2 * (size_t)Wbf, row);
-        const uint64_t lo = std::min<uint64_t>(n, (uint64_t)t * q), hi = ((uint32_t)t == levels) ? n : std::min<uint64_t>(n, (uint64_t)(t + 1) * q);
-        for (uint64_t rnk = lo; rnk < hi; ++rnk) setbit(named + (uint32_t)t, pos_of[rnk]);
-    }
-    // sample arrays for the three-round searches: last element of every block of 64 / of 4096
-    {
-        const uint32_t n1 = (n + 63u) / 64u, n2 = (n + 4095u) / 4096u;
-        std::vector<int64_t> smp(2 * (size_t)(n1 + n2));
-        for (int which = 0; which < 2; ++which) {
-            int64_t *s1 = smp.data() + (size_t)which * (n1 + n2), *s2 = s1 + n1;
-            auto at = [&](uint32_t i) { return which == 0 ? c->h_mem[order[i]] : sorted[i]; };
-            for (uint32_t j = 0; j < n1; ++j) s1[j] = at(std::min(n, (j + 1u) * 64u) - 1u);
-            for (uint32_t j = 0; j < n2; ++j) s2[j] = at(std::min<uint64_t>(n, (uint64_t)(j + 1u) * 4096u) - 1u);
+}
+
+// before the snapshot changes: the ctx's stream waits for everything already enqueued on the remembered streams
+int snapshot_begin(ksched_ctx *c) {
+    for (size_t i = 0; i < c->user_streams.size();) {
+        auto &u = c->user_streams[i];
+        if (hipEventRecord(u.ev, u.s) != hipSuccess) {  // the caller destroyed that stream: forget it
+            (void)hipGetLastError();
+            (void)hipEventDestroy(u.ev);
+            c->user_streams.erase(c->user_streams.begin() + (std::ptrdiff_t)i);
+            continue;
         }
-        HIPCHK(c, c->bf_samples.reserve(smp.size()));
-        HIPCHK(c, hipMemcpy(c->bf_samples.ptr, smp.data(), smp.size() * 8, hipMemcpyHostToDevice));
-        c->bf_n1 = n1;
-        c->bf_n2 = n2;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, u.ev, 0));
+        ++i;
     }
-    HIPCHK(c, c->bf_rows.reserve(R.size()));
-    HIPCHK(c, hipMemcpy(c->bf_rows.ptr, R.data(), R.size() * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->cpu_sorted.ptr, sorted.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-    c->bf_row_cpu0 = named;
-    c->bf_q = q;
-    c->bf_rows_built = true;
     return KSCHED_OK;
+}
+
+// after the change has been enqueued on the ctx's stream
+int snapshot_end(ksched_ctx *c) {
+    HIPCHK(c, hipEventRecord(c->ev_build, c->stream));
+    ++c->build_gen;
+    return KSCHED_OK;
+}
+
+// pinned staging: returns a host pointer to `bytes` bytes whose previous use (an async copy) has completed
+int stage_reserve(ksched_ctx *c, size_t bytes, uint8_t **out) {
+    if (c->h_stage) HIPCHK(c, hipEventSynchronize(c->ev_stage));
+    if (bytes > c->h_stage_cap) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        c->h_stage_cap = 0;
+        const size_t cap = std::max<size_t>(bytes + bytes / 4, 1u << 16);
+        HIPCHK(c, hipHostMalloc((void **)&c->h_stage, cap, hipHostMallocDefault));
+        c->h_stage_cap = cap;
+    }
+    *out = c->h_stage;
+    return KSCHED_OK;
+}
+
+// ---- index and best-fit build (kernels_build.hpp) --------------------------------------------------------------------
+
+// (re)build the fit part of the listed tiles (or of every tile: tiles == nullptr) on the ctx's stream
+int launch_build_fit(ksched_ctx *c, const uint32_t *d_tile_list, uint32_t count) {
+    const IndexedLayout &l = c->idx.lay;
+    BuildFitArgs a{};
+    a.ncpu = c->ncpu.ptr;
+    a.nmem = c->nmem.ptr;
+    a.tables = c->idx.d_tables;
+    a.aux = c->idx.d_aux;
+    a.tile_list = d_tile_list;
+    a.n = l.n;
+    a.rows = l.rows;
+    a.row_cpu = l.row_cpu;
+    hipLaunchKernelGGL(k_build_tile_fit, dim3(d_tile_list ? count : l.tiles, 2), dim3(1024), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return KSCHED_OK;
+}
+
+int launch_build_named(ksched_ctx *c) {
+    const IndexedLayout &l = c->idx.lay;
+    BuildNamedArgs a{};
+    a.nlab = c->nlab.ptr;
+    a.ntaint = c->have_taints ? c->ntaint.ptr : nullptr;
+    a.tables = c->idx.d_tables;
+    a.lab_meta = c->idx.d_lab_meta;
+    a.n = l.n;
+    a.rows = l.rows;
+    a.nkeys = l.nkeys;
+    a.ngroups = l.ngroups;
+    a.row_valid = l.row_valid;
+    a.row_taint = l.row_taint;
+    a.named_rows = l.row_cpu;
+    const uint32_t lds = l.row_cpu * 128u;
+    HIPCHK(c, hipFuncSetAttribute((const void *)k_build_tile_named, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_build_tile_named, dim3(l.tiles), dim3(1024), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return KSCHED_OK;
+}
+
+// Best-fit candidate order of the snapshot, ascending (avail_mem, avail_cpu, node), its inverse, the node
+// columns in that order, the sorted cpu column with the sample arrays of the two rank searches, and -- when the snapshot has a
+// bitmap index -- the named rows once more over best-fit positions plus the 257 cpu threshold rows (k_pick_bestfit_rows).
+// Two stable device radix sorts (rocPRIM) and two kernels, on the ctx's stream; called lazily by the first PICK_BESTFIT request
+// after the snapshot changed (ksched_set_nodes / ksched_update_nodes only mark it dirty).
+int build_bestfit(ksched_ctx *c) {
+    const uint32_t n = c->n;
+    c->bf_rows_built = false;
+    if (n == 0) {
+        c->bf_dirty = false;
+        return KSCHED_OK;
+    }
+    hipStream_t s = c->stream;
+    const uint32_t n1 = (n + 63u) / 64u, n2 = (n + 4095u) / 4096u;
+    HIPCHK(c, c->by_cpu.reserve(n));
+    HIPCHK(c, c->cpurank.reserve(n));
+    HIPCHK(c, c->iota.reserve(n));
+    HIPCHK(c, c->sort_keys.reserve(n));
+    HIPCHK(c, c->bf_samples.reserve(2 * (size_t)(n1 + n2)));
+    const dim3 grid((n + 255u) / 256u), block(256);
+    size_t tmp1 = 0, tmp2 = 0;
+    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp1, (const int64_t *)c->ncpu.ptr, c->cpu_sorted.ptr, (const uint32_t *)c->iota.ptr, c->by_cpu.ptr, n, 0, 64, s));
+    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp2, (const int64_t *)c->sort_keys.ptr, c->bf_mem.ptr, (const uint32_t *)c->by_cpu.ptr, c->bf_order.ptr, n, 0, 64, s));
+    HIPCHK(c, c->sort_tmp.reserve(std::max(tmp1, tmp2)));
+    size_t tmp = c->sort_tmp.cap;
+    hipLaunchKernelGGL(k_iota, grid, block, 0, s, c->iota.ptr, n);
+    // sort 1: ascending (cpu, node): stable radix sort of cpu with the node index as payload
+    HIPCHK(c, rocprim::radix_sort_pairs((void *)c->sort_tmp.ptr, tmp, (const int64_t *)c->ncpu.ptr, c->cpu_sorted.ptr, (const uint32_t *)c->iota.ptr, c->by_cpu.ptr, n, 0, 64, s));
+    // sort 2: stable by memory of that order = ascending (mem, cpu, node)
+    hipLaunchKernelGGL(k_gather_i64, grid, block, 0, s, (const int64_t *)c->nmem.ptr, (const uint32_t *)c->by_cpu.ptr, c->sort_keys.ptr, n);
+    tmp = c->sort_tmp.cap;
+    HIPCHK(c, rocprim::radix_sort_pairs((void *)c->sort_tmp.ptr, tmp, (const int64_t *)c->sort_keys.ptr, c->bf_mem.ptr, (const uint32_t *)c->by_cpu.ptr, c->bf_order.ptr, n, 0, 64, s));
+    BfGatherArgs g{};
+    g.ncpu = c->ncpu.ptr;
+    g.nmem = c->nmem.ptr;
+    g.bf_order = c->bf_order.ptr;
+    g.by_cpu = c->by_cpu.ptr;
+    g.bf_rank = c->bf_rank.ptr;
+    g.cpurank = c->cpurank.ptr;
+    g.bf_mem = c->bf_mem.ptr;
+    g.bf_cpu = c->bf_cpu.ptr;
+    g.cpu_sorted = c->cpu_sorted.ptr;
+    g.samples = c->bf_samples.ptr;
+    g.n = n;
+    g.n1 = n1;
+    g.n2 = n2;
+    hipLaunchKernelGGL(k_bf_gather, grid, block, 0, s, g);
+    HIPCHK(c, hipGetLastError());
+    c->bf_n1 = n1;
+    c->bf_n2 = n2;
+    if (c->idx.built) {
+        const IndexedLayout &l = c->idx.lay;
+        const uint32_t Wbf = (n + 63u) / 64u, named = l.row_cpu, levels = 256u, q = (n + levels - 1u) / levels;
+        const uint32_t rows = named + levels + 1u;
+        HIPCHK(c, c->bf_rows.reserve((size_t)rows * Wbf));
+        HIPCHK(c, hipMemsetAsync(c->bf_rows.ptr, 0, (size_t)rows * Wbf * 8, s));
+        BfRowsArgs r{};
+        r.nlab = c->nlab.ptr;
+        r.ntaint = c->have_taints ? c->ntaint.ptr : nullptr;
+        r.bf_order = c->bf_order.ptr;
+        r.cpurank = c->cpurank.ptr;
+        r.lab_meta = c->idx.d_lab_meta;
+        r.rows = c->bf_rows.ptr;
+        r.n = n;
+        r.Wbf = Wbf;
+        r.nkeys = c->nkeys;
+        r.ngroups = l.ngroups;
+        r.row_valid = l.row_valid;
+        r.row_taint = l.row_taint;
+        r.row_cpu0 = named;
+        r.q = q;
+        r.levels = levels;
+        hipLaunchKernelGGL(k_bf_rows, dim3((Wbf + 3u) / 4u), dim3(256), 0, s, r);
+        HIPCHK(c, hipGetLastError());
+        c->bf_row_cpu0 = named;
+        c->bf_q = q;
+        c->bf_rows_built = true;
+    }
+    c->bf_dirty = false;
+    return KSCHED_OK;
+}
+
+// will the best-fit rows exist once ensure_bestfit has run?  (they are built with the bitmap index's row numbering)
+inline bool bf_rows_expected(const ksched_ctx *c) { return c->idx.built && c->n > 0; }
+
+// a PICK_BESTFIT request is about to be enqueued: make sure the structures match the snapshot
+int ensure_bestfit(ksched_ctx *c) {
+    if (!c->bf_dirty) return KSCHED_OK;
+    int rc = snapshot_begin(c);  // picks already enqueued read the previous order
+    if (rc) return rc;
+    if ((rc = build_bestfit(c))) return rc;
+    return snapshot_end(c);
 }
 
 // ---- mask kernel dispatch ---------------------------------------------------------------------
@@ -335,6 +462,9 @@ int run_direct(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pm
 // the pick of select_node_for_pod (src/main.rs:51-71) / the best-fit extension, from a feasibility mask on the device
 int launch_pick(ksched_ctx *c, uint32_t p, const uint64_t *feas, uint32_t pitch, const int64_t *pmem, const uint32_t *samples,
                 uint32_t attempts, uint32_t flags, int32_t *out_binding, hipStream_t s) {
+    if ((flags & KSCHED_PICK_BESTFIT) && c->n > 0)
+        if (int rcb = ensure_bestfit(c)) return rcb;
+    if (int rce = stream_enter(c, s)) return rce;
     if (flags & KSCHED_PICK_SAMPLED) {
         hipLaunchKernelGGL(k_pick_sampled, dim3((p + 255) / 256), dim3(256), 0, s, feas, samples, out_binding, p, c->n,
                            pitch, attempts);
@@ -385,6 +515,9 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
                    uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, uint32_t pitch, hipStream_t s) {
     const bool pick_s = flags & KSCHED_PICK_SAMPLED, pick_b = flags & KSCHED_PICK_BESTFIT;
     if (p == 0) return KSCHED_OK;
+    if (pick_b && c->n > 0)
+        if (int rcb = ensure_bestfit(c)) return rcb;  // lazily (re)built after a snapshot change, on the ctx's stream
+    if (int rce = stream_enter(c, s)) return rce;      // `s` waits for the latest snapshot change; remembered for the next one
     if (c->n == 0) {
         // no nodes: empty mask rows, no binding possible (reference: choose() on an empty store
         // yields None on every attempt, src/main.rs:56,70)
@@ -543,7 +676,11 @@ int ksched_create(ksched_ctx **out, int device_id) {
     if (!c) return KSCHED_E_NOMEM;
     c->device = device_id;
     DeviceGuard g(device_id);
-    if (!g.ok || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (!g.ok || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_build, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming) != hipSuccess) {
+        if (c->ev_build) (void)hipEventDestroy(c->ev_build);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return KSCHED_E_HIP;
     }
@@ -561,6 +698,11 @@ void ksched_destroy(ksched_ctx *c) {
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
         c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release(); c->xpairs.release(); c->xreason.release();
         c->scratch_mask.release(); c->trace.release();
+        c->by_cpu.release(); c->cpurank.release(); c->iota.release(); c->sort_keys.release(); c->sort_tmp.release(); c->d_stage.release();
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        for (auto &u : c->user_streams) (void)hipEventDestroy(u.ev);
+        if (c->ev_build) (void)hipEventDestroy(c->ev_build);
+        if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
         indexed_release(c->idx);
         for (auto &ep : c->ev_pool) {
             (void)hipEventDestroy(ep.a);
@@ -598,10 +740,22 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
         case KSCHED_OPT_PICK_FROM_MASK:
             c->opt_pick_from_mask = value != 0;
             return KSCHED_OK;
+        case KSCHED_OPT_INDEX_BUILD:
+            if (value != 0 && value != 1) return KSCHED_E_INVAL;
+            c->opt_index_build = (int)value;
+            return KSCHED_OK;
 
         default:
             return KSCHED_E_INVAL;
     }
+}
+
+int ksched_forget_stream(ksched_ctx *c, void *hip_stream) {
+    if (!c) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    stream_forget(c, (hipStream_t)hip_stream);
+    return KSCHED_OK;
 }
 
 int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_t *mem, const uint32_t *lab,
@@ -610,19 +764,32 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     if (n > 0 && (!cpu || !mem)) return KSCHED_E_INVAL;
     if (n_keys > KSCHED_MAX_KEYS) return KSCHED_E_INVAL;
     if (n_keys > 0 && n > 0 && !lab) return KSCHED_E_INVAL;
-    if (lab)
-        for (size_t i = 0; i < (size_t)n_keys * n; ++i)
-            if (lab[i] == KSCHED_SEL_NEVER) return KSCHED_E_INVAL;
+    // one pass over the label columns: the largest id per key (the index layout needs it) doubles as the validity check
+    uint32_t lab_max[KSCHED_MAX_KEYS] = {};
+    for (uint32_t k = 0; k < n_keys; ++k) {
+        uint32_t mx = 0;
+        const uint32_t *col = lab + (size_t)k * n;
+        for (uint32_t i = 0; i < n; ++i) mx = std::max(mx, col[i]);
+        if (mx == KSCHED_SEL_NEVER) return KSCHED_E_INVAL;
+        lab_max[k] = mx;
+    }
+    uint64_t all_taints = 0;
+    if (taints)
+        for (uint32_t i = 0; i < n; ++i) all_taints |= taints[i];
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     if (!g.ok) return KSCHED_E_HIP;
-    // the previous snapshot may still be in use by enqueued work
-    HIPCHK(c, hipDeviceSynchronize());
-    c->have_nodes = false;
+    c->have_nodes = false;  // stays false if anything below fails: a half-built snapshot is never evaluated
+    // evaluations already enqueued on the caller's streams read the previous snapshot: the ctx's stream waits for them
+    // (events; the host does not)
+    if (int rc = snapshot_begin(c)) return rc;
     c->n = n;
     c->nkeys = n_keys;
     c->W = ksched_mask_words(n);
     c->have_taints = taints != nullptr;
+    c->bf_dirty = true;
+    c->bf_rows_built = false;
+    c->idx.built = false;
     HIPCHK(c, c->ncpu.reserve(n));
     HIPCHK(c, c->nmem.reserve(n));
     HIPCHK(c, c->ncm.reserve((size_t)n * 2));
@@ -633,35 +800,47 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     HIPCHK(c, c->bf_mem.reserve(n));
     HIPCHK(c, c->bf_cpu.reserve(n));
     HIPCHK(c, c->cpu_sorted.reserve(n));
-    int rc_bf = KSCHED_OK;
+    hipStream_t s = c->stream;
     if (n > 0) {
-        HIPCHK(c, hipMemcpy(c->ncpu.ptr, cpu, (size_t)n * 8, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->nmem.ptr, mem, (size_t)n * 8, hipMemcpyHostToDevice));
-        if (n_keys) HIPCHK(c, hipMemcpy(c->nlab.ptr, lab, (size_t)n * n_keys * 4, hipMemcpyHostToDevice));
-        if (taints) HIPCHK(c, hipMemcpy(c->ntaint.ptr, taints, (size_t)n * 8, hipMemcpyHostToDevice));
-        c->h_cpu.assign(cpu, cpu + n);
-        c->h_mem.assign(mem, mem + n);
-        if (n_keys) c->h_lab.assign(lab, lab + (size_t)n * n_keys);
-        else c->h_lab.clear();
-        if (taints) c->h_taint.assign(taints, taints + n);
-        else c->h_taint.clear();
-        {
-            std::vector<int64_t> cm((size_t)n * 2);
-            for (uint32_t i = 0; i < n; ++i) {
-                cm[2 * (size_t)i] = cpu[i];
-                cm[2 * (size_t)i + 1] = mem[i];
-            }
-            HIPCHK(c, hipMemcpy(c->ncm.ptr, cm.data(), cm.size() * 8, hipMemcpyHostToDevice));
-        }
-        rc_bf = upload_bestfit_order(c);
-    } else {
-        c->h_cpu.clear();
-        c->h_mem.clear();
+        // the caller's arrays -> pinned staging -> asynchronous copies on the ctx's stream
+        const size_t b_col = (size_t)n * 8, b_lab = (size_t)n * n_keys * 4, b_taint = taints ? b_col : 0;
+        uint8_t *h = nullptr;
+        if (int rc = stage_reserve(c, 2 * b_col + b_lab + b_taint, &h)) return rc;
+        memcpy(h, cpu, b_col);
+        memcpy(h + b_col, mem, b_col);
+        if (b_lab) memcpy(h + 2 * b_col, lab, b_lab);
+        if (b_taint) memcpy(h + 2 * b_col + b_lab, taints, b_taint);
+        HIPCHK(c, hipMemcpyAsync(c->ncpu.ptr, h, b_col, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->nmem.ptr, h + b_col, b_col, hipMemcpyHostToDevice, s));
+        if (b_lab) HIPCHK(c, hipMemcpyAsync(c->nlab.ptr, h + 2 * b_col, b_lab, hipMemcpyHostToDevice, s));
+        if (b_taint) HIPCHK(c, hipMemcpyAsync(c->ntaint.ptr, h + 2 * b_col + b_lab, b_taint, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipEventRecord(c->ev_stage, s));
+        hipLaunchKernelGGL(k_interleave_cm, dim3((n + 255u) / 256u), dim3(256), 0, s, (const int64_t *)c->ncpu.ptr, (const int64_t *)c->nmem.ptr, c->ncm.ptr, n);
+        HIPCHK(c, hipGetLastError());
     }
-    if (rc_bf) return rc_bf;
-    hipError_t e = indexed_build(c->idx, n, cpu, mem, lab, n_keys, taints);
-    if (e != hipSuccess) return fail_hip(c, e, "indexed_build");
-    if (int rcr = upload_bestfit_rows(c)) return rcr;
+    // the per-tile bitmap index: layout on the host (it fixes kernel arguments and LDS sizes), contents on the device
+    IndexedLayout l{};
+    const char *why = "";
+    if (indexed_plan(l, n, n_keys, lab_max, all_taints, &why)) {
+        hipError_t e = indexed_reserve(c->idx, l);
+        if (e != hipSuccess) return fail_hip(c, e, "indexed_reserve");
+        uint32_t meta[72];
+        indexed_meta(l, meta);
+        HIPCHK(c, hipMemcpyAsync(c->idx.d_lab_meta, meta, sizeof meta, hipMemcpyHostToDevice, s));  // pageable and small: staged before the call returns
+        c->idx.lay = l;
+        if (c->opt_index_build == 1) {
+            e = indexed_build_host(c->idx, l, cpu, mem, lab, taints, s);
+            if (e != hipSuccess) return fail_hip(c, e, "indexed_build_host");
+        } else {
+            if (int rc = launch_build_named(c)) return rc;
+            if (int rc = launch_build_fit(c, nullptr, 0)) return rc;
+        }
+        c->idx.built = true;
+        c->index_reason.clear();
+    } else {
+        c->index_reason = why;
+    }
+    if (int rc = snapshot_end(c)) return rc;
     c->have_nodes = true;
     return KSCHED_OK;
 }
@@ -676,47 +855,82 @@ int ksched_update_nodes(ksched_ctx *c, uint32_t count, const uint32_t *node_inde
     if (count == 0) return KSCHED_OK;
     DeviceGuard g(c->device);
     if (!g.ok) return KSCHED_E_HIP;
-    // evaluations already enqueued read the snapshot as it was
-    HIPCHK(c, hipDeviceSynchronize());
-    std::vector<uint32_t> tiles;
-    for (uint32_t i = 0; i < count; ++i) {  // a node listed twice takes its last values
-        const uint32_t n = node_index[i];
-        c->h_cpu[n] = cpu[i];
-        c->h_mem[n] = mem[i];
-        tiles.push_back(n / kTileNodes);
+    // a node listed twice takes its last values: keep the last occurrence of every index (the patch kernel's threads are unordered)
+    std::vector<uint32_t> keep;
+    if (count > 1) {
+        std::vector<uint32_t> order(count);
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return node_index[a] < node_index[b]; });
+        for (uint32_t i = 0; i < count; ++i)
+            if (i + 1 == count || node_index[order[i + 1]] != node_index[order[i]]) keep.push_back(order[i]);
+    } else {
+        keep.push_back(0u);
     }
-    std::sort(tiles.begin(), tiles.end());
+    const uint32_t m = (uint32_t)keep.size();
+    std::vector<uint32_t> tiles;
+    for (uint32_t i : keep) tiles.push_back(node_index[i] / kTileNodes);  // ascending already
     tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
-    // device columns (direct kernel, best-fit pick): sparse rows one by one, else the tile ranges that changed
-    if (count <= 32) {
-        for (uint32_t i = 0; i < count; ++i) {
-            const uint32_t n = node_index[i];
-            HIPCHK(c, hipMemcpy(c->ncpu.ptr + n, &c->h_cpu[n], 8, hipMemcpyHostToDevice));
-            HIPCHK(c, hipMemcpy(c->nmem.ptr + n, &c->h_mem[n], 8, hipMemcpyHostToDevice));
-            const int64_t pair[2] = {c->h_cpu[n], c->h_mem[n]};
-            HIPCHK(c, hipMemcpy(c->ncm.ptr + 2 * (size_t)n, pair, 16, hipMemcpyHostToDevice));
+    // evaluations already enqueued read the snapshot as it was (events, no host wait)
+    if (int rc = snapshot_begin(c)) return rc;
+    hipStream_t s = c->stream;
+    auto fail = [&](int rc) {
+        c->have_nodes = false;  // columns, index and best-fit order may now disagree: refuse evaluations until the next ksched_set_nodes
+        return rc;
+    };
+    PatchArgs pa{};
+    pa.ncpu = c->ncpu.ptr;
+    pa.nmem = c->nmem.ptr;
+    pa.ncm = c->ncm.ptr;
+    pa.count = m;
+    const uint32_t *d_tiles = nullptr;
+    const bool want_tiles = c->idx.built;
+    if (m <= kPatchInline && tiles.size() <= kPatchInline) {
+        // small updates (the watch-event case) travel in kernel arguments: no copy, no staging buffer
+        for (uint32_t j = 0; j < m; ++j) {
+            pa.idx_in[j] = node_index[keep[j]];
+            pa.cpu_in[j] = cpu[keep[j]];
+            pa.mem_in[j] = mem[keep[j]];
         }
     } else {
-        for (uint32_t t : tiles) {
-            const size_t lo = (size_t)t * kTileNodes, len = std::min<size_t>(kTileNodes, c->n - lo);
-            HIPCHK(c, hipMemcpy(c->ncpu.ptr + lo, c->h_cpu.data() + lo, len * 8, hipMemcpyHostToDevice));
-            HIPCHK(c, hipMemcpy(c->nmem.ptr + lo, c->h_mem.data() + lo, len * 8, hipMemcpyHostToDevice));
-            std::vector<int64_t> cm(len * 2);
-            for (size_t i = 0; i < len; ++i) {
-                cm[2 * i] = c->h_cpu[lo + i];
-                cm[2 * i + 1] = c->h_mem[lo + i];
-            }
-            HIPCHK(c, hipMemcpy(c->ncm.ptr + 2 * lo, cm.data(), cm.size() * 8, hipMemcpyHostToDevice));
+        const size_t b_idx = ((size_t)m * 4 + 7) & ~(size_t)7, b_val = (size_t)m * 8, b_tiles = tiles.size() * 4;
+        uint8_t *h = nullptr;
+        if (int rc = stage_reserve(c, b_idx + 2 * b_val + b_tiles, &h)) return fail(rc);
+        uint32_t *hi = reinterpret_cast<uint32_t *>(h);
+        int64_t *hc = reinterpret_cast<int64_t *>(h + b_idx), *hm = hc + m;
+        for (uint32_t j = 0; j < m; ++j) {
+            hi[j] = node_index[keep[j]];
+            hc[j] = cpu[keep[j]];
+            hm[j] = mem[keep[j]];
         }
+        memcpy(h + b_idx + 2 * b_val, tiles.data(), b_tiles);
+        if (c->d_stage.reserve(b_idx + 2 * b_val + b_tiles) != hipSuccess) return fail(KSCHED_E_NOMEM);
+        if (hipMemcpyAsync(c->d_stage.ptr, h, b_idx + 2 * b_val + b_tiles, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipEventRecord(c->ev_stage, s) != hipSuccess)
+            return fail(KSCHED_E_HIP);
+        pa.idx = reinterpret_cast<const uint32_t *>(c->d_stage.ptr);
+        pa.cpu = reinterpret_cast<const int64_t *>(c->d_stage.ptr + b_idx);
+        pa.mem = pa.cpu + m;
+        d_tiles = reinterpret_cast<const uint32_t *>(c->d_stage.ptr + b_idx + 2 * b_val);
     }
-    int rc = upload_bestfit_order(c);
-    if (rc) return rc;
-    if (c->idx.built)
-        for (uint32_t t : tiles) {
-            hipError_t e = indexed_update_tile(c->idx, t, c->h_cpu.data(), c->h_mem.data());
-            if (e != hipSuccess) return fail_hip(c, e, "indexed_update_tile");
+    hipLaunchKernelGGL(k_patch_nodes, dim3((m + 255u) / 256u), dim3(256), 0, s, pa);
+    if (hipGetLastError() != hipSuccess) return fail(KSCHED_E_HIP);
+    if (want_tiles) {
+        // only the touched 1024-node tiles are re-indexed (fit rows, search trees, cnt tables); label and taint rows are untouched
+        if (!d_tiles) {
+            if (c->d_stage.reserve(kPatchInline * 4) != hipSuccess) return fail(KSCHED_E_NOMEM);
+            // the tile list of a small update rides in a second tiny kernel's arguments
+            TileListArgs tl{};
+            tl.out = reinterpret_cast<uint32_t *>(c->d_stage.ptr);
+            tl.count = (uint32_t)tiles.size();
+            for (size_t j = 0; j < tiles.size(); ++j) tl.tiles[j] = tiles[j];
+            hipLaunchKernelGGL(k_write_tile_list, dim3(1), dim3(64), 0, s, tl);
+            d_tiles = tl.out;
         }
-    return upload_bestfit_rows(c);
+        if (int rc = launch_build_fit(c, d_tiles, (uint32_t)tiles.size())) return fail(rc);
+    }
+    c->bf_dirty = true;  // the best-fit order is rebuilt by the next PICK_BESTFIT request, not here
+    if (int rc = snapshot_end(c)) return fail(rc);
+    return KSCHED_OK;
 }
 
 int ksched_eval_device_pitched(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
@@ -781,6 +995,11 @@ void ksched_pipe_destroy(ksched_pipe *q) {
         DeviceGuard g(q->ctx->device);
         if (q->s_mask) (void)hipStreamSynchronize(q->s_mask);
         if (q->s_pick) (void)hipStreamSynchronize(q->s_pick);
+        {
+            std::lock_guard<std::mutex> lk(q->ctx->mu);  // the ctx must not record events on streams that are about to go away
+            stream_forget(q->ctx, q->s_mask);
+            stream_forget(q->ctx, q->s_pick);
+        }
         for (auto e : q->mask_done) (void)hipEventDestroy(e);
         for (auto e : q->pick_done) (void)hipEventDestroy(e);
         if (q->s_mask) (void)hipStreamDestroy(q->s_mask);
@@ -808,7 +1027,7 @@ int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t 
     // Does the pick read the mask?  By default it does not (sampled: the drawn candidates are tested from the columns;
     // best fit: bitmaps kept in best-fit order), so the two streams need no ordering at all: each is in order by itself
     // (mask kernels of successive batches on one, picks on the other), which also covers the reuse of a slot's buffers.
-    const bool pick_reads_mask = c->opt_pick_from_mask || ((pick & KSCHED_PICK_BESTFIT) && !c->bf_rows_built);
+    const bool pick_reads_mask = c->opt_pick_from_mask || ((pick & KSCHED_PICK_BESTFIT) && !bf_rows_expected(c));
     if (pick_reads_mask) HIPCHK(c, hipStreamWaitEvent(q->s_mask, q->pick_done[slot], 0));  // the slot's mask may be overwritten once its pick has run
     rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, nullptr, 0, flags & ~pick, mask, nullptr, nullptr, mask_pitch_words, q->s_mask);
     if (rc) return rc;
@@ -897,7 +1116,7 @@ int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *p
     int32_t *d_bind = nullptr;
     // a mask is needed when the caller wants it, or when the pick reads it (best fit; sampled only with KSCHED_OPT_PICK_FROM_MASK)
     const bool pick_reads_mask = (flags & (KSCHED_PICK_BESTFIT | KSCHED_PICK_SAMPLED)) &&
-                                 (c->opt_pick_from_mask || ((flags & KSCHED_PICK_BESTFIT) && !c->bf_rows_built));
+                                 (c->opt_pick_from_mask || ((flags & KSCHED_PICK_BESTFIT) && !bf_rows_expected(c)));
     if (out_feas || pick_reads_mask) {
         HIPCHK(c, c->feas.reserve((size_t)p * pitch));
         d_feas = c->feas.ptr;
@@ -1129,6 +1348,32 @@ int ksched_allgather_bindings_local(ksched_comm *const *comms, int n, const int3
     r = api.GroupEnd();
     if (first != ncclSuccess) return comm_fail("ncclAllGather", first);
     return r == ncclSuccess ? KSCHED_OK : comm_fail("ncclGroupEnd", r);
+}
+
+int ksched_index_checksum(ksched_ctx *c, uint64_t *out) {
+    if (!c || !out) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_nodes) return KSCHED_E_STATE;
+    out[0] = out[1] = 0;
+    if (!c->idx.built) return KSCHED_OK;
+    DeviceGuard g(c->device);
+    const IndexedLayout &l = c->idx.lay;
+    std::vector<uint64_t> tab((size_t)l.tiles * l.rows * kTileWords), aux((size_t)l.tiles * kAuxWords);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(tab.data(), c->idx.d_tables, tab.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(aux.data(), c->idx.d_aux, aux.size() * 8, hipMemcpyDeviceToHost));
+    auto fnv = [](const std::vector<uint64_t> &v) {
+        uint64_t h = 0xCBF29CE484222325ull;
+        for (uint64_t w : v) {
+            h ^= w;
+            h *= 0x100000001B3ull;
+            h ^= h >> 29;
+        }
+        return h ? h : 1ull;
+    };
+    out[0] = fnv(tab);
+    out[1] = fnv(aux);
+    return KSCHED_OK;
 }
 
 int ksched_trace_read(ksched_ctx *c, uint64_t *out, uint32_t max_blocks) {

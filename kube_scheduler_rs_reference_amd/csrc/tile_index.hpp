@@ -1,5 +1,6 @@
-// tile_index.hpp -- the per-tile bitmap index of a node snapshot (built once per ksched_set_nodes)
-// that the fused mask kernel (kernels_fused.hpp) evaluates against.
+// tile_index.hpp -- the per-tile bitmap index of a node snapshot that the fused mask kernel (kernels_fused.hpp) evaluates
+// against: its layout, and its SPEC as host code (index_tile_fit, indexed_build_host).  The product builds it on the device
+// (kernels_build.hpp); the host functions here define what those kernels must produce and serve the host-only arithmetic test.
 //
 // Why an index: the output (P x ceil(N/64) words) is the HBM traffic; deciding every bit with its
 // own compare (kernels_direct.hpp) costs >= 4 VALU issues per output word per wave64 and lands an
@@ -75,15 +76,13 @@ struct IndexedSnapshot {
     uint64_t *d_aux = nullptr;        // [tiles][kAuxWords]: search trees (eytzinger_from_sorted, padded with INT64_MAX) + cnt tables
     uint32_t *d_lab_meta = nullptr;   // lab_base[32], lab_max[32], then 8 zero words
     size_t aux_cap = 0, tables_cap = 0;
-    // host images of the device arrays, kept so that ksched_update_nodes can rebuild the fit part of single tiles
-    std::vector<uint64_t> h_tables, h_aux;
 };
 
 inline void indexed_release(IndexedSnapshot &s) {
     if (s.d_aux) (void)hipFree(s.d_aux);
     if (s.d_tables) (void)hipFree(s.d_tables);
     if (s.d_lab_meta) (void)hipFree(s.d_lab_meta);
-    s = IndexedSnapshot{};  // also drops the host images
+    s = IndexedSnapshot{};
 }
 
 inline uint32_t indexed_lds_bytes(const IndexedLayout &l) { return l.rows * 128u; }
@@ -135,23 +134,24 @@ inline void index_tile_fit(const IndexedLayout &l, uint32_t t, const int64_t *cp
     }
 }
 
-// Build the per-tile index on the host and upload it.  Leaves s.built == false (and returns
-// hipSuccess) when the snapshot is outside what the indexed kernel supports; the caller then
-// uses the direct kernel.
-inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *cpu, const int64_t *mem, const uint32_t *lab,
-                                uint32_t nkeys, const uint64_t *taints) {
-    s.built = false;
-    if (n == 0 || nkeys > kIdxMaxKeys) return hipSuccess;
-    IndexedLayout l{};
+// Decide the row layout of a snapshot: which rows exist and where.  `lab_max[k]` = largest value id some node carries for
+// key k, `all_taints` = OR of every node's taint bits.  Returns false (with the reason in *why) when the snapshot is outside
+// what the fused kernel supports; the caller then uses the direct kernel.
+inline bool indexed_plan(IndexedLayout &l, uint32_t n, uint32_t nkeys, const uint32_t *lab_max, uint64_t all_taints, const char **why) {
+    if (n == 0) {
+        *why = "no nodes";
+        return false;
+    }
+    if (nkeys > kIdxMaxKeys) {
+        *why = "more label keys than the bitmap index holds";
+        return false;
+    }
+    l = IndexedLayout{};
     l.n = n;
     l.W = (n + 63u) / 64u;
     l.tiles = (n + kTileNodes - 1) / kTileNodes;
     l.nkeys = nkeys;
-    uint64_t all_taints = 0;
-    if (taints)
-        for (uint32_t i = 0; i < n; ++i) all_taints |= taints[i];
     l.ngroups = all_taints ? (uint32_t)((64 - __builtin_clzll(all_taints)) + 3) / 4 : 0;
-
     // Row order: [zero, valid, taint rows, label rows, fit rows of cpu, fit rows of memory].  The rows a pod names by
     // record (labels, taints, valid, zero) come first so that their BYTE offsets fit 16 bits (kernels_fused.hpp).
     uint32_t r = 0;
@@ -160,13 +160,14 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
     l.row_taint = r; r += 16 * l.ngroups;
     uint64_t label_rows = 0;
     for (uint32_t k = 0; k < nkeys; ++k) {
-        uint32_t mx = 0;
-        for (uint32_t i = 0; i < n; ++i) mx = std::max(mx, lab[(size_t)k * n + i]);
-        l.lab_max[k] = mx;
-        label_rows += mx + 1u;  // + the key's all-zero row (ids above mx clamp to it)
+        l.lab_max[k] = lab_max[k];
+        label_rows += (uint64_t)lab_max[k] + 1u;  // + the key's all-zero row (ids above the max clamp to it)
     }
     // all rows of a tile must fit in LDS next to the aux block and the per-pod records, and the named rows below 64 KiB
-    if ((r + label_rows + 2u * kFitRows) * 128u + kLdsNonRowBytesMax > kLdsBudget || (r + label_rows) * 128u > 65536u) return hipSuccess;
+    if ((r + label_rows + 2u * kFitRows) * 128u + kLdsNonRowBytesMax > kLdsBudget || (r + label_rows) * 128u > 65536u) {
+        *why = "label (key, value) rows exceed the LDS budget of the fused kernel (a high-cardinality label key)";
+        return false;
+    }
     for (uint32_t k = 0; k < nkeys; ++k) {
         l.lab_base[k] = r;
         r += l.lab_max[k] + 1u;
@@ -174,7 +175,44 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
     l.row_cpu = r; r += kFitRows;
     l.row_mem = r; r += kFitRows;
     l.rows = r;
+    return true;
+}
 
+inline hipError_t indexed_reserve(IndexedSnapshot &s, const IndexedLayout &l) {
+    hipError_t e;
+    const size_t aux_words = (size_t)l.tiles * kAuxWords, tab_words = (size_t)l.tiles * l.rows * kTileWords;
+    if (aux_words > s.aux_cap) {
+        if (s.d_aux) (void)hipFree(s.d_aux);
+        s.d_aux = nullptr;
+        s.aux_cap = 0;
+        if ((e = hipMalloc((void **)&s.d_aux, aux_words * 8)) != hipSuccess) return e;
+        s.aux_cap = aux_words;
+    }
+    if (tab_words > s.tables_cap) {
+        if (s.d_tables) (void)hipFree(s.d_tables);
+        s.d_tables = nullptr;
+        s.tables_cap = 0;
+        if ((e = hipMalloc((void **)&s.d_tables, tab_words * 8)) != hipSuccess) return e;
+        s.tables_cap = tab_words;
+    }
+    if (!s.d_lab_meta && (e = hipMalloc((void **)&s.d_lab_meta, 72 * sizeof(uint32_t))) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+inline void indexed_meta(const IndexedLayout &l, uint32_t meta[72]) {
+    for (int k = 0; k < 72; ++k) meta[k] = 0;
+    for (int k = 0; k < 32; ++k) {
+        meta[k] = l.lab_base[k];
+        meta[32 + k] = l.lab_max[k];
+    }
+}
+
+// The SPEC of the index, on the host (the device build of kernels_build.hpp must reproduce these tables bit for bit;
+// KSCHED_OPT_INDEX_BUILD = 1 selects this path, tests/test_gpu_index_build.py compares the two).  Fills the host images
+// s.h_tables / s.h_aux for the layout `l` and uploads them.
+inline hipError_t indexed_build_host(IndexedSnapshot &s, const IndexedLayout &l, const int64_t *cpu, const int64_t *mem, const uint32_t *lab,
+                                     const uint64_t *taints, hipStream_t stream) {
+    const uint32_t n = l.n, nkeys = l.nkeys;
     const size_t tile_words = (size_t)l.rows * kTileWords;
     std::vector<uint64_t> tab((size_t)l.tiles * tile_words, 0ull);
     std::vector<uint64_t> aux((size_t)l.tiles * kAuxWords, 0ull);
@@ -200,50 +238,10 @@ inline hipError_t indexed_build(IndexedSnapshot &s, uint32_t n, const int64_t *c
             }
     }
     hipError_t e;
-    if (aux.size() > s.aux_cap) {
-        if (s.d_aux) (void)hipFree(s.d_aux);
-        s.d_aux = nullptr;
-        s.aux_cap = 0;
-        if ((e = hipMalloc((void **)&s.d_aux, aux.size() * 8)) != hipSuccess) return e;
-        s.aux_cap = aux.size();
-    }
-    if (tab.size() > s.tables_cap) {
-        if (s.d_tables) (void)hipFree(s.d_tables);
-        s.d_tables = nullptr;
-        s.tables_cap = 0;
-        if ((e = hipMalloc((void **)&s.d_tables, tab.size() * 8)) != hipSuccess) return e;
-        s.tables_cap = tab.size();
-    }
-    if ((e = hipMemcpy(s.d_aux, aux.data(), aux.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMemcpy(s.d_tables, tab.data(), tab.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if (!s.d_lab_meta && (e = hipMalloc((void **)&s.d_lab_meta, 72 * sizeof(uint32_t))) != hipSuccess) return e;
-    {
-        uint32_t meta[72] = {};
-        for (int k = 0; k < 32; ++k) {
-            meta[k] = l.lab_base[k];
-            meta[32 + k] = l.lab_max[k];
-        }
-        if ((e = hipMemcpy(s.d_lab_meta, meta, sizeof meta, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    }
-    s.h_tables = std::move(tab);
-    s.h_aux = std::move(aux);
-    s.lay = l;
-    s.built = true;
+    if ((e = hipMemcpyAsync(s.d_aux, aux.data(), aux.size() * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(s.d_tables, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // the vectors go out of scope
     return hipSuccess;
-}
-
-// ksched_update_nodes: `available` changed on some nodes of tile t -> rebuild that tile's fit rows, search trees and
-// cnt tables on the host image and re-upload just those (label and taint rows are untouched).
-inline hipError_t indexed_update_tile(IndexedSnapshot &s, uint32_t t, const int64_t *cpu, const int64_t *mem) {
-    const IndexedLayout &l = s.lay;
-    const size_t tile_words = (size_t)l.rows * kTileWords;
-    uint64_t *T = s.h_tables.data() + (size_t)t * tile_words;
-    uint64_t *aux = s.h_aux.data() + (size_t)t * kAuxWords;
-    index_tile_fit(l, t, cpu, mem, T, aux);
-    hipError_t e;
-    const size_t fit_off = (size_t)l.row_cpu * kTileWords, fit_words = (size_t)2 * kFitRows * kTileWords;
-    if ((e = hipMemcpy(s.d_tables + (size_t)t * tile_words + fit_off, T + fit_off, fit_words * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    return hipMemcpy(s.d_aux + (size_t)t * kAuxWords, aux, (size_t)kAuxWords * 8, hipMemcpyHostToDevice);
 }
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));

@@ -105,6 +105,12 @@ class Evaluator:
             self._check(n, "ksched_trace_read")
         return out[:n]
 
+    def index_checksum(self):
+        """(rows, aux) checksums of the per-tile bitmap index on the device; (0, 0) when the snapshot has none."""
+        out = np.zeros((2,), dtype=np.uint64)
+        self._check(self._lib.ksched_index_checksum(self._h, out.ctypes.data_as(C.c_void_p)), "ksched_index_checksum")
+        return int(out[0]), int(out[1])
+
     @property
     def last_kernel(self) -> str:
         return self._lib.ksched_last_kernel(self._h).decode()

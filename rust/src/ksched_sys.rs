@@ -49,6 +49,7 @@ pub const KSCHED_OPT_TIMING: c_int = 2;
 pub const KSCHED_OPT_DEBUG: c_int = 3;
 pub const KSCHED_OPT_TRACE: c_int = 4;
 pub const KSCHED_OPT_PICK_FROM_MASK: c_int = 5;
+pub const KSCHED_OPT_INDEX_BUILD: c_int = 6;
 
 extern "C" {
     // ---- lifetime
@@ -67,6 +68,7 @@ extern "C" {
     pub fn ksched_update_nodes(
         ctx: *mut ksched_ctx, count: u32, node_index: *const u32, avail_cpu_milli: *const i64, avail_mem_bytes: *const i64,
     ) -> c_int;
+    pub fn ksched_forget_stream(ctx: *mut ksched_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn ksched_num_nodes(ctx: *const ksched_ctx) -> u32;
     pub fn ksched_num_keys(ctx: *const ksched_ctx) -> u32;
     // ---- evaluation
@@ -124,6 +126,7 @@ extern "C" {
     // ---- measurement / diagnostics
     pub fn ksched_kernel_time_ms(ctx: *mut ksched_ctx, total_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn ksched_kernel_time_samples(ctx: *mut ksched_ctx, out_ms: *mut f64, cap: u32) -> c_int;
+    pub fn ksched_index_checksum(ctx: *mut ksched_ctx, out: *mut u64) -> c_int;
     pub fn ksched_trace_read(ctx: *mut ksched_ctx, out: *mut u64, max_blocks: u32) -> c_int;
     pub fn ksched_last_kernel(ctx: *const ksched_ctx) -> *const c_char;
 }

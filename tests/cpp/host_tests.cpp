@@ -725,6 +725,7 @@ static void comm_tests() {
         run_once([&] { return ksched_allgather_bindings_local(qs, 1, locals, alls, p, streams); });
         ksched_comm_destroy(qs[0]);
         (void)hipFree(d_pcpu); (void)hipFree(d_pmem); (void)hipFree(d_smp); (void)hipFree(d_local); (void)hipFree(d_all);
+        CHECK(ksched_forget_stream(c, s) == KSCHED_OK);  // the stream goes away before the ctx does
         (void)hipStreamDestroy(s);
         ksched_destroy(c);
     });

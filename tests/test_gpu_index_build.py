@@ -1,0 +1,102 @@
+"""The snapshot builder on the device (csrc/kernels_build.hpp) against its host specification (csrc/tile_index.hpp).
+
+ksched_set_nodes builds the per-tile bitmap index with HIP kernels from the columns in HBM; ksched_update_nodes re-indexes the
+touched tiles with the same kernel; the best-fit order is sorted on the device.  KSCHED_OPT_INDEX_BUILD = 1 selects the host
+code that specifies the index.  Here: the three are the same BITS (ksched_index_checksum), on snapshots chosen to hit the edges
+(partial tiles, ties, extreme values, taints, many label values), and the picks that read the device-sorted best-fit order equal
+the oracle.  (Mask parity against the oracle on device-built snapshots is what every other gpu test already checks.)
+"""
+import numpy as np
+import pytest
+
+from kube_scheduler_rs_reference_amd import FIT, PICK_BESTFIT, SEL, TAINT, _lib, synth
+from oracle import capi
+
+pytestmark = pytest.mark.gpu
+I64 = np.iinfo(np.int64)
+
+
+def checksums(ev, cols, host):
+    ev.set_option(_lib.OPT_INDEX_BUILD, 1 if host else 0)
+    try:
+        ev.set_nodes(**cols)
+        return ev.index_checksum()
+    finally:
+        ev.set_option(_lib.OPT_INDEX_BUILD, 0)
+
+
+def snapshots():
+    yield "C3-like 5000 x 8 keys", synth.make_cluster(16, 5000, n_keys=8, n_taints=0, seed=1).node_columns()
+    yield "taints, 2100 nodes", synth.make_cluster(16, 2100, n_keys=8, n_taints=16, seed=2).node_columns()
+    yield "one node", synth.make_cluster(4, 1, n_keys=3, n_taints=2, seed=3).node_columns()
+    yield "exactly one tile", synth.make_cluster(4, 1024, n_keys=2, n_taints=0, seed=4).node_columns()
+    yield "one over a tile", synth.make_cluster(4, 1025, n_keys=2, n_taints=5, seed=5).node_columns()
+    rng = np.random.default_rng(6)
+    n = 3000
+    ties = dict(avail_cpu_milli=rng.integers(0, 4, n).astype(np.int64) * 1000, avail_mem_bytes=np.full(n, 1 << 30, dtype=np.int64),
+                label_val_ids=rng.integers(0, 3, (2, n)).astype(np.uint32), taints=None)
+    yield "heavy ties", ties
+    ext = np.array([I64.min, I64.min + 1, -1, 0, 1, I64.max - 1, I64.max], dtype=np.int64)
+    yield "extreme values", dict(avail_cpu_milli=rng.choice(ext, n), avail_mem_bytes=rng.choice(ext, n), label_val_ids=None, taints=None)
+    yield "no labels no taints", dict(avail_cpu_milli=rng.integers(-5000, 64000, 7001), avail_mem_bytes=rng.integers(0, 1 << 40, 7001), label_val_ids=None, taints=None)
+    yield "60 taint bits", dict(avail_cpu_milli=rng.integers(0, 64000, 1500), avail_mem_bytes=rng.integers(0, 1 << 40, 1500), label_val_ids=None,
+                                taints=(rng.integers(0, 1 << 60, 1500).astype(np.uint64) & rng.integers(0, 1 << 60, 1500).astype(np.uint64)))
+
+
+@pytest.mark.parametrize("name,cols", list(snapshots()), ids=[n for n, _ in snapshots()])
+def test_device_built_index_is_bit_identical_to_the_host_spec(evaluator, name, cols):
+    dev = checksums(evaluator, cols, host=False)
+    host = checksums(evaluator, cols, host=True)
+    assert dev == host and dev[0] != 0
+    assert checksums(evaluator, cols, host=False) == dev, "the build is deterministic"
+
+
+@pytest.mark.parametrize("count", [1, 3, 16, 17, 400, 6000])
+def test_incremental_update_is_bit_identical_to_a_fresh_build(evaluator, count):
+    ev = evaluator
+    c = synth.make_cluster(64, 5300, n_keys=8, n_taints=16, seed=40 + count)
+    cols = c.node_columns()
+    ev.set_nodes(**cols)
+    rng = np.random.default_rng(count)
+    idx = rng.integers(0, c.N, count).astype(np.uint32)  # duplicates allowed: the last value wins
+    if count >= 3:
+        idx[-1] = idx[0]
+    cpu = rng.integers(-2000, 128000, count).astype(np.int64)
+    mem = rng.integers(-(1 << 30), 1 << 40, count).astype(np.int64)
+    ev.update_nodes(idx, cpu, mem)
+    got = ev.index_checksum()
+    new_cpu, new_mem = cols["avail_cpu_milli"].copy(), cols["avail_mem_bytes"].copy()
+    for j in range(count):
+        new_cpu[idx[j]], new_mem[idx[j]] = cpu[j], mem[j]
+    fresh = dict(cols, avail_cpu_milli=new_cpu, avail_mem_bytes=new_mem)
+    assert got == checksums(ev, fresh, host=True)
+    # and a second, overlapping update on top of the first
+    ev.set_nodes(**cols)
+    ev.update_nodes(idx, cpu, mem)
+    ev.update_nodes(idx[: max(1, count // 2)], cpu[: max(1, count // 2)] + 7, mem[: max(1, count // 2)] - 7)
+    for j in range(max(1, count // 2)):
+        new_cpu[idx[j]], new_mem[idx[j]] = cpu[j] + 7, mem[j] - 7
+    assert ev.index_checksum() == checksums(ev, dict(cols, avail_cpu_milli=new_cpu, avail_mem_bytes=new_mem), host=True)
+
+
+@pytest.mark.parametrize("n_taints", [0, 16])
+def test_bestfit_after_updates_uses_the_resorted_order(evaluator, n_taints):
+    """The best-fit order is stale after ksched_update_nodes and rebuilt (device sort) by the next PICK_BESTFIT request."""
+    ev = evaluator
+    c = synth.make_cluster(3000, 9000, n_keys=8, n_taints=n_taints, seed=77)
+    ev.set_kernel("auto")
+    ev.set_nodes(**c.node_columns())
+    pc = c.pod_columns()
+    flags = FIT | SEL | (TAINT if n_taints else 0) | PICK_BESTFIT
+    cpu, mem = c.avail_cpu.copy(), c.avail_mem.copy()
+    rng = np.random.default_rng(3)
+    for rnd in range(3):
+        r = ev.eval(pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], pc["tolerations"], None, flags)
+        _, _, want = capi.eval_encoded(cpu, mem, c.node_labels, c.node_taints if n_taints else None, c.req_cpu, c.req_mem, c.pod_sel,
+                                       c.pod_tol if n_taints else None, None, flags)
+        assert np.array_equal(r.binding, want), f"round {rnd}"
+        # bind the picked nodes' capacity away (what a scheduler does), then pick again
+        idx = np.unique(want[want >= 0])[: 50 + 400 * rnd].astype(np.uint32)
+        cpu[idx] -= rng.integers(100, 3000, idx.size)
+        mem[idx] -= rng.integers(1 << 20, 1 << 32, idx.size)
+        ev.update_nodes(idx, cpu[idx], mem[idx])
