@@ -11,6 +11,7 @@ bindings over RCCL.  One evaluation = one (pod, node) feasibility bit.
 Workloads (per GPU; weak scaling: rank r evaluates its own P pods against the replicated snapshot):
     C2  10k pods x 1k nodes, fit only                       BASELINE.json configs[1] (launch-bound)
     C3  100k pods x 5k nodes, fit + nodeSelector (8 keys)   BASELINE.json configs[2]  <- default
+    C3h C3 with a hostname-like label key (5 000 values)      not a BASELINE config: the high-cardinality case
     C4s 125k pods x 10k nodes, fit + sel                    configs[3] = 8 of these (1M x 10k)
     C5s 125k pods x 50k nodes, fit + sel + taints, best fit configs[4] = 8 of these (1M x 50k)
 
@@ -42,6 +43,8 @@ WORKLOADS = {
     "C2": ("C2", 10_000, 1_000, ("FIT",), "sampled", "C2: 10k pods x 1k nodes, fit only (BASELINE.json configs[1])"),
     "C3": ("C3", 100_000, 5_000, ("FIT", "SEL"), "sampled",
            "C3: 100k pods x 5k nodes, fit + nodeSelector over 8 label keys (BASELINE.json configs[2])"),
+    "C3h": ("C3h", 100_000, 5_000, ("FIT", "SEL"), "sampled",
+            "C3 with a hostname-like eighth label key (5 000 values, one per node; 15 % of the pods name a node): the high-cardinality case, not a BASELINE config"),
     "C4s": ("C4", 125_000, 10_000, ("FIT", "SEL"), "sampled",
             "C4 shard: 125k pods x 10k nodes per GPU, fit + sel (BASELINE.json configs[3] = 8 shards)"),
     "C5s": ("C5", 125_000, 50_000, ("FIT", "SEL", "TAINT"), "bestfit",
@@ -132,6 +135,10 @@ def main():
     ap.add_argument("--torch-gather", action="store_true",
                     help="N > 1: all-gather with torch.distributed.all_gather_into_tensor instead of the C ABI's communicator "
                          "(ksched_allgather_bindings); A/B only, the default is the ABI")
+    ap.add_argument("--refresh-every", type=int, default=0,
+                    help="every this many steps the snapshot changes before the step: ksched_update_nodes with new `available` values for "
+                         "--refresh-nodes nodes (what pod watch events do to a live scheduler).  0 = static snapshot (default)")
+    ap.add_argument("--refresh-nodes", type=int, default=8)
     ap.add_argument("--one-stream", action="store_true", help="N > 1: keep pick, all-gather (side stream) and mask kernel off the two-stream pipe")
     ap.add_argument("--two-stream", action="store_true",
                     help="with --depth >= 2: mask kernels on one HIP stream, pick kernels (+ all-gather) on another (ksched_pipe).  The picks "
@@ -246,7 +253,20 @@ def main():
     d_mask = loop.masks[0]
     pitch = int(d_mask.stride(0)) if d_mask is not None else W
 
+    refresh = {"n": 0, "calls": 0}
+    if args.refresh_every > 0:
+        rr = np.random.default_rng(1234 + rank)
+        r_idx = [rr.choice(N, size=min(N, args.refresh_nodes), replace=False).astype(np.uint32) for _ in range(64)]
+        r_cpu = [c.avail_cpu[i] - rr.integers(0, 500, i.size) for i in r_idx]
+        r_mem = [c.avail_mem[i] - rr.integers(0, 1 << 28, i.size) for i in r_idx]
+
     def one_step():
+        if args.refresh_every > 0:
+            refresh["n"] += 1
+            if refresh["n"] % args.refresh_every == 0:
+                j = refresh["calls"] % 64
+                ev.update_nodes(r_idx[j], r_cpu[j], r_mem[j])  # enqueued on the ctx's stream; the next evaluation is ordered behind it by an event
+                refresh["calls"] += 1
         return loop.step()
 
     def sync():
@@ -362,7 +382,9 @@ def main():
                        "allgather_every_4": alt,
                        "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
                        "allgather(int32 bindings)" if world > 1 else "single GPU",
-                       "bound_fraction": bound_frac},
+                       "bound_fraction": bound_frac,
+                       "snapshot_refresh": ({"every_steps": args.refresh_every, "nodes_per_update": args.refresh_nodes,
+                                             "updates_issued": refresh["calls"]} if args.refresh_every > 0 else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,

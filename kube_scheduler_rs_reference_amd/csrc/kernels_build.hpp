@@ -31,24 +31,13 @@ struct BuildFitArgs {
     uint32_t n, rows, row_cpu;   // layout: rows per tile, first fit row of cpu (memory's follow kFitRows later)
 };
 
-__global__ __launch_bounds__(1024) void k_build_tile_fit(const BuildFitArgs a) {
-    __shared__ int64_t s_key[kTileNodes];  // bitonic network: value; afterwards the sorted values (position order)
-    __shared__ uint16_t s_idx[kTileNodes];  // ... node of the element; afterwards s_lr: local rank by node
-    __shared__ uint64_t s_wave[16];
-    __shared__ uint64_t s_rows[kFitRows * kTileWords];
-    const uint32_t tile = a.tile_list ? a.tile_list[blockIdx.x] : blockIdx.x;
-    const uint32_t res = blockIdx.y;
-    const int64_t *col = res == 0 ? a.ncpu : a.nmem;
-    const uint32_t base = tile * kTileNodes;
-    const uint32_t m = min((uint32_t)kTileNodes, a.n - base);
-    const uint32_t i = threadIdx.x, lane = i & 63u, wave = i >> 6;
-    // Sort the tile's (value, node) pairs ascending -- ties by node index, so the order is total and the positions are a
-    // permutation (tile_index.hpp).  Padding (node >= m) carries INT64_MAX and the largest indices: it sorts last.
-    // Bitonic network over LDS, one element per thread: 55 compare-exchange stages; the 45 stages whose partners sit in the same
-    // wave need no block barrier (LDS operations of a wave execute in order).  (Ranking by counting -- 1024 broadcast compares per
-    // thread -- was measured at 54 us per tile: 8k VALU instructions per thread on one CU; this is ~1k.)
-    int64_t kv = (i < m) ? col[base + i] : INT64_MAX;
-    uint32_t ki = i;
+// Sort the tile's kTileNodes (key, node) pairs ascending by (key, node): a bitonic network over LDS, one element per thread
+// (1024 threads).  On return thread i holds the element at POSITION i (kv, ki), and s_key / s_idx hold the sorted keys / their
+// nodes by position.  55 compare-exchange stages; the 45 whose partners are lanes of the same wave need no block barrier (LDS
+// operations of a wave execute in order).  (Ranking by counting -- 1024 broadcast compares per thread -- was measured at 54 us
+// per tile: 8k VALU instructions per thread on one CU; this is ~1k.)
+template <class K>
+__device__ __forceinline__ void bitonic_sort_tile(K &kv, uint32_t &ki, K *s_key, uint16_t *s_idx, uint32_t i) {
     s_key[i] = kv;
     s_idx[i] = (uint16_t)ki;
     __syncthreads();
@@ -56,7 +45,7 @@ __global__ __launch_bounds__(1024) void k_build_tile_fit(const BuildFitArgs a) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             if (j >= 64u) __syncthreads();  // the partner's wave has finished the previous stage
             const uint32_t p = i ^ j;
-            const int64_t pv = s_key[p];
+            const K pv = s_key[p];
             const uint32_t pi = s_idx[p];
             const bool ascending = (i & k) == 0u, lower = (i & j) == 0u;
             const bool p_less = pv < kv || (pv == kv && pi < ki);
@@ -81,8 +70,26 @@ __global__ __launch_bounds__(1024) void k_build_tile_fit(const BuildFitArgs a) {
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // thread i now holds the element at POSITION i: value kv, node ki; s_key is the sorted column
     __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_build_tile_fit(const BuildFitArgs a) {
+    __shared__ int64_t s_key[kTileNodes];  // bitonic network: value; afterwards the sorted values (position order)
+    __shared__ uint16_t s_idx[kTileNodes];  // ... node of the element; afterwards s_lr: local rank by node
+    __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_rows[kFitRows * kTileWords];
+    const uint32_t tile = a.tile_list ? a.tile_list[blockIdx.x] : blockIdx.x;
+    const uint32_t res = blockIdx.y;
+    const int64_t *col = res == 0 ? a.ncpu : a.nmem;
+    const uint32_t base = tile * kTileNodes;
+    const uint32_t m = min((uint32_t)kTileNodes, a.n - base);
+    const uint32_t i = threadIdx.x, lane = i & 63u, wave = i >> 6;
+    // sort the tile's (value, node) pairs: ties go by node index, so the order is total and the positions are a permutation
+    // (tile_index.hpp); padding (node >= m) carries INT64_MAX and the largest indices: it sorts last
+    int64_t kv = (i < m) ? col[base + i] : INT64_MAX;
+    uint32_t ki = i;
+    bitonic_sort_tile(kv, ki, s_key, s_idx, i);
+    // thread i now holds the element at POSITION i: value kv, node ki; s_key is the sorted column
     uint64_t *aux = a.aux + (size_t)tile * kAuxWords;
     // search tree (eytzinger_from_sorted): slot k of level L = floor(log2 k), j = k - 2^L holds sorted[(2j + 1) * 2^(9 - L) - 1]
     {
@@ -137,6 +144,27 @@ __global__ __launch_bounds__(1024) void k_build_tile_fit(const BuildFitArgs a) {
     for (uint32_t k = i; k < (uint32_t)kFitRows * kTileWords; k += 1024u) T[k] = s_rows[k];
 }
 
+// List keys (tile_index.hpp): per (tile, list key) the tile's slots ascending by (value id, node); padding carries id 0 (absent).
+struct BuildListArgs {
+    const uint32_t *nlab;  // [nkeys][n]
+    uint8_t *lists;        // IndexedSnapshot::d_list
+    uint32_t n, nlist;
+    uint32_t list_col[kMaxListKeys];
+};
+__global__ __launch_bounds__(1024) void k_build_tile_list(const BuildListArgs a) {
+    __shared__ uint32_t s_key[kTileNodes];
+    __shared__ uint16_t s_idx[kTileNodes];
+    const uint32_t tile = blockIdx.x, j = blockIdx.y, i = threadIdx.x;
+    const uint32_t base = tile * kTileNodes;
+    const uint32_t m = min((uint32_t)kTileNodes, a.n - base);
+    uint32_t kv = (i < m) ? a.nlab[(size_t)a.list_col[j] * a.n + base + i] : 0u;
+    uint32_t ki = i;
+    bitonic_sort_tile(kv, ki, s_key, s_idx, i);
+    uint8_t *L = a.lists + ((size_t)tile * a.nlist + j) * kListBytes;
+    reinterpret_cast<uint32_t *>(L)[i] = kv;
+    reinterpret_cast<uint16_t *>(L + kTileNodes * 4u)[i] = (uint16_t)ki;
+}
+
 struct BuildNamedArgs {
     const uint32_t *nlab;      // [nkeys][n]
     const uint64_t *ntaint;    // [n] or nullptr
@@ -145,7 +173,6 @@ struct BuildNamedArgs {
     uint32_t n, rows, nkeys, ngroups, row_valid, row_taint, named_rows;  // named_rows = row_cpu: rows [0, named_rows) are built here
 };
 
-constexpr uint32_t kLabList = 0xFFFFFFFFu;  // lab_base value of a key kept as a sorted list instead of bitmap rows
 
 // dynamic LDS: named_rows * 128 bytes
 __global__ __launch_bounds__(1024) void k_build_tile_named(const BuildNamedArgs a) {

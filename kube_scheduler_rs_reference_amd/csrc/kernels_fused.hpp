@@ -77,12 +77,16 @@ struct FusedArgs {
     uint32_t p, units, chunks, run;    // units = ceil(p / 8); run = (chunk, tile) pairs per XCD
     uint32_t unit_q, unit_rem, tiles_rcp;  // units / chunks, units % chunks, floor(2^32 / tiles)
     uint32_t off_aux, off_fit, off_lab, off_trow;  // LDS byte offsets of the regions after the bitmap rows
+    uint32_t nlist, list_mask8, off_list, off_lrec;  // list keys (tile_index.hpp): count, which of the first eight columns are lists, LDS offsets
+    uint32_t list_col[kMaxListKeys];                 // their label columns
     uint32_t debug;
+    uint32_t has_tol;  // tolerations were given (g_ptol is not null)
     uint64_t *trace;  // diagnostics: per-block phase timestamps (100 MHz), or nullptr
 };
 
 // LDS carve-up: [rows * 128 : bitmap rows][aux block: 2 search trees + 2 cnt tables (FIT)]
 //               per wave x 64 pods: [16 B fit record (FIT)][16 B label rows 1..8 (SEL)][8 B taint rows (TAINT)]
+//               [nlist * 6 KiB: the tile's list keys][per wave x 64 pods: 16 B list record]   (snapshots with list keys only)
 inline uint32_t fused_lds_bytes(const IndexedLayout &l, bool fit, bool sel, bool taint, FusedArgs *a = nullptr) {
     uint32_t off = l.rows * 128u;
     const uint32_t off_aux = off;
@@ -93,7 +97,13 @@ inline uint32_t fused_lds_bytes(const IndexedLayout &l, bool fit, bool sel, bool
     if (sel) off += kFusedWaves * 64u * 16u;
     const uint32_t off_trow = off;
     if (taint) off += kFusedWaves * 64u * 8u;
+    const uint32_t off_list = off;
+    if (sel && l.nlist) off += l.nlist * kListBytes;
+    const uint32_t off_lrec = off;
+    if (sel && l.nlist) off += kFusedWaves * 64u * kListRecBytes;
     if (a) {
+        a->off_list = off_list;
+        a->off_lrec = off_lrec;
         a->off_aux = off_aux;
         a->off_fit = off_fit;
         a->off_lab = off_lab;
@@ -105,11 +115,14 @@ inline uint32_t fused_lds_bytes(const IndexedLayout &l, bool fit, bool sel, bool
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 
-template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT>
+// LIST: the snapshot keeps some label keys as per-tile sorted lists (high-cardinality keys, tile_index.hpp).  A separate
+// instantiation, so that snapshots without such keys run exactly the code they ran before.
+template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST = false>
 __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     const uint64_t *__restrict__ g_tables, const uint64_t *__restrict__ g_aux, const int64_t *__restrict__ g_pcpu,
     const int64_t *__restrict__ g_pmem, const uint32_t *__restrict__ g_psel, const uint64_t *__restrict__ g_ptol,
-    uint64_t *__restrict__ out_feas, uint64_t *__restrict__ out_fit, const FusedArgs a) {
+    uint64_t *__restrict__ out_feas, uint64_t *__restrict__ out_fit, const uint8_t *__restrict__ g_list, const FusedArgs a) {
+    static_assert(!LIST || SEL, "list keys only exist with the selector predicate");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t b = blockIdx.x;
     // (chunk, tile) pairs in chunk-major order are dealt to the XCDs in contiguous runs: XCD x = block id % 8
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         }
         if (TAINT) {  // no tolerations given = tolerate nothing: every lane reads one zero word (the select is on the address,
                       // never on the in-flight destination register)
-            const uint64_t *tp = g_ptol ? g_ptol + pc : a.zero64;
+            const uint64_t *tp = a.has_tol ? g_ptol + pc : a.zero64;
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tol) : "v"(tp) : "memory");
         }
     };
@@ -201,6 +214,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     uint4 *s_fit = reinterpret_cast<uint4 *>(smem + a.off_fit) + wave * 64u;   // cnt[rank]: 8 bytes of cpu (x, y), 8 of memory (z, w)
     uint4 *s_lab = reinterpret_cast<uint4 *>(smem + a.off_lab) + wave * 64u;   // row offsets of the pod's constrained keys 1..8 (8 x 16 bit)
     uint2 *s_trow = reinterpret_cast<uint2 *>(smem + a.off_trow) + wave * 64u;  // four taint row offsets per pod
+    // (the list code addresses LDS through an explicit local-address-space pointer: with generic pointers one TAINT + LIST
+    // instantiation ran into a compiler back-end error, "Illegal instruction ... V_CMP_NE_U32 0, $src_shared_base")
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    lds_u8 *const lds = (lds_u8 *)smem;
+    uint2 *s_lrec = reinterpret_cast<uint2 *>(smem + a.off_lrec) + wave * 64u;  // LIST: per list key (first entry | count << 16); count 0xFFFF = unconstrained
+    constexpr uint32_t kListCap = 8u;  // the unchecked phase 2 walks at most this many entries per list key; longer ranges take the checked path
 
     // phase-2 lane layout (file header): quad q = (lane & 31) >> 2 -> pod 0,2,2,0,3,1,1,3 of the half, chunk base
     // 0,0,4,4,0,0,4,4; `sub` = pod of the 8-pod step, `wp` = chunk (sub-tile) of the row
@@ -223,6 +242,44 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     const uint8_t *fit_lane = reinterpret_cast<const uint8_t *>(s_fit + sub) + wp;  // [0] = cnt byte of cpu, [8] = of memory (one per sub-tile)
     const uint2 *lab_lane = reinterpret_cast<const uint2 *>(s_lab + sub);           // [0] = row offsets of keys 1..4, [1] = keys 5..8
     const uint2 *trow_lane = s_trow + sub;
+    // LIST: the nodes of this tile that carry the pod's value of a list key sit at entries [first, first + count) of the key's
+    // sorted list; this lane owns sub-tile `wp` (128 nodes): set the bits of the entries that fall into it.  `bound` is the
+    // (wave-uniform) number of entries to look at; entries past the pod's own count are masked.
+    // (The list code derives its per-lane addresses from opaque copies of `sub` / `wp` at the point of use: as loop invariants
+    // of the main loop they would be hoisted into registers that live through every round, and the widest instantiation
+    // -- FIT, SEL, TAINT, WANT_FIT, LIST -- would spill; tools/audit_asm.py allows no spills.)
+    auto opaque = [](uint32_t x) -> uint32_t {
+        asm volatile("" : "+v"(x));
+        return x;
+    };
+    auto lrec_of = [&](uint32_t it) -> uint2 { return (s_lrec + opaque(sub) + it * 8u)[0]; };
+    auto list_mask = [&](uint32_t j, uint32_t rec, uint32_t bound, uint32_t wp) -> u32x4 {
+        const uint32_t noff = a.off_list + j * kListBytes + kTileNodes * 4u;  // LDS byte offset of the key's node numbers
+        const uint32_t first = rec & 0xFFFFu, count = rec >> 16;
+        u32x4 m = {0u, 0u, 0u, 0u};
+        const uint32_t n_e = (bound != 0xFFFFFFFFu) ? bound : ((count == 0xFFFFu) ? 0u : count);  // 0xFFFFFFFF: this lane's own count
+        for (uint32_t e = 0; e < n_e; ++e) {
+            const uint32_t node = *(const __attribute__((address_space(3))) uint16_t *)(lds + noff + min(first + e, (uint32_t)kTileNodes - 1u) * 2u);
+            const bool hit = e < count && (node >> 7) == wp;
+            const uint32_t bit = hit ? (1u << (node & 31u)) : 0u, w = (node >> 5) & 3u;
+            m.x |= (w == 0u) ? bit : 0u;
+            m.y |= (w == 1u) ? bit : 0u;
+            m.z |= (w == 2u) ? bit : 0u;
+            m.w |= (w == 3u) ? bit : 0u;
+        }
+        const uint32_t all = (count == 0xFFFFu) ? 0xFFFFFFFFu : 0u;  // the pod does not constrain this key
+        m.x |= all, m.y |= all, m.z |= all, m.w |= all;
+        return m;
+    };
+    auto apply_lists = [&](u32x4 f, const uint2 lr, uint32_t bound) -> u32x4 {
+        static_assert(kMaxListKeys == 2 && kListRecBytes == 8, "one 32-bit record slot per list key");
+        const uint32_t r[2] = {lr.x, lr.y};
+        const uint32_t wp_o = opaque(wp);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j)
+            if (j < a.nlist) f &= list_mask(j, r[j], bound, wp_o);
+        return f;
+    };
 
     // Row loads of one pod-row of phase 2 (issued together, consumed later: two iterations are
     // interleaved by hand so that many LDS reads are in flight per wave).
@@ -324,8 +381,18 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     auto emit_checked = [&](uint32_t pod, uint32_t it, bool over) {
         const bool live = pod < a.p && has0;
         Rows R;
-        load_rows(rec_cc(it), rec_cm(it), rec_lb(it), rec_tr(it), R);
-        if (SEL) load_extra(rec_lx(it), R);
+        if (LIST) {  // record addresses from opaque copies (see `opaque` below): no loop-invariant registers in this variant
+            uint32_t sub_o = sub, wp_o = wp;
+            asm volatile("" : "+v"(sub_o), "+v"(wp_o));
+            const uint8_t *fit_o = reinterpret_cast<const uint8_t *>(s_fit + sub_o) + wp_o;
+            const uint2 *lab_o = reinterpret_cast<const uint2 *>(s_lab + sub_o);
+            load_rows(FIT ? (uint32_t)(fit_o + it * 128u)[0] : 0u, FIT ? (uint32_t)(fit_o + it * 128u)[8] : 0u, (lab_o + it * 16u)[0],
+                      TAINT ? (s_trow + sub_o + it * 8u)[0] : make_uint2(0u, 0u), R);
+            load_extra((lab_o + it * 16u)[1], R);
+        } else {
+            load_rows(rec_cc(it), rec_cm(it), rec_lb(it), rec_tr(it), R);
+            if (SEL) load_extra(rec_lx(it), R);
+        }
         u32x4 f = fit_of(R);
         const size_t o = (size_t)pod * a.pitch + w0;
         auto store = [&](uint64_t *dst) {
@@ -339,6 +406,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                 f = ((f & R.x0) & R.x1) & (R.x2 & R.x3);
             } else if (live) {  // more than eight constrained keys: walk every key of this pod
                 for (uint32_t k = 0; k < a.nkeys; ++k) {
+                    if (LIST && a.lab_meta[k] == kLabList) continue;  // list keys have no rows (applied below)
                     const uint32_t s = g_psel[(size_t)k * a.p + pod];
                     if (s != 0u) f &= ldrow((s <= a.lab_meta[32u + k]) ? (a.lab_meta[k] + s - 1u) : a.row_zero);
                 }
@@ -348,15 +416,20 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             if (taint_inline) {
                 f = ((f & R.t0) & R.t1) & (R.t2 & R.t3);
             } else if (live) {
-                const uint64_t t = g_ptol ? g_ptol[pod] : 0ull;
+                const uint64_t t = a.has_tol ? g_ptol[pod] : 0ull;
                 for (uint32_t g = 0; g < a.ngroups; ++g) f &= ldrow(a.row_taint + 16u * g + (uint32_t)((t >> (4u * g)) & 15ull));
             }
+        }
+        if (LIST) {
+            __builtin_amdgcn_sched_barrier(0);  // the row registers are dead by now: keeps this variant inside the VGPR budget
+            f = apply_lists(f, lrec_of(it), 0xFFFFFFFFu);  // every entry of this pod's ranges, however long
         }
         if (live && out_feas && !(a.debug & 1u)) store(out_feas);
     };
 
     // ---- phase 1: lane = pod pod0 + lane (branch-free); returns the overflow ballot ---------------
-    bool extra_any = false;
+    bool extra_any = false, list_any = false;
+    uint32_t list_bound = 0;
     auto phase1 = [&](uint32_t pod0) -> uint64_t {
         if (FIT) {
             // r = #sorted values < req: two interleaved descents of the tile's implicit search trees.  The sorted
@@ -395,7 +468,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k) {
                 const uint32_t s = sv[k];
-                if (s != 0u) {
+                if (s != 0u && !(LIST && ((a.list_mask8 >> k) & 1u))) {  // (list keys have no rows: handled below)
                     // value id s of key k -> its row; ids no node carries (KSCHED_SEL_NEVER, unknown) clamp to the key's all-zero row
                     *slot++ = (uint16_t)(min(s, a.lab_mx1[k]) * 128u + a.lab_off[k]);
                 }
@@ -403,8 +476,65 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             cnt = (uint32_t)(slot - slots);
             if (a.nkeys > 8u) {  // keys 9.. : any constraint there sends the pod down the overflow walk
                 const uint32_t pc = min(pod0 + lane, a.p - 1u);
-                for (uint32_t k = 8; k < a.nkeys; ++k) cnt += (g_psel[(size_t)k * a.p + pc] != 0u) ? 9u : 0u;
+                for (uint32_t k = 8; k < a.nkeys; ++k) {
+                    if (LIST && a.lab_meta[k] == kLabList) continue;
+                    cnt += (g_psel[(size_t)k * a.p + pc] != 0u) ? 9u : 0u;
+                }
             }
+        }
+        uint32_t lmax = 0;
+        if (LIST) {
+            // list keys: the pod's id -> the range of the tile's sorted list that carries it (two branch-free lower bounds over
+            // 1024 entries in LDS); only lanes that constrain the key search
+            // The pod's ids of the list keys: a list key among the first eight columns is already in the pipelined operand
+            // registers (picked by the wave-uniform column number); one beyond them is read here (a compiler-issued load: it waits
+            // for the wave's outstanding stores -- only snapshots with more than eight label keys AND a list key among the later ones)
+            uint32_t lv[kMaxListKeys] = {0u, 0u};
+#pragma unroll
+            for (uint32_t j = 0; j < kMaxListKeys; ++j) {
+                if (j >= a.nlist) continue;
+                const uint32_t col = a.list_col[j];
+                if (col < 8u) {
+                    uint32_t v = s0;
+                    v = (col == 1u) ? s1 : v;
+                    v = (col == 2u) ? s2 : v;
+                    v = (col == 3u) ? s3 : v;
+                    v = (col == 4u) ? s4 : v;
+                    v = (col == 5u) ? s5 : v;
+                    v = (col == 6u) ? s6 : v;
+                    v = (col == 7u) ? s7 : v;
+                    lv[j] = v;
+                } else {
+                    lv[j] = g_psel[(size_t)col * a.p + min(pod0 + lane, a.p - 1u)];
+                }
+            }
+            uint32_t rec[kMaxListKeys] = {0xFFFF0000u, 0xFFFF0000u};
+            bool any = false;
+#pragma unroll
+            for (uint32_t j = 0; j < kMaxListKeys; ++j) {
+                rec[j] = 0xFFFF0000u;  // unconstrained
+                const uint32_t s = lv[j];
+                if (j < a.nlist && s != 0u) {
+                    const uint32_t voff = a.off_list + j * kListBytes;  // LDS byte offset of the key's sorted ids
+                    auto val_at = [&](uint32_t e) -> uint32_t { return *(const __attribute__((address_space(3))) uint32_t *)(lds + voff + e * 4u); };
+                    auto lower = [&](uint32_t key) -> uint32_t {  // number of entries below `key`
+                        uint32_t base = 0;
+#pragma unroll
+                        for (uint32_t half = (uint32_t)kTileNodes / 2u; half >= 1u; half >>= 1) base += (val_at(base + half - 1u) < key) ? half : 0u;
+                        return base + ((val_at(base) < key) ? 1u : 0u);
+                    };
+                    const uint32_t lo = lower(s);
+                    const uint32_t hi = (s == 0xFFFFFFFFu) ? lo : lower(s + 1u);  // KSCHED_SEL_NEVER: no node carries it
+                    rec[j] = lo | ((hi - lo) << 16);
+                    lmax = max(lmax, hi - lo);
+                    any = true;
+                }
+            }
+            s_lrec[lane] = make_uint2(rec[0], rec[1]);
+            list_any = __ballot(any) != 0ull;
+#pragma unroll
+            for (uint32_t d = 32; d >= 1; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
+            list_bound = (uint32_t)__builtin_amdgcn_readfirstlane((int)lmax);
         }
         if (TAINT) {
             uint32_t t[4];
@@ -414,7 +544,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             s_trow[lane] = make_uint2(t[0] | (t[1] << 16), t[2] | (t[3] << 16));
         }
         extra_any = __ballot(cnt > 4u) != 0ull;  // some pod of the round needs label rows 5..8
-        const uint64_t over = __ballot(cnt > 8u);  // only possible with more than eight label keys
+        const uint64_t over = __ballot(cnt > 8u || (LIST && lmax > kListCap));  // more than eight row keys constrained, or a long list range
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         return over;
@@ -430,7 +560,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     bool more = u < u_hi, have_prev = false, first = true, stamped4 = false;
     uint32_t prev_u = 0, prev_nu = 0;
     uint64_t prev_over = 0;
-    bool prev_extra = false;
+    bool prev_extra = false, prev_list = false;
+    uint32_t prev_bound = 0;
 #if KSCHED_PROFILE
     uint64_t prof_p2 = 0, prof_wait = 0, prof_p1 = 0, prof_rounds = 0, prof_t = 0;
 #define KSCHED_PROF(ACC)                                       \
@@ -455,10 +586,11 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                 for (uint32_t off = wave * 1024u; off < bytes; off += kFusedWaves * 1024u) {
                     if (off + lane * 16u < bytes)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off + lane * 16u),
-                                                         (__attribute__((address_space(3))) void *)(smem + lds_off + off), 16, 0, 0);
+                                                         (__attribute__((address_space(3))) void *)(lds + lds_off + off), 16, 0, 0);
                 }
             };
             if (FIT) stage(g_aux + (size_t)tile * kAuxWords, a.off_aux, kAuxWords * 8u);  // needed first (phase 1)
+            if (LIST) stage(g_list + (size_t)tile * a.nlist * kListBytes, a.off_list, a.nlist * kListBytes);
             if (!(a.debug & 8u)) stage(g_tables + (size_t)tile * a.rows * kTileWords, 0u, a.rows * 128u);
             if (!(a.debug & 128u)) stamp(1);
             __syncthreads();
@@ -476,7 +608,32 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             // it, so the counted wait does not depend on how many stores it issues.
             const bool fast = (prev_nu == 8u || !more) && prev_over == 0ull && pod0 + prev_nu * 8u <= a.p && tile_full &&
                               (!TAINT || taint_inline) && !(a.debug & 16u);
-            if (fast && prev_nu == 8u) {
+            if (LIST && fast && (prev_list || prev_nu != 8u)) {  // (also the wave's short last round: one rolled loop less in this variant)
+                // Some pod of the round constrains a list key: same unchecked rows, one at a time, plus the list bits
+                // (LDS only: the round issues exactly the stores of the plain path, so the counted wait still holds).
+                // (record addresses re-derived here from opaque copies, see `opaque` above: no loop-invariant registers)
+                const uint32_t sub_o = opaque(sub), wp_o = opaque(wp);
+                const uint8_t *fit_o = reinterpret_cast<const uint8_t *>(s_fit + sub_o) + wp_o;
+                const uint2 *lab_o = reinterpret_cast<const uint2 *>(s_lab + sub_o);
+                const uint2 *trow_o = s_trow + sub_o;
+#pragma unroll 1
+                for (uint32_t it = 0; it < prev_nu; ++it) {
+                    Rows A;
+                    const uint64_t step = (uint64_t)it * step_bytes;
+                    load_rows(FIT ? (uint32_t)(fit_o + it * 128u)[0] : 0u, FIT ? (uint32_t)(fit_o + it * 128u)[8] : 0u, (lab_o + it * 16u)[0],
+                              TAINT ? (trow_o + it * 8u)[0] : make_uint2(0u, 0u), A);
+                    u32x4 f = fit_of(A);
+                    if (WANT_FIT) store_rel(rb_fit + step, lane_off, f);
+                    f = ((f & A.l0) & A.l1) & (A.l2 & A.l3);
+                    if (TAINT) f = ((f & A.t0) & A.t1) & (A.t2 & A.t3);
+                    __builtin_amdgcn_sched_barrier(0);  // in stages, like the eight-row branch below: bounds the live row registers
+                    load_extra((lab_o + it * 16u)[1], A);
+                    f = ((f & A.x0) & A.x1) & (A.x2 & A.x3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f = apply_lists(f, (s_lrec + sub_o + it * 8u)[0], prev_bound);
+                    store_rel(rb_feas + step, lane_off, f);
+                }
+            } else if (fast && prev_nu == 8u) {
                 // STEP pod rows per step; the records of the next step are fetched while this step's rows are combined.
                 constexpr uint32_t STEP = TAINT ? 1u : 2u;  // as many as the row registers allow (no spills: tools/audit_asm.py)
                 uint32_t cn[STEP], mn[STEP];
@@ -533,7 +690,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                         }
                     }
                 }
-            } else if (fast) {
+            } else if (!LIST && fast) {
                 // short last round of the wave: same unchecked rows, one at a time
 #pragma unroll 1
                 for (uint32_t it = 0; it < prev_nu; ++it) {
@@ -566,11 +723,14 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             prof_t = __builtin_readcyclecounter();
             ++prof_rounds;
 #endif
-            KSCHED_WAIT_OPS(kFastStores);  // operands of round u have landed; up to kFastStores younger stores may be in flight
+            // operands of round u have landed; up to kFastStores younger stores may be in flight
+            KSCHED_WAIT_OPS(kFastStores);
             KSCHED_PROF(prof_wait);
             prev_over = phase1(u * 8u);
             KSCHED_PROF(prof_p1);
             prev_extra = extra_any;
+            prev_list = list_any;
+            prev_bound = list_bound;
             if (!have_prev) stamp(3);
             prev_u = u;
             prev_nu = min(8u, u_hi - u);
@@ -615,24 +775,27 @@ struct FusedLaunch {
     hipEvent_t ev_start, ev_stop;  // optional: attached to the dispatch itself (exact kernel duration)
 };
 
-template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT>
+template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST>
 inline hipError_t launch_fused_k(const FusedLaunch &q, const FusedArgs &a) {
-    auto kern = k_eval_fused<FIT, SEL, TAINT, WANT_FIT>;
+    auto kern = k_eval_fused<FIT, SEL, TAINT, WANT_FIT, LIST>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds);
     if (e != hipSuccess) return e;
     const IndexedSnapshot &s = *q.snap;
     if (q.ev_start || q.ev_stop)
         hipExtLaunchKernelGGL(kern, q.grid, dim3(kFusedThreads), q.lds, q.stream, q.ev_start, q.ev_stop, 0, s.d_tables, s.d_aux, q.pcpu,
-                              q.pmem, q.psel, q.ptol, q.out_feas, q.out_fit, a);
+                              q.pmem, q.psel, q.ptol, q.out_feas, q.out_fit, (const uint8_t *)s.d_list, a);
     else
         hipLaunchKernelGGL(kern, q.grid, dim3(kFusedThreads), q.lds, q.stream, s.d_tables, s.d_aux, q.pcpu, q.pmem, q.psel, q.ptol,
-                           q.out_feas, q.out_fit, a);
+                           q.out_feas, q.out_fit, (const uint8_t *)s.d_list, a);
     return hipGetLastError();
 }
 
 template <bool FIT, bool SEL, bool TAINT>
-inline hipError_t launch_fused_t(bool want_fit, const FusedLaunch &q, const FusedArgs &a) {
-    return want_fit ? launch_fused_k<FIT, SEL, TAINT, true>(q, a) : launch_fused_k<FIT, SEL, TAINT, false>(q, a);
+inline hipError_t launch_fused_t(bool want_fit, bool list, const FusedLaunch &q, const FusedArgs &a) {
+    if constexpr (SEL) {
+        if (list) return want_fit ? launch_fused_k<FIT, SEL, TAINT, true, true>(q, a) : launch_fused_k<FIT, SEL, TAINT, false, true>(q, a);
+    }
+    return want_fit ? launch_fused_k<FIT, SEL, TAINT, true, false>(q, a) : launch_fused_k<FIT, SEL, TAINT, false, false>(q, a);
 }
 
 inline bool fused_applicable(const IndexedSnapshot &s, uint32_t flags) {
@@ -659,14 +822,16 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     a.row_mem = l.row_mem;
     a.row_taint = l.row_taint;
     for (int k = 0; k < 8; ++k) {
-        a.lab_off[k] = (l.lab_base[k] - 1u) * 128u;  // id s -> row lab_base + s - 1 (ids start at 1; keys without rows never match s != 0 below nkeys)
-        a.lab_mx1[k] = l.lab_max[k] + 1u;
+        const bool is_list = l.lab_base[k] == kLabList;  // no rows: phase 1 skips the column (list_mask8)
+        a.lab_off[k] = is_list ? 0u : (l.lab_base[k] - 1u) * 128u;  // id s -> row lab_base + s - 1 (ids start at 1; keys without rows never match s != 0 below nkeys)
+        a.lab_mx1[k] = is_list ? 0u : l.lab_max[k] + 1u;
     }
     a.lab_meta = s.d_lab_meta;
     a.zero64 = reinterpret_cast<const uint64_t *>(s.d_lab_meta + 64);
     a.p = p;
     a.units = (p + 7u) / 8u;
     a.debug = debug;
+    a.has_tol = ptol != nullptr ? 1u : 0u;
     const bool do_fit = flags & KSCHED_FIT;
     const bool do_sel = (flags & KSCHED_SEL) && psel && l.nkeys;
     const bool do_taint = (flags & KSCHED_TAINT) && l.ngroups;
@@ -688,7 +853,14 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     const bool want_fit = (flags & KSCHED_WANT_FIT_MASK) && out_fit;
     const int sel = do_sel ? 1 : 0, tnt = do_taint ? 1 : 0, fit = do_fit ? 1 : 0;
     const FusedLaunch q{grid, lds, stream, &s, pcpu, pmem, psel, ptol, out_feas, out_fit, ev_start, ev_stop};
-#define KSCHED_FUSED_CASE(F, S, T) return launch_fused_t<F, S, T>(want_fit, q, a)
+    const bool list = do_sel && l.nlist > 0;
+    a.nlist = list ? l.nlist : 0u;
+    a.list_mask8 = 0;
+    for (uint32_t j = 0; j < a.nlist; ++j) {
+        a.list_col[j] = l.list_col[j];
+        if (l.list_col[j] < 8u) a.list_mask8 |= 1u << l.list_col[j];
+    }
+#define KSCHED_FUSED_CASE(F, S, T) return launch_fused_t<F, S, T>(want_fit, list, q, a)
     switch (fit * 4 + sel * 2 + tnt) {
         case 0: KSCHED_FUSED_CASE(false, false, false);
         case 1: KSCHED_FUSED_CASE(false, false, true);

@@ -258,6 +258,20 @@ int launch_build_fit(ksched_ctx *c, const uint32_t *d_tile_list, uint32_t count)
     return KSCHED_OK;
 }
 
+int launch_build_lists(ksched_ctx *c) {
+    const IndexedLayout &l = c->idx.lay;
+    if (l.nlist == 0) return KSCHED_OK;
+    BuildListArgs a{};
+    a.nlab = c->nlab.ptr;
+    a.lists = c->idx.d_list;
+    a.n = l.n;
+    a.nlist = l.nlist;
+    for (uint32_t j = 0; j < l.nlist; ++j) a.list_col[j] = l.list_col[j];
+    hipLaunchKernelGGL(k_build_tile_list, dim3(l.tiles, l.nlist), dim3(1024), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return KSCHED_OK;
+}
+
 int launch_build_named(ksched_ctx *c) {
     const IndexedLayout &l = c->idx.lay;
     BuildNamedArgs a{};
@@ -329,7 +343,7 @@ int build_bestfit(ksched_ctx *c) {
     HIPCHK(c, hipGetLastError());
     c->bf_n1 = n1;
     c->bf_n2 = n2;
-    if (c->idx.built) {
+    if (c->idx.built && c->idx.lay.nlist == 0) {  // (list keys have no rows to re-order: the mask-reading pick serves those snapshots)
         const IndexedLayout &l = c->idx.lay;
         const uint32_t Wbf = (n + 63u) / 64u, named = l.row_cpu, levels = 256u, q = (n + levels - 1u) / levels;
         const uint32_t rows = named + levels + 1u;
@@ -362,7 +376,7 @@ int build_bestfit(ksched_ctx *c) {
 }
 
 // will the best-fit rows exist once ensure_bestfit has run?  (they are built with the bitmap index's row numbering)
-inline bool bf_rows_expected(const ksched_ctx *c) { return c->idx.built && c->n > 0; }
+inline bool bf_rows_expected(const ksched_ctx *c) { return c->idx.built && c->idx.lay.nlist == 0 && c->n > 0; }
 
 // a PICK_BESTFIT request is about to be enqueued: make sure the structures match the snapshot
 int ensure_bestfit(ksched_ctx *c) {
@@ -591,7 +605,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     int kern = c->opt_kernel;
     if (kern == KSCHED_KERNEL_AUTO) kern = can_fused ? KSCHED_KERNEL_FUSED : KSCHED_KERNEL_DIRECT;
     if (kern == KSCHED_KERNEL_FUSED && !can_fused) {
-        c->last_error = "fused kernel not applicable to this snapshot/request (bitmap index does not fit LDS)";
+        c->last_error = "fused kernel not applicable to this snapshot/request: " + (c->index_reason.empty() ? std::string("the bitmap index does not fit LDS") : c->index_reason);
         return KSCHED_E_UNSUPPORTED;
     }
     size_t slot = 0;
@@ -833,6 +847,7 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
             if (e != hipSuccess) return fail_hip(c, e, "indexed_build_host");
         } else {
             if (int rc = launch_build_named(c)) return rc;
+            if (int rc = launch_build_lists(c)) return rc;
             if (int rc = launch_build_fit(c, nullptr, 0)) return rc;
         }
         c->idx.built = true;
@@ -1371,8 +1386,10 @@ int ksched_index_checksum(ksched_ctx *c, uint64_t *out) {
         }
         return h ? h : 1ull;
     };
+    std::vector<uint64_t> lists((size_t)l.tiles * l.nlist * kListBytes / 8);
+    if (!lists.empty()) HIPCHK(c, hipMemcpy(lists.data(), c->idx.d_list, lists.size() * 8, hipMemcpyDeviceToHost));
     out[0] = fnv(tab);
-    out[1] = fnv(aux);
+    out[1] = fnv(aux) ^ (lists.empty() ? 0ull : fnv(lists) * 0x9E3779B97F4A7C15ull);
     return KSCHED_OK;
 }
 

@@ -59,14 +59,25 @@ constexpr uint32_t kAuxWords = 2u * kAuxTreeWords + 2u * kCntEntries;  // 4100 w
 // LDS the kernel needs besides the bitmap rows: the aux block and up to 40 bytes of per-pod records for
 // 16 waves x 64 pods (kernels_fused.hpp: fused_lds_bytes)
 constexpr uint32_t kLdsNonRowBytesMax = kAuxWords * 8u + 1024u * 40u;
+// High-cardinality label keys (e.g. kubernetes.io/hostname: one value per node) do not get one bitmap row per value -- 5000
+// values x 128 B would not fit any LDS.  Such a key is kept per tile as a LIST instead: the tile's nodes sorted by the key's
+// value id (u32 ids, then u16 node numbers).  A pod that constrains the key binary-searches its id (phase 1) and gets a range
+// of at most a few nodes, whose bits phase 2 sets one by one.  Up to kMaxListKeys (2) keys per snapshot (each costs a pipelined operand register in the kernel); rows are given to the
+// keys with the fewest values first.
+constexpr uint32_t kMaxListKeys = 2;
+constexpr uint32_t kListBytes = kTileNodes * 4u + kTileNodes * 2u;  // per (tile, list key): 6 KiB
+constexpr uint32_t kListRecBytes = 8u;                              // per pod of a round: kMaxListKeys x (first entry u16 | count u16)
+constexpr uint32_t kLabList = 0xFFFFFFFFu;                          // lab_base of a list key
 
 struct IndexedLayout {
     uint32_t n, W, tiles, rows, nkeys, ngroups;
     uint32_t row_zero, row_valid;
     uint32_t row_cpu, row_mem;          // first of the kFitRows rows {lr >= c} of each resource
     uint32_t row_taint;                 // + 16 * group + subset
-    uint32_t lab_base[kIdxMaxKeys];     // row of value id 1 of key k; row lab_base + lab_max is the key's all-zero row
+    uint32_t lab_base[kIdxMaxKeys];     // row of value id 1 of key k; row lab_base + lab_max is the key's all-zero row; kLabList = list key
     uint32_t lab_max[kIdxMaxKeys];      // largest id some node carries
+    uint32_t nlist;                     // keys kept as sorted lists instead of rows
+    uint32_t list_col[kMaxListKeys];    // their label columns
 };
 
 struct IndexedSnapshot {
@@ -75,13 +86,15 @@ struct IndexedSnapshot {
     uint64_t *d_tables = nullptr;     // [tiles][rows][16]
     uint64_t *d_aux = nullptr;        // [tiles][kAuxWords]: search trees (eytzinger_from_sorted, padded with INT64_MAX) + cnt tables
     uint32_t *d_lab_meta = nullptr;   // lab_base[32], lab_max[32], then 8 zero words
-    size_t aux_cap = 0, tables_cap = 0;
+    uint8_t *d_list = nullptr;        // [tiles][nlist][kListBytes]: per list key the tile's value ids ascending (u32[1024]), then their nodes (u16[1024])
+    size_t aux_cap = 0, tables_cap = 0, list_cap = 0;
 };
 
 inline void indexed_release(IndexedSnapshot &s) {
     if (s.d_aux) (void)hipFree(s.d_aux);
     if (s.d_tables) (void)hipFree(s.d_tables);
     if (s.d_lab_meta) (void)hipFree(s.d_lab_meta);
+    if (s.d_list) (void)hipFree(s.d_list);
     s = IndexedSnapshot{};
 }
 
@@ -158,17 +171,42 @@ inline bool indexed_plan(IndexedLayout &l, uint32_t n, uint32_t nkeys, const uin
     l.row_zero = r++;
     l.row_valid = r++;
     l.row_taint = r; r += 16 * l.ngroups;
-    uint64_t label_rows = 0;
-    for (uint32_t k = 0; k < nkeys; ++k) {
-        l.lab_max[k] = lab_max[k];
-        label_rows += (uint64_t)lab_max[k] + 1u;  // + the key's all-zero row (ids above the max clamp to it)
+    for (uint32_t k = 0; k < nkeys; ++k) l.lab_max[k] = lab_max[k];
+    // Rows go to the keys with the fewest values; keys that do not fit become lists (largest first), at most kMaxListKeys.
+    // All rows of a tile must fit in LDS next to the aux block, the lists and the per-pod records, and the named rows (the ones
+    // a pod's record addresses with 16 bits) below 64 KiB.
+    bool is_list[kIdxMaxKeys] = {};
+    for (;;) {
+        uint64_t label_rows = 0;
+        for (uint32_t k = 0; k < nkeys; ++k)
+            if (!is_list[k]) label_rows += (uint64_t)lab_max[k] + 1u;  // + the key's all-zero row (ids above the max clamp to it)
+        const uint64_t lds = (r + label_rows + 2u * kFitRows) * 128u + kLdsNonRowBytesMax + (uint64_t)l.nlist * kListBytes +
+                             (l.nlist ? 1024u * kListRecBytes : 0u);
+        if (lds <= kLdsBudget && (r + label_rows) * 128u <= 65536u) break;
+        if (l.nlist == kMaxListKeys) {
+            *why = "more than two high-cardinality label keys: their (key, value) rows exceed the LDS budget of the fused kernel";
+            return false;
+        }
+        uint32_t big = nkeys;
+        for (uint32_t k = 0; k < nkeys; ++k)
+            if (!is_list[k] && (big == nkeys || lab_max[k] > lab_max[big])) big = k;
+        if (big == nkeys) {
+            *why = "the fit rows alone exceed the LDS budget";
+            return false;
+        }
+        is_list[big] = true;
+        ++l.nlist;
     }
-    // all rows of a tile must fit in LDS next to the aux block and the per-pod records, and the named rows below 64 KiB
-    if ((r + label_rows + 2u * kFitRows) * 128u + kLdsNonRowBytesMax > kLdsBudget || (r + label_rows) * 128u > 65536u) {
-        *why = "label (key, value) rows exceed the LDS budget of the fused kernel (a high-cardinality label key)";
-        return false;
+    {
+        uint32_t j = 0;
+        for (uint32_t k = 0; k < nkeys; ++k)
+            if (is_list[k]) l.list_col[j++] = k;  // ascending column order
     }
     for (uint32_t k = 0; k < nkeys; ++k) {
+        if (is_list[k]) {
+            l.lab_base[k] = kLabList;
+            continue;
+        }
         l.lab_base[k] = r;
         r += l.lab_max[k] + 1u;
     }
@@ -196,6 +234,14 @@ inline hipError_t indexed_reserve(IndexedSnapshot &s, const IndexedLayout &l) {
         s.tables_cap = tab_words;
     }
     if (!s.d_lab_meta && (e = hipMalloc((void **)&s.d_lab_meta, 72 * sizeof(uint32_t))) != hipSuccess) return e;
+    const size_t list_bytes = (size_t)l.tiles * l.nlist * kListBytes;
+    if (list_bytes > s.list_cap) {
+        if (s.d_list) (void)hipFree(s.d_list);
+        s.d_list = nullptr;
+        s.list_cap = 0;
+        if ((e = hipMalloc((void **)&s.d_list, list_bytes)) != hipSuccess) return e;
+        s.list_cap = list_bytes;
+    }
     return hipSuccess;
 }
 
@@ -216,6 +262,7 @@ inline hipError_t indexed_build_host(IndexedSnapshot &s, const IndexedLayout &l,
     const size_t tile_words = (size_t)l.rows * kTileWords;
     std::vector<uint64_t> tab((size_t)l.tiles * tile_words, 0ull);
     std::vector<uint64_t> aux((size_t)l.tiles * kAuxWords, 0ull);
+    std::vector<uint8_t> lists((size_t)l.tiles * l.nlist * kListBytes, 0);
     for (uint32_t t = 0; t < l.tiles; ++t) {
         const uint32_t base = t * kTileNodes;
         const uint32_t m = std::min<uint32_t>(kTileNodes, n - base);
@@ -224,11 +271,30 @@ inline hipError_t indexed_build_host(IndexedSnapshot &s, const IndexedLayout &l,
         for (uint32_t i = 0; i < m; ++i) setbit(l.row_valid, i);
         index_tile_fit(l, t, cpu, mem, T, aux.data() + (size_t)t * kAuxWords);
         // labels
-        for (uint32_t k = 0; k < nkeys; ++k)
+        for (uint32_t k = 0; k < nkeys; ++k) {
+            if (l.lab_base[k] == kLabList) continue;
             for (uint32_t i = 0; i < m; ++i) {
                 const uint32_t id = lab[(size_t)k * n + base + i];
                 if (id) setbit(l.lab_base[k] + id - 1, i);
             }
+        }
+        // list keys: the tile's 1024 slots (padding carries id 0 = absent) ascending by (id, node)
+        for (uint32_t j = 0; j < l.nlist; ++j) {
+            const uint32_t k = l.list_col[j];
+            uint32_t ord[kTileNodes], val[kTileNodes];
+            for (uint32_t i = 0; i < (uint32_t)kTileNodes; ++i) {
+                ord[i] = i;
+                val[i] = i < m ? lab[(size_t)k * n + base + i] : 0u;
+            }
+            std::stable_sort(ord, ord + kTileNodes, [&](uint32_t x, uint32_t y) { return val[x] < val[y]; });
+            uint8_t *L = lists.data() + ((size_t)t * l.nlist + j) * kListBytes;
+            uint32_t *vals = reinterpret_cast<uint32_t *>(L);
+            uint16_t *nodes = reinterpret_cast<uint16_t *>(L + kTileNodes * 4u);
+            for (uint32_t i = 0; i < (uint32_t)kTileNodes; ++i) {
+                vals[i] = val[ord[i]];
+                nodes[i] = (uint16_t)ord[i];
+            }
+        }
         // taints: row (g, s) = nodes whose taint bits of group g are a subset of s
         for (uint32_t g = 0; g < l.ngroups; ++g)
             for (uint32_t i = 0; i < m; ++i) {
@@ -240,6 +306,7 @@ inline hipError_t indexed_build_host(IndexedSnapshot &s, const IndexedLayout &l,
     hipError_t e;
     if ((e = hipMemcpyAsync(s.d_aux, aux.data(), aux.size() * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(s.d_tables, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if (!lists.empty() && (e = hipMemcpyAsync(s.d_list, lists.data(), lists.size(), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // the vectors go out of scope
     return hipSuccess;
 }

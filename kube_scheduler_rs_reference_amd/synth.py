@@ -197,8 +197,10 @@ class Cluster:
 
 
 def make_cluster(P: int, N: int, n_keys: int = 8, n_taints: int = 0, seed: int = 0x5EED0000, attempts: int = 5,
-                 binary_suffixes: bool = False) -> Cluster:
-    """Build the cluster of SURVEY.md section 8d for P pending pods and N nodes."""
+                 binary_suffixes: bool = False, hostname_key: Optional[int] = None) -> Cluster:
+    """Build the cluster of SURVEY.md section 8d for P pending pods and N nodes.
+    hostname_key = k: label key k is kubernetes.io/hostname-like -- every node carries its own value (cardinality N), and the pods
+    that constrain it (same 15 %) each name one node."""
     if not (0 <= n_keys <= len(KEY_CARDINALITY)):
         raise ValueError("n_keys must be 0..16")
     if not (0 <= n_taints <= 64):
@@ -234,6 +236,9 @@ def make_cluster(P: int, N: int, n_keys: int = 8, n_taints: int = 0, seed: int =
 
     c.node_labels = np.zeros((n_keys, N), dtype=np.uint32)
     for k in range(n_keys):
+        if hostname_key is not None and k == hostname_key:
+            c.node_labels[k] = (1 + np.argsort(S(40 + k, N), kind="stable")).astype(np.uint32)  # a permutation: one value per node
+            continue
         has = _bern(S(20 + k, N), 0.9)
         val = 1 + _below(S(40 + k, N), KEY_CARDINALITY[k])
         c.node_labels[k] = np.where(has, val, 0).astype(np.uint32)
@@ -261,7 +266,7 @@ def make_cluster(P: int, N: int, n_keys: int = 8, n_taints: int = 0, seed: int =
     c.pod_sel = np.zeros((n_keys, P), dtype=np.uint32)
     for k in range(n_keys):
         con = _bern(S(300 + k, P), 0.15)
-        val = 1 + _below(S(320 + k, P), KEY_CARDINALITY[k])
+        val = 1 + _below(S(320 + k, P), N if (hostname_key is not None and k == hostname_key and N > 0) else KEY_CARDINALITY[k])
         never = _bern(S(340 + k, P), 0.01)
         c.pod_sel[k] = np.where(con, np.where(never, SEL_NEVER, val), 0).astype(np.uint32)
     c.pod_tol = np.zeros(P, dtype=np.uint64)
@@ -281,6 +286,8 @@ CONFIGS: Dict[str, dict] = {
     "C3": dict(P=100_000, N=5_000, n_keys=8, n_taints=0, flags=("FIT", "SEL")),
     "C4": dict(P=1_000_000, N=10_000, n_keys=8, n_taints=0, flags=("FIT", "SEL")),
     "C5": dict(P=1_000_000, N=50_000, n_keys=8, n_taints=16, flags=("FIT", "SEL", "TAINT")),
+    # C3 with its eighth label key replaced by a hostname-like key (5 000 values): the high-cardinality case (not a BASELINE config)
+    "C3h": dict(P=100_000, N=5_000, n_keys=8, n_taints=0, flags=("FIT", "SEL"), hostname_key=7),
 }
 
 
@@ -288,4 +295,4 @@ def make_config(name: str, P: Optional[int] = None, N: Optional[int] = None) -> 
     cfg = CONFIGS[name]
     idx = list(CONFIGS).index(name)
     return make_cluster(P if P is not None else cfg["P"], N if N is not None else cfg["N"], n_keys=cfg["n_keys"],
-                        n_taints=cfg["n_taints"], seed=0x5EED0000 + idx)
+                        n_taints=cfg["n_taints"], seed=0x5EED0000 + idx, hostname_key=cfg.get("hostname_key"))

@@ -320,30 +320,31 @@ def test_snapshot_replacement(evaluator):
 
 
 def test_auto_prefers_fused_and_falls_back(evaluator):
-    """auto = fused when the snapshot fits the LDS index, direct otherwise (huge sparse label ids)."""
+    """auto = fused when the snapshot has a bitmap index; keys whose ids are too many / too sparse for one bitmap row per id become
+    lists (up to two); only a third such key leaves no index and auto falls back to the direct kernel."""
     ev = evaluator
     ev.set_kernel("auto")
     c = synth.make_cluster(200, 300, n_keys=8, n_taints=16, seed=3)
     check(ev, c, FIT | SEL | TAINT)
     assert ev.last_kernel == "fused"
-    # label ids far too sparse for one bitmap row per id: the bitmap index is not built
     rng = np.random.default_rng(1)
     N, P = 300, 100
-    lab = rng.integers(1, 4_000_000, size=(2, N)).astype(np.uint32)
-    sel = np.zeros((2, P), dtype=np.uint32)
-    sel[0, ::3] = lab[0, rng.integers(0, N, size=len(sel[0, ::3]))]
     big = np.full(N, 1 << 40, dtype=np.int64)
     zero = np.zeros(P, dtype=np.int64)
-    ev.set_nodes(big, big, lab)
-    r = ev.eval(zero, zero, sel, flags=FIT | SEL)
-    assert ev.last_kernel == "direct"
-    feas, _, _ = capi.eval_encoded(big, big, lab, None, zero, zero, sel, None, None, capi.FIT | capi.SEL)
-    assert np.array_equal(r.feasible, feas)
-    for forced in ("fused",):
-        ev.set_kernel(forced)
-        with pytest.raises(KschedError) as e:
-            ev.eval(zero, zero, sel, flags=FIT | SEL)
-        assert e.value.code == _lib.E_UNSUPPORTED
+    for n_sparse, expect in ((2, "fused"), (3, "direct")):
+        lab = rng.integers(1, 4_000_000, size=(n_sparse, N)).astype(np.uint32)
+        sel = np.zeros((n_sparse, P), dtype=np.uint32)
+        sel[0, ::3] = lab[0, rng.integers(0, N, size=len(sel[0, ::3]))]
+        sel[n_sparse - 1, ::4] = lab[n_sparse - 1, rng.integers(0, N, size=len(sel[0, ::4]))]
+        ev.set_nodes(big, big, lab)
+        r = ev.eval(zero, zero, sel, flags=FIT | SEL)
+        assert ev.last_kernel == expect
+        feas, _, _ = capi.eval_encoded(big, big, lab, None, zero, zero, sel, None, None, capi.FIT | capi.SEL)
+        assert np.array_equal(r.feasible, feas)
+    ev.set_kernel("fused")
+    with pytest.raises(KschedError) as e:
+        ev.eval(zero, zero, sel, flags=FIT | SEL)
+    assert e.value.code == _lib.E_UNSUPPORTED
     ev.set_kernel("auto")
 
 
