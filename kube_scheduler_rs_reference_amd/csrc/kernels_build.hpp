@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "kernels_direct.hpp"
 #include "tile_index.hpp"
 
 namespace ksched {
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(1024) void k_build_tile_named(const BuildNamedArgs 
 // ---- ksched_update_nodes ------------------------------------------------------------------------------------------------
 constexpr uint32_t kPatchInline = 16;  // updates of up to this many nodes travel in the kernel arguments (no copy, no staging)
 struct PatchArgs {
-    int64_t *ncpu, *nmem, *ncm;  // columns; ncm = [n][2] interleaved
+    int64_t *ncpu, *nmem, *nrec;  // columns; nrec = [n][kNodeRecWords] node records (kernels_direct.hpp): words 0, 1 = cpu, mem
     const uint32_t *idx;         // device arrays for count > kPatchInline, else nullptr
     const int64_t *cpu, *mem;
     uint32_t count;
@@ -236,8 +237,8 @@ __global__ __launch_bounds__(256) void k_patch_nodes(const PatchArgs a) {
     }
     a.ncpu[node] = c;
     a.nmem[node] = m;
-    a.ncm[2 * (size_t)node] = c;
-    a.ncm[2 * (size_t)node + 1] = m;
+    a.nrec[(size_t)kNodeRecWords * node] = c;
+    a.nrec[(size_t)kNodeRecWords * node + 1] = m;
 }
 
 struct TileListArgs {
@@ -249,12 +250,21 @@ __global__ void k_write_tile_list(const TileListArgs a) {
     if (threadIdx.x < a.count) a.out[threadIdx.x] = a.tiles[threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void k_interleave_cm(const int64_t *__restrict__ cpu, const int64_t *__restrict__ mem, int64_t *__restrict__ cm, uint32_t n) {
+// node records (kernels_direct.hpp "Node records"): one 64-byte line per node for the candidate-testing picks
+__global__ __launch_bounds__(256) void k_build_nrec(const int64_t *__restrict__ cpu, const int64_t *__restrict__ mem, const uint64_t *__restrict__ taints,
+                                                    const uint32_t *__restrict__ lab, uint32_t nkeys, int64_t *__restrict__ rec, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        cm[2 * (size_t)i] = cpu[i];
-        cm[2 * (size_t)i + 1] = mem[i];
-    }
+    if (i >= n) return;
+    uint32_t l[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) l[k] = k < nkeys ? lab[(size_t)k * n + i] : 0u;
+    int64_t *r = rec + (size_t)kNodeRecWords * i;
+    r[0] = cpu[i];
+    r[1] = mem[i];
+    r[2] = taints ? (int64_t)taints[i] : 0;
+    r[3] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) r[4 + k] = (int64_t)(((uint64_t)l[2 * k + 1] << 32) | l[2 * k]);
 }
 
 // ---- best-fit structures, after the two device sorts ------------------------------------------------------

@@ -190,10 +190,16 @@ __global__ __launch_bounds__(256) void k_pick_sampled(const uint64_t *__restrict
 // pass are loaded together: two dependent memory round trips per pass).  (Running this inside the fused
 // mask kernel's staging wait was tried: its ~50 registers per lane spill there and its scattered gathers
 // compete with the staging DMA for the texture-address unit -- the mask kernel grew by 10 us.)
+// Node records for the picks that test single candidates: everything check_node_validity reads about ONE node in ONE 64-byte
+// line -- a drawn candidate costs one cache-line request instead of one per column it touches (it was 1 + one per constrained key
+// + 1 with taints: up to ten scattered lines per candidate; profiles/r01_h5_sq_counters_C3.json showed the kernel waiting on them
+// for half of its cycles).  16-byte units: [0] {avail_cpu, avail_mem}  [1] {taints, 0}  [2] label ids of keys 0..3  [3] of keys 4..7.
+// Keys beyond the eighth stay in the label columns (read only when a pod constrains them).
+constexpr uint32_t kNodeRecWords = 8;  // int64 words per record
+
 struct SelectArgs {
-    const int64_t *ncm;           // node columns interleaved: [n][2] = {avail_cpu, avail_mem} (one 16-byte gather per candidate)
-    const uint32_t *nlab;         // [nkeys][n]
-    const uint64_t *ntaint;       // [n] or nullptr
+    const int64_t *nrec;          // [n][kNodeRecWords] node records
+    const uint32_t *nlab;         // [nkeys][n] (keys >= 8 only)
     const int64_t *pcpu, *pmem;   // pod columns [p]
     const uint32_t *psel;         // [nkeys][p] or nullptr
     const uint64_t *ptol;         // [p] or nullptr
@@ -202,76 +208,80 @@ struct SelectArgs {
     uint32_t p, n, nkeys, attempts, do_fit, do_taint;
 };
 
-template <int ATT>
+// ATT = draws handled per pass; the first EAGER of them are fetched and tested at once, the rest only by the lanes that are
+// still undecided (with ~40 % of the draws feasible most pods are decided after two: src/main.rs:53-66 stops at the first Ok too).
+template <int ATT, int EAGER>
 __device__ __forceinline__ int32_t select_one_pod(const SelectArgs &a, uint32_t pod) {
-    // the arrays are global memory: say so (pointers that arrive in a by-value struct are generic to the compiler, and the
-    // fused kernel, which also juggles LDS pointers, would emit flat loads with aperture checks)
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define KSCHED_G(T, P) ((const __attribute__((address_space(1))) T *)(P))
-    struct {
-        const __attribute__((address_space(1))) i64x2 *ncm;
-        const __attribute__((address_space(1))) uint32_t *nlab, *psel, *samples;
-        const __attribute__((address_space(1))) uint64_t *ntaint, *ptol;
-        const __attribute__((address_space(1))) int64_t *pcpu, *pmem;
-        uint32_t p, n, nkeys, attempts, do_fit, do_taint;
-    } q = {KSCHED_G(i64x2, a.ncm), KSCHED_G(uint32_t, a.nlab), KSCHED_G(uint32_t, a.psel), KSCHED_G(uint32_t, a.samples),
-           KSCHED_G(uint64_t, a.ntaint), KSCHED_G(uint64_t, a.ptol), KSCHED_G(int64_t, a.pcpu), KSCHED_G(int64_t, a.pmem),
-           a.p, a.n, a.nkeys, a.attempts, a.do_fit, a.do_taint};
+    const __attribute__((address_space(1))) i64x2 *rec2 = KSCHED_G(i64x2, a.nrec);
+    const __attribute__((address_space(1))) u32x4 *rec4 = KSCHED_G(u32x4, a.nrec);
+    const __attribute__((address_space(1))) uint32_t *nlab = KSCHED_G(uint32_t, a.nlab), *psel = KSCHED_G(uint32_t, a.psel);
+    const __attribute__((address_space(1))) uint32_t *smp = KSCHED_G(uint32_t, a.samples) + (size_t)pod * a.attempts;
+    const int64_t rc = a.do_fit ? KSCHED_G(int64_t, a.pcpu)[pod] : 0, rm = a.do_fit ? KSCHED_G(int64_t, a.pmem)[pod] : 0;
+    const uint64_t tol = (a.do_taint && a.ptol) ? KSCHED_G(uint64_t, a.ptol)[pod] : 0ull;
 #undef KSCHED_G
-    const __attribute__((address_space(1))) uint32_t *smp = q.samples + (size_t)pod * q.attempts;
-    const int64_t rc = q.do_fit ? q.pcpu[pod] : 0, rm = q.do_fit ? q.pmem[pod] : 0;
-    const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
-    // the pod's selector ids of the first eight keys in registers; further keys are re-read per candidate (rare)
     uint32_t sel[8];
 #pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) sel[k] = (q.psel && k < q.nkeys) ? q.psel[(size_t)k * q.p + pod] : 0u;
-    int32_t b = -1;
-    for (uint32_t i0 = 0; i0 < q.attempts && b < 0; i0 += ATT) {
-        uint32_t s[ATT];
-        bool ok[ATT];
-#pragma unroll
-        for (int j = 0; j < ATT; ++j) {
-            s[j] = (i0 + j < q.attempts) ? smp[i0 + j] : 0xFFFFFFFFu;
-            ok[j] = s[j] < q.n;  // an index >= n is an infeasible draw (include/ksched.h)
-        }
-        // Scattered gathers cost one cache-line request per distinct line: the fit columns come interleaved (one
-        // 16-byte gather instead of two), and the lanes that do not constrain a key all read the SAME word (one line)
-        // instead of being masked off -- the compiler would otherwise turn the masked load into an unconditional
-        // scattered one.
-        i64x2 acm[ATT];
-        uint64_t nt[ATT];
-        uint32_t nl[ATT][8];
-#pragma unroll
-        for (int j = 0; j < ATT; ++j) {
-            const uint32_t node = ok[j] ? s[j] : 0u;
-            acm[j] = q.do_fit ? q.ncm[node] : i64x2{0, 0};
-            nt[j] = (q.do_taint && q.ntaint) ? q.ntaint[node] : 0ull;
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) nl[j][k] = (k < q.nkeys) ? q.nlab[(sel[k] != 0u) ? (size_t)k * q.n + node : (size_t)0] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < ATT; ++j) {
-            bool f = ok[j];
-            if (q.do_fit) f = f && rc <= acm[j].x && rm <= acm[j].y;
-            if (q.do_taint) f = f && (nt[j] & ~tol) == 0ull;
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) f = f && (sel[k] == 0u || sel[k] == nl[j][k]);
-            if (f && q.nkeys > 8u) {
-                for (uint32_t k = 8; k < q.nkeys; ++k) {
-                    const uint32_t want = q.psel[(size_t)k * q.p + pod];
-                    if (want != 0u && want != q.nlab[(size_t)k * q.n + s[j]]) f = false;
-                }
+    for (uint32_t k = 0; k < 8; ++k) sel[k] = (a.psel && k < a.nkeys) ? psel[(size_t)k * a.p + pod] : 0u;
+    const bool want_lo = (sel[0] | sel[1] | sel[2] | sel[3]) != 0u, want_hi = (sel[4] | sel[5] | sel[6] | sel[7]) != 0u;
+    bool want_more = false;  // a constraint on a key beyond the eighth
+    if (a.psel)
+        for (uint32_t k = 8; k < a.nkeys; ++k) want_more |= psel[(size_t)k * a.p + pod] != 0u;
+
+    // check_node_validity(pod, node) (src/predicates.rs:63-77) from the node's record; units the pod does not need are not fetched
+    struct Cand {
+        i64x2 cm, tt;
+        u32x4 lo, hi;
+    };
+    auto fetch = [&](uint32_t node, Cand &c) {
+        if (a.do_fit) c.cm = rec2[(size_t)node * 4u];
+        if (a.do_taint) c.tt = rec2[(size_t)node * 4u + 1u];
+        if (want_lo) c.lo = rec4[(size_t)node * 4u + 2u];
+        if (want_hi) c.hi = rec4[(size_t)node * 4u + 3u];
+    };
+    auto passes = [&](uint32_t node, const Cand &c) -> bool {
+        bool f = true;
+        if (a.do_fit) f = rc <= c.cm.x && rm <= c.cm.y;                      // src/predicates.rs:42
+        if (a.do_taint) f = f && ((uint64_t)c.tt.x & ~tol) == 0ull;
+        if (want_lo) f = f && (sel[0] == 0u || sel[0] == c.lo.x) && (sel[1] == 0u || sel[1] == c.lo.y) && (sel[2] == 0u || sel[2] == c.lo.z) &&
+                         (sel[3] == 0u || sel[3] == c.lo.w);                  // src/predicates.rs:48-57
+        if (want_hi) f = f && (sel[4] == 0u || sel[4] == c.hi.x) && (sel[5] == 0u || sel[5] == c.hi.y) && (sel[6] == 0u || sel[6] == c.hi.z) &&
+                         (sel[7] == 0u || sel[7] == c.hi.w);
+        if (f && want_more)
+            for (uint32_t k = 8; k < a.nkeys; ++k) {
+                const uint32_t want = psel[(size_t)k * a.p + pod];
+                if (want != 0u && want != nlab[(size_t)k * a.n + node]) f = false;
             }
-            if (b < 0 && f) b = (int32_t)s[j];  // first feasible draw wins (src/main.rs:61-65)
+        return f;
+    };
+    int32_t b = -1;
+    for (uint32_t i0 = 0; i0 < a.attempts && b < 0; i0 += ATT) {
+        uint32_t s[ATT];
+#pragma unroll
+        for (int j = 0; j < ATT; ++j) s[j] = (i0 + j < a.attempts) ? smp[i0 + j] : 0xFFFFFFFFu;
+        Cand c[ATT];
+#pragma unroll
+        for (int j = 0; j < EAGER; ++j) fetch(s[j] < a.n ? s[j] : 0u, c[j]);  // an index >= n is an infeasible draw (include/ksched.h)
+#pragma unroll
+        for (int j = 0; j < EAGER; ++j)
+            if (b < 0 && s[j] < a.n && passes(s[j], c[j])) b = (int32_t)s[j];  // first feasible draw wins (src/main.rs:61-65)
+        if (b < 0) {  // the undecided lanes only: their remaining draws of the pass, fetched together
+#pragma unroll
+            for (int j = EAGER; j < ATT; ++j) fetch(s[j] < a.n ? s[j] : 0u, c[j]);
+#pragma unroll
+            for (int j = EAGER; j < ATT; ++j)
+                if (b < 0 && s[j] < a.n && passes(s[j], c[j])) b = (int32_t)s[j];
         }
     }
     return b;
 }
 
-template <int ATT>
+template <int ATT, int EAGER>
 __global__ __launch_bounds__(256) void k_select_sampled(const SelectArgs q) {
     const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pod < q.p) q.binding[pod] = select_one_pod<ATT>(q, pod);
+    if (pod < q.p) q.binding[pod] = select_one_pod<ATT, EAGER>(q, pod);
 }
 
 // check_node_validity for a list of (pod, node) pairs, with the REASON: what the reference logs at WARN for every rejected
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(256) void k_select_sampled(const SelectArgs q) {
 // (src/predicates.rs:68-70), then the selector (:72-74), then the taint extension (E2).  One lane per pair, straight from
 // the columns (same compares as k_select_sampled).  Unlike two masks, this tells selector and taint failures apart.
 struct ExplainArgs {
-    const int64_t *ncm;           // [n][2] = {avail_cpu, avail_mem}
+    const int64_t *nrec;          // [n][kNodeRecWords] node records (cpu, mem in words 0, 1)
     const uint32_t *nlab;         // [nkeys][n]
     const uint64_t *ntaint;       // [n] or nullptr
     const int64_t *pcpu, *pmem;   // [p]
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(256) void k_explain_pairs(const ExplainArgs q) {
     if (i >= q.count) return;
     const uint32_t pod = q.pair_pod[i], node = q.pair_node[i];
     int32_t r = KSCHED_REASON_OK;
-    if (q.do_fit && !(q.pcpu[pod] <= q.ncm[2 * (size_t)node] && q.pmem[pod] <= q.ncm[2 * (size_t)node + 1])) {
+    if (q.do_fit && !(q.pcpu[pod] <= q.nrec[(size_t)kNodeRecWords * node] && q.pmem[pod] <= q.nrec[(size_t)kNodeRecWords * node + 1])) {
         r = KSCHED_REASON_NOT_ENOUGH_RESOURCES;  // src/predicates.rs:42,68-70
     } else {
         if (q.psel)

@@ -62,7 +62,7 @@ struct ksched_ctx {
     uint32_t n = 0, nkeys = 0, W = 0;
     bool have_taints = false;
     DevBuf<int64_t> ncpu, nmem;
-    DevBuf<int64_t> ncm;  // {avail_cpu, avail_mem} interleaved per node (k_select_sampled: one 16-byte gather per candidate)
+    DevBuf<int64_t> nrec;  // 64-byte node records (kernels_direct.hpp): one cache line per candidate for the candidate-testing picks
     DevBuf<uint32_t> nlab;
     DevBuf<uint64_t> ntaint;
     DevBuf<uint32_t> bf_order, bf_rank;
@@ -495,9 +495,8 @@ SelectArgs make_select_args(const ksched_ctx *c, uint32_t p, const int64_t *pcpu
     const bool sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
     const bool taint = (flags & KSCHED_TAINT) && c->have_taints;
     SelectArgs q{};
-    q.ncm = c->ncm.ptr;
+    q.nrec = c->nrec.ptr;
     q.nlab = c->nlab.ptr;
-    q.ntaint = taint ? c->ntaint.ptr : nullptr;
     q.pcpu = pcpu;
     q.pmem = pmem;
     q.psel = sel ? psel : nullptr;
@@ -518,8 +517,15 @@ int launch_select(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t 
                   const uint32_t *samples, uint32_t attempts, uint32_t flags, int32_t *out_binding, hipStream_t s) {
     const SelectArgs q = make_select_args(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_binding);
     const dim3 grid((p + 255) / 256), block(256);
-    if (attempts <= 5) hipLaunchKernelGGL(k_select_sampled<5>, grid, block, 0, s, q);
-    else hipLaunchKernelGGL(k_select_sampled<8>, grid, block, 0, s, q);
+    if (attempts <= 5) {
+        switch ((c->opt_debug >> 8) & 3u) {  // KSCHED_OPT_DEBUG bits 8-9: A/B of the number of eagerly fetched draws (tools/)
+            case 1: hipLaunchKernelGGL((k_select_sampled<5, 3>), grid, block, 0, s, q); break;
+            case 2: hipLaunchKernelGGL((k_select_sampled<5, 5>), grid, block, 0, s, q); break;
+            case 3: hipLaunchKernelGGL((k_select_sampled<5, 1>), grid, block, 0, s, q); break;
+            default: hipLaunchKernelGGL((k_select_sampled<5, 2>), grid, block, 0, s, q);
+        }
+    }
+    else hipLaunchKernelGGL((k_select_sampled<8, 2>), grid, block, 0, s, q);
     HIPCHK(c, hipGetLastError());
     return KSCHED_OK;
 }
@@ -707,7 +713,7 @@ void ksched_destroy(ksched_ctx *c) {
     {
         DeviceGuard g(c->device);
         (void)hipDeviceSynchronize();
-        c->ncpu.release(); c->nmem.release(); c->ncm.release(); c->nlab.release(); c->ntaint.release();
+        c->ncpu.release(); c->nmem.release(); c->nrec.release(); c->nlab.release(); c->ntaint.release();
         c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release(); c->bf_cpu.release(); c->cpu_sorted.release(); c->bf_rows.release(); c->bf_samples.release();
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
         c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release(); c->xpairs.release(); c->xreason.release();
@@ -806,7 +812,7 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     c->idx.built = false;
     HIPCHK(c, c->ncpu.reserve(n));
     HIPCHK(c, c->nmem.reserve(n));
-    HIPCHK(c, c->ncm.reserve((size_t)n * 2));
+    HIPCHK(c, c->nrec.reserve((size_t)n * kNodeRecWords));
     HIPCHK(c, c->nlab.reserve((size_t)n * n_keys));
     HIPCHK(c, c->ntaint.reserve(n));
     HIPCHK(c, c->bf_order.reserve(n));
@@ -829,7 +835,8 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
         if (b_lab) HIPCHK(c, hipMemcpyAsync(c->nlab.ptr, h + 2 * b_col, b_lab, hipMemcpyHostToDevice, s));
         if (b_taint) HIPCHK(c, hipMemcpyAsync(c->ntaint.ptr, h + 2 * b_col + b_lab, b_taint, hipMemcpyHostToDevice, s));
         HIPCHK(c, hipEventRecord(c->ev_stage, s));
-        hipLaunchKernelGGL(k_interleave_cm, dim3((n + 255u) / 256u), dim3(256), 0, s, (const int64_t *)c->ncpu.ptr, (const int64_t *)c->nmem.ptr, c->ncm.ptr, n);
+        hipLaunchKernelGGL(k_build_nrec, dim3((n + 255u) / 256u), dim3(256), 0, s, (const int64_t *)c->ncpu.ptr, (const int64_t *)c->nmem.ptr,
+                           taints ? (const uint64_t *)c->ntaint.ptr : nullptr, (const uint32_t *)c->nlab.ptr, n_keys, c->nrec.ptr, n);
         HIPCHK(c, hipGetLastError());
     }
     // the per-tile bitmap index: layout on the host (it fixes kernel arguments and LDS sizes), contents on the device
@@ -895,7 +902,7 @@ int ksched_update_nodes(ksched_ctx *c, uint32_t count, const uint32_t *node_inde
     PatchArgs pa{};
     pa.ncpu = c->ncpu.ptr;
     pa.nmem = c->nmem.ptr;
-    pa.ncm = c->ncm.ptr;
+    pa.nrec = c->nrec.ptr;
     pa.count = m;
     const uint32_t *d_tiles = nullptr;
     const bool want_tiles = c->idx.built;
@@ -1043,11 +1050,12 @@ int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t 
     // best fit: bitmaps kept in best-fit order), so the two streams need no ordering at all: each is in order by itself
     // (mask kernels of successive batches on one, picks on the other), which also covers the reuse of a slot's buffers.
     const bool pick_reads_mask = c->opt_pick_from_mask || ((pick & KSCHED_PICK_BESTFIT) && !bf_rows_expected(c));
-    if (pick_reads_mask) HIPCHK(c, hipStreamWaitEvent(q->s_mask, q->pick_done[slot], 0));  // the slot's mask may be overwritten once its pick has run
-    rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, nullptr, 0, flags & ~pick, mask, nullptr, nullptr, mask_pitch_words, q->s_mask);
+    hipStream_t sm = q->s_mask;
+    if (pick_reads_mask) HIPCHK(c, hipStreamWaitEvent(sm, q->pick_done[slot], 0));  // the slot's mask may be overwritten once its pick has run
+    rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, nullptr, 0, flags & ~pick, mask, nullptr, nullptr, mask_pitch_words, sm);
     if (rc) return rc;
     if (pick_reads_mask) {
-        HIPCHK(c, hipEventRecord(q->mask_done[slot], q->s_mask));
+        HIPCHK(c, hipEventRecord(q->mask_done[slot], sm));
         HIPCHK(c, hipStreamWaitEvent(q->s_pick, q->mask_done[slot], 0));
         if (p > 0) {
             if (c->n == 0) HIPCHK(c, hipMemsetAsync(binding, 0xFF, (size_t)p * sizeof(int32_t), q->s_pick));
@@ -1205,7 +1213,7 @@ int ksched_explain(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     HIPCHK(c, hipMemcpyAsync(c->xpairs.ptr, pair_pod, (size_t)count * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->xpairs.ptr + count, pair_node, (size_t)count * 4, hipMemcpyHostToDevice, s));
     ExplainArgs q{};
-    q.ncm = c->ncm.ptr;
+    q.nrec = c->nrec.ptr;
     q.nlab = c->nlab.ptr;
     q.ntaint = use_taint ? c->ntaint.ptr : nullptr;
     q.pcpu = c->pcpu.ptr;
