@@ -47,11 +47,11 @@ if has pmc; then
   timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -o p -- $REPO/tools/pmc_calib > $OUT/calib_fetch.log 2>&1
   timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -o p -- $REPO/tools/pmc_calib > $OUT/calib_write.log 2>&1
   for wl in ${PMC_WLS:-C3 C4s}; do
-    timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${wl}_fetch -o p -- python $REPO/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${wl}_fetch.log 2>&1
-    timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${wl}_write -o p -- python $REPO/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${wl}_write.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${wl}_fetch -o p -- python $REPO/bench.py --workload $wl --steps 10 --warmup 2 --ramp-ms 0 --kernel-samples 2 --no-cpu-baseline > $OUT/${wl}_fetch.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${wl}_write -o p -- python $REPO/bench.py --workload $wl --steps 10 --warmup 2 --ramp-ms 0 --kernel-samples 2 --no-cpu-baseline > $OUT/${wl}_write.log 2>&1
   done
   # a third pass: SQ activity of the mask kernel (VALU / LDS / wait split) on the default workload
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/C3_sq -o p -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/C3_sq.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/C3_sq -o p -- python $REPO/bench.py --steps 10 --warmup 2 --ramp-ms 0 --kernel-samples 2 --no-cpu-baseline > $OUT/C3_sq.log 2>&1
   cd $REPO
   python tools/pmc_traffic.py $OUT ${PMC_WLS:-C3 C4s} > $OUT/pmc_traffic.log 2>&1; tail -30 $OUT/pmc_traffic.log
   # drop the bulky raw traces, keep the counter csvs

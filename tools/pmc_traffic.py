@@ -78,8 +78,9 @@ def main():
                 rec["write_bytes"] = wr * cal["write_tile128_bytes_per_count"]
                 rec["hbm_bytes_per_launch"] = rec["fetch_bytes"] + rec["write_bytes"]
             res[f"{wl}:{short}"] = rec
+    res["_session"] = "session " + os.path.basename(os.path.normpath(out_dir))
     json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps({k: v for k, v in res.items() if k != "calibration"}, indent=1))
+    print(json.dumps({k: v for k, v in res.items() if k not in ("calibration", "_session")}, indent=1))
     print("calibration:", {k: v for k, v in cal.items() if k != "raw"})
 
 
