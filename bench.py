@@ -347,6 +347,32 @@ def main():
         alt = {"value": float(P_total) * N * args.steps / e_alt, "ms_per_step": e_alt / args.steps * 1e3, "steps": args.steps}
         loop_alt.close()
 
+    # ---- N > 1, reference point: this rank's own shard with NO exchange (same kernels, same pipe, no collective), K steps ------
+    # per-GPU rate of the same workload without the all-gather: value / (N x min over ranks of this) is the cost of the exchange
+    solo = None
+    if multi and pipelined:
+        loop.drain()
+        k_steps = [None]
+        def solo_steps(n):
+            for j in range(n):
+                if loop.pipe is not None:
+                    k_steps[0](j % (depth * loop.G))
+                else:
+                    loop.step()
+        if loop.pipe is not None:
+            outs = [loop.sched.binding_buffer(k, g) for k in range(depth) for g in range(loop.G)]
+            k_steps[0] = loop.pipe.bind(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, loop.masks, outs)
+            solo_steps(32)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            solo_steps(args.steps)
+            torch.cuda.synchronize()
+            e_solo = time.perf_counter() - t2
+            ts = torch.tensor([e_solo], dtype=torch.float64, device=dev)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            solo = {"per_gpu_value_max_time": float(hi - lo) * N * args.steps / float(ts.item()), "ms_per_step": float(ts.item()) / args.steps * 1e3,
+                    "note": "each rank alone: the same ksched_pipe steps on its shard, no all-gather; slowest rank"}
+
     # sanity inside the bench: the fraction of pods the last timed step bound (a degenerate workload would show 0 or 1)
     bound_frac = float((bindings >= 0).float().mean().item())
 
@@ -379,7 +405,7 @@ def main():
                        "kernel": ev.last_kernel, "steps_in_flight": depth if pipelined else 1, "two_stream": pipe is not None,
                        "steps_per_allgather": gather_every if (pipelined and multi) else (1 if multi else None),
                        "allgather": (("torch.distributed.all_gather_into_tensor" if args.torch_gather else "ksched_allgather_bindings (C ABI, ncclAllGather on the pick's stream)") if multi else None),
-                       "allgather_every_4": alt,
+                       "allgather_every_4": alt, "no_allgather": solo,
                        "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
                        "allgather(int32 bindings)" if world > 1 else "single GPU",
                        "bound_fraction": bound_frac,
