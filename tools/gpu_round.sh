@@ -59,8 +59,8 @@ if has pmc; then
 fi
 if has lines; then
   stamp "bench lines of the other workloads"
-  for wl in ${LINE_WLS:-C2 C4s C5s}; do
-    timeout 600 python bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_${wl}.json
+  for wl in ${LINE_WLS:-C2 C3h C4s C5s}; do
+    timeout 600 python bench.py --workload $wl --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_${wl}.json
     python - <<PY
 import json
 try:
