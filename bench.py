@@ -198,7 +198,23 @@ def main():
         # N > 1 default: ksched_pipe -- mask kernels on one stream; pick -> all-gather -> pick -> ... on the other.  The gather is
         # ordered behind its pick by the stream itself (no event per step) and overlaps the next batches' mask kernels.
         args.two_stream = True
-    comm = AbiComm(ev) if (multi and not args.torch_gather) else None  # ksched_comm_create: the C ABI's RCCL communicator
+    comm, comm_note = None, None
+    if multi and not args.torch_gather:
+        # ksched_comm_create: the C ABI's RCCL communicator.  Its creation is collective; if it fails on ANY rank (e.g. no usable
+        # librccl for dlopen) every rank falls back to torch's collective together, and the JSON line says so.
+        try:
+            comm = AbiComm(ev)
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            comm, ok, comm_note = None, 0, f"AbiComm failed on rank {rank}: {e}"
+        okt = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            comm_note = comm_note or "AbiComm failed on another rank"
+            args.torch_gather = True
     lo, hi, _ = shard_bounds(P_total, world, rank)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
     d_cpu, d_mem = t(c.req_cpu[lo:hi], np.int64), t(c.req_mem[lo:hi], np.int64)
@@ -405,7 +421,7 @@ def main():
                        "kernel": ev.last_kernel, "steps_in_flight": depth if pipelined else 1, "two_stream": pipe is not None,
                        "steps_per_allgather": gather_every if (pipelined and multi) else (1 if multi else None),
                        "allgather": (("torch.distributed.all_gather_into_tensor" if args.torch_gather else "ksched_allgather_bindings (C ABI, ncclAllGather on the pick's stream)") if multi else None),
-                       "allgather_every_4": alt, "no_allgather": solo,
+                       "allgather_every_4": alt, "no_allgather": solo, "allgather_fallback": comm_note,
                        "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
                        "allgather(int32 bindings)" if world > 1 else "single GPU",
                        "bound_fraction": bound_frac,
