@@ -286,6 +286,9 @@ def main():
         return loop.step()
 
     def sync():
+        # drain this rank's streams first (so the barrier's collective never interleaves with all-gathers still in flight on the
+        # ABI's communicator), then barrier + synchronize
+        torch.cuda.synchronize()
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
