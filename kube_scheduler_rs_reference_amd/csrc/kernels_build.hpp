@@ -343,6 +343,27 @@ __global__ __launch_bounds__(256) void k_bf_rows(const BfRowsArgs a) {
     }
 }
 
+// 8-ary level arrays of the two sorted columns (k_pick_bestfit_lanes): level k, entry j = last element of block j of 8^k entries
+struct BfLevelsArgs {
+    const int64_t *bf_mem, *cpu_sorted;
+    int64_t *lvl;
+    uint32_t n, nlev, lvl_half, lvl_off[6];
+};
+__global__ __launch_bounds__(256) void k_bf_levels(const BfLevelsArgs a) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t span = 1;
+    uint32_t nk = a.n;
+    for (uint32_t k = 1; k <= a.nlev; ++k) {
+        span *= 8u;
+        nk = (nk + 7u) / 8u;
+        if (t < nk) {
+            const uint32_t src = (uint32_t)min((uint64_t)a.n, (uint64_t)(t + 1u) * span) - 1u;
+            a.lvl[a.lvl_off[k - 1u] + t] = a.bf_mem[src];
+            a.lvl[a.lvl_half + a.lvl_off[k - 1u] + t] = a.cpu_sorted[src];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_iota(uint32_t *out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = i;

@@ -414,6 +414,14 @@ struct BestfitRowsArgs {
     int32_t *binding;
     uint32_t p, n, Wbf, nkeys, ngroups, row_valid, row_zero, row_taint, row_cpu0, q, do_fit, do_taint;
     uint32_t lab_base8[8], lab_max8[8];  // the first eight keys' row numbers as arguments (no dependent load)
+    // second stage of the two-stage pick (k_pick_bestfit_lanes): only the listed pods, count read from device memory
+    const uint32_t *pod_list, *pod_count;
+    // 8-ary level arrays of bf_mem / cpu_sorted for the lane-per-pod searches: level k (1..nlev) holds the last element of every
+    // block of 8^k entries; [mem level 1][mem level 2]...[cpu level 1]...; lvl_off[k - 1] = offset of level k inside one half
+    const int64_t *lvl;
+    uint32_t nlev, lvl_half, lvl_off[6];
+    uint32_t *fallback_list, *fallback_count;
+    uint32_t lane_words;  // candidate words (64 positions each) a lane looks at before handing the pod over
 };
 
 // first i in [0, n) with arr[i] >= key (n if none), by the whole wave: 64-ary search, three rounds for n <= 262144
@@ -555,10 +563,112 @@ __device__ __forceinline__ int32_t bestfit_rows_one_pod(const BestfitRowsArgs &q
 // launches or memory latency, and the short-lived waves balance better.)
 __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs q) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t pod = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q.pod_list) {  // second stage of the two-stage pick: the pods the lane-per-pod kernel could not decide in its first words
+        // (one short-lived wave per listed pod, the grid sized for the worst case: waves beyond the count exit at once; a persistent
+        // grid walking the list was measured slower, like the persistent form of the one-stage kernel)
+        if (wave >= *q.pod_count) return;
+        const uint32_t pod = q.pod_list[wave];
+        const int32_t b = bestfit_rows_one_pod(q, pod, lane);
+        if (lane == 0) q.binding[pod] = b;
+        return;
+    }
+    if (wave >= q.p) return;
+    const int32_t b = bestfit_rows_one_pod(q, wave, lane);
+    if (lane == 0) q.binding[wave] = b;
+}
+
+// Best fit, first stage, ONE LANE PER POD.  The wave-per-pod kernel above spends a whole wave's chain of dependent round trips on
+// every pod (rank searches -> rows -> winner; 135 us for 125k pods at the C5 shard, occupancy x latency bound), although the
+// answer almost always sits in the first word of candidates: the pick is the first set bit, at or after `start`, of the AND of a
+// few row words.  Here a lane does the whole pod: two interleaved 8-ary searches over level arrays (each round reads one 64-byte
+// line per search: six dependent rounds for n <= 262144), then the row words at `start`'s word and the next one.  A pod with no
+// feasible candidate among those <= 128 positions is appended to a list for the wave-per-pod kernel (well under 1 % of the pods).
+// Same result as the wave-per-pod kernel by construction: both take the first position >= start whose bits are set in every row
+// the pod ANDs and whose cpu fits.
+__global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArgs q) {
+    const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
     if (pod >= q.p) return;
-    const int32_t b = bestfit_rows_one_pod(q, pod, lane);
-    if (lane == 0) q.binding[pod] = b;
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    const int64_t req_c = q.do_fit ? q.pcpu[pod] : 0, req_m = q.do_fit ? q.pmem[pod] : 0;
+    const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
+    uint32_t sel[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) sel[k] = (q.psel && k < q.nkeys) ? q.psel[(size_t)k * q.p + pod] : 0u;
+    uint32_t start = 0, r = 0;
+    if (q.do_fit) {
+        // lower bounds of req_m in bf_mem and of req_c in cpu_sorted, level by level from the top (block = 8 entries = one line)
+        auto count8 = [](const int64_t *a, uint32_t base, uint32_t limit, int64_t key) -> uint32_t {
+            if (base >= limit) return 0u;  // the search has run off the end (key above every entry)
+            const i64x2 *v = reinterpret_cast<const i64x2 *>(a + base);  // base is a multiple of 8: 64-byte aligned
+            const i64x2 v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];      // (reads past `limit` stay inside the padded arrays)
+            const int64_t e[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+            uint32_t c = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) c += (base + j < limit && e[j] < key) ? 1u : 0u;
+            return c;
+        };
+        uint32_t bm = 0, bc = 0;  // block index at the level above
+        for (uint32_t k = q.nlev; k >= 1u; --k) {
+            uint32_t nk = q.n;  // entries of level k = ceil(n / 8^k)
+            for (uint32_t t = 0; t < k; ++t) nk = (nk + 7u) / 8u;
+            const int64_t *lm = q.lvl + q.lvl_off[k - 1u], *lc = lm + q.lvl_half;
+            bm = bm * 8u + count8(lm, bm * 8u, nk, req_m);
+            bc = bc * 8u + count8(lc, bc * 8u, nk, req_c);
+        }
+        start = bm * 8u + count8(q.bf_mem, bm * 8u, q.n, req_m);
+        r = bc * 8u + count8(q.cpu_sorted, bc * 8u, q.n, req_c);
+        start = min(start, q.n);
+        r = min(r, q.n);
+    }
+    int32_t found = -1;
+    bool undecided = start < q.n;
+    if (undecided) {
+        const uint32_t r_hi = q.do_fit ? q.row_cpu0 + (r + q.q - 1u) / q.q : q.row_valid;  // only nodes that fit
+        const uint32_t r_lo = q.do_fit ? q.row_cpu0 + r / q.q : q.row_valid;               // every node that fits
+        uint32_t lrow[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) lrow[k] = (sel[k] <= q.lab_max8[k]) ? q.lab_base8[k] + sel[k] - 1u : q.row_zero;
+        const uint32_t w0 = start >> 6;
+        for (uint32_t t = 0; t < q.lane_words && undecided; ++t) {
+            const uint32_t w = w0 + t;
+            if (w >= q.Wbf) {
+                undecided = false;  // ran off the end: no feasible node
+                break;
+            }
+            uint64_t base = q.rows[(size_t)q.row_valid * q.Wbf + w];
+            const uint64_t hi = q.rows[(size_t)r_hi * q.Wbf + w], lo = q.rows[(size_t)r_lo * q.Wbf + w];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k)
+                if (sel[k] != 0u) base &= q.rows[(size_t)lrow[k] * q.Wbf + w];
+            for (uint32_t k = 8; k < q.nkeys; ++k) {
+                const uint32_t s = q.psel[(size_t)k * q.p + pod];
+                if (s != 0u) base &= q.rows[(size_t)((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero) * q.Wbf + w];
+            }
+            if (q.do_taint)
+                for (uint32_t g = 0; g < q.ngroups; ++g)
+                    base &= q.rows[(size_t)(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * q.Wbf + w];
+            if (t == 0) base &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
+            const uint64_t sure = q.do_fit ? (base & hi) : base;
+            uint64_t cand = q.do_fit ? (sure | (base & lo & ~hi)) : base;
+            while (cand) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(cand);
+                const uint32_t i = w * 64u + b;
+                if (((sure >> b) & 1ull) || req_c <= q.bf_cpu[i]) {
+                    found = (int32_t)q.bf_order[i];
+                    undecided = false;
+                    break;
+                }
+                cand &= cand - 1ull;
+            }
+            if (undecided && w + 1u >= q.Wbf) undecided = false;  // that was the last word: no feasible node
+        }
+    }
+    if (undecided) {
+        q.fallback_list[atomicAdd(q.fallback_count, 1u)] = pod;  // the wave-per-pod kernel scans on from `start`
+    } else {
+        q.binding[pod] = found;
+    }
 }
 
 }  // namespace ksched

@@ -70,6 +70,9 @@ struct ksched_ctx {
     DevBuf<int64_t> cpu_sorted;      // ascending avail_cpu (rank of a cpu request)
     DevBuf<int64_t> bf_samples;      // sample arrays of bf_mem and cpu_sorted: [mem s1][mem s2][cpu s1][cpu s2]
     uint32_t bf_n1 = 0, bf_n2 = 0;
+    DevBuf<int64_t> bf_levels;       // 8-ary level arrays of bf_mem / cpu_sorted (k_pick_bestfit_lanes)
+    uint32_t bf_nlev = 0, bf_lvl_half = 0, bf_lvl_off[6] = {};
+    DevBuf<uint32_t> bf_fallback;    // [1 + p]: counter, then the pods the lane-per-pod pick hands to the wave-per-pod kernel
     DevBuf<uint64_t> bf_rows;        // [rows][Wbf] bitmaps over best-fit positions (k_pick_bestfit_rows); built with the tile index
     bool bf_rows_built = false;
     uint32_t bf_row_cpu0 = 0, bf_q = 1;
@@ -343,6 +346,29 @@ int build_bestfit(ksched_ctx *c) {
     HIPCHK(c, hipGetLastError());
     c->bf_n1 = n1;
     c->bf_n2 = n2;
+    {   // 8-ary level arrays for the lane-per-pod searches: level k = last element of every block of 8^k entries
+        BfLevelsArgs lv{};
+        uint32_t nk = n, off = 0;
+        c->bf_nlev = 0;
+        while (nk > 8u && c->bf_nlev < 6u) {
+            nk = (nk + 7u) / 8u;
+            c->bf_lvl_off[c->bf_nlev++] = off;
+            off += (nk + 7u) & ~7u;  // every level starts on a 64-byte boundary and may be read in whole blocks of eight
+        }
+        c->bf_lvl_half = off;
+        HIPCHK(c, c->bf_levels.reserve(2 * (size_t)off + 8));
+        if (c->bf_nlev) {
+            lv.bf_mem = c->bf_mem.ptr;
+            lv.cpu_sorted = c->cpu_sorted.ptr;
+            lv.lvl = c->bf_levels.ptr;
+            lv.n = n;
+            lv.nlev = c->bf_nlev;
+            lv.lvl_half = off;
+            for (uint32_t k = 0; k < 6; ++k) lv.lvl_off[k] = c->bf_lvl_off[k];
+            hipLaunchKernelGGL(k_bf_levels, dim3(((n + 7u) / 8u + 255u) / 256u), dim3(256), 0, s, lv);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
     if (c->idx.built && c->idx.lay.nlist == 0) {  // (list keys have no rows to re-order: the mask-reading pick serves those snapshots)
         const IndexedLayout &l = c->idx.lay;
         const uint32_t Wbf = (n + 63u) / 64u, named = l.row_cpu, levels = 256u, q = (n + levels - 1u) / levels;
@@ -592,7 +618,25 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
             q.lab_base8[k] = l.lab_base[k];
             q.lab_max8[k] = l.lab_max[k];
         }
-        hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q);
+        if ((c->opt_debug & 0x400u) || c->n > (1u << 21)) {  // KSCHED_OPT_DEBUG bit 10: the one-stage wave-per-pod pick (A/B, cross-check)
+            hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q);
+        } else {
+            // two stages: one lane per pod decides from the first two candidate words; the rare rest goes to the wave-per-pod kernel
+            HIPCHK(c, c->bf_fallback.reserve((size_t)p + 1));
+            HIPCHK(c, hipMemsetAsync(c->bf_fallback.ptr, 0, 4, s));
+            q.lvl = c->bf_levels.ptr;
+            q.nlev = c->bf_nlev;
+            q.lvl_half = c->bf_lvl_half;
+            for (uint32_t k = 0; k < 6; ++k) q.lvl_off[k] = c->bf_lvl_off[k];
+            q.fallback_count = c->bf_fallback.ptr;
+            q.fallback_list = c->bf_fallback.ptr + 1;
+            q.lane_words = ((c->opt_debug >> 12) & 15u) ? ((c->opt_debug >> 12) & 15u) : 8u;  // KSCHED_OPT_DEBUG bits 12-15: A/B of the hand-over point (8 words = 512 candidates measured best at the C5 shard)
+            hipLaunchKernelGGL(k_pick_bestfit_lanes, dim3((p + 255) / 256), dim3(256), 0, s, q);
+            BestfitRowsArgs q2 = q;
+            q2.pod_list = q.fallback_list;
+            q2.pod_count = q.fallback_count;
+            hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q2);
+        }
         HIPCHK(c, hipGetLastError());
         if (!out_feas && !out_fit) return KSCHED_OK;
     }
@@ -714,7 +758,7 @@ void ksched_destroy(ksched_ctx *c) {
         DeviceGuard g(c->device);
         (void)hipDeviceSynchronize();
         c->ncpu.release(); c->nmem.release(); c->nrec.release(); c->nlab.release(); c->ntaint.release();
-        c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release(); c->bf_cpu.release(); c->cpu_sorted.release(); c->bf_rows.release(); c->bf_samples.release();
+        c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release(); c->bf_cpu.release(); c->cpu_sorted.release(); c->bf_rows.release(); c->bf_samples.release(); c->bf_levels.release(); c->bf_fallback.release();
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
         c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release(); c->xpairs.release(); c->xreason.release();
         c->scratch_mask.release(); c->trace.release();
@@ -817,9 +861,9 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     HIPCHK(c, c->ntaint.reserve(n));
     HIPCHK(c, c->bf_order.reserve(n));
     HIPCHK(c, c->bf_rank.reserve(n));
-    HIPCHK(c, c->bf_mem.reserve(n));
+    HIPCHK(c, c->bf_mem.reserve((size_t)n + 8));  // (+8: the 8-ary searches read whole blocks of eight)
     HIPCHK(c, c->bf_cpu.reserve(n));
-    HIPCHK(c, c->cpu_sorted.reserve(n));
+    HIPCHK(c, c->cpu_sorted.reserve((size_t)n + 8));
     hipStream_t s = c->stream;
     if (n > 0) {
         // the caller's arrays -> pinned staging -> asynchronous copies on the ctx's stream
