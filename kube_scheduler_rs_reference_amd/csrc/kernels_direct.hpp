@@ -485,27 +485,17 @@ __device__ __forceinline__ void wave_lower_bound_sampled2(const int64_t *__restr
     out1 = (cA1 >= n2) ? n : b1 * 64u + cC1;
 }
 
-// one pod, by the whole wave; returns the chosen node (every lane holds the same value)
-__device__ __forceinline__ int32_t bestfit_rows_one_pod(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane) {
-    // Everything that depends only on the pod is loaded up front, together (the chain of dependent memory round trips
-    // is what this kernel's time is made of: operands -> two more search rounds -> rows -> winner's node id).
-    const uint32_t n2 = (q.n + 4095u) / 4096u;
-    const bool sampled = q.do_fit && q.mem_s1 != nullptr;
-    const int64_t top_m = (sampled && lane < n2) ? q.mem_s2[lane] : 0, top_c = (sampled && lane < n2) ? q.cpu_s2[lane] : 0;
-    const int64_t req_c = q.do_fit ? q.pcpu[pod] : 0, req_m = q.do_fit ? q.pmem[pod] : 0;
+// The scan of one pod by the whole wave, given start = first position whose memory can hold the pod, r = #nodes with cpu below the
+// request, and the first word to look at (w_first >= start >> 6; the caller vouches that no feasible position lies before it).
+// Returns the chosen node (every lane holds the same value).
+__device__ __forceinline__ int32_t bestfit_rows_scan(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane, uint32_t start, uint32_t r, uint32_t w_first,
+                                                     int64_t req_c) {
     const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
     uint32_t sel[8];
 #pragma unroll
     for (uint32_t k = 0; k < 8; ++k) sel[k] = (q.psel && k < q.nkeys) ? q.psel[(size_t)k * q.p + pod] : 0u;  // wave-uniform
-    uint32_t start = 0, r_hi = q.row_valid, r_lo = q.row_valid;
+    uint32_t r_hi = q.row_valid, r_lo = q.row_valid;
     if (q.do_fit) {
-        uint32_t r;  // #nodes with cpu < request
-        if (q.mem_s1) {
-            wave_lower_bound_sampled2(q.bf_mem, q.mem_s1, q.mem_s2, req_m, q.cpu_sorted, q.cpu_s1, q.cpu_s2, req_c, q.n, lane, top_m, top_c, start, r);
-        } else {
-            start = wave_lower_bound(q.bf_mem, q.n, req_m, lane);
-            r = wave_lower_bound(q.cpu_sorted, q.n, req_c, lane);
-        }
         r_hi = q.row_cpu0 + (r + q.q - 1u) / q.q;  // only nodes that fit
         r_lo = q.row_cpu0 + r / q.q;               // every node that fits
     }
@@ -514,7 +504,6 @@ __device__ __forceinline__ int32_t bestfit_rows_one_pod(const BestfitRowsArgs &q
     uint32_t lrow[8];
 #pragma unroll
     for (uint32_t k = 0; k < 8; ++k) lrow[k] = (sel[k] <= q.lab_max8[k]) ? q.lab_base8[k] + sel[k] - 1u : q.row_zero;
-    const uint32_t w_first = start >> 6;
     for (uint32_t wb = w_first; wb < q.Wbf; wb += 64u) {
         const uint32_t w = wb + lane;
         const bool in = w < q.Wbf;
@@ -533,7 +522,7 @@ __device__ __forceinline__ int32_t bestfit_rows_one_pod(const BestfitRowsArgs &q
             for (uint32_t g = 0; g < q.ngroups; ++g)
                 base &= q.rows[(size_t)(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * q.Wbf + wc];
         if (!in) base = 0;
-        if (w == w_first) base &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
+        if (w == (start >> 6)) base &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
         const uint64_t sure = q.do_fit ? (base & hi) : base;
         const uint64_t maybe = q.do_fit ? (base & lo & ~hi) : 0ull;
         // this lane's first feasible position (rarely more than one trip: `maybe` holds < 1/256 of the nodes)
@@ -557,6 +546,26 @@ __device__ __forceinline__ int32_t bestfit_rows_one_pod(const BestfitRowsArgs &q
     return -1;
 }
 
+// one pod, by the whole wave: the two rank searches, then the scan
+__device__ __forceinline__ int32_t bestfit_rows_one_pod(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane) {
+    // Everything that depends only on the pod is loaded up front, together (the chain of dependent memory round trips
+    // is what this kernel's time is made of: operands -> two more search rounds -> rows -> winner's node id).
+    const uint32_t n2 = (q.n + 4095u) / 4096u;
+    const bool sampled = q.do_fit && q.mem_s1 != nullptr;
+    const int64_t top_m = (sampled && lane < n2) ? q.mem_s2[lane] : 0, top_c = (sampled && lane < n2) ? q.cpu_s2[lane] : 0;
+    const int64_t req_c = q.do_fit ? q.pcpu[pod] : 0, req_m = q.do_fit ? q.pmem[pod] : 0;
+    uint32_t start = 0, r = 0;
+    if (q.do_fit) {
+        if (q.mem_s1) {
+            wave_lower_bound_sampled2(q.bf_mem, q.mem_s1, q.mem_s2, req_m, q.cpu_sorted, q.cpu_s1, q.cpu_s2, req_c, q.n, lane, top_m, top_c, start, r);
+        } else {
+            start = wave_lower_bound(q.bf_mem, q.n, req_m, lane);
+            r = wave_lower_bound(q.cpu_sorted, q.n, req_c, lane);
+        }
+    }
+    return bestfit_rows_scan(q, pod, lane, start, r, start >> 6, req_c);
+}
+
 // One wave per pod, one launch slot per pod.  (A persistent grid of 8192 waves walking the pods was measured slower,
 // 210 us against 147 us at the C5 shard: the kernel is bound by instruction issue -- ~280 scalar and ~240 vector
 // instructions per pod, mostly address arithmetic and wave-uniform control flow, rocprofv3 SQ counters -- not by wave
@@ -568,9 +577,10 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
         // (one short-lived wave per listed pod, the grid sized for the worst case: waves beyond the count exit at once; a persistent
         // grid walking the list was measured slower, like the persistent form of the one-stage kernel)
         if (wave >= *q.pod_count) return;
-        const uint32_t pod = q.pod_list[wave];
-        const int32_t b = bestfit_rows_one_pod(q, pod, lane);
-        if (lane == 0) q.binding[pod] = b;
+        // the first stage hands over what it already knows: {pod, start, r, next word}: no rank search here
+        const uint4 rec = reinterpret_cast<const uint4 *>(q.pod_list)[wave];
+        const int32_t b = bestfit_rows_scan(q, rec.x, lane, rec.y, rec.z, rec.w, q.do_fit ? q.pcpu[rec.x] : 0);
+        if (lane == 0) q.binding[rec.x] = b;
         return;
     }
     if (wave >= q.p) return;
@@ -664,8 +674,8 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
             if (undecided && w + 1u >= q.Wbf) undecided = false;  // that was the last word: no feasible node
         }
     }
-    if (undecided) {
-        q.fallback_list[atomicAdd(q.fallback_count, 1u)] = pod;  // the wave-per-pod kernel scans on from `start`
+    if (undecided) {  // the wave-per-pod kernel scans on behind the words looked at here
+        reinterpret_cast<uint4 *>(q.fallback_list)[atomicAdd(q.fallback_count, 1u)] = make_uint4(pod, start, r, (start >> 6) + q.lane_words);
     } else {
         q.binding[pod] = found;
     }

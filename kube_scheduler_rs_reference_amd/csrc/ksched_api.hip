@@ -72,7 +72,7 @@ struct ksched_ctx {
     uint32_t bf_n1 = 0, bf_n2 = 0;
     DevBuf<int64_t> bf_levels;       // 8-ary level arrays of bf_mem / cpu_sorted (k_pick_bestfit_lanes)
     uint32_t bf_nlev = 0, bf_lvl_half = 0, bf_lvl_off[6] = {};
-    DevBuf<uint32_t> bf_fallback;    // [1 + p]: counter, then the pods the lane-per-pod pick hands to the wave-per-pod kernel
+    DevBuf<uint32_t> bf_fallback;    // counter (16 bytes), then one uint4 per pod the lane-per-pod pick hands to the wave-per-pod kernel
     DevBuf<uint64_t> bf_rows;        // [rows][Wbf] bitmaps over best-fit positions (k_pick_bestfit_rows); built with the tile index
     bool bf_rows_built = false;
     uint32_t bf_row_cpu0 = 0, bf_q = 1;
@@ -622,14 +622,14 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
             hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q);
         } else {
             // two stages: one lane per pod decides from the first two candidate words; the rare rest goes to the wave-per-pod kernel
-            HIPCHK(c, c->bf_fallback.reserve((size_t)p + 1));
+            HIPCHK(c, c->bf_fallback.reserve(4 * ((size_t)p + 1)));  // [counter, pad x3][{pod, start, r, next word} x p]
             HIPCHK(c, hipMemsetAsync(c->bf_fallback.ptr, 0, 4, s));
             q.lvl = c->bf_levels.ptr;
             q.nlev = c->bf_nlev;
             q.lvl_half = c->bf_lvl_half;
             for (uint32_t k = 0; k < 6; ++k) q.lvl_off[k] = c->bf_lvl_off[k];
             q.fallback_count = c->bf_fallback.ptr;
-            q.fallback_list = c->bf_fallback.ptr + 1;
+            q.fallback_list = c->bf_fallback.ptr + 4;
             q.lane_words = ((c->opt_debug >> 12) & 15u) ? ((c->opt_debug >> 12) & 15u) : 8u;  // KSCHED_OPT_DEBUG bits 12-15: A/B of the hand-over point (8 words = 512 candidates measured best at the C5 shard)
             hipLaunchKernelGGL(k_pick_bestfit_lanes, dim3((p + 255) / 256), dim3(256), 0, s, q);
             BestfitRowsArgs q2 = q;
