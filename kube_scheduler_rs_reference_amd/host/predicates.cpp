@@ -150,5 +150,36 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
     return out;
 }
 
+std::vector<Validity> explain_pairs(const std::vector<const corev1::Pod *> &pods, Context &ctx,
+                                    const std::vector<std::pair<uint32_t, uint32_t>> &pairs, bool taints) {
+    if (!ctx.snapshot) ctx.refresh_snapshot();
+    Snapshot &snap = *ctx.snapshot;
+    if (taints && snap.has_taints()) snap.enable_taints();
+    std::vector<Validity> out(pairs.size());
+    if (pairs.empty()) return out;
+    PodColumns pc = snap.encode_pods(pods);  // (one call: at most KSCHED_MAX_KEYS distinct selector keys among `pods`)
+    std::vector<uint32_t> pp(pairs.size()), pn(pairs.size());
+    for (size_t i = 0; i < pairs.size(); ++i) {
+        pp[i] = pairs[i].first;
+        pn[i] = pairs[i].second;
+    }
+    std::vector<int32_t> reason(pairs.size());
+    const uint32_t flags = KSCHED_FIT | KSCHED_SEL | ((taints && snap.has_taints()) ? KSCHED_TAINT : 0u);
+    DeviceEvaluator &dev = snap.device();
+    dev.check(ksched_explain(dev.handle(), pc.p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), pc.n_keys ? pc.sel_val_ids.data() : nullptr,
+                             (flags & KSCHED_TAINT) ? pc.tolerations.data() : nullptr, (uint32_t)pairs.size(), pp.data(), pn.data(), flags,
+                             reason.data()),
+              "ksched_explain");
+    for (size_t i = 0; i < pairs.size(); ++i) {
+        switch (reason[i]) {
+            case KSCHED_REASON_OK: out[i] = std::nullopt; break;
+            case KSCHED_REASON_NOT_ENOUGH_RESOURCES: out[i] = InvalidNodeReason::NotEnoughResources; break;
+            case KSCHED_REASON_TAINT_NOT_TOLERATED: out[i] = InvalidNodeReason::TaintNotTolerated; break;
+            default: out[i] = InvalidNodeReason::NodeSelectorMismatch;
+        }
+    }
+    return out;
+}
+
 }  // namespace predicates
 }  // namespace ksched_host

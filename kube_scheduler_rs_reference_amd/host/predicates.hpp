@@ -62,5 +62,11 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
                                         uint32_t pick_flags = 0, const std::vector<uint32_t> *samples = nullptr,
                                         uint32_t attempts = 0);
 
+// check_node_validity's result for listed (pod, node) pairs, decided pair by pair on the device (ksched_explain): what the
+// reference logs at WARN for every rejected candidate (src/main.rs:62).  Unlike BatchValidity::validity (two masks) this tells a
+// selector failure from a taint failure when the taint extension is on.  pairs[i] = {index into `pods`, CANONICAL node index}.
+std::vector<Validity> explain_pairs(const std::vector<const corev1::Pod *> &pods, Context &ctx,
+                                    const std::vector<std::pair<uint32_t, uint32_t>> &pairs, bool taints = false);
+
 }  // namespace predicates
 }  // namespace ksched_host

@@ -455,6 +455,30 @@ static void gpu_tests() {
         CHECK(!check_node_validity(ok, n, ctx).has_value());
     });
 
+    run("explain_pairs: selector and taint failures told apart on the device (ksched_explain)", [] {
+        corev1::Node plain = node_with("n-plain", "4", "8589934592"), tainted = node_with("n-tainted", "4", "8589934592"),
+                     small = node_with("n-small", "1", "8589934592");
+        plain.metadata.labels = corev1::StringMap{{"zone", "a"}};
+        tainted.metadata.labels = corev1::StringMap{{"zone", "a"}};
+        small.metadata.labels = corev1::StringMap{{"zone", "a"}};
+        corev1::NodeSpec ns;
+        ns.taints = std::vector<corev1::Taint>{{"dedicated", std::string("gpu"), "NoSchedule"}};
+        tainted.spec = ns;
+        Context ctx = make_ctx({tainted, small, plain});  // canonical order: n-plain 0, n-small 1, n-tainted 2
+        corev1::Pod ok = pod_with("ok", {container("2", "1")}), wrong_zone = pod_with("wz", {container("2", "1")});
+        ok.spec->node_selector = corev1::StringMap{{"zone", "a"}};
+        wrong_zone.spec->node_selector = corev1::StringMap{{"zone", "b"}};
+        const std::vector<const corev1::Pod *> pods = {&ok, &wrong_zone};
+        const auto v = predicates::explain_pairs(pods, ctx, {{0, 0}, {0, 1}, {0, 2}, {1, 0}, {1, 2}, {1, 1}}, /*taints=*/true);
+        CHECK(!v[0]);                                                        // fits, zone matches, no taint
+        CHECK(v[1] && *v[1] == InvalidNodeReason::NotEnoughResources);       // 2 cpu on a 1-cpu node
+        CHECK(v[2] && *v[2] == InvalidNodeReason::TaintNotTolerated);        // two masks would say NodeSelectorMismatch here
+        CHECK(v[3] && *v[3] == InvalidNodeReason::NodeSelectorMismatch);
+        CHECK(v[4] && *v[4] == InvalidNodeReason::NodeSelectorMismatch);     // selector before taint
+        CHECK(v[5] && *v[5] == InvalidNodeReason::NotEnoughResources);       // resources first (src/predicates.rs:68-70)
+        const auto w = predicates::explain_pairs(pods, ctx, {{0, 2}}, /*taints=*/false);
+        CHECK(!w[0]);                                                        // the reference's own path has no taint predicate
+    });
     run("select_node_for_pod: D-P1..D-P3 (src/main.rs:51-71)", [] {
         std::vector<corev1::Node> nodes;
         for (int i = 0; i < 10; ++i) nodes.push_back(node_with("node-" + std::to_string(i), i == 7 ? "4" : "100m", "1073741824"));
