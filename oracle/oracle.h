@@ -16,7 +16,10 @@
  *     restates the published Kubernetes quantity grammar with exact integer arithmetic
  *     (nano-units in a 128-bit integer); on the canonical domain D of SURVEY.md section 8c
  *     (CPU "<n>" / "<n>m", memory plain integer bytes, optionally Ki/Mi) every reading of the
- *     crate agrees with it.
+ *     crate agrees with it.  Neither the build container nor the GPU box has cargo/rustc (profiles/
+ *     r02_a_toolchain_probe_gpu_box.txt), so there is no oracle/_ref.  Pinning is one command for anyone who has cargo:
+ *     rust/pin_parity.sh runs the reference's OWN fits() / does_node_selector_match on tests/golden/*_objects.json and
+ *     tests/test_reference_fixtures.py compares the result with the fixtures this oracle reproduces.
  *   - Taints/tolerations and best-fit are extensions (BASELINE.json config 5) with no
  *     reference code: semantics are defined in DESIGN.md and restated here independently.
  */
