@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session that produces the round's evidence set.  usage: bash tools/gpu_round.sh <tag> [steps...]
-#   steps (default: all but probe): probe test bench prof pmc lines trace smoke host
+#   steps (default: test bench prof pmc lines trace smoke host): probe test smoke bench prof pmc lines ab dist evflags abpick host trace
 # Everything lands under gpurun_out/<tag>/ ; tools/collect_profiles.py copies the summaries into profiles/.
 TAG=${1:-r}; shift
 STEPS=${@:-"test bench prof pmc lines trace smoke host"}
@@ -84,6 +84,39 @@ except Exception as e:
     print("$wl debug=$bits: FAILED", e)
 PY
   done; done
+fi
+if has dist; then
+  stamp "N > 1 bench path in a ONE-rank RCCL group (KSCHED_BENCH_FORCE_DIST=1): C ABI communicator vs torch, pipe vs one stream"
+  for wl in C3 C4s; do for mode in "" "--torch-gather" "--one-stream"; do
+    KSCHED_BENCH_FORCE_DIST=1 timeout 300 python bench.py --workload $wl --no-cpu-baseline $mode 2>&1 | tail -1 > $OUT/dist_${wl}_${mode#--}.json
+    python - <<PY
+import json
+try:
+    d=json.load(open("$OUT/dist_${wl}_${mode#--}.json")); c=d["config"]
+    print("$wl $mode: gather/step %.1f us/step %.3e evals/s | every 4: %s | no gather: %s | mask kernel %.1f us" % (d["ms_per_step"]*1e3, d["value"], (c["allgather_every_4"] or {}).get("ms_per_step"), (c.get("no_allgather") or {}).get("ms_per_step"), d["roofline"]["avg_kernel_us"]))
+except Exception as e:
+    print("$wl $mode FAILED", e)
+PY
+  done; done
+fi
+if has evflags; then
+  stamp "A/B of the HIP event flags of the per-dispatch kernel timing (bench.py post-pass) vs rocprofv3 (the prof step)"
+  for f in 0x0 0x20000000 0x40000000; do
+    KSCHED_TIMING_EVENT_FLAGS=$f timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 > $OUT/evflags_$f.json
+    python -c "
+import json; r=json.load(open('$OUT/evflags_$f.json'))['roofline']; print('flags $f: mean %.2f median %.2f min %.2f max %.2f us' % (r['avg_kernel_us'], r['median_kernel_us'], r['min_kernel_us'], r['max_kernel_us']))"
+  done
+fi
+if has abpick; then
+  stamp "A/B of the picks (KSCHED_OPT_DEBUG): sampled pick eager draws (bits 8-9), best-fit one stage (bit 10) / lane words (bits 12-15); bindings-only steps"
+  for wl in C3 C2; do for dbg in 0 256 512 768; do
+    timeout 200 python bench.py --workload $wl --no-cpu-baseline --no-mask --debug $dbg 2>&1 | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$wl debug=$dbg: bindings-only step %.2f us' % (d['ms_per_step']*1e3))"
+  done; done
+  for dbg in 1024 4096 8192 16384 32768; do
+    timeout 200 python bench.py --workload C5s --no-cpu-baseline --no-mask --debug $dbg --steps 300 2>&1 | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('C5s debug=$dbg: bindings-only step %.1f us' % (d['ms_per_step']*1e3))"
+  done
 fi
 if has host; then
   stamp "host-side cost of the snapshot calls"
