@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Randomised differential test of the HIP path against the oracle (GPU box): random shapes, key counts and cardinalities (incl.
+list keys and > 8 keys), taints, predicate subsets, both picks, snapshot updates between evaluations, both kernels.
+usage: python tools/fuzz_parity.py [seconds] [seed]       prints one line per failure and a summary; exit code 1 on any failure"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kube_scheduler_rs_reference_amd import Evaluator, _lib as L
+from oracle import capi
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ev = Evaluator(0)
+t_end = time.time() + budget
+cases = fails = 0
+I64 = np.iinfo(np.int64)
+while time.time() < t_end:
+    cases += 1
+    cs = int(rng.integers(0, 1 << 31))
+    r = np.random.default_rng(cs)
+    N = int(r.choice([1, 2, 63, 64, 65, 300, 1023, 1024, 1025, 2500, 4097, 6000]))
+    P = int(r.choice([1, 7, 64, 65, 500, 1500, 3000]))
+    K = int(r.choice([0, 1, 3, 8, 9, 12]))
+    cards = [int(r.choice([1, 2, 5, 40, 300, N, 4 * N + 7])) for _ in range(K)]
+    scale = int(r.choice([10, 1000, 1 << 20]))
+    cpu = r.integers(-scale, 64 * scale, N).astype(np.int64)
+    mem = r.integers(-scale, 64 * scale, N).astype(np.int64)
+    if r.random() < 0.1:
+        cpu[r.integers(0, N, 3)] = r.choice([I64.min, I64.max, 0])
+    lab = np.stack([r.integers(0, c + 1, N).astype(np.uint32) for c in cards]) if K else None
+    nt = int(r.choice([0, 0, 3, 16, 60]))
+    taints = (r.integers(0, 1 << nt, N).astype(np.uint64) & r.integers(0, 1 << nt, N).astype(np.uint64)) if nt else None
+    rc = r.integers(-5, 70 * scale, P).astype(np.int64)
+    rm = r.integers(-5, 70 * scale, P).astype(np.int64)
+    pk = float(r.choice([0.05, 0.3, 0.9]))
+    sel = np.stack([np.where(r.random(P) < pk, r.integers(1, c + 3, P), 0).astype(np.uint32) for c in cards]) if K else None
+    if K and r.random() < 0.5:
+        sel[r.integers(0, K), r.integers(0, P, max(1, P // 20))] = L.SEL_NEVER
+    tol = r.integers(0, 1 << nt, P).astype(np.uint64) if nt else None
+    smp = r.integers(0, N + (2 if r.random() < 0.2 else 0), (P, 5)).astype(np.uint32)
+    preds = int(r.choice([L.FIT, L.FIT | L.SEL, L.FIT | L.SEL | L.TAINT, L.SEL, L.SEL | L.TAINT, L.FIT | L.TAINT]))
+    if not K:
+        preds &= ~L.SEL
+    if not nt:
+        preds &= ~L.TAINT
+    if preds == 0:
+        preds = L.FIT
+    pick = int(r.choice([0, L.PICK_SAMPLED, L.PICK_BESTFIT]))
+    flags = preds | pick | (L.WANT_FIT_MASK if r.random() < 0.5 else 0)
+    try:
+        ev.set_nodes(cpu, mem, lab, taints)
+        for step in range(int(r.choice([1, 1, 3]))):
+            if step:  # a snapshot update between evaluations
+                idx = r.integers(0, N, int(r.choice([1, 5, 40, N]))).astype(np.uint32)
+                nc, nm = r.integers(-scale, 64 * scale, idx.size).astype(np.int64), r.integers(-scale, 64 * scale, idx.size).astype(np.int64)
+                ev.update_nodes(idx, nc, nm)
+                for j in range(idx.size):
+                    cpu[idx[j]], mem[idx[j]] = nc[j], nm[j]
+            want = capi.eval_encoded(cpu, mem, lab, taints if (preds & L.TAINT) else None, rc, rm, sel, tol if (preds & L.TAINT) else None, smp, flags)
+            for kernel in ("auto", "direct"):
+                ev.set_kernel(kernel)
+                got = ev.eval(rc, rm, sel if K else None, tol if (preds & L.TAINT) else None, smp if pick == L.PICK_SAMPLED else None, flags)
+                ok = np.array_equal(got.feasible, want[0]) and (not (flags & L.WANT_FIT_MASK) or np.array_equal(got.fit, want[1])) and \
+                    (not pick or np.array_equal(got.binding, want[2]))
+                if not ok:
+                    fails += 1
+                    print(f"FAIL case seed {cs}: N={N} P={P} K={K} cards={cards} nt={nt} flags={flags:#x} kernel={kernel}/{ev.last_kernel} step={step}", flush=True)
+        ev.set_kernel("auto")
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print(f"EXCEPTION case seed {cs}: N={N} P={P} K={K} cards={cards} nt={nt} flags={flags:#x}: {e}", flush=True)
+        ev.set_kernel("auto")
+print(f"fuzz: {cases} cases, {fails} failures, seed {seed}")
+sys.exit(1 if fails else 0)
