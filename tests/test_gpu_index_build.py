@@ -100,3 +100,43 @@ def test_bestfit_after_updates_uses_the_resorted_order(evaluator, n_taints):
         cpu[idx] -= rng.integers(100, 3000, idx.size)
         mem[idx] -= rng.integers(1 << 20, 1 << 32, idx.size)
         ev.update_nodes(idx, cpu[idx], mem[idx])
+
+
+def test_updates_and_evaluations_interleaved_without_host_waits(evaluator):
+    """ksched_update_nodes / ksched_set_nodes no longer wait for the device: the ordering against evaluations on the caller's streams
+    is by events.  Stress it: updates and device-pointer evaluations on two torch streams interleave with no synchronisation for
+    many iterations; every evaluation must see exactly the snapshot that was current when it was enqueued."""
+    import torch
+    ev = evaluator
+    c = synth.make_cluster(3000, 4100, n_keys=8, n_taints=0, seed=61)
+    ev.set_kernel("auto")
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", ev.device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    d_cpu, d_mem, d_sel, d_smp = t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.samples, np.int32)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    flags = FIT | SEL | PICK_BESTFIT
+    cpu, mem = c.avail_cpu.copy(), c.avail_mem.copy()
+    rng = np.random.default_rng(9)
+    iters, pending = 60, []
+    for it in range(iters):
+        if it % 7 == 6:  # now and then a whole new snapshot
+            cpu = cpu + rng.integers(-50, 50, cpu.size)
+            ev.set_nodes(cpu, mem, c.node_labels, None)
+        else:
+            idx = rng.integers(0, c.N, int(rng.choice([1, 3, 30]))).astype(np.uint32)
+            idx = np.unique(idx)
+            cpu[idx] -= rng.integers(0, 2000, idx.size)
+            mem[idx] -= rng.integers(0, 1 << 30, idx.size)
+            ev.update_nodes(idx, cpu[idx], mem[idx])
+        s = streams[it % 2]
+        mask, bind = ev.alloc_mask(c.P), torch.empty((c.P,), dtype=torch.int32, device=dev)
+        with torch.cuda.stream(s):
+            ev.eval_device(d_cpu, d_mem, d_sel, None, None, flags, out_feasible=mask, out_binding=bind, stream=s)
+        pending.append((mask, bind, cpu.copy(), mem.copy()))
+    torch.cuda.synchronize()
+    for it, (mask, bind, pc, pm) in enumerate(pending):
+        feas, _, want = capi.eval_encoded(pc, pm, c.node_labels, None, c.req_cpu, c.req_mem, c.pod_sel, None, None, flags)
+        assert np.array_equal(mask.contiguous().cpu().numpy().view(np.uint64), feas), f"iteration {it}: mask is not of the snapshot current at enqueue time"
+        assert np.array_equal(bind.cpu().numpy(), want), f"iteration {it}: best-fit pick"
