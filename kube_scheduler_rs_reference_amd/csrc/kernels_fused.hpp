@@ -524,9 +524,18 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                         return base + ((val_at(base) < key) ? 1u : 0u);
                     };
                     const uint32_t lo = lower(s);
-                    const uint32_t hi = (s == 0xFFFFFFFFu) ? lo : lower(s + 1u);  // KSCHED_SEL_NEVER: no node carries it
-                    rec[j] = lo | ((hi - lo) << 16);
-                    lmax = max(lmax, hi - lo);
+                    // the length of the run of `s` from there: the next kListCap + 1 entries are read at once (independent reads,
+                    // one latency) instead of a second dependent search; only a longer run pays for the second search
+                    uint32_t cnt = 0;
+                    bool run = true;
+#pragma unroll
+                    for (uint32_t e = 0; e <= kListCap; ++e) {
+                        run = run && lo + e < (uint32_t)kTileNodes && val_at(min(lo + e, (uint32_t)kTileNodes - 1u)) == s;
+                        cnt += run ? 1u : 0u;
+                    }
+                    if (cnt > kListCap) cnt = lower(s + 1u) - lo;  // (ids are < KSCHED_SEL_NEVER here: SEL_NEVER itself is carried by no node, cnt = 0)
+                    rec[j] = lo | (cnt << 16);
+                    lmax = max(lmax, cnt);
                     any = true;
                 }
             }
@@ -616,21 +625,29 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                 const uint8_t *fit_o = reinterpret_cast<const uint8_t *>(s_fit + sub_o) + wp_o;
                 const uint2 *lab_o = reinterpret_cast<const uint2 *>(s_lab + sub_o);
                 const uint2 *trow_o = s_trow + sub_o;
+                // software pipeline by hand: the records and rows of pod row it + 1 are fetched before row `it` is combined, so the
+                // LDS latency of one row hides under the list arithmetic of the previous one
+                Rows A;
+                uint2 lr = (s_lrec + sub_o)[0];
+                load_rows(FIT ? (uint32_t)fit_o[0] : 0u, FIT ? (uint32_t)fit_o[8] : 0u, lab_o[0], TAINT ? trow_o[0] : make_uint2(0u, 0u), A);
 #pragma unroll 1
                 for (uint32_t it = 0; it < prev_nu; ++it) {
-                    Rows A;
                     const uint64_t step = (uint64_t)it * step_bytes;
-                    load_rows(FIT ? (uint32_t)(fit_o + it * 128u)[0] : 0u, FIT ? (uint32_t)(fit_o + it * 128u)[8] : 0u, (lab_o + it * 16u)[0],
-                              TAINT ? (trow_o + it * 8u)[0] : make_uint2(0u, 0u), A);
                     u32x4 f = fit_of(A);
                     if (WANT_FIT) store_rel(rb_fit + step, lane_off, f);
                     f = ((f & A.l0) & A.l1) & (A.l2 & A.l3);
                     if (TAINT) f = ((f & A.t0) & A.t1) & (A.t2 & A.t3);
-                    __builtin_amdgcn_sched_barrier(0);  // in stages, like the eight-row branch below: bounds the live row registers
-                    load_extra((lab_o + it * 16u)[1], A);
-                    f = ((f & A.x0) & A.x1) & (A.x2 & A.x3);
+                    if (prev_extra) {  // wave-uniform: some pod of the round constrains five to eight row keys
+                        load_extra((lab_o + it * 16u)[1], A);
+                        f = ((f & A.x0) & A.x1) & (A.x2 & A.x3);
+                    }
+                    const uint2 lr_now = lr;
+                    const uint32_t nx = min(it + 1u, prev_nu - 1u);  // (the last trip re-reads its own row: harmless)
                     __builtin_amdgcn_sched_barrier(0);
-                    f = apply_lists(f, (s_lrec + sub_o + it * 8u)[0], prev_bound);
+                    lr = (s_lrec + sub_o + nx * 8u)[0];
+                    load_rows(FIT ? (uint32_t)(fit_o + nx * 128u)[0] : 0u, FIT ? (uint32_t)(fit_o + nx * 128u)[8] : 0u, (lab_o + nx * 16u)[0],
+                              TAINT ? (trow_o + nx * 8u)[0] : make_uint2(0u, 0u), A);
+                    f = apply_lists(f, lr_now, prev_bound);
                     store_rel(rb_feas + step, lane_off, f);
                 }
             } else if (fast && prev_nu == 8u) {
