@@ -103,6 +103,10 @@ extern "C" {
 /* KSCHED_OPT_INDEX_BUILD: how ksched_set_nodes fills the per-tile bitmap index: 0 (default) = HIP kernels from the columns in
  * HBM; 1 = the host code that specifies it (csrc/tile_index.hpp), uploaded.  Same tables bit for bit (ksched_index_checksum). */
 #define KSCHED_OPT_INDEX_BUILD 6
+/* KSCHED_OPT_BESTFIT_STAGES: the best-fit pick from the bitmaps in best-fit order runs in one stage (a wave per pod) or in two
+ * (a lane per pod decides from the first 512 candidates, a wave per pod finishes the rest): 0 (default) = two stages from 65536
+ * pods per call on, 1 = always one, 2 = always two.  Same bindings either way. */
+#define KSCHED_OPT_BESTFIT_STAGES 7
 
 typedef struct ksched_ctx ksched_ctx;
 

@@ -32,45 +32,43 @@ struct BuildFitArgs {
     uint32_t n, rows, row_cpu;   // layout: rows per tile, first fit row of cpu (memory's follow kFitRows later)
 };
 
-// Sort the tile's kTileNodes (key, node) pairs ascending by (key, node): a bitonic network over LDS, one element per thread
-// (1024 threads).  On return thread i holds the element at POSITION i (kv, ki), and s_key / s_idx hold the sorted keys / their
-// nodes by position.  55 compare-exchange stages; the 45 whose partners are lanes of the same wave need no block barrier (LDS
-// operations of a wave execute in order).  (Ranking by counting -- 1024 broadcast compares per thread -- was measured at 54 us
-// per tile: 8k VALU instructions per thread on one CU; this is ~1k.)
+// Sort the tile's kTileNodes (key, node) pairs ascending by (key, node): a bitonic network, one element per thread (1024
+// threads).  On return thread i holds the element at POSITION i (kv, ki), and s_key / s_idx hold the sorted keys / their nodes by
+// position.  55 compare-exchange stages; the 45 whose partners are lanes of the same wave exchange through lane shuffles (no
+// LDS, no barrier), the 10 cross-wave ones through LDS between block barriers.  (Ranking by counting -- 1024 broadcast compares
+// per thread -- was measured at 54 us per tile: 8k VALU instructions per thread on one CU; the all-LDS network at 22 us.)
+__device__ __forceinline__ int64_t shfl_xor_key(int64_t x, uint32_t j) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, (int)j, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)x >> 32), (int)j, 64);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ uint32_t shfl_xor_key(uint32_t x, uint32_t j) { return (uint32_t)__shfl_xor((int)x, (int)j, 64); }
+
 template <class K>
 __device__ __forceinline__ void bitonic_sort_tile(K &kv, uint32_t &ki, K *s_key, uint16_t *s_idx, uint32_t i) {
-    s_key[i] = kv;
-    s_idx[i] = (uint16_t)ki;
-    __syncthreads();
     for (uint32_t k = 2; k <= (uint32_t)kTileNodes; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64u) __syncthreads();  // the partner's wave has finished the previous stage
-            const uint32_t p = i ^ j;
-            const K pv = s_key[p];
-            const uint32_t pi = s_idx[p];
+            K pv;
+            uint32_t pi;
+            if (j >= 64u) {  // the partner sits in another wave: through LDS, between block barriers
+                s_key[i] = kv;
+                s_idx[i] = (uint16_t)ki;
+                __syncthreads();
+                pv = s_key[i ^ j];
+                pi = s_idx[i ^ j];
+                __syncthreads();  // everybody has read before anybody writes its slot again
+            } else {          // a lane of this wave: registers only (45 of the 55 stages)
+                pv = shfl_xor_key(kv, j);
+                pi = shfl_xor_key(ki, j);
+            }
             const bool ascending = (i & k) == 0u, lower = (i & j) == 0u;
             const bool p_less = pv < kv || (pv == kv && pi < ki);
             const bool take = (lower == ascending) ? p_less : !p_less;  // the lower slot of an ascending pair keeps the smaller element
-            // reads of this stage before its writes, writes before the next stage's reads: block barriers when the partner is in
-            // another wave, wavefront-scope fences (ordering for the compiler; the hardware runs a wave's LDS operations in order)
-            // when it is a lane of this one
-            if (j >= 64u) {
-                __syncthreads();
-            } else {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (take) {
-                kv = pv;
-                ki = pi;
-                s_key[i] = kv;
-                s_idx[i] = (uint16_t)ki;
-            }
-            // (no block barrier here: the next stage either starts with one, or its partners are lanes of this wave)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            kv = take ? pv : kv;
+            ki = take ? pi : ki;
         }
     }
+    s_key[i] = kv;
+    s_idx[i] = (uint16_t)ki;
     __syncthreads();
 }
 
@@ -128,17 +126,48 @@ __global__ __launch_bounds__(1024) void k_build_tile_fit(const BuildFitArgs a) {
         uint64_t *cnt = aux + 2u * kAuxTreeWords + (size_t)res * kCntEntries;
         cnt[i] = excl;
         if (i < (uint32_t)kCntEntries - (uint32_t)kTileNodes) cnt[kTileNodes + i] = total;  // r = 1024, 1025
-        s_idx[ki] = (uint16_t)((excl >> (8u * sub)) & 0xFFull);  // local rank, by node (every node appears at exactly one position)
+        // The node at this position has local rank lr = its sub-tile's byte of the prefix: inside a sub-tile the live nodes' local
+        // ranks are 0, 1, 2, ... without gaps.  s_idx becomes the inverse, per sub-tile: s_idx[sub * 128 + lr] = the node (0..127 inside
+        // the sub-tile) with that local rank; 0xFFFF where no live node has it.
+        __syncthreads();  // everybody has read s_idx / s_key as the sort left them (tree entries above)
+        s_idx[i] = 0xFFFFu;
+        __syncthreads();
+        if (live) s_idx[sub * kSubNodes + (uint32_t)((excl >> (8u * sub)) & 0xFFull)] = (uint16_t)(ki & (kSubNodes - 1u));
     }
     __syncthreads();
-    // rows {lr >= c}: thread i is node i again; wave w owns word w of every row
+    // rows {lr >= c}, c = 0..128.  Chunk s of row c (16 bytes = the 128 nodes of sub-tile s) = OR over l >= c of the bit of the node
+    // with local rank l: a suffix OR over 128 ranks -- thread (s, c) owns s_rows[c][2s..2s+1], exactly where the finished chunk
+    // belongs.  (One wave ballot per (row, word), 129 of them per wave, took 7 us; a 7-step LDS scan with 14 block barriers 5 us.)
     {
-        const bool live = i < m;
-        const uint32_t lr = s_idx[i];
-        for (uint32_t c = 0; c < (uint32_t)kFitRows; ++c) {
-            const uint64_t word = __ballot(live && lr >= c);
-            if (lane == 0) s_rows[c * kTileWords + wave] = word;
+        const uint32_t sub = i >> 7, c = i & 127u;
+        uint64_t *mine = s_rows + c * kTileWords + 2u * sub;
+        const uint32_t node = s_idx[sub * kSubNodes + c];
+        uint64_t lo = (node < 64u) ? (1ull << node) : 0ull, hi = (node >= 64u && node < 128u) ? (1ull << (node - 64u)) : 0ull;
+        if (i < (uint32_t)kTileWords) s_rows[(kFitRows - 1) * kTileWords + i] = 0ull;  // row 128: no node has a local rank that high
+        // suffix OR over the wave's 64 ranks with lane shuffles, then the upper wave of the sub-tile hands its total to the lower one
+        auto shfl_down64 = [](uint64_t x, uint32_t d) -> uint64_t {
+            const uint32_t l = (uint32_t)__shfl_down((int)(uint32_t)x, d, 64), h = (uint32_t)__shfl_down((int)(uint32_t)(x >> 32), d, 64);
+            return ((uint64_t)h << 32) | l;
+        };
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint64_t olo = shfl_down64(lo, d), ohi = shfl_down64(hi, d);
+            if (lane + d < 64u) {
+                lo |= olo;
+                hi |= ohi;
+            }
         }
+        if ((c >> 6) == 1u && lane == 0) {  // the upper wave's total = its suffix at lane 0
+            s_wave[2u * sub] = lo;
+            s_wave[2u * sub + 1u] = hi;
+        }
+        __syncthreads();
+        if ((c >> 6) == 0u) {
+            lo |= s_wave[2u * sub];
+            hi |= s_wave[2u * sub + 1u];
+        }
+        mine[0] = lo;
+        mine[1] = hi;
     }
     __syncthreads();
     uint64_t *T = a.tables + ((size_t)tile * a.rows + a.row_cpu + (size_t)res * kFitRows) * kTileWords;

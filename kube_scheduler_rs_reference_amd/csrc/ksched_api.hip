@@ -118,6 +118,7 @@ struct ksched_ctx {
     uint32_t opt_debug = 0;
     bool opt_trace = false;
     bool opt_pick_from_mask = false;
+    int opt_bestfit_stages = 0;  // KSCHED_OPT_BESTFIT_STAGES: 0 auto, 1 one stage, 2 two stages
     int opt_index_build = 0;  // KSCHED_OPT_INDEX_BUILD: 0 = device kernels (default), 1 = host spec (tile_index.hpp)
     DevBuf<uint64_t> trace;
     uint32_t trace_blocks_last = 0;
@@ -618,7 +619,10 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
             q.lab_base8[k] = l.lab_base[k];
             q.lab_max8[k] = l.lab_max[k];
         }
-        if ((c->opt_debug & 0x400u) || c->n > (1u << 21)) {  // KSCHED_OPT_DEBUG bit 10: the one-stage wave-per-pod pick (A/B, cross-check)
+        // one stage (a wave per pod) or two (a lane per pod first): the second launch and the hand-over list pay off from tens of
+        // thousands of pods on (20k pods: 33 us against 44; 125k pods: 160 against 120) -- KSCHED_OPT_BESTFIT_STAGES overrides
+        const bool two_stage = c->opt_bestfit_stages == 2 || (c->opt_bestfit_stages == 0 && p >= 65536u);
+        if (!two_stage || (c->opt_debug & 0x400u) || c->n > (1u << 21)) {
             hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q);
         } else {
             // two stages: one lane per pod decides from the first two candidate words; the rare rest goes to the wave-per-pod kernel
@@ -803,6 +807,10 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
             return KSCHED_OK;
         case KSCHED_OPT_PICK_FROM_MASK:
             c->opt_pick_from_mask = value != 0;
+            return KSCHED_OK;
+        case KSCHED_OPT_BESTFIT_STAGES:
+            if (value < 0 || value > 2) return KSCHED_E_INVAL;
+            c->opt_bestfit_stages = (int)value;
             return KSCHED_OK;
         case KSCHED_OPT_INDEX_BUILD:
             if (value != 0 && value != 1) return KSCHED_E_INVAL;

@@ -652,16 +652,19 @@ def test_sampled_pick_direct_equals_pick_from_mask(evaluator, kernel):
             r = ev.eval(c.req_cpu, c.req_mem, sel, c.pod_tol, samples, sub | PICK_SAMPLED, want_mask=False)
             assert np.array_equal(r.binding, w2), (P, N, K, attempts, sub)
     ev.set_option(_lib.OPT_PICK_FROM_MASK, 0)
+    ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
     ev.set_kernel("auto")
 
 
+@pytest.mark.parametrize("stages", [1, 2])
 @pytest.mark.parametrize("kernel", KERNELS)
-def test_bestfit_direct_equals_bestfit_from_mask(evaluator, kernel):
+def test_bestfit_direct_equals_bestfit_from_mask(evaluator, kernel, stages):
     """KSCHED_PICK_BESTFIT two ways: first set bit of the AND of bitmaps kept in best-fit order (default, no mask read) and
     every candidate's bit looked up in the mask (KSCHED_OPT_PICK_FROM_MASK) -- both == oracle; with taints, > 8 label keys, predicate subsets, rows whose only feasible nodes sit beyond the direct window,
     and after ksched_update_nodes (the order changes)."""
     ev = evaluator
     ev.set_kernel(kernel)
+    ev.set_option(_lib.OPT_BESTFIT_STAGES, stages)  # 1: a wave per pod; 2: a lane per pod first (the default only from 65536 pods on)
     rng = np.random.default_rng(23)
     for (P, N, K) in [(1500, 6000, 8), (600, 2500, 12), (200, 100, 3), (64, 1, 8)]:
         c = synth.make_cluster(P, N, n_keys=min(K, 8), n_taints=16, seed=3 * P + K)
@@ -689,4 +692,5 @@ def test_bestfit_direct_equals_bestfit_from_mask(evaluator, kernel):
             ev.set_option(_lib.OPT_PICK_FROM_MASK, 0)
             ev.update_nodes(idx, cpu[idx], mem[idx])
     ev.set_option(_lib.OPT_PICK_FROM_MASK, 0)
+    ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
     ev.set_kernel("auto")

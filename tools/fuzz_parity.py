@@ -49,6 +49,7 @@ while time.time() < t_end:
     pick = int(r.choice([0, L.PICK_SAMPLED, L.PICK_BESTFIT]))
     flags = preds | pick | (L.WANT_FIT_MASK if r.random() < 0.5 else 0)
     try:
+        ev.set_option(L.OPT_BESTFIT_STAGES, int(r.choice([0, 1, 2])))
         ev.set_nodes(cpu, mem, lab, taints)
         for step in range(int(r.choice([1, 1, 3]))):
             if step:  # a snapshot update between evaluations
