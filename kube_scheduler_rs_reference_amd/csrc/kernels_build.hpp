@@ -249,10 +249,15 @@ struct PatchArgs {
     uint32_t count;
     uint32_t idx_in[kPatchInline];
     int64_t cpu_in[kPatchInline], mem_in[kPatchInline];
+    // small updates: the list of touched tiles for the re-index kernel that follows rides along (no separate launch, no copy)
+    uint32_t *tile_out;
+    uint32_t ntiles;  // <= count: every touched tile holds at least one updated node
+    uint32_t tiles_in[kPatchInline];
 };
 __global__ __launch_bounds__(256) void k_patch_nodes(const PatchArgs a) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.count) return;
+    if (a.tile_out && t < a.ntiles) a.tile_out[t] = a.tiles_in[t];
     uint32_t node;
     int64_t c, m;
     if (a.idx) {
@@ -268,15 +273,6 @@ __global__ __launch_bounds__(256) void k_patch_nodes(const PatchArgs a) {
     a.nmem[node] = m;
     a.nrec[(size_t)kNodeRecWords * node] = c;
     a.nrec[(size_t)kNodeRecWords * node + 1] = m;
-}
-
-struct TileListArgs {
-    uint32_t *out;
-    uint32_t count;
-    uint32_t tiles[kPatchInline];
-};
-__global__ void k_write_tile_list(const TileListArgs a) {
-    if (threadIdx.x < a.count) a.out[threadIdx.x] = a.tiles[threadIdx.x];
 }
 
 // node records (kernels_direct.hpp "Node records"): one 64-byte line per node for the candidate-testing picks

@@ -986,20 +986,17 @@ int ksched_update_nodes(ksched_ctx *c, uint32_t count, const uint32_t *node_inde
         pa.mem = pa.cpu + m;
         d_tiles = reinterpret_cast<const uint32_t *>(c->d_stage.ptr + b_idx + 2 * b_val);
     }
+    if (want_tiles && !d_tiles) {  // small update: the tile list rides in the patch kernel's arguments
+        if (c->d_stage.reserve(kPatchInline * 4) != hipSuccess) return fail(KSCHED_E_NOMEM);
+        pa.tile_out = reinterpret_cast<uint32_t *>(c->d_stage.ptr);
+        pa.ntiles = (uint32_t)tiles.size();
+        for (size_t j = 0; j < tiles.size(); ++j) pa.tiles_in[j] = tiles[j];
+        d_tiles = pa.tile_out;
+    }
     hipLaunchKernelGGL(k_patch_nodes, dim3((m + 255u) / 256u), dim3(256), 0, s, pa);
     if (hipGetLastError() != hipSuccess) return fail(KSCHED_E_HIP);
     if (want_tiles) {
         // only the touched 1024-node tiles are re-indexed (fit rows, search trees, cnt tables); label and taint rows are untouched
-        if (!d_tiles) {
-            if (c->d_stage.reserve(kPatchInline * 4) != hipSuccess) return fail(KSCHED_E_NOMEM);
-            // the tile list of a small update rides in a second tiny kernel's arguments
-            TileListArgs tl{};
-            tl.out = reinterpret_cast<uint32_t *>(c->d_stage.ptr);
-            tl.count = (uint32_t)tiles.size();
-            for (size_t j = 0; j < tiles.size(); ++j) tl.tiles[j] = tiles[j];
-            hipLaunchKernelGGL(k_write_tile_list, dim3(1), dim3(64), 0, s, tl);
-            d_tiles = tl.out;
-        }
         if (int rc = launch_build_fit(c, d_tiles, (uint32_t)tiles.size())) return fail(rc);
     }
     c->bf_dirty = true;  // the best-fit order is rebuilt by the next PICK_BESTFIT request, not here
