@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <numeric>
+#include <thread>
 
 namespace ksched_host {
 
@@ -244,30 +245,56 @@ PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
     pc.req_mem_bytes.resize(pc.p);
     pc.sel_val_ids.assign((size_t)pc.n_keys * pc.p, 0u);
     pc.tolerations.assign(pc.p, 0ull);
-    for (uint32_t i = 0; i < pc.p; ++i) {
-        const corev1::Pod &pod = *pods[i];
-        try {
-            const PodResources r = total_pod_resources(pod);  // src/predicates.rs:40
-            pc.req_cpu_milli[i] = r.cpu.to_milli();
-            pc.req_mem_bytes[i] = r.memory.to_units();
-        } catch (const QuantityError &e) {
-            throw EncodeError("pod " + full_name(pod.metadata) + ": invalid pod spec: " + e.what());
-        }
-        if (pod.spec && pod.spec->node_selector) {
-            for (const auto &[k, v] : *pod.spec->node_selector) {  // src/predicates.rs:48-53
-                const uint32_t col = (uint32_t)(std::find(cols_.keys.begin(), cols_.keys.end(), k) - cols_.keys.begin());
-                auto it = value_ids_[col].find(v);
-                pc.sel_val_ids[(size_t)col * pc.p + i] = (it == value_ids_[col].end()) ? KSCHED_SEL_NEVER : it->second;
+    // column index of every key once (the batch's keys all have a column now)
+    std::map<std::string, uint32_t> col_of;
+    for (uint32_t k = 0; k < cols_.n_keys; ++k) col_of.emplace(cols_.keys[k], k);
+    auto encode_range = [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; ++i) {
+            const corev1::Pod &pod = *pods[i];
+            try {
+                const PodResources r = total_pod_resources(pod);  // src/predicates.rs:40
+                pc.req_cpu_milli[i] = r.cpu.to_milli();
+                pc.req_mem_bytes[i] = r.memory.to_units();
+            } catch (const QuantityError &e) {
+                throw EncodeError("pod " + full_name(pod.metadata) + ": invalid pod spec: " + e.what());
+            }
+            if (pod.spec && pod.spec->node_selector) {
+                for (const auto &[k, v] : *pod.spec->node_selector) {  // src/predicates.rs:48-53
+                    const uint32_t col = col_of.at(k);
+                    auto it = value_ids_[col].find(v);
+                    pc.sel_val_ids[(size_t)col * pc.p + i] = (it == value_ids_[col].end()) ? KSCHED_SEL_NEVER : it->second;
+                }
+            }
+            if (taints_enabled_ && pod.spec && pod.spec->tolerations) {
+                for (const auto &[id, bit] : taint_ids_)
+                    for (const auto &t : *pod.spec->tolerations)
+                        if (toleration_matches(t, id)) {
+                            pc.tolerations[i] |= 1ull << bit;
+                            break;
+                        }
             }
         }
-        if (taints_enabled_ && pod.spec && pod.spec->tolerations) {
-            for (const auto &[id, bit] : taint_ids_)
-                for (const auto &t : *pod.spec->tolerations)
-                    if (toleration_matches(t, id)) {
-                        pc.tolerations[i] |= 1ull << bit;
-                        break;
-                    }
-        }
+    };
+    // The wire-format step is per-pod string work (quantity parsing, dictionary lookups): for a large batch it is what the host
+    // spends its time on, and the pods are independent -- fan it out over threads (each writes only its own rows).
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t nthreads = pc.p >= 4096u ? std::min<uint32_t>({hw, 32u, pc.p / 1024u}) : 1u;
+    if (nthreads <= 1) {
+        encode_range(0, pc.p);
+    } else {
+        std::vector<std::thread> pool;
+        std::vector<std::string> errors(nthreads);
+        for (uint32_t t = 0; t < nthreads; ++t)
+            pool.emplace_back([&, t] {
+                try {
+                    encode_range((uint32_t)((uint64_t)pc.p * t / nthreads), (uint32_t)((uint64_t)pc.p * (t + 1) / nthreads));
+                } catch (const std::exception &e) {
+                    errors[t] = e.what();
+                }
+            });
+        for (auto &th : pool) th.join();
+        for (const auto &e : errors)
+            if (!e.empty()) throw EncodeError(e);  // the lowest pod range's error, like the sequential walk would have raised first
     }
     return pc;
 }
