@@ -489,11 +489,7 @@ __device__ __forceinline__ void wave_lower_bound_sampled2(const int64_t *__restr
 // request, and the first word to look at (w_first >= start >> 6; the caller vouches that no feasible position lies before it).
 // Returns the chosen node (every lane holds the same value).
 __device__ __forceinline__ int32_t bestfit_rows_scan(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane, uint32_t start, uint32_t r, uint32_t w_first,
-                                                     int64_t req_c) {
-    const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
-    uint32_t sel[8];
-#pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) sel[k] = (q.psel && k < q.nkeys) ? q.psel[(size_t)k * q.p + pod] : 0u;  // wave-uniform
+                                                     int64_t req_c, uint64_t tol, const uint32_t (&sel)[8]) {
     uint32_t r_hi = q.row_valid, r_lo = q.row_valid;
     if (q.do_fit) {
         r_hi = q.row_cpu0 + (r + q.q - 1u) / q.q;  // only nodes that fit
@@ -563,7 +559,11 @@ __device__ __forceinline__ int32_t bestfit_rows_one_pod(const BestfitRowsArgs &q
             r = wave_lower_bound(q.cpu_sorted, q.n, req_c, lane);
         }
     }
-    return bestfit_rows_scan(q, pod, lane, start, r, start >> 6, req_c);
+    const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
+    uint32_t sel[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) sel[k] = (q.psel && k < q.nkeys) ? q.psel[(size_t)k * q.p + pod] : 0u;  // wave-uniform
+    return bestfit_rows_scan(q, pod, lane, start, r, start >> 6, req_c, tol, sel);
 }
 
 // One wave per pod, one launch slot per pod.  (A persistent grid of 8192 waves walking the pods was measured slower,
@@ -577,10 +577,13 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
         // (one short-lived wave per listed pod, the grid sized for the worst case: waves beyond the count exit at once; a persistent
         // grid walking the list was measured slower, like the persistent form of the one-stage kernel)
         if (wave >= *q.pod_count) return;
-        // the first stage hands over what it already knows: {pod, start, r, next word}: no rank search here
-        const uint4 rec = reinterpret_cast<const uint4 *>(q.pod_list)[wave];
-        const int32_t b = bestfit_rows_scan(q, rec.x, lane, rec.y, rec.z, rec.w, q.do_fit ? q.pcpu[rec.x] : 0);
-        if (lane == 0) q.binding[rec.x] = b;
+        // the first stage hands over everything it had in registers -- one 64-byte record {pod, start, cpu rank, next word,
+        // tolerations, cpu request, selector ids 0..7}: no rank search and no operand round trip here, the row loads go out at once
+        const uint4 *rec = reinterpret_cast<const uint4 *>(q.pod_list) + (size_t)wave * 4u;
+        const uint4 h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
+        const uint32_t sel[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const int32_t b = bestfit_rows_scan(q, h.x, lane, h.y, h.z, h.w, (int64_t)(((uint64_t)o.w << 32) | o.z), ((uint64_t)o.y << 32) | o.x, sel);
+        if (lane == 0) q.binding[h.x] = b;
         return;
     }
     if (wave >= q.p) return;
@@ -675,7 +678,11 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
         }
     }
     if (undecided) {  // the wave-per-pod kernel scans on behind the words looked at here
-        reinterpret_cast<uint4 *>(q.fallback_list)[atomicAdd(q.fallback_count, 1u)] = make_uint4(pod, start, r, (start >> 6) + q.lane_words);
+        uint4 *rec = reinterpret_cast<uint4 *>(q.fallback_list) + (size_t)atomicAdd(q.fallback_count, 1u) * 4u;
+        rec[0] = make_uint4(pod, start, r, (start >> 6) + q.lane_words);
+        rec[1] = make_uint4((uint32_t)tol, (uint32_t)(tol >> 32), (uint32_t)(uint64_t)req_c, (uint32_t)((uint64_t)req_c >> 32));
+        rec[2] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
+        rec[3] = make_uint4(sel[4], sel[5], sel[6], sel[7]);
     } else {
         q.binding[pod] = found;
     }

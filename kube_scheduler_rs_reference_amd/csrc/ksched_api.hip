@@ -626,14 +626,14 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
             hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q);
         } else {
             // two stages: one lane per pod decides from the first two candidate words; the rare rest goes to the wave-per-pod kernel
-            HIPCHK(c, c->bf_fallback.reserve(4 * ((size_t)p + 1)));  // [counter, pad x3][{pod, start, r, next word} x p]
+            HIPCHK(c, c->bf_fallback.reserve(16 * ((size_t)p + 1)));  // [counter, padding to 64 bytes][one 64-byte hand-over record x p]
             HIPCHK(c, hipMemsetAsync(c->bf_fallback.ptr, 0, 4, s));
             q.lvl = c->bf_levels.ptr;
             q.nlev = c->bf_nlev;
             q.lvl_half = c->bf_lvl_half;
             for (uint32_t k = 0; k < 6; ++k) q.lvl_off[k] = c->bf_lvl_off[k];
             q.fallback_count = c->bf_fallback.ptr;
-            q.fallback_list = c->bf_fallback.ptr + 4;
+            q.fallback_list = c->bf_fallback.ptr + 16;
             q.lane_words = ((c->opt_debug >> 12) & 15u) ? ((c->opt_debug >> 12) & 15u) : 8u;  // KSCHED_OPT_DEBUG bits 12-15: A/B of the hand-over point (8 words = 512 candidates measured best at the C5 shard)
             hipLaunchKernelGGL(k_pick_bestfit_lanes, dim3((p + 255) / 256), dim3(256), 0, s, q);
             BestfitRowsArgs q2 = q;
