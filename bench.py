@@ -45,6 +45,8 @@ WORKLOADS = {
            "C3: 100k pods x 5k nodes, fit + nodeSelector over 8 label keys (BASELINE.json configs[2])"),
     "C3h": ("C3h", 100_000, 5_000, ("FIT", "SEL"), "sampled",
             "C3 with a hostname-like eighth label key (5 000 values, one per node; 15 % of the pods name a node): the high-cardinality case, not a BASELINE config"),
+    "C5hs": ("C5h", 125_000, 50_000, ("FIT", "SEL", "TAINT"), "bestfit",
+             "C5 shard with a hostname-like eighth label key (50 000 values; 15 % of the pods name a node), best-fit pick: not a BASELINE config"),
     "C4s": ("C4", 125_000, 10_000, ("FIT", "SEL"), "sampled",
             "C4 shard: 125k pods x 10k nodes per GPU, fit + sel (BASELINE.json configs[3] = 8 shards)"),
     "C5s": ("C5", 125_000, 50_000, ("FIT", "SEL", "TAINT"), "bestfit",

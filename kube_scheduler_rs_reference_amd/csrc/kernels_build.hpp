@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256) void k_bf_rows(const BfRowsArgs a) {
         if (lane == 0) a.rows[(size_t)a.row_valid * a.Wbf + w] = word;
     }
     for (uint32_t k = 0; k < a.nkeys; ++k) {
+        if (a.lab_meta[k] == kLabList) continue;  // list keys have no rows: pods that constrain them take k_pick_bestfit_listed
         const uint32_t id = live ? a.nlab[(size_t)k * a.n + node] : 0u;
         // lanes of one wave own one word of each row: combine per distinct id with a ballot-free OR (atomics on distinct
         // words are rare collisions only inside the wave)

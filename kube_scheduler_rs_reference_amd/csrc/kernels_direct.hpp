@@ -423,6 +423,9 @@ struct BestfitRowsArgs {
     uint32_t nlev, lvl_half, lvl_off[6];
     uint32_t *fallback_list, *fallback_count;
     uint32_t lane_words;  // candidate words (64 positions each) a lane looks at before handing the pod over
+    // snapshots with list keys (tile_index.hpp): pods that constrain one are collected for k_pick_bestfit_listed
+    uint32_t nlist, list_col[2];
+    uint32_t *listed_list, *listed_count;
 };
 
 // first i in [0, n) with arr[i] >= key (n if none), by the whole wave: 64-ary search, three rounds for n <= 262144
@@ -604,6 +607,14 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
     const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
     if (pod >= q.p) return;
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    if (q.nlist && q.psel) {  // a list key has no bitmap rows: a pod that constrains one is picked from the key's sorted lists instead
+        bool listed = false;
+        for (uint32_t j = 0; j < q.nlist; ++j) listed |= q.psel[(size_t)q.list_col[j] * q.p + pod] != 0u;
+        if (listed) {
+            q.listed_list[atomicAdd(q.listed_count, 1u)] = pod;
+            return;
+        }
+    }
     const int64_t req_c = q.do_fit ? q.pcpu[pod] : 0, req_m = q.do_fit ? q.pmem[pod] : 0;
     const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
     uint32_t sel[8];
@@ -687,6 +698,63 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
     } else {
         q.binding[pod] = found;
     }
+}
+
+// Best fit for pods that constrain a LIST key (a high-cardinality label key kept per tile as a sorted list, tile_index.hpp): only
+// the few nodes carrying the pod's value can be feasible at all, so instead of scanning best-fit positions the wave walks those
+// nodes -- lane = tile: two lower bounds in the tile's list give the range, every node of the range is tested in full from its
+// node record (same predicate as k_select_sampled) -- and takes the one with the smallest best-fit position.
+struct BestfitListedArgs {
+    const uint8_t *lists;          // IndexedSnapshot::d_list: [tiles][nlist][kListBytes]
+    const int64_t *nrec;           // node records
+    const uint32_t *nlab;          // [nkeys][n]
+    const uint32_t *bf_rank, *bf_order;
+    const int64_t *pcpu, *pmem;
+    const uint32_t *psel;
+    const uint64_t *ptol;
+    const uint32_t *listed_list, *listed_count;
+    int32_t *binding;
+    uint32_t p, n, nkeys, tiles, nlist, list_col[2], do_fit, do_taint;
+};
+__global__ __launch_bounds__(256) void k_pick_bestfit_listed(const BestfitListedArgs q) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= *q.listed_count) return;
+    const uint32_t pod = q.listed_list[wave];
+    const int64_t rc = q.do_fit ? q.pcpu[pod] : 0, rm = q.do_fit ? q.pmem[pod] : 0;
+    const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
+    // walk the lists of the first list key the pod constrains; the other constraints are checked per candidate
+    uint32_t j0 = 0;
+    while (j0 + 1u < q.nlist && q.psel[(size_t)q.list_col[j0] * q.p + pod] == 0u) ++j0;
+    const uint32_t want = q.psel[(size_t)q.list_col[j0] * q.p + pod];
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t t = lane; t < q.tiles; t += 64u) {
+        const uint8_t *L = q.lists + ((size_t)t * q.nlist + j0) * 6144u;  // kListBytes
+        const uint32_t *vals = reinterpret_cast<const uint32_t *>(L);
+        const uint16_t *nodes = reinterpret_cast<const uint16_t *>(L + 4096u);
+        uint32_t lo = 0;  // entries below `want`
+        for (uint32_t half = 512u; half >= 1u; half >>= 1) lo += (vals[lo + half - 1u] < want) ? half : 0u;
+        lo += (vals[lo] < want) ? 1u : 0u;
+        for (uint32_t e = lo; e < 1024u && vals[e] == want; ++e) {
+            const uint32_t node = t * 1024u + nodes[e];
+            if (node >= q.n) continue;  // (padding carries id 0, never a wanted id; kept for safety)
+            bool f = true;
+            if (q.do_fit) {
+                const i64x2 cm = reinterpret_cast<const i64x2 *>(q.nrec)[(size_t)node * 4u];
+                f = rc <= cm.x && rm <= cm.y;  // src/predicates.rs:42
+            }
+            if (f && q.do_taint) f = ((uint64_t)q.nrec[(size_t)node * kNodeRecWords + 2u] & ~tol) == 0ull;
+            for (uint32_t k = 0; f && k < q.nkeys; ++k) {  // src/predicates.rs:48-57, every key incl. the list keys
+                const uint32_t s = q.psel[(size_t)k * q.p + pod];
+                if (s != 0u && s != q.nlab[(size_t)k * q.n + node]) f = false;
+            }
+            if (f) best = min(best, q.bf_rank[node]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off, 64));
+    if (lane == 0) q.binding[pod] = (best == 0xFFFFFFFFu) ? -1 : (int32_t)q.bf_order[best];
 }
 
 }  // namespace ksched

@@ -27,6 +27,8 @@
 
 using namespace ksched;
 
+static_assert(kListBytes == 6144u && kTileNodes == 1024, "k_pick_bestfit_listed (kernels_direct.hpp) addresses the tile lists with these sizes");
+
 namespace {
 
 template <class T>
@@ -370,7 +372,7 @@ int build_bestfit(ksched_ctx *c) {
             HIPCHK(c, hipGetLastError());
         }
     }
-    if (c->idx.built && c->idx.lay.nlist == 0) {  // (list keys have no rows to re-order: the mask-reading pick serves those snapshots)
+    if (c->idx.built) {  // (list keys have no rows: pods that constrain one are picked from the key's sorted lists, k_pick_bestfit_listed)
         const IndexedLayout &l = c->idx.lay;
         const uint32_t Wbf = (n + 63u) / 64u, named = l.row_cpu, levels = 256u, q = (n + levels - 1u) / levels;
         const uint32_t rows = named + levels + 1u;
@@ -403,7 +405,7 @@ int build_bestfit(ksched_ctx *c) {
 }
 
 // will the best-fit rows exist once ensure_bestfit has run?  (they are built with the bitmap index's row numbering)
-inline bool bf_rows_expected(const ksched_ctx *c) { return c->idx.built && c->idx.lay.nlist == 0 && c->n > 0; }
+inline bool bf_rows_expected(const ksched_ctx *c) { return c->idx.built && c->n > 0; }
 
 // a PICK_BESTFIT request is about to be enqueued: make sure the structures match the snapshot
 int ensure_bestfit(ksched_ctx *c) {
@@ -621,25 +623,58 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         }
         // one stage (a wave per pod) or two (a lane per pod first): the second launch and the hand-over list pay off from tens of
         // thousands of pods on (20k pods: 33 us against 44; 125k pods: 160 against 120) -- KSCHED_OPT_BESTFIT_STAGES overrides
-        const bool two_stage = c->opt_bestfit_stages == 2 || (c->opt_bestfit_stages == 0 && p >= 65536u);
-        if (!two_stage || (c->opt_debug & 0x400u) || c->n > (1u << 21)) {
+        const bool lists = sel && l.nlist > 0;  // pods that constrain a list key are split off by the first stage: two stages it is
+        const bool two_stage = lists || c->opt_bestfit_stages == 2 || (c->opt_bestfit_stages == 0 && p >= 65536u);
+        if (!lists && (!two_stage || (c->opt_debug & 0x400u) || c->n > (1u << 21))) {
             hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q);
         } else {
             // two stages: one lane per pod decides from the first two candidate words; the rare rest goes to the wave-per-pod kernel
-            HIPCHK(c, c->bf_fallback.reserve(16 * ((size_t)p + 1)));  // [counter, padding to 64 bytes][one 64-byte hand-over record x p]
-            HIPCHK(c, hipMemsetAsync(c->bf_fallback.ptr, 0, 4, s));
+            if (c->n > (1u << 21)) {
+                c->last_error = "best fit over a snapshot with list keys supports at most 2097152 nodes";
+                return KSCHED_E_UNSUPPORTED;
+            }
+            HIPCHK(c, c->bf_fallback.reserve(16 * ((size_t)p + 1) + p));  // [2 counters, padding to 64 bytes][64-byte hand-over record x p][listed pods x p]
+            HIPCHK(c, hipMemsetAsync(c->bf_fallback.ptr, 0, 8, s));
             q.lvl = c->bf_levels.ptr;
             q.nlev = c->bf_nlev;
             q.lvl_half = c->bf_lvl_half;
             for (uint32_t k = 0; k < 6; ++k) q.lvl_off[k] = c->bf_lvl_off[k];
             q.fallback_count = c->bf_fallback.ptr;
             q.fallback_list = c->bf_fallback.ptr + 16;
+            q.nlist = lists ? l.nlist : 0u;
+            for (uint32_t j = 0; j < q.nlist; ++j) q.list_col[j] = l.list_col[j];
+            q.listed_count = c->bf_fallback.ptr + 1;
+            q.listed_list = c->bf_fallback.ptr + 16 * ((size_t)p + 1);
             q.lane_words = ((c->opt_debug >> 12) & 15u) ? ((c->opt_debug >> 12) & 15u) : 8u;  // KSCHED_OPT_DEBUG bits 12-15: A/B of the hand-over point (8 words = 512 candidates measured best at the C5 shard)
             hipLaunchKernelGGL(k_pick_bestfit_lanes, dim3((p + 255) / 256), dim3(256), 0, s, q);
             BestfitRowsArgs q2 = q;
             q2.pod_list = q.fallback_list;
             q2.pod_count = q.fallback_count;
             hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q2);
+            if (lists) {
+                BestfitListedArgs la{};
+                la.lists = c->idx.d_list;
+                la.nrec = c->nrec.ptr;
+                la.nlab = c->nlab.ptr;
+                la.bf_rank = c->bf_rank.ptr;
+                la.bf_order = c->bf_order.ptr;
+                la.pcpu = pcpu;
+                la.pmem = pmem;
+                la.psel = psel;
+                la.ptol = ptol;
+                la.listed_list = q.listed_list;
+                la.listed_count = q.listed_count;
+                la.binding = out_binding;
+                la.p = p;
+                la.n = c->n;
+                la.nkeys = c->nkeys;
+                la.tiles = l.tiles;
+                la.nlist = l.nlist;
+                for (uint32_t j = 0; j < l.nlist; ++j) la.list_col[j] = l.list_col[j];
+                la.do_fit = q.do_fit;
+                la.do_taint = q.do_taint;
+                hipLaunchKernelGGL(k_pick_bestfit_listed, dim3((p + 3) / 4), dim3(256), 0, s, la);
+            }
         }
         HIPCHK(c, hipGetLastError());
         if (!out_feas && !out_fit) return KSCHED_OK;

@@ -288,6 +288,7 @@ CONFIGS: Dict[str, dict] = {
     "C5": dict(P=1_000_000, N=50_000, n_keys=8, n_taints=16, flags=("FIT", "SEL", "TAINT")),
     # C3 with its eighth label key replaced by a hostname-like key (5 000 values): the high-cardinality case (not a BASELINE config)
     "C3h": dict(P=100_000, N=5_000, n_keys=8, n_taints=0, flags=("FIT", "SEL"), hostname_key=7),
+    "C5h": dict(P=1_000_000, N=50_000, n_keys=8, n_taints=16, flags=("FIT", "SEL", "TAINT"), hostname_key=7),
 }
 
 

@@ -136,3 +136,32 @@ def test_three_high_cardinality_keys_fall_back_with_a_reason(evaluator):
         ev.eval(c.req_cpu, c.req_mem, sel, None, None, FIT | SEL)
     assert "high-cardinality" in str(e.value)
     ev.set_kernel("auto")
+
+
+@pytest.mark.parametrize("n_taints", [0, 16])
+def test_bestfit_on_a_snapshot_with_list_keys(evaluator, n_taints):
+    """Best fit when some pods name a node (hostname key) or a mid-cardinality list key: those pods are picked from the key's sorted
+    lists (k_pick_bestfit_listed: only the nodes carrying the value are candidates), the others from the bitmaps in best-fit order;
+    no mask is read -- also as a bindings-only request, and again after the snapshot changed."""
+    ev = evaluator
+    c = synth.make_cluster(4000, 5500, n_keys=8, n_taints=n_taints, seed=29 + n_taints)
+    lab, sel = with_keys(c, [5500, 700], p_constrain=0.3, seed=10)
+    tnt = c.node_taints if n_taints else None
+    tol = c.pod_tol if n_taints else None
+    flags = FIT | SEL | (TAINT if n_taints else 0) | PICK_BESTFIT
+    cpu, mem = c.avail_cpu.copy(), c.avail_mem.copy()
+    ev.set_kernel("auto")
+    ev.set_nodes(cpu, mem, lab, tnt)
+    rng = np.random.default_rng(3)
+    for step in range(2):
+        _, _, want = capi.eval_encoded(cpu, mem, lab, tnt, c.req_cpu, c.req_mem, sel, tol, None, flags)
+        got = ev.eval(c.req_cpu, c.req_mem, sel, tol, None, flags, want_mask=False)  # bindings only: no mask kernel at all
+        assert np.array_equal(got.binding, want), step
+        got = ev.eval(c.req_cpu, c.req_mem, sel, tol, None, flags)
+        assert np.array_equal(got.binding, want), step
+        pinned = (sel[8] != 0) & (sel[8] != SEL_NEVER)
+        assert pinned.sum() > 500 and (want[pinned] >= 0).sum() > 50, "the case must exercise hostname-pinned pods that do get a node"
+        idx = rng.choice(c.N, 40, replace=False).astype(np.uint32)
+        cpu[idx] += rng.integers(-3000, 3000, idx.size)
+        mem[idx] += rng.integers(-(1 << 30), 1 << 30, idx.size)
+        ev.update_nodes(idx, cpu[idx], mem[idx])
