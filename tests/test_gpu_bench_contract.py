@@ -1,0 +1,47 @@
+"""bench.py's output contract (the driver parses this line): ONE JSON line, the metric / unit / workload names of BASELINE.json,
+the `roofline` and `cpu_baseline` objects, value consistent with steps and ms_per_step.  Short run (reduced steps, small CPU sample)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_default_line_contract(built):
+    d = run_bench("--steps", "100", "--warmup", "5", "--ramp-ms", "10", "--kernel-samples", "16")
+    assert d["metric"] == "pod x node predicate evals/s" and d["unit"] == "evals/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 100 and d["warmup"] == 5 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "int64" and d["data"] == "synthetic"
+    c = d["config"]
+    assert c["workload"].startswith("C3: 100k pods x 5k nodes") and c["pods_total"] == 100_000 and c["nodes"] == 5_000 and c["kernel"] == "fused"
+    assert c["mask_written"] is True and 0.2 < c["bound_fraction"] < 0.8
+    assert abs(d["value"] - 100_000 * 5_000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["value"] > 1e9, "north_star: >= 1e9 evals/s on one MI355X"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["launches_timed"] == 16
+    assert r["algorithmic_bytes_per_launch"] == 100_000 * 48 + 5_000 * 48 + 100_000 * 79 * 8  # C3, 8 label keys
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_kernel_us"] * 1e-6) / 1e9) < 1e-3 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-9 and r["frac"] >= 0.40, "north_star: >= 40 % of the HBM roofline"
+    assert r["min_kernel_us"] <= r["median_kernel_us"] <= r["max_kernel_us"]
+    assert r["traffic"] is None or r["traffic_source"].startswith("profiles/pmc_traffic.json")
+    b = d["cpu_baseline"]
+    assert b["kind"] == "port" and b["unit"] == "evals/s" and b["cores"] >= 1 and b["value"] > 0 and "sample" in b
+
+
+def test_other_workloads_and_bindings_only(built):
+    d = run_bench("--workload", "C2", "--steps", "50", "--warmup", "5", "--ramp-ms", "5", "--kernel-samples", "8", "--no-cpu-baseline")
+    assert d["config"]["nodes"] == 1000 and d["config"]["predicates"] == "FIT" and d["cpu_baseline"] is None
+    d = run_bench("--steps", "50", "--warmup", "5", "--ramp-ms", "5", "--kernel-samples", "8", "--no-cpu-baseline", "--no-mask")
+    assert d["config"]["mask_written"] is False and d["config"]["kernel"] == "none"
