@@ -32,7 +32,9 @@
  *   - the *_device entry points take device pointers (HBM resident, e.g. torch tensors'
  *     data_ptr()) and a hipStream_t passed as void*; they enqueue and return without syncing.
  *     The host-pointer entry points copy in, run, copy out and synchronise.
- *   - a ksched_ctx is internally serialised by a mutex; use one ctx per device.
+ *   - a ksched_ctx is internally serialised by a mutex (host side); use one ctx per device.  Evaluations may be enqueued on
+ *     any number of the caller's streams: the library orders them against snapshot changes and against each other's use
+ *     of ctx-owned scratch memory with events.  Tell it before a stream is destroyed (ksched_forget_stream).
  */
 #ifndef KSCHED_H
 #define KSCHED_H
@@ -231,6 +233,9 @@ int ksched_pick_device(ksched_ctx *ctx, uint32_t p, const uint64_t *feasible, ui
  *      slot's pick has run.  A caller that enqueues its own work on the pick stream behind the pick (reading
  *      `binding`) thereby also delays the slot's next use correctly (the next pick of the slot is ordered after it).
  *   ksched_pipe_wait(slot, stream)  make `hip_stream` wait for the slot's pick; stream == NULL blocks the host.
+ *   ksched_pipe_wait_mask(slot, stream)  the same for the slot's MASK (the two streams are not ordered against each other, so
+ *        a finished pick says nothing about the mask kernel).  Waits for everything submitted to the mask stream so far; the
+ *        event is recorded by this call, so consumers that only read bindings pay nothing for it.
  *   ksched_pipe_stream(which)       the internal hipStream_t: 0 = mask stream, 1 = pick stream.
  * Results are identical to ksched_eval_device_pitched with the same arguments (tests/test_gpu_parity.py).
  */
@@ -241,6 +246,7 @@ int ksched_pipe_submit(ksched_pipe *pipe, uint32_t slot, uint32_t p, const int64
                        const uint32_t *sel_val_ids, const uint64_t *tolerations, const uint32_t *samples, uint32_t attempts,
                        uint32_t flags, uint64_t *mask, uint32_t mask_pitch_words, int32_t *binding);
 int ksched_pipe_wait(ksched_pipe *pipe, uint32_t slot, void *hip_stream);
+int ksched_pipe_wait_mask(ksched_pipe *pipe, uint32_t slot, void *hip_stream);
 void *ksched_pipe_stream(ksched_pipe *pipe, int which);
 
 /* ---- reasons ------------------------------------------------------------------------------

@@ -79,6 +79,7 @@ SYMBOLS = {
     "ksched_pipe_destroy": (None, [_vp]),
     "ksched_pipe_submit": (C.c_int, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _vp]),
     "ksched_pipe_wait": (C.c_int, [_vp, _u32, _vp]),
+    "ksched_pipe_wait_mask": (C.c_int, [_vp, _u32, _vp]),
     "ksched_pipe_stream": (_vp, [_vp, C.c_int]),
     "ksched_reason": (C.c_int, [_vp, _vp, _u32, _u32]),
     "ksched_comm_unique_id": (C.c_int, [_vp]),

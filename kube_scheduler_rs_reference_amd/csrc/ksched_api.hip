@@ -102,6 +102,12 @@ struct ksched_ctx {
     std::vector<UserStream> user_streams;
     hipEvent_t ev_build = nullptr;
     uint64_t build_gen = 0;
+    // The ctx-owned device scratch that evaluations on the caller's streams use (bf_fallback, scratch_mask, trace) belongs to one
+    // stream at a time: when another stream is about to use it, that stream first waits for what the previous one holds
+    // (scratch_enter; an event recorded at that moment, nothing on the common one-stream path).
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_owned = false, scratch_ev_pending = false;
+    hipEvent_t ev_scratch = nullptr;
 
     // scratch for the host-pointer path
     DevBuf<int64_t> pcpu, pmem;
@@ -198,7 +204,27 @@ int stream_enter(ksched_ctx *c, hipStream_t s) {
     return KSCHED_OK;
 }
 
+// `s` is about to enqueue work that uses the ctx-owned scratch buffers
+int scratch_enter(ksched_ctx *c, hipStream_t s) {
+    if (c->scratch_owned && c->scratch_stream != s) {
+        HIPCHK(c, hipEventRecord(c->ev_scratch, c->scratch_stream));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_scratch, 0));
+    } else if (!c->scratch_owned && c->scratch_ev_pending) {
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_scratch, 0));
+    }
+    c->scratch_stream = s;
+    c->scratch_owned = true;
+    c->scratch_ev_pending = false;
+    return KSCHED_OK;
+}
+
 void stream_forget(ksched_ctx *c, hipStream_t s) {
+    if (c->scratch_owned && c->scratch_stream == s) {  // its last use of the scratch buffers stays ordered: as an event
+        c->scratch_ev_pending = hipEventRecord(c->ev_scratch, s) == hipSuccess;
+        if (!c->scratch_ev_pending) (void)hipGetLastError();
+        c->scratch_owned = false;
+        c->scratch_stream = nullptr;
+    }
     for (size_t i = 0; i < c->user_streams.size(); ++i)
         if (c->user_streams[i].s == s) {
             (void)hipEventDestroy(c->user_streams[i].ev);
@@ -633,6 +659,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
                 c->last_error = "best fit over a snapshot with list keys supports at most 2097152 nodes";
                 return KSCHED_E_UNSUPPORTED;
             }
+            if (int rsc = scratch_enter(c, s)) return rsc;
             HIPCHK(c, c->bf_fallback.reserve(16 * ((size_t)p + 1) + p));  // [2 counters, padding to 64 bytes][64-byte hand-over record x p][listed pods x p]
             HIPCHK(c, hipMemsetAsync(c->bf_fallback.ptr, 0, 8, s));
             q.lvl = c->bf_levels.ptr;
@@ -681,6 +708,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     }
     uint64_t *feas = out_feas;
     if (!feas) {  // the mask kernels always write the feasible mask: a pick that reads it, or a fit-mask-only request, gets a scratch one
+        if (int rsc = scratch_enter(c, s)) return rsc;
         HIPCHK(c, c->scratch_mask.reserve((size_t)p * pitch));
         feas = c->scratch_mask.ptr;
     }
@@ -698,7 +726,8 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         return KSCHED_E_UNSUPPORTED;
     }
     size_t slot = 0;
-    const bool timed = c->opt_timing && (c->timing_seq++ % c->opt_timing) == 0;
+    // (at most 65536 unread samples: a caller that switches timing on and never reads it does not grow the event pool for ever)
+    const bool timed = c->opt_timing && c->ev_used < 65536u && (c->timing_seq++ % c->opt_timing) == 0;
     if (timed) {
         int trc = timing_slot(c, &slot);
         if (trc) return trc;
@@ -708,6 +737,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         constexpr uint32_t kTraceBlocks = 8192;
         if (c->opt_trace) {
             DeviceGuard g2(c->device);
+            if (int rsc = scratch_enter(c, s)) return rsc;
             HIPCHK(c, c->trace.reserve((size_t)kTraceBlocks * KSCHED_TRACE_WORDS));
             HIPCHK(c, hipMemsetAsync(c->trace.ptr, 0, (size_t)kTraceBlocks * KSCHED_TRACE_WORDS * 8, s));
         }
@@ -781,8 +811,10 @@ int ksched_create(ksched_ctx **out, int device_id) {
     DeviceGuard g(device_id);
     if (!g.ok || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_build, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming) != hipSuccess) {
         if (c->ev_build) (void)hipEventDestroy(c->ev_build);
+        if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
         if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return KSCHED_E_HIP;
@@ -806,6 +838,7 @@ void ksched_destroy(ksched_ctx *c) {
         for (auto &u : c->user_streams) (void)hipEventDestroy(u.ev);
         if (c->ev_build) (void)hipEventDestroy(c->ev_build);
         if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
+        if (c->ev_scratch) (void)hipEventDestroy(c->ev_scratch);
         indexed_release(c->idx);
         for (auto &ep : c->ev_pool) {
             (void)hipEventDestroy(ep.a);
@@ -1161,6 +1194,20 @@ int ksched_pipe_wait(ksched_pipe *q, uint32_t slot, void *hip_stream) {
     if (!g.ok) return KSCHED_E_HIP;
     if (hip_stream) HIPCHK(c, hipStreamWaitEvent((hipStream_t)hip_stream, q->pick_done[slot], 0));
     else HIPCHK(c, hipEventSynchronize(q->pick_done[slot]));
+    return KSCHED_OK;
+}
+
+int ksched_pipe_wait_mask(ksched_pipe *q, uint32_t slot, void *hip_stream) {
+    if (!q || slot >= q->depth) return KSCHED_E_INVAL;
+    ksched_ctx *c = q->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);  // (ksched_pipe_submit records the same events)
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    // The mask stream is in order: "everything enqueued on it so far" contains the slot's latest mask kernel.  Recorded here, on
+    // demand, so that the submit path carries no event for consumers that never read the masks.
+    HIPCHK(c, hipEventRecord(q->mask_done[slot], q->s_mask));
+    if (hip_stream) HIPCHK(c, hipStreamWaitEvent((hipStream_t)hip_stream, q->mask_done[slot], 0));
+    else HIPCHK(c, hipEventSynchronize(q->mask_done[slot]));
     return KSCHED_OK;
 }
 

@@ -76,6 +76,10 @@ class Evaluator:
     def set_option(self, option: int, value: int):
         self._check(self._lib.ksched_set_option(self._h, option, value), "ksched_set_option")
 
+    def forget_stream(self, stream):
+        """Call BEFORE destroying a stream evaluations were enqueued on while this evaluator lives (ksched_forget_stream)."""
+        self._check(self._lib.ksched_forget_stream(self._h, C.c_void_p(stream.cuda_stream)), "ksched_forget_stream")
+
     def set_kernel(self, name: str):
         self.set_option(L.OPT_KERNEL, {"auto": L.KERNEL_AUTO, "direct": L.KERNEL_DIRECT, "fused": L.KERNEL_FUSED}[name])
 
@@ -378,8 +382,7 @@ class Pipe:
                 check(rc, "ksched_pipe_submit")
         return submit
 
-    def wait(self, slot: int, stream=None, host: bool = False):
-        """Order `stream` (default: torch's current stream) after the slot's pick; host=True blocks the host instead."""
+    def _wait(self, name: str, slot: int, stream, host: bool):
         import torch
         if host:
             sp = None
@@ -387,7 +390,15 @@ class Pipe:
             sp = C.c_void_p((stream or torch.cuda.current_stream(self.ev.device)).cuda_stream or 0)
             if not sp.value:  # the legacy default stream has handle 0 = "block the host" in the C ABI: use a host wait instead
                 sp = None
-        self.ev._check(self._lib.ksched_pipe_wait(self._h, slot, sp), "ksched_pipe_wait")
+        self.ev._check(getattr(self._lib, name)(self._h, slot, sp), name)
+
+    def wait(self, slot: int, stream=None, host: bool = False):
+        """Order `stream` (default: torch's current stream) after the slot's pick; host=True blocks the host instead."""
+        self._wait("ksched_pipe_wait", slot, stream, host)
+
+    def wait_mask(self, slot: int, stream=None, host: bool = False):
+        """The same for the slot's mask kernel (the pick does not read the mask: a finished pick says nothing about it)."""
+        self._wait("ksched_pipe_wait_mask", slot, stream, host)
 
 
 # ---- pure helpers on masks (numpy; no predicate logic here) -----------------------------------------

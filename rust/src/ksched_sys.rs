@@ -102,6 +102,7 @@ extern "C" {
         mask_pitch_words: u32, binding: *mut i32,
     ) -> c_int;
     pub fn ksched_pipe_wait(pipe: *mut ksched_pipe, slot: u32, hip_stream: *mut c_void) -> c_int;
+    pub fn ksched_pipe_wait_mask(pipe: *mut ksched_pipe, slot: u32, hip_stream: *mut c_void) -> c_int;
     pub fn ksched_pipe_stream(pipe: *mut ksched_pipe, which: c_int) -> *mut c_void;
     // ---- reasons
     pub fn ksched_reason(feasible_row: *const u64, fit_row: *const u64, node: u32, flags: u32) -> c_int;

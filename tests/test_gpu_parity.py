@@ -694,3 +694,77 @@ def test_bestfit_direct_equals_bestfit_from_mask(evaluator, kernel, stages):
     ev.set_option(_lib.OPT_PICK_FROM_MASK, 0)
     ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
     ev.set_kernel("auto")
+
+
+def test_pipe_wait_mask_orders_a_consumer_stream(evaluator):
+    """ksched_pipe_wait_mask: the pick does not read the mask, so the pipe's two streams are unordered and a finished pick says
+    nothing about the mask kernel.  A consumer stream ordered by wait_mask (and a host wait) sees the complete mask == oracle."""
+    import torch
+    ev = evaluator
+    c = synth.make_cluster(30000, 5000, n_keys=8, n_taints=0, seed=505)
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", ev.device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    cpu, mem, sel, smp = t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.samples, np.int32)
+    feas, _, bind = oracle_eval(c, FIT | SEL | PICK_SAMPLED)
+    pipe = ev.pipe(2)
+    masks = [ev.alloc_mask(c.P) for _ in range(2)]
+    outs = [torch.empty((c.P,), dtype=torch.int32, device=dev) for _ in range(2)]
+    consumer = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        slot = rep % 2
+        masks[slot].zero_()
+        torch.cuda.synchronize()
+        pipe.submit(slot, cpu, mem, sel, None, smp, FIT | SEL | PICK_SAMPLED, masks[slot], outs[slot])
+        pipe.wait_mask(slot, stream=consumer)
+        pipe.wait(slot, stream=consumer)
+        with torch.cuda.stream(consumer):
+            m_copy, b_copy = masks[slot].clone(), outs[slot].clone()
+        consumer.synchronize()  # only the consumer: the pipe's streams are not touched by the host
+        assert np.array_equal(m_copy.cpu().numpy().view(np.uint64), feas), rep
+        assert np.array_equal(b_copy.cpu().numpy(), bind), rep
+    masks[0].zero_()
+    torch.cuda.synchronize()
+    pipe.submit(0, cpu, mem, sel, None, smp, FIT | SEL | PICK_SAMPLED, masks[0], outs[0])
+    pipe.wait_mask(0, host=True)
+    assert np.array_equal(masks[0].cpu().numpy().view(np.uint64), feas)
+    pipe.close()
+
+
+def test_evaluations_on_two_streams_share_the_ctx_scratch(evaluator):
+    """Two caller streams alternate bindings-only best-fit evaluations (two stages: the hand-over lists live in ctx-owned scratch)
+    and fit-mask-only evaluations (the feasible mask goes to a ctx-owned scratch mask): the library orders the streams' use of
+    that memory itself.  Every result == oracle; then one stream is forgotten and destroyed and the other carries on."""
+    import torch
+    ev = evaluator
+    ev.set_option(_lib.OPT_BESTFIT_STAGES, 2)
+    c = synth.make_cluster(20000, 6000, n_keys=8, n_taints=16, seed=811)
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", ev.device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    flags = FIT | SEL | TAINT
+    rolled = [np.roll(np.arange(c.P), 101 * j) for j in range(6)]
+    batches = [dict(cpu=t(c.req_cpu[r], np.int64), mem=t(c.req_mem[r], np.int64), sel=t(c.pod_sel[:, r], np.int32),
+                    tol=t(c.pod_tol[r], np.int64)) for r in rolled]
+    _, fit, want = oracle_eval(c, flags | PICK_BESTFIT | _lib.WANT_FIT_MASK)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = [torch.empty((c.P,), dtype=torch.int32, device=dev) for _ in rolled]
+    fits = [ev.alloc_mask(c.P) for _ in rolled]
+    torch.cuda.synchronize()
+    for j, b in enumerate(batches):  # no host wait in between: the kernels of consecutive calls are in flight together
+        s = streams[j % 2]
+        ev.eval_device(b["cpu"], b["mem"], b["sel"], b["tol"], None, flags | PICK_BESTFIT, out_binding=outs[j], stream=s)
+        ev.eval_device(b["cpu"], b["mem"], b["sel"], b["tol"], None, flags | _lib.WANT_FIT_MASK, out_fit=fits[j], stream=streams[(j + 1) % 2])
+    torch.cuda.synchronize()
+    for j, r in enumerate(rolled):
+        assert np.array_equal(outs[j].cpu().numpy(), want[r]), f"bindings of call {j}"
+        assert np.array_equal(fits[j].cpu().numpy().view(np.uint64), fit[r]), f"fit mask of call {j}"
+    # the stream that used the scratch last goes away (ksched_forget_stream first, as the header asks); the other one carries on
+    ev.eval_device(batches[0]["cpu"], batches[0]["mem"], batches[0]["sel"], batches[0]["tol"], None, flags | PICK_BESTFIT, out_binding=outs[0], stream=streams[1])
+    ev.forget_stream(streams[1])
+    del streams[1]
+    ev.eval_device(batches[1]["cpu"], batches[1]["mem"], batches[1]["sel"], batches[1]["tol"], None, flags | PICK_BESTFIT, out_binding=outs[1], stream=streams[0])
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[0].cpu().numpy(), want[rolled[0]]) and np.array_equal(outs[1].cpu().numpy(), want[rolled[1]])
+    ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
