@@ -68,13 +68,21 @@ class AbiComm:
         self._lib, self._ev = evaluator._lib, evaluator
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # Every rank draws an id: rank 0's is the one used, the others only prove that RCCL can be loaded on their side.  The
+        # outcomes travel in ONE collective of the launcher's group, so a rank whose RCCL is unusable makes EVERY rank raise
+        # here -- before ksched_comm_create, which blocks until all ranks have joined and would otherwise hang the healthy ones.
         ident = (C.c_uint8 * L.COMM_ID_BYTES)()
-        if self.rank == 0:
-            self._check(self._lib.ksched_comm_unique_id(C.cast(ident, C.c_void_p)), "ksched_comm_unique_id")
+        rc = self._lib.ksched_comm_unique_id(C.cast(ident, C.c_void_p))
+        mine = (None if rc == 0 else f"rank {self.rank}: ksched_comm_unique_id: {self._lib.ksched_comm_last_error().decode()}", bytes(ident))
         if self.world > 1:
-            box = [bytes(ident) if self.rank == 0 else None]
-            dist.broadcast_object_list(box, src=0, group=group)
-            ident = (C.c_uint8 * L.COMM_ID_BYTES).from_buffer_copy(box[0])
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, mine, group=group)
+        else:
+            everyone = [mine]
+        errors = [e for e, _ in everyone if e]
+        if errors:
+            raise L.KschedError(L.E_RCCL, "ksched_comm_unique_id", "; ".join(errors))
+        ident = (C.c_uint8 * L.COMM_ID_BYTES).from_buffer_copy(everyone[0][1])
         h = C.c_void_p()
         self._check(self._lib.ksched_comm_create(evaluator._h, C.cast(ident, C.c_void_p), self.rank, self.world, C.byref(h)), "ksched_comm_create")
         self._h = h
