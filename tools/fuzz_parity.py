@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised differential test of the HIP path against the oracle (GPU box): random shapes, key counts and cardinalities (incl.
-list keys and > 8 keys), taints, predicate subsets, both picks, snapshot updates between evaluations, both kernels.
+list keys and > 8 keys), taints, predicate subsets, both picks, snapshot updates between evaluations, both kernels, per-pair reasons (ksched_explain).
 usage: python tools/fuzz_parity.py [seconds] [seed]       prints one line per failure and a summary; exit code 1 on any failure"""
 import os, sys, time
 import numpy as np
@@ -68,6 +68,18 @@ while time.time() < t_end:
                     fails += 1
                     print(f"FAIL case seed {cs}: N={N} P={P} K={K} cards={cards} nt={nt} flags={flags:#x} kernel={kernel}/{ev.last_kernel} step={step}", flush=True)
         ev.set_kernel("auto")
+        if r.random() < 0.3:  # ksched_explain on random pairs == the reason rebuilt from three single-predicate oracle masks
+            from kube_scheduler_rs_reference_amd.evaluator import unpack_mask
+            one = lambda f: unpack_mask(capi.eval_encoded(cpu, mem, lab, taints, rc, rm, sel, tol, None, f)[0], N)  # noqa: E731
+            ok_f = one(L.FIT) if preds & L.FIT else np.ones((P, N), bool)
+            ok_s = one(L.SEL) if preds & L.SEL else np.ones((P, N), bool)
+            ok_t = one(L.TAINT) if preds & L.TAINT else np.ones((P, N), bool)
+            want_r = np.where(~ok_f, L.REASON_NOT_ENOUGH_RESOURCES, np.where(~ok_s, L.REASON_NODE_SELECTOR_MISMATCH, np.where(~ok_t, L.REASON_TAINT_NOT_TOLERATED, L.REASON_OK)))
+            pp, pn = r.integers(0, P, 4000).astype(np.uint32), r.integers(0, N, 4000).astype(np.uint32)
+            got_r = ev.explain(rc, rm, sel if K else None, tol if (preds & L.TAINT) else None, pp, pn, preds)
+            if not np.array_equal(got_r, want_r[pp, pn]):
+                fails += 1
+                print(f"FAIL explain case seed {cs}: N={N} P={P} K={K} cards={cards} nt={nt} preds={preds:#x}", flush=True)
     except Exception as e:  # noqa: BLE001
         fails += 1
         print(f"EXCEPTION case seed {cs}: N={N} P={P} K={K} cards={cards} nt={nt} flags={flags:#x}: {e}", flush=True)
