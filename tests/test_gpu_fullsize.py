@@ -119,3 +119,40 @@ def test_full_size_properties(evaluator, name):
     assert torch.equal(bind_p, bind[perm])
     assert int(_row_checksums(feas_p).sum()) == int(cs.sum())
     ev.set_kernel("auto")
+
+
+def test_mask_larger_than_4_gib(evaluator):
+    """One evaluation whose mask does not fit 32-bit byte offsets: 700k pods x 50k nodes (C5's predicates, pitched rows of 784 words)
+    = 4.39 GB of feasible mask, more than half of BASELINE.json's configs[4] on ONE GPU.  Every word and every binding == the oracle
+    (rows past the 4 GiB mark included), fused == direct on the device."""
+    import torch
+    P, N = 700_000, 50_000
+    c = synth.make_config("C5", P=P, N=N)
+    ev = evaluator
+    dev = torch.device("cuda", ev.device)
+    ev.set_nodes(**c.node_columns())
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    d_cpu, d_mem, d_sel, d_tol = t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.pod_tol, np.int64)
+    flags = FIT | SEL | TAINT | PICK_BESTFIT
+    out = {}
+    for kernel in ("fused", "direct"):
+        ev.set_kernel(kernel)
+        feas = ev.alloc_mask(P, pitched=True)
+        bind = torch.empty((P,), dtype=torch.int32, device=dev)
+        ev.eval_device(d_cpu, d_mem, d_sel, d_tol, None, flags, out_feasible=feas, out_binding=bind)
+        torch.cuda.synchronize()
+        assert ev.last_kernel == kernel
+        out[kernel] = (feas, bind)
+    ev.set_kernel("auto")
+    feas, bind = out["fused"]
+    assert feas.stride(0) * 8 * P > (1 << 32), "the mask must cross the 4 GiB mark for this test to mean anything"
+    for lo in range(0, P, 65536):  # (chunked: torch.equal on strided 4 GB views would materialise copies)
+        assert torch.equal(feas[lo:lo + 65536], out["direct"][0][lo:lo + 65536]), f"fused != direct in rows from {lo}"
+    assert torch.equal(bind, out["direct"][1])
+    del out
+    for lo in range(0, P, 4 * CHUNK_ROWS):
+        hi = min(P, lo + 4 * CHUNK_ROWS)
+        o_feas, _, o_bind = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, c.node_taints, c.req_cpu[lo:hi], c.req_mem[lo:hi],
+                                              np.ascontiguousarray(c.pod_sel[:, lo:hi]), c.pod_tol[lo:hi], None, flags)
+        assert np.array_equal(feas[lo:hi].contiguous().cpu().numpy().view(np.uint64), o_feas), f"feasible != oracle in rows [{lo}, {hi})"
+        assert np.array_equal(bind[lo:hi].cpu().numpy(), o_bind), f"bindings != oracle in rows [{lo}, {hi})"
