@@ -109,6 +109,13 @@ extern "C" {
  * (a lane per pod decides from the first 512 candidates, a wave per pod finishes the rest): 0 (default) = two stages from 65536
  * pods per call on, 1 = always one, 2 = always two.  Same bindings either way. */
 #define KSCHED_OPT_BESTFIT_STAGES 7
+/* KSCHED_OPT_SNAPSHOT_STREAM: where ksched_set_nodes / ksched_update_nodes (and the lazy best-fit rebuild) enqueue their device
+ * work.  0 (default) = when evaluations have been enqueued on exactly ONE caller stream so far, onto that stream: the change is
+ * ordered behind the evaluations already there and ahead of the next ones by the stream itself, with no event and no
+ * cross-stream wait (a scheduler loop "pod events -> update -> evaluate" on one stream then never leaves it); with no or several
+ * caller streams, onto the ctx's own stream, ordered against the callers' streams by events.  1 = always the ctx's own stream.
+ * Same results either way: every evaluation sees the snapshot that was current when it was enqueued. */
+#define KSCHED_OPT_SNAPSHOT_STREAM 8
 
 typedef struct ksched_ctx ksched_ctx;
 

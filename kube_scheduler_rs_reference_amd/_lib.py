@@ -49,6 +49,7 @@ OPT_TRACE = 4
 OPT_PICK_FROM_MASK = 5
 OPT_INDEX_BUILD = 6
 OPT_BESTFIT_STAGES = 7
+OPT_SNAPSHOT_STREAM = 8
 TRACE_WORDS = 8
 KERNEL_AUTO = 0
 KERNEL_DIRECT = 1

@@ -73,6 +73,7 @@ __device__ __forceinline__ void bitonic_sort_tile(K &kv, uint32_t &ki, K *s_key,
 }
 
 __global__ __launch_bounds__(1024) void k_build_tile_fit(const BuildFitArgs a) {
+    kernarg_warm<sizeof(BuildFitArgs)>();
     __shared__ int64_t s_key[kTileNodes];  // bitonic network: value; afterwards the sorted values (position order)
     __shared__ uint16_t s_idx[kTileNodes];  // ... node of the element; afterwards s_lr: local rank by node
     __shared__ uint64_t s_wave[16];
@@ -182,6 +183,7 @@ struct BuildListArgs {
     uint32_t list_col[kMaxListKeys];
 };
 __global__ __launch_bounds__(1024) void k_build_tile_list(const BuildListArgs a) {
+    kernarg_warm<sizeof(BuildListArgs)>();
     __shared__ uint32_t s_key[kTileNodes];
     __shared__ uint16_t s_idx[kTileNodes];
     const uint32_t tile = blockIdx.x, j = blockIdx.y, i = threadIdx.x;
@@ -206,6 +208,7 @@ struct BuildNamedArgs {
 
 // dynamic LDS: named_rows * 128 bytes
 __global__ __launch_bounds__(1024) void k_build_tile_named(const BuildNamedArgs a) {
+    kernarg_warm<sizeof(BuildNamedArgs)>();
     extern __shared__ __attribute__((aligned(16))) uint64_t s_named[];
     const uint32_t tile = blockIdx.x;
     const uint32_t base = tile * kTileNodes;
@@ -255,6 +258,7 @@ struct PatchArgs {
     uint32_t tiles_in[kPatchInline];
 };
 __global__ __launch_bounds__(256) void k_patch_nodes(const PatchArgs a) {
+    kernarg_warm<sizeof(PatchArgs)>();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.count) return;
     if (a.tile_out && t < a.ntiles) a.tile_out[t] = a.tiles_in[t];
@@ -304,6 +308,7 @@ struct BfGatherArgs {
     uint32_t n, n1, n2;
 };
 __global__ __launch_bounds__(256) void k_bf_gather(const BfGatherArgs a) {
+    kernarg_warm<sizeof(BfGatherArgs)>();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const uint32_t node = a.bf_order[i], cn = a.by_cpu[i];
@@ -334,6 +339,7 @@ struct BfRowsArgs {
 };
 // one wave per 64 best-fit positions (one word of every row)
 __global__ __launch_bounds__(256) void k_bf_rows(const BfRowsArgs a) {
+    kernarg_warm<sizeof(BfRowsArgs)>();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= a.Wbf) return;
@@ -376,6 +382,7 @@ struct BfLevelsArgs {
     uint32_t n, nlev, lvl_half, lvl_off[6];
 };
 __global__ __launch_bounds__(256) void k_bf_levels(const BfLevelsArgs a) {
+    kernarg_warm<sizeof(BfLevelsArgs)>();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t span = 1;
     uint32_t nk = a.n;

@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "../../include/ksched.h"
+#include "kernarg.hpp"
 
 // clang (ROCm 7.2) exposes no __builtin_amdgcn_writelane; bind the LLVM intrinsic by name.
 // v_writelane_b32: lane `lane` of the result takes the wave-uniform `val`, the others keep `old`.
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(64 * kDirectWaves) void k_eval_direct(
     const uint64_t *__restrict__ g_ntaint, const int64_t *__restrict__ g_pcpu, const int64_t *__restrict__ g_pmem,
     const uint32_t *__restrict__ g_psel, const uint64_t *__restrict__ g_ptol, uint64_t *__restrict__ out_feas,
     uint64_t *__restrict__ out_fit, const DirectArgs a) {
+    kernarg_warm<10 * 8 + sizeof(DirectArgs)>();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t w0 = (blockIdx.x * kDirectWaves + wave) * kDirectCW;  // first word column of this wave
@@ -281,6 +283,7 @@ __device__ __forceinline__ int32_t select_one_pod(const SelectArgs &a, uint32_t 
 
 template <int ATT, int EAGER>
 __global__ __launch_bounds__(256) void k_select_sampled(const SelectArgs q) {
+    kernarg_warm<sizeof(SelectArgs)>();
     const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
     if (pod < q.p) q.binding[pod] = select_one_pod<ATT, EAGER>(q, pod);
 }
@@ -575,6 +578,7 @@ __device__ __forceinline__ int32_t bestfit_rows_one_pod(const BestfitRowsArgs &q
 // instructions per pod, mostly address arithmetic and wave-uniform control flow, rocprofv3 SQ counters -- not by wave
 // launches or memory latency, and the short-lived waves balance better.)
 __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs q) {
+    kernarg_warm<sizeof(BestfitRowsArgs)>();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (q.pod_list) {  // second stage of the two-stage pick: the pods the lane-per-pod kernel could not decide in its first words
@@ -604,6 +608,7 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
 // Same result as the wave-per-pod kernel by construction: both take the first position >= start whose bits are set in every row
 // the pod ANDs and whose cpu fits.
 __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArgs q) {
+    kernarg_warm<sizeof(BestfitRowsArgs)>();
     const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
     if (pod >= q.p) return;
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
@@ -717,6 +722,7 @@ struct BestfitListedArgs {
     uint32_t p, n, nkeys, tiles, nlist, list_col[2], do_fit, do_taint;
 };
 __global__ __launch_bounds__(256) void k_pick_bestfit_listed(const BestfitListedArgs q) {
+    kernarg_warm<sizeof(BestfitListedArgs)>();
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);

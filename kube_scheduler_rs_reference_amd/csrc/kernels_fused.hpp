@@ -42,6 +42,7 @@
 
 #include <type_traits>
 
+#include "kernarg.hpp"
 #include "tile_index.hpp"
 
 // Build-time variants (tools/build_variants.sh builds one library per setting for A/B timing; the shipped library
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     const int64_t *__restrict__ g_pmem, const uint32_t *__restrict__ g_psel, const uint64_t *__restrict__ g_ptol,
     uint64_t *__restrict__ out_feas, uint64_t *__restrict__ out_fit, const uint8_t *__restrict__ g_list, const FusedArgs a) {
     static_assert(!LIST || SEL, "list keys only exist with the selector predicate");
+    kernarg_warm<9 * 8 + sizeof(FusedArgs)>();  // the prologue makes four dependent groups of argument loads (kernarg.hpp)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t b = blockIdx.x;
     // (chunk, tile) pairs in chunk-major order are dealt to the XCDs in contiguous runs: XCD x = block id % 8

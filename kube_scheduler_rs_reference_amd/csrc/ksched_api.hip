@@ -102,6 +102,14 @@ struct ksched_ctx {
     std::vector<UserStream> user_streams;
     hipEvent_t ev_build = nullptr;
     uint64_t build_gen = 0;
+    // Where a snapshot change is enqueued (snapshot_begin decides, the build / patch code uses it, snapshot_end records ev_build
+    // there).  With exactly ONE caller stream known -- one scheduler loop on one stream, the common case -- the change goes onto
+    // that stream itself: ordered behind the evaluations already there and ahead of the next ones by the stream, with no event
+    // and no cross-stream wait at all (each costs ~5 us; on some hardware queues ~180 us, tools/stream_probe.py).  Otherwise:
+    // the ctx's own stream and the events described above.  KSCHED_OPT_SNAPSHOT_STREAM = 1 keeps every change on the ctx's stream.
+    hipStream_t change_stream = nullptr;
+    uint64_t own_gen = 0;  // snapshot generation the ctx's own stream is ordered behind
+    bool opt_own_stream = false;
     // The ctx-owned device scratch that evaluations on the caller's streams use (bf_fallback, scratch_mask, trace) belongs to one
     // stream at a time: when another stream is about to use it, that stream first waits for what the previous one holds
     // (scratch_enter; an event recorded at that moment, nothing on the common one-stream path).
@@ -187,7 +195,13 @@ int timing_slot(ksched_ctx *c, size_t *slot) {
 
 // remember `s` as a stream evaluations are enqueued on; make it wait for the latest snapshot change if it has not yet
 int stream_enter(ksched_ctx *c, hipStream_t s) {
-    if (s == c->stream) return KSCHED_OK;  // the snapshot is built on this very stream: in order by itself
+    if (s == c->stream) {  // the ctx's own stream: in order by itself unless the latest change went onto a caller's stream
+        if (c->own_gen != c->build_gen) {
+            HIPCHK(c, hipStreamWaitEvent(s, c->ev_build, 0));
+            c->own_gen = c->build_gen;
+        }
+        return KSCHED_OK;
+    }
     ksched_ctx::UserStream *u = nullptr;
     for (auto &x : c->user_streams)
         if (x.s == s) u = &x;
@@ -235,6 +249,24 @@ void stream_forget(ksched_ctx *c, hipStream_t s) {
 
 // before the snapshot changes: the ctx's stream waits for everything already enqueued on the remembered streams
 int snapshot_begin(ksched_ctx *c) {
+    c->change_stream = c->stream;
+    if (c->user_streams.size() == 1 && !c->opt_own_stream) {
+        auto &u = c->user_streams[0];
+        const hipError_t q = hipStreamQuery(u.s);  // host-side probe: a stream the caller destroyed without telling is not used
+        if (q == hipSuccess || q == hipErrorNotReady) {
+            if (u.gen != c->build_gen) {  // (an earlier change went onto the ctx's stream and this stream has not met it yet)
+                HIPCHK(c, hipStreamWaitEvent(u.s, c->ev_build, 0));
+                u.gen = c->build_gen;
+            }
+            c->change_stream = u.s;
+            return KSCHED_OK;
+        }
+        (void)hipGetLastError();  // fall through: the loop below forgets the stream
+    }
+    if (c->own_gen != c->build_gen) {  // an earlier change went onto a caller's stream: this one is ordered behind it
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_build, 0));
+        c->own_gen = c->build_gen;
+    }
     for (size_t i = 0; i < c->user_streams.size();) {
         auto &u = c->user_streams[i];
         if (hipEventRecord(u.ev, u.s) != hipSuccess) {  // the caller destroyed that stream: forget it
@@ -251,8 +283,12 @@ int snapshot_begin(ksched_ctx *c) {
 
 // after the change has been enqueued on the ctx's stream
 int snapshot_end(ksched_ctx *c) {
-    HIPCHK(c, hipEventRecord(c->ev_build, c->stream));
+    const hipStream_t s = c->change_stream;
+    HIPCHK(c, hipEventRecord(c->ev_build, s));
     ++c->build_gen;
+    if (s == c->stream) c->own_gen = c->build_gen;
+    for (auto &u : c->user_streams)
+        if (u.s == s) u.gen = c->build_gen;  // the stream that carries the change is behind it by itself
     return KSCHED_OK;
 }
 
@@ -285,7 +321,7 @@ int launch_build_fit(ksched_ctx *c, const uint32_t *d_tile_list, uint32_t count)
     a.n = l.n;
     a.rows = l.rows;
     a.row_cpu = l.row_cpu;
-    hipLaunchKernelGGL(k_build_tile_fit, dim3(d_tile_list ? count : l.tiles, 2), dim3(1024), 0, c->stream, a);
+    hipLaunchKernelGGL(k_build_tile_fit, dim3(d_tile_list ? count : l.tiles, 2), dim3(1024), 0, c->change_stream, a);
     HIPCHK(c, hipGetLastError());
     return KSCHED_OK;
 }
@@ -299,7 +335,7 @@ int launch_build_lists(ksched_ctx *c) {
     a.n = l.n;
     a.nlist = l.nlist;
     for (uint32_t j = 0; j < l.nlist; ++j) a.list_col[j] = l.list_col[j];
-    hipLaunchKernelGGL(k_build_tile_list, dim3(l.tiles, l.nlist), dim3(1024), 0, c->stream, a);
+    hipLaunchKernelGGL(k_build_tile_list, dim3(l.tiles, l.nlist), dim3(1024), 0, c->change_stream, a);
     HIPCHK(c, hipGetLastError());
     return KSCHED_OK;
 }
@@ -320,7 +356,7 @@ int launch_build_named(ksched_ctx *c) {
     a.named_rows = l.row_cpu;
     const uint32_t lds = l.row_cpu * 128u;
     HIPCHK(c, hipFuncSetAttribute((const void *)k_build_tile_named, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_build_tile_named, dim3(l.tiles), dim3(1024), lds, c->stream, a);
+    hipLaunchKernelGGL(k_build_tile_named, dim3(l.tiles), dim3(1024), lds, c->change_stream, a);
     HIPCHK(c, hipGetLastError());
     return KSCHED_OK;
 }
@@ -337,7 +373,7 @@ int build_bestfit(ksched_ctx *c) {
         c->bf_dirty = false;
         return KSCHED_OK;
     }
-    hipStream_t s = c->stream;
+    hipStream_t s = c->change_stream;
     const uint32_t n1 = (n + 63u) / 64u, n2 = (n + 4095u) / 4096u;
     HIPCHK(c, c->by_cpu.reserve(n));
     HIPCHK(c, c->cpurank.reserve(n));
@@ -819,6 +855,7 @@ int ksched_create(ksched_ctx **out, int device_id) {
         delete c;
         return KSCHED_E_HIP;
     }
+    c->change_stream = c->stream;
     *out = c;
     return KSCHED_OK;
 }
@@ -884,6 +921,10 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
             if (value != 0 && value != 1) return KSCHED_E_INVAL;
             c->opt_index_build = (int)value;
             return KSCHED_OK;
+        case KSCHED_OPT_SNAPSHOT_STREAM:
+            if (value != 0 && value != 1) return KSCHED_E_INVAL;
+            c->opt_own_stream = value == 1;
+            return KSCHED_OK;
 
         default:
             return KSCHED_E_INVAL;
@@ -940,7 +981,7 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     HIPCHK(c, c->bf_mem.reserve((size_t)n + 8));  // (+8: the 8-ary searches read whole blocks of eight)
     HIPCHK(c, c->bf_cpu.reserve(n));
     HIPCHK(c, c->cpu_sorted.reserve((size_t)n + 8));
-    hipStream_t s = c->stream;
+    hipStream_t s = c->change_stream;  // (snapshot_begin chose it)
     if (n > 0) {
         // the caller's arrays -> pinned staging -> asynchronous copies on the ctx's stream
         const size_t b_col = (size_t)n * 8, b_lab = (size_t)n * n_keys * 4, b_taint = taints ? b_col : 0;
@@ -1014,7 +1055,7 @@ int ksched_update_nodes(ksched_ctx *c, uint32_t count, const uint32_t *node_inde
     tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
     // evaluations already enqueued read the snapshot as it was (events, no host wait)
     if (int rc = snapshot_begin(c)) return rc;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->change_stream;  // (snapshot_begin chose it)
     auto fail = [&](int rc) {
         c->have_nodes = false;  // columns, index and best-fit order may now disagree: refuse evaluations until the next ksched_set_nodes
         return rc;
@@ -1322,6 +1363,7 @@ int ksched_explain(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     DeviceGuard g(c->device);
     if (!g.ok) return KSCHED_E_HIP;
     hipStream_t s = c->stream;
+    if (int rce = stream_enter(c, s)) return rce;  // behind the latest snapshot change, whichever stream carried it
     const bool use_fit = flags & KSCHED_FIT;
     const bool use_sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
     const bool use_taint = (flags & KSCHED_TAINT) && c->have_taints;
@@ -1513,7 +1555,7 @@ int ksched_index_checksum(ksched_ctx *c, uint64_t *out) {
     DeviceGuard g(c->device);
     const IndexedLayout &l = c->idx.lay;
     std::vector<uint64_t> tab((size_t)l.tiles * l.rows * kTileWords), aux((size_t)l.tiles * kAuxWords);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev_build));  // the latest snapshot change, whichever stream carried it
     HIPCHK(c, hipMemcpy(tab.data(), c->idx.d_tables, tab.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(aux.data(), c->idx.d_aux, aux.size() * 8, hipMemcpyDeviceToHost));
     auto fnv = [](const std::vector<uint64_t> &v) {

@@ -51,6 +51,7 @@ pub const KSCHED_OPT_TRACE: c_int = 4;
 pub const KSCHED_OPT_PICK_FROM_MASK: c_int = 5;
 pub const KSCHED_OPT_INDEX_BUILD: c_int = 6;
 pub const KSCHED_OPT_BESTFIT_STAGES: c_int = 7;
+pub const KSCHED_OPT_SNAPSHOT_STREAM: c_int = 8;
 
 extern "C" {
     // ---- lifetime

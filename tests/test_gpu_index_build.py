@@ -102,25 +102,33 @@ def test_bestfit_after_updates_uses_the_resorted_order(evaluator, n_taints):
         ev.update_nodes(idx, cpu[idx], mem[idx])
 
 
-def test_updates_and_evaluations_interleaved_without_host_waits(evaluator):
-    """ksched_update_nodes / ksched_set_nodes no longer wait for the device: the ordering against evaluations on the caller's streams
-    is by events.  Stress it: updates and device-pointer evaluations on two torch streams interleave with no synchronisation for
-    many iterations; every evaluation must see exactly the snapshot that was current when it was enqueued."""
+@pytest.mark.parametrize("n_streams,own_stream", [(2, 0), (1, 0), (1, 1), (3, 0)])
+def test_updates_and_evaluations_interleaved_without_host_waits(evaluator, n_streams, own_stream):
+    """ksched_update_nodes / ksched_set_nodes do not wait for the device.  With ONE caller stream the change is enqueued on that
+    stream itself (KSCHED_OPT_SNAPSHOT_STREAM = 0: no event, no cross-stream wait); with several, or with the option at 1, on the
+    ctx's own stream, ordered against the callers' streams by events.  Stress all of it: updates / new snapshots and device-pointer
+    evaluations interleave with no synchronisation for many iterations -- a host-pointer evaluation (ctx's own stream) and an
+    explain now and then, the single stream forgotten and replaced half way -- and every evaluation must see exactly the
+    snapshot that was current when it was enqueued."""
     import torch
     ev = evaluator
+    ev.set_option(_lib.OPT_SNAPSHOT_STREAM, own_stream)
     c = synth.make_cluster(3000, 4100, n_keys=8, n_taints=0, seed=61)
     ev.set_kernel("auto")
     ev.set_nodes(**c.node_columns())
     dev = torch.device("cuda", ev.device)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
     d_cpu, d_mem, d_sel, d_smp = t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.samples, np.int32)
-    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     torch.cuda.synchronize()
     flags = FIT | SEL | PICK_BESTFIT
     cpu, mem = c.avail_cpu.copy(), c.avail_mem.copy()
     rng = np.random.default_rng(9)
-    iters, pending = 60, []
+    iters, pending, host_checks = 60, [], 0
     for it in range(iters):
+        if n_streams == 1 and it == iters // 2:  # the one caller stream goes away (told first, as the header asks); a new one takes over
+            ev.forget_stream(streams[0])
+            streams[0] = torch.cuda.Stream(device=dev)
         if it % 7 == 6:  # now and then a whole new snapshot
             cpu = cpu + rng.integers(-50, 50, cpu.size)
             ev.set_nodes(cpu, mem, c.node_labels, None)
@@ -130,13 +138,25 @@ def test_updates_and_evaluations_interleaved_without_host_waits(evaluator):
             cpu[idx] -= rng.integers(0, 2000, idx.size)
             mem[idx] -= rng.integers(0, 1 << 30, idx.size)
             ev.update_nodes(idx, cpu[idx], mem[idx])
-        s = streams[it % 2]
+        s = streams[it % n_streams]
         mask, bind = ev.alloc_mask(c.P), torch.empty((c.P,), dtype=torch.int32, device=dev)
         with torch.cuda.stream(s):
             ev.eval_device(d_cpu, d_mem, d_sel, None, None, flags, out_feasible=mask, out_binding=bind, stream=s)
         pending.append((mask, bind, cpu.copy(), mem.copy()))
+        if it % 9 == 4:  # host-pointer entry points run on the ctx's own stream: behind the change, whichever stream carried it
+            sl = slice(100, 164)
+            r = ev.eval(c.req_cpu[sl], c.req_mem[sl], c.pod_sel[:, sl], None, None, FIT | SEL)
+            feas, _, _ = capi.eval_encoded(cpu, mem, c.node_labels, None, c.req_cpu[sl], c.req_mem[sl], c.pod_sel[:, sl], None, None, FIT | SEL)
+            assert np.array_equal(r.feasible, feas), f"iteration {it}: host-pointer evaluation"
+            pp, nn = np.arange(100, 164, dtype=np.uint32), rng.integers(0, c.N, 64).astype(np.uint32)
+            reasons = ev.explain(c.req_cpu, c.req_mem, c.pod_sel, None, pp, nn, FIT | SEL)
+            ok = (feas[np.arange(64), nn >> 6] >> (nn & 63).astype(np.uint64)) & np.uint64(1)
+            assert np.array_equal(reasons == 0, ok.astype(bool)), f"iteration {it}: explain"
+            host_checks += 1
     torch.cuda.synchronize()
+    assert host_checks >= 6
     for it, (mask, bind, pc, pm) in enumerate(pending):
         feas, _, want = capi.eval_encoded(pc, pm, c.node_labels, None, c.req_cpu, c.req_mem, c.pod_sel, None, None, flags)
         assert np.array_equal(mask.contiguous().cpu().numpy().view(np.uint64), feas), f"iteration {it}: mask is not of the snapshot current at enqueue time"
         assert np.array_equal(bind.cpu().numpy(), want), f"iteration {it}: best-fit pick"
+    ev.set_option(_lib.OPT_SNAPSHOT_STREAM, 0)

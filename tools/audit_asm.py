@@ -11,6 +11,7 @@ bookkeeping does not see, and waits for them with a hand-counted `s_waitcnt vmcn
   3. exactly the expected number of vector-memory instructions sits between the last operand
      load and the counted wait on the unchecked path.
 usage: python tools/audit_asm.py [--keep DIR]   -> exit code 0 when every k_eval_fused variant passes
+(KSCHED_AUDIT_FLAGS="-D..." audits a build variant, tools/build_variants.sh)
 """
 from __future__ import annotations
 
@@ -40,7 +41,7 @@ def regs_of(text: str) -> set[int]:
 
 def compile_asm(workdir: str) -> str:
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "-c", SRC, "-o", os.path.join(workdir, "k.o"),
-                           "-save-temps"], cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                           "-save-temps"] + os.environ.get("KSCHED_AUDIT_FLAGS", "").split(), cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for f in os.listdir(workdir):
         if f.endswith("gfx950.s"):
             return open(os.path.join(workdir, f)).read()
