@@ -31,6 +31,15 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _attempts(samples, flags: int, p: int) -> int:
+    """Draws per pod of a device `samples` tensor; a wrong shape would be an out-of-bounds device read, so it is refused here."""
+    if not (flags & L.PICK_SAMPLED):
+        return 0
+    if samples is None or samples.dim() != 2 or int(samples.shape[0]) != p or int(samples.shape[1]) == 0 or not samples.is_contiguous():
+        raise ValueError(f"samples must be a contiguous [{p}, attempts] tensor with KSCHED_PICK_SAMPLED")
+    return int(samples.shape[1])
+
+
 @dataclass
 class EvalResult:
     feasible: Optional[np.ndarray] = None  # [P, W] uint64
@@ -256,7 +265,7 @@ class Evaluator:
                 if tuple(m.shape) != (p, W) or (W and m.stride(1) != 1):
                     raise ValueError(f"mask must be a [{p}, {W}] view with unit column stride")
                 pitch = int(m.stride(0)) if p > 1 else W
-        attempts = int(samples.shape[1]) if (flags & L.PICK_SAMPLED and samples is not None) else 0
+        attempts = _attempts(samples, flags, p)
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
         head = (self._h, p, ptr(req_cpu_milli), ptr(req_mem_bytes), ptr(sel_val_ids), ptr(tolerations), ptr(samples), attempts, flags,
                 ptr(out_feasible), ptr(out_fit))
@@ -281,7 +290,7 @@ class Evaluator:
         pitch = int(feasible.stride(0)) if p > 1 else W  # a single row: any pitch >= W
         if out_binding.dtype != torch.int32 or tuple(out_binding.shape) != (p,) or not out_binding.is_contiguous():
             raise ValueError("out_binding must be a contiguous int32 [p] CUDA tensor")
-        attempts = int(samples.shape[1]) if (flags & L.PICK_SAMPLED and samples is not None) else 0
+        attempts = _attempts(samples, flags, p)
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
@@ -358,7 +367,7 @@ class Pipe:
         """torch CUDA tensors (see Evaluator.eval_device); `mask` is a [p, W] (possibly pitched) view, `binding` int32 [p]."""
         p, W = int(req_cpu_milli.shape[0]), self.ev.W
         pitch = int(mask.stride(0)) if p > 1 else W
-        attempts = int(samples.shape[1]) if (flags & L.PICK_SAMPLED and samples is not None) else 0
+        attempts = _attempts(samples, flags, p)
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
         rc = self._lib.ksched_pipe_submit(self._h, slot, p, ptr(req_cpu_milli), ptr(req_mem_bytes), ptr(sel_val_ids), ptr(tolerations),
                                           ptr(samples), attempts, flags, ptr(mask), pitch, ptr(binding))
@@ -368,7 +377,7 @@ class Pipe:
         """Pre-marshal a batch whose inputs stay in place (steady-state loops): returns submit(slot) for slot-indexed `masks` /
         `bindings` lists.  Saves the per-call tensor -> pointer conversions (the host would otherwise bound the step rate)."""
         p, W = int(req_cpu_milli.shape[0]), self.ev.W
-        attempts = int(samples.shape[1]) if (flags & L.PICK_SAMPLED and samples is not None) else 0
+        attempts = _attempts(samples, flags, p)
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
         fixed = (ptr(req_cpu_milli), ptr(req_mem_bytes), ptr(sel_val_ids), ptr(tolerations), ptr(samples), attempts, flags)
         per_slot = [(ptr(m), int(m.stride(0)) if p > 1 else W, ptr(b)) for m, b in zip(masks, bindings)]
