@@ -121,6 +121,28 @@ def audit_kernel(name: str, lines: list[str], meta: dict) -> list[str]:
     return errs
 
 
+def audit_kernarg_warm(asm: str) -> list[str]:
+    """csrc/kernarg.hpp: the hot kernels open with ONE group of scalar loads that touches every 64-byte line of the kernarg segment
+    (s_load_dword at 0x0, 0x40, ... inside one asm statement, one wait) ahead of the first branch."""
+    errs = []
+    want = {"12k_eval_fused": 6, "16k_select_sampled": 2, "20k_pick_bestfit_lanes": 6, "19k_pick_bestfit_rows": 6, "13k_eval_direct": 2}
+    seen = {k: 0 for k in want}
+    for m in re.finditer(r"^(_ZN6ksched(\d+k_\w+?)I?[^:\n]*):.*?\n(.*?)\n\s+s_endpgm", asm, re.S | re.M):
+        key = next((k for k in want if m.group(1).startswith("_ZN6ksched" + k)), None)
+        if key is None:
+            continue
+        seen[key] += 1
+        head = m.group(3).split("s_cbranch")[0]
+        blk = re.search(r";;#ASMSTART\n((?:\s+s_load_dword s\d+, s\[\d+:\d+\], 0x[0-9a-f]+\n)+)\s+s_waitcnt lgkmcnt\(0\)\n\s+;;#ASMEND", head)
+        n = len(re.findall(r"s_load_dword ", blk.group(1))) if blk else 0
+        if n < want[key]:
+            errs.append(f"{m.group(1)[:60]}: kernarg warm-up group has {n} loads ahead of the first branch, expected >= {want[key]}")
+    for k, n in seen.items():
+        if n == 0:
+            errs.append(f"no instantiation of {k} found in the assembly")
+    return errs
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--keep", default=None)
@@ -137,8 +159,11 @@ def main() -> int:
         if errs:
             bad += 1
             print(f"FAIL {tag}: " + "; ".join(errs[:4]))
-    print(f"audited {n} k_eval_fused instantiations, {bad} failing")
-    return 1 if bad or n == 0 else 0
+    kw = audit_kernarg_warm(asm)
+    for e in kw:
+        print("FAIL kernarg warm-up:", e)
+    print(f"audited {n} k_eval_fused instantiations, {bad} failing; kernarg warm-up groups: {'ok' if not kw else str(len(kw)) + ' failing'}")
+    return 1 if bad or n == 0 or kw else 0
 
 
 if __name__ == "__main__":

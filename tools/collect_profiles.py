@@ -26,6 +26,8 @@ cp("trace_C3.txt", "fused_phase_trace_C3.txt")
 cp("pytest_gpu.log", "pytest_gpu.log")
 cp("smoke.log", "smoke.log")
 cp("host_costs.txt", "host_costs_snapshot_calls.txt")
+cp("fuzz.txt", "fuzz.txt")
+cp("stream_probe.txt", "stream_probe.txt")
 if os.path.exists(os.path.join(src, "pmc_traffic.json")):
     shutil.copy(os.path.join(src, "pmc_traffic.json"), os.path.join(dst, "pmc_traffic.json"))  # what bench.py reports as roofline.traffic
 lines = {}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session that produces the round's evidence set.  usage: bash tools/gpu_round.sh <tag> [steps...]
-#   steps (default: test bench prof pmc lines trace smoke host): probe test smoke bench prof pmc lines ab dist evflags abpick host trace
+#   steps (default: test bench prof pmc lines trace smoke host): probe test smoke bench prof pmc lines ab dist evflags abpick host fuzz probe2 trace
 # Everything lands under gpurun_out/<tag>/ ; tools/collect_profiles.py copies the summaries into profiles/.
 TAG=${1:-r}; shift
 STEPS=${@:-"test bench prof pmc lines trace smoke host"}
@@ -121,6 +121,14 @@ fi
 if has host; then
   stamp "host-side cost of the snapshot calls"
   timeout 300 python tools/host_costs.py > $OUT/host_costs.txt 2>&1; cat $OUT/host_costs.txt
+fi
+if has fuzz; then
+  stamp "randomised differential parity against the oracle (${FUZZ_S:-60} s, seed ${FUZZ_SEED:-20260923})"
+  timeout $(( ${FUZZ_S:-60} + 60 )) python tools/fuzz_parity.py ${FUZZ_S:-60} ${FUZZ_SEED:-20260923} > $OUT/fuzz.txt 2>&1; tail -3 $OUT/fuzz.txt
+fi
+if has probe2; then
+  stamp "update + pick loop per context, consecutive loops (tools/stream_probe.py --repeat)"
+  PROBE_N=2 timeout 200 python tools/stream_probe.py --repeat 2>&1 | grep "context #\|consecutive" > $OUT/stream_probe.txt; cat $OUT/stream_probe.txt
 fi
 if has trace; then
   stamp "fused kernel phase trace (C3)"
