@@ -4,6 +4,7 @@
 // ksched_set_nodes / ksched_eval -> masks, against an INDEPENDENT parser (regex + Fraction), on whole clusters.
 //
 //   objects_eval masks      <objects.json> [taints]      check_node_validity_batch: fit / feasible masks (hex rows), canonical node order
+//   objects_eval columns    <objects.json> [taints]      the encoder alone (no device): the integer columns of include/ksched.h as JSON
 //   objects_eval batch      <objects.json> <seed> [fail_every]   reconcile_batch            (src/main.rs:73-120 per pod)
 //   objects_eval sequential <objects.json> <seed> [fail_every]   reconcile_batch_sequential (8f n3, opt-in)
 // The node store is given to the host in REVERSED canonical order (the reference's store order is arbitrary, src/main.rs:56):
@@ -156,7 +157,7 @@ static void print_outcomes(const std::vector<ReconcileOutcome> &out, const Recor
 
 int main(int argc, char **argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: objects_eval masks|batch|sequential <objects.json> [...]\n");
+        std::fprintf(stderr, "usage: objects_eval masks|columns|batch|sequential <objects.json> [...]\n");
         return 2;
     }
     try {
@@ -189,6 +190,47 @@ int main(int argc, char **argv) {
             std::printf(",\"names\":[");
             for (uint32_t i = 0; i < v.n; ++i) std::printf("%s\"%s\"", i ? "," : "", ctx.snapshot->columns().names[i].c_str());
             std::printf("],\"list_calls\":%llu}\n", (unsigned long long)lister->list_calls);
+            return 0;
+        }
+        if (mode == "columns") {
+            // the wire-format step alone, no device: objects -> host/quantity.cpp + host/encoder.cpp -> the integer columns of
+            // include/ksched.h (Snapshot::kEncodeOnly uploads nothing).  Runs where there is no GPU.
+            const bool taints = argc > 3 && std::string(argv[3]) == "taints";
+            Snapshot snap(Snapshot::kEncodeOnly);
+            snap.rebuild(ctx.node_store, lister.get());
+            if (taints) snap.enable_taints();
+            const PodColumns pc = snap.encode_pods(pp);
+            const NodeColumns &nc = snap.columns();
+            auto arr64 = [](const char *k, const std::vector<int64_t> &v) {
+                std::printf("\"%s\":[", k);
+                for (size_t i = 0; i < v.size(); ++i) std::printf("%s%lld", i ? "," : "", (long long)v[i]);
+                std::printf("]");
+            };
+            auto arru64 = [](const char *k, const std::vector<uint64_t> &v) {  // (as strings: JSON numbers lose bits past 2^53)
+                std::printf("\"%s\":[", k);
+                for (size_t i = 0; i < v.size(); ++i) std::printf("%s\"%llu\"", i ? "," : "", (unsigned long long)v[i]);
+                std::printf("]");
+            };
+            auto arr32 = [](const char *k, const std::vector<uint32_t> &v) {
+                std::printf("\"%s\":[", k);
+                for (size_t i = 0; i < v.size(); ++i) std::printf("%s%u", i ? "," : "", v[i]);
+                std::printf("]");
+            };
+            std::printf("{\"p\":%u,\"n\":%u,\"n_keys\":%u,\"pod_keys\":%u,", pc.p, nc.n, nc.n_keys, pc.n_keys);
+            std::printf("\"names\":[");
+            for (uint32_t i = 0; i < nc.n; ++i) std::printf("%s\"%s\"", i ? "," : "", nc.names[i].c_str());
+            std::printf("],\"keys\":[");
+            for (size_t i = 0; i < nc.keys.size(); ++i) std::printf("%s\"%s\"", i ? "," : "", nc.keys[i].c_str());
+            std::printf("],");
+            arr64("avail_cpu_milli", nc.avail_cpu_milli); std::printf(",");
+            arr64("avail_mem_bytes", nc.avail_mem_bytes); std::printf(",");
+            arr32("label_val_ids", nc.label_val_ids); std::printf(",");
+            arru64("taints", nc.taints); std::printf(",");
+            arr64("req_cpu_milli", pc.req_cpu_milli); std::printf(",");
+            arr64("req_mem_bytes", pc.req_mem_bytes); std::printf(",");
+            arr32("sel_val_ids", pc.sel_val_ids); std::printf(",");
+            arru64("tolerations", pc.tolerations);
+            std::printf(",\"list_calls\":%llu}\n", (unsigned long long)lister->list_calls);
             return 0;
         }
         if (mode == "batch" || mode == "sequential") {

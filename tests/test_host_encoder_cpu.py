@@ -1,0 +1,165 @@
+"""The PRODUCT's object -> column path (host/quantity.cpp, host/util.cpp, host/encoder.cpp) on whole clusters WITHOUT a GPU.
+
+`tests/cpp/objects_eval columns` runs Kubernetes JSON objects through the C++ encoder in its encode-only mode (no device, nothing
+uploaded) and prints the integer columns of include/ksched.h.  Two checks, both against oracle/oracle_ref.py (regex + Fraction
+parser, dict lookups -- independent of the C++ parser; oracle.c's parser mirrors the host's structure and is not used here):
+
+  * the columns, evaluated pair by pair with the oracle's scalar loop on encoded integers (ora_eval_encoded: `req <= avail`,
+    dictionary ids, taint bits -- no parsing in it), give exactly the masks the object-level oracle computes from the strings
+    (src/predicates.rs:20-77, src/util.rs:54-75): the five golden object sets and a 2000 x 500 cluster with Ki / Mi spellings,
+    12 label keys and 16 taints;
+  * every `available` / request column entry equals the oracle's exact Fraction, for randomly generated spellings of the
+    Kubernetes quantity grammar (hypothesis): signs, fractions, decimal and binary suffixes, exponents -- and what the reference
+    would panic on (src/util.rs:65,68; src/predicates.rs:29,31) or what is not an integer number of milli-cores / bytes is refused
+    by the encoder (exit code 1), never silently rounded.
+
+The same path through the device is tests/test_gpu_objects.py."""
+import json
+import os
+import subprocess
+from fractions import Fraction
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from kube_scheduler_rs_reference_amd import FIT, SEL, TAINT, _lib, pack_mask, synth
+from oracle import capi
+from oracle import oracle_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+TOOL = os.path.join(ROOT, "tests", "cpp", "objects_eval")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.check_call(["make", "-C", ROOT, "-s", "host"])
+    if not os.path.exists(TOOL):
+        pytest.skip("tests/cpp/objects_eval is not built (make host)")
+
+
+def columns(path, taints=False, expect_fail=False):
+    r = subprocess.run([TOOL, "columns", str(path), *(["taints"] if taints else [])], capture_output=True, text=True, timeout=600)
+    if expect_fail:
+        return r
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout)
+
+
+def masks_of_columns(c, use_taint):
+    n, p, K = c["n"], c["p"], c["n_keys"]
+    assert c["pod_keys"] == K
+    lab = np.array(c["label_val_ids"], dtype=np.uint32).reshape(K, n) if K else None
+    sel = np.array(c["sel_val_ids"], dtype=np.uint32).reshape(K, p) if K else None
+    tnt = np.array([int(x) for x in c["taints"]], dtype=np.uint64) if use_taint else None
+    tol = np.array([int(x) for x in c["tolerations"]], dtype=np.uint64) if use_taint else None
+    flags = FIT | (SEL if K else 0) | (TAINT if use_taint else 0) | _lib.WANT_FIT_MASK
+    feas, fit, _ = capi.eval_encoded(np.array(c["avail_cpu_milli"], dtype=np.int64), np.array(c["avail_mem_bytes"], dtype=np.int64), lab, tnt,
+                                     np.array(c["req_cpu_milli"], dtype=np.int64), np.array(c["req_mem_bytes"], dtype=np.int64), sel, tol, None, flags)
+    return feas, fit
+
+
+def expect_masks(pods, nodes, bound, use_taint, cache):
+    P, N = len(pods), len(nodes)
+    feas, fit = R.eval_matrix(pods, nodes, bound, use_taint=use_taint, cache=cache)
+    return pack_mask(np.array(feas, dtype=bool).reshape(P, N)), pack_mask(np.array(fit, dtype=bool).reshape(P, N))
+
+
+@pytest.mark.parametrize("name,taints", [("c1_100x20", False), ("ragged_70x130_taints", True), ("one_node_33x1", True),
+                                         ("binsuffix_60x40", False), ("hazard_gi_24x10", False)])
+def test_golden_objects_through_the_host_encoder_without_a_device(name, taints):
+    path = os.path.join(GOLD, name + "_objects.json")
+    doc = json.load(open(path))
+    c = columns(path, taints)
+    assert c["names"] == [n["metadata"]["name"] for n in doc["nodes"]], "canonical order = ascending node name"
+    assert c["list_calls"] == doc["n"], "one LIST per node per snapshot (src/predicates.rs:34 does one per evaluation)"
+    feas, fit = masks_of_columns(c, taints)
+    want_feas, want_fit = expect_masks(doc["pods"], doc["nodes"], doc["bound"], taints, cache=False)  # every pair re-parsed, as the reference does
+    assert np.array_equal(fit, want_fit)
+    assert np.array_equal(feas, want_feas)
+    # and the columns themselves are the oracle's exact values
+    for i, node in enumerate(doc["nodes"]):
+        av = R.available_of(node, doc["bound"])
+        assert Fraction(c["avail_cpu_milli"][i], 1000) == av.cpu and Fraction(c["avail_mem_bytes"][i]) == av.memory, node["metadata"]["name"]
+    for i, pod in enumerate(doc["pods"]):
+        rq = R.total_pod_resources(pod)
+        assert Fraction(c["req_cpu_milli"][i], 1000) == rq.cpu and Fraction(c["req_mem_bytes"][i]) == rq.memory
+
+
+def test_cluster_2000x500_binary_suffixes_12_keys_taints_without_a_device(tmp_path):
+    c = synth.make_cluster(P=2000, N=500, n_keys=12, n_taints=16, seed=0x0B1EC7, binary_suffixes=True)
+    pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()
+    path = tmp_path / "objs.json"
+    json.dump({"name": "tmp", "pods": pods, "nodes": nodes, "bound": bound, "samples": []}, open(path, "w"))
+    cols = columns(path, True)
+    assert cols["n_keys"] == 12
+    feas, fit = masks_of_columns(cols, True)
+    want_feas, want_fit = expect_masks(pods, nodes, bound, True, cache=True)
+    assert np.array_equal(fit, want_fit)
+    assert np.array_equal(feas, want_feas)
+    dens = np.unpackbits(want_feas.view(np.uint8)).sum() / (c.P * c.N)
+    assert 0.001 < dens < 0.9
+
+
+# ---- the quantity grammar, randomly spelled ---------------------------------------------------------------------------------
+
+_digits = st.text("0123456789", min_size=1, max_size=9)
+_SUFFIX = {  # spellings that mostly stay integer numbers of milli-cores / bytes, with a minority that do not (those must be refused)
+    "cpu": ["", "", "m", "m", "k", "e0", "e3", "e-3", "e-1", "E2", "u", "M"],
+    "memory": ["", "", "k", "M", "G", "Ki", "Mi", "Gi", "Ti", "T", "e3", "E2", "e0", "m", "e-1", "n"],
+}
+
+
+@st.composite
+def quantity(draw, kind="cpu"):
+    ip = draw(_digits)
+    fp = draw(st.one_of(st.none(), st.none(), st.text("0123456789", min_size=0, max_size=3)))
+    sign = draw(st.sampled_from(["", "", "", "+", "-"]))
+    return sign + ip + ("" if fp is None else "." + fp) + draw(st.sampled_from(_SUFFIX[kind]))
+
+
+def _obj_pod(name, cpu, mem, node=None):
+    spec = {"containers": [{"name": "c", "resources": {"requests": {"cpu": cpu, "memory": mem}}}]}
+    if node:
+        spec["nodeName"] = node
+    return {"metadata": {"name": name, "namespace": "ns"}, "spec": spec}
+
+
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(alloc_cpu=quantity("cpu"), alloc_mem=quantity("memory"), b_cpu=quantity("cpu"), b_mem=quantity("memory"), r_cpu=quantity("cpu"), r_mem=quantity("memory"))
+def test_random_quantity_spellings_encode_exactly_or_are_refused(tmp_path, alloc_cpu, alloc_mem, b_cpu, b_mem, r_cpu, r_mem):
+    node = {"metadata": {"name": "n0"}, "status": {"allocatable": {"cpu": alloc_cpu, "memory": alloc_mem}}}
+    bound = [_obj_pod("b0", b_cpu, b_mem, node="n0")]
+    pods = [_obj_pod("p0", r_cpu, r_mem)]
+    path = tmp_path / "q.json"
+    json.dump({"name": "q", "pods": pods, "nodes": [node], "bound": bound, "samples": []}, open(path, "w"))
+    av, rq = R.available_of(node, bound), R.total_pod_resources(pods[0])
+    vals = [av.cpu * 1000, av.memory, rq.cpu * 1000, rq.memory]
+    representable = all(v.denominator == 1 and -(1 << 63) <= v.numerator < (1 << 63) for v in vals)
+    # (every single quantity must also be an int64 number of nano-units' worth for the 128-bit accumulator: 9 digits x 10^18 fits)
+    r = columns(path, expect_fail=True)
+    if representable:
+        assert r.returncode == 0, (r.stderr[-400:], alloc_cpu, alloc_mem, b_cpu, b_mem, r_cpu, r_mem)
+        c = json.loads(r.stdout)
+        got = [Fraction(c["avail_cpu_milli"][0]), Fraction(c["avail_mem_bytes"][0]), Fraction(c["req_cpu_milli"][0]), Fraction(c["req_mem_bytes"][0])]
+        assert got == vals, (got, vals, alloc_cpu, alloc_mem, b_cpu, b_mem, r_cpu, r_mem)
+        feas, fit = masks_of_columns(c, False)
+        want = R.can_pod_fit(pods[0], node, bound)  # src/predicates.rs:20-43 on the strings
+        assert bool(fit[0, 0] & np.uint64(1)) == want
+    else:
+        assert r.returncode == 1 and "objects_eval:" in r.stderr, "a value that is not an integer number of milli-cores / bytes (or leaves int64) must be refused, not rounded"
+
+
+@pytest.mark.parametrize("bad", ["", "abc", "1.2.3", "1ki", "12 Mi", "Mi", "1e", "--1", "0x10", "1,5"])
+def test_what_the_reference_panics_on_is_an_encode_error(tmp_path, bad):
+    """`.try_into().expect(...)` panics on these (src/util.rs:65,68; src/predicates.rs:29,31); the oracle raises ReferencePanic, the encoder refuses."""
+    with pytest.raises(R.ReferencePanic):
+        R.parse_quantity(bad)
+    node = {"metadata": {"name": "n0"}, "status": {"allocatable": {"cpu": "4", "memory": "1Gi"}}}
+    path = tmp_path / "bad.json"
+    json.dump({"name": "bad", "pods": [_obj_pod("p0", bad, "1Mi")], "nodes": [node], "bound": [], "samples": []}, open(path, "w"))
+    r = columns(path, expect_fail=True)
+    assert r.returncode == 1 and "objects_eval:" in r.stderr
