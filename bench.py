@@ -301,6 +301,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.refresh_every > 0:
+        # The HIP runtime stalls ONCE per process for ~37 ms around its ~600th snapshot update (profiles/r02_m_snapshot_stream.txt);
+        # get past that point before anything is timed, or it lands in the timed region of some --refresh-every / --steps combinations.
+        for j in range(700):
+            ev.update_nodes(r_idx[j % 64], r_cpu[j % 64], r_mem[j % 64])
+        ev.set_nodes(**c.node_columns())
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         last = one_step()
     # clock ramp (untimed, part of the warm-up): step until about --ramp-ms have passed.  The step count is agreed across ranks
