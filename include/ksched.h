@@ -138,8 +138,9 @@ int ksched_set_option(ksched_ctx *ctx, int option, int64_t value);
  * Replaces, for a whole batch, what can_pod_fit recomputes per evaluation
  * (src/predicates.rs:27-38): available[n] = allocatable[n] - sum(requests of pods bound to n).
  * Host pointers; the library copies them (they may be reused when the call returns) and builds its device-side indexes with
- * HIP kernels on the ctx's stream; the call does not wait for the device.  Evaluations already enqueued keep reading the
- * previous snapshot; evaluations enqueued afterwards (on any stream) are ordered behind the build by events.
+ * HIP kernels; the call does not wait for the device.  Evaluations already enqueued keep reading the previous snapshot;
+ * evaluations enqueued afterwards (on any stream) are ordered behind the build -- by the stream itself when the build rides the
+ * one caller stream this ctx has seen, by events otherwise (KSCHED_OPT_SNAPSHOT_STREAM).
  *   avail_cpu_milli, avail_mem_bytes : [n] signed
  *   label_val_ids : [n_keys][n] or NULL when n_keys == 0; ids must be < KSCHED_SEL_NEVER
  *   taints        : [n] bit set of (interned) taints, or NULL = no taints
@@ -153,9 +154,11 @@ int ksched_set_nodes(ksched_ctx *ctx, uint32_t n, const int64_t *avail_cpu_milli
  * (< ksched_num_nodes); the two value arrays hold the node's NEW available cpu / memory.  Labels and taints are
  * not touched (use ksched_set_nodes when the node set or its labels change).  A node listed twice takes its last values.
  * Cost: the new values are scattered into the columns and the fit part (rows, search trees, cnt tables) of the touched
- * 1024-node tiles is rebuilt by one kernel on the ctx's stream; updates of up to 16 nodes travel in kernel arguments (no
- * copy).  The best-fit order is only marked stale: the next KSCHED_PICK_BESTFIT request rebuilds it.  The host does not wait:
- * evaluations already enqueued on any stream this ctx has seen read the snapshot as it was, later ones the new one (events).
+ * 1024-node tiles is rebuilt by one kernel; updates of up to 16 nodes travel in kernel arguments (no copy).  The best-fit
+ * order is only marked stale: the next KSCHED_PICK_BESTFIT request rebuilds it.  The host does not wait: evaluations already
+ * enqueued on any stream this ctx has seen read the snapshot as it was, later ones the new one.  With ONE caller stream the
+ * two kernels are enqueued on that stream (no event, no cross-stream wait: an [update + bindings-only pick] loop runs 32 us per
+ * iteration instead of 49); with several, on the ctx's own stream, ordered by events (KSCHED_OPT_SNAPSHOT_STREAM).
  * If a HIP call fails midway the snapshot is invalidated (KSCHED_E_STATE until the next ksched_set_nodes).
  */
 int ksched_update_nodes(ksched_ctx *ctx, uint32_t count, const uint32_t *node_index, const int64_t *avail_cpu_milli,
