@@ -1,5 +1,9 @@
 #include "scheduler.hpp"
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
 namespace ksched_host {
 
 std::optional<size_t> SplitMixChooser::choose(size_t n) {
@@ -113,6 +117,39 @@ ReconcileOutcome bind(const corev1::Pod &pod, const corev1::Node *chosen, Bindin
 
 }  // namespace
 
+std::vector<ReconcileOutcome> post_bindings(const std::vector<const corev1::Pod *> &pods, const std::vector<const corev1::Node *> &chosen,
+                                            BindingSink &sink, unsigned post_concurrency) {
+    const size_t p = pods.size();
+    std::vector<ReconcileOutcome> out(p);
+    auto one = [&](size_t i) {
+        try {
+            out[i] = bind(*pods[i], i < chosen.size() ? chosen[i] : nullptr, sink);
+        } catch (...) {  // a throwing sink is a failed POST (src/main.rs:105-108), never an exception crossing a worker thread
+            ReconcileOutcome r;
+            r.ok = false;
+            r.error = ReconcileError::CreateBindingFailed;
+            r.action = error_policy(*pods[i], r.error);
+            out[i] = r;
+        }
+    };
+    const size_t workers = std::min<size_t>(post_concurrency, p);
+    if (workers <= 1) {
+        for (size_t i = 0; i < p; ++i) one(i);
+        return out;
+    }
+    // pods are handed out one at a time (a POST is a network round trip: no point in static ranges), each outcome slot is
+    // written by exactly one worker
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    pool.reserve(workers);
+    for (size_t w = 0; w < workers; ++w)
+        pool.emplace_back([&] {
+            for (size_t i = next.fetch_add(1, std::memory_order_relaxed); i < p; i = next.fetch_add(1, std::memory_order_relaxed)) one(i);
+        });
+    for (auto &t : pool) t.join();
+    return out;
+}
+
 ReconcileOutcome reconcile(const corev1::Pod &pod, Context &ctx, NodeChooser &chooser, BindingSink &sink) {
     if (is_pod_bound(pod)) return ReconcileOutcome{};  // src/main.rs:74-76
     const std::optional<corev1::Node> chosen = select_node_for_pod(pod, ctx, chooser);
@@ -120,7 +157,7 @@ ReconcileOutcome reconcile(const corev1::Pod &pod, Context &ctx, NodeChooser &ch
 }
 
 std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
-                                              BindingSink &sink) {
+                                              BindingSink &sink, unsigned post_concurrency) {
     std::vector<ReconcileOutcome> out(pods.size());
     std::vector<const corev1::Pod *> pending;
     std::vector<size_t> where;
@@ -130,10 +167,13 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
         where.push_back(i);
     }
     const BatchSelection sel = select_nodes_for_pods(pending, ctx, chooser);
+    std::vector<const corev1::Node *> chosen(pending.size(), nullptr);
+    for (size_t j = 0; j < pending.size(); ++j)
+        if (sel.node_store_index[j] >= 0) chosen[j] = &ctx.node_store[(size_t)sel.node_store_index[j]];
+    const std::vector<ReconcileOutcome> posted = post_bindings(pending, chosen, sink, post_concurrency);  // src/main.rs:94-108, overlapped
     std::vector<corev1::Pod> landed;  // copies carrying spec.nodeName, for the snapshot update
     for (size_t j = 0; j < pending.size(); ++j) {
-        const int32_t idx = sel.node_store_index[j];
-        out[where[j]] = bind(*pending[j], idx >= 0 ? &ctx.node_store[(size_t)idx] : nullptr, sink);
+        out[where[j]] = posted[j];
         if (out[where[j]].ok && out[where[j]].bound_to) {
             corev1::Pod p = *pending[j];
             if (!p.spec) p.spec = corev1::PodSpec{};

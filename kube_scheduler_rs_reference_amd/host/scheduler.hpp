@@ -99,10 +99,21 @@ struct ReconcileOutcome {
 // src/main.rs:73-120 for one pod.
 ReconcileOutcome reconcile(const corev1::Pod &pod, Context &ctx, NodeChooser &chooser, BindingSink &sink);
 
+// The binding POSTs of a batch, up to `post_concurrency` in flight at once.  In the reference every
+// reconcile is its own tokio task under the kube-rs Controller (src/main.rs:141-144), so the POSTs of pending pods
+// (src/main.rs:94-103) overlap; a batch that POSTed one by one would serialise P network round trips behind a device step of
+// tens of microseconds.  chosen[i] = the node picked for pods[i] or nullptr (-> NoNodeFound, src/main.rs:116-118).  Outcomes are
+// per pod and do not depend on the order the POSTs complete in (the reference's have no order either).
+// post_concurrency <= 1: the calling thread POSTs in batch order.  > 1: that many worker threads share the batch, and
+// `sink.create_pod_binding` is called from several threads at once -- the sink must allow that.  A sink that throws is
+// reported as CreateBindingFailed for that pod (nothing unwinds through the workers).
+std::vector<ReconcileOutcome> post_bindings(const std::vector<const corev1::Pod *> &pods, const std::vector<const corev1::Node *> &chosen,
+                                            BindingSink &sink, unsigned post_concurrency = 1);
+
 // The batching reconciler: bound pods are skipped (src/main.rs:74-76), the rest go
-// through ONE batched evaluation and pick, then each gets its own binding POST and outcome.
+// through ONE batched evaluation and pick, then each gets its own binding POST (post_bindings) and outcome.
 std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
-                                              BindingSink &sink);
+                                              BindingSink &sink, unsigned post_concurrency = 1);
 
 // In-batch capacity accounting -- OPT-IN and OUTSIDE the parity claim: the reference has no
 // assume/reserve step (src/main.rs:78-119), so reconciles racing on one API-server state may over-commit a node,

@@ -9,6 +9,10 @@
 #include <functional>
 #include <map>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -342,6 +346,75 @@ static void cpu_tests() {
         corev1::Toleration all;
         all.operator_ = std::string("Exists");
         CHECK(toleration_matches(all, t));
+    });
+    run("post_bindings: the POSTs of a batch overlap (SURVEY.md 8f n4; src/main.rs:94-108, 141-144), outcomes per pod", [] {
+        struct SlowSink : BindingSink {  // a POST = 2 ms of "network"; counts how many are in flight at once
+            std::mutex mu;
+            std::vector<std::pair<std::string, std::string>> posts;
+            std::atomic<int> in_flight{0}, max_in_flight{0}, calls{0};
+            bool create_pod_binding(const std::string &pod_name, const std::string &ns, const Binding &b) override {
+                const int now = ++in_flight;
+                int seen = max_in_flight.load();
+                while (now > seen && !max_in_flight.compare_exchange_weak(seen, now)) {
+                }
+                ++calls;
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                --in_flight;
+                if (pod_name == "p7" || pod_name == "p21") return false;         // the API server refused these (src/main.rs:105-108)
+                if (pod_name == "p33") throw std::runtime_error("connection reset");  // a sink that throws = a failed POST
+                std::lock_guard<std::mutex> lk(mu);
+                posts.push_back({ns + "/" + pod_name, b.target_name});
+                return true;
+            }
+        };
+        std::vector<corev1::Node> nodes;
+        for (int i = 0; i < 4; ++i) nodes.push_back(node_with("node" + std::to_string(i), "8", "1Gi"));
+        std::vector<corev1::Pod> pods;
+        for (int i = 0; i < 64; ++i) pods.push_back(pod_with("p" + std::to_string(i), {container("100m", "1Mi")}));
+        pods[40].metadata.namespace_.reset();  // pod.namespace().unwrap() panics in the reference (src/main.rs:80): reported, no POST
+        std::vector<const corev1::Pod *> pp;
+        std::vector<const corev1::Node *> chosen;
+        for (int i = 0; i < 64; ++i) {
+            pp.push_back(&pods[i]);
+            chosen.push_back(i % 9 == 8 ? nullptr : &nodes[i % 4]);  // every ninth pod found no node (src/main.rs:116-118)
+        }
+        auto check = [&](const std::vector<ReconcileOutcome> &out, SlowSink &sink) {
+            CHECK(out.size() == 64);
+            int ok = 0;
+            for (int i = 0; i < 64; ++i) {
+                const ReconcileOutcome &o = out[i];
+                if (i % 9 == 8) CHECK(!o.ok && o.error == ReconcileError::NoNodeFound && o.action == Action::RequeueAfter5Min && !o.bound_to);
+                else if (i == 40) CHECK(!o.ok && o.error == ReconcileError::CreateBindingObjectFailed);
+                else if (i == 7 || i == 21 || i == 33) CHECK(!o.ok && o.error == ReconcileError::CreateBindingFailed && o.action == Action::RequeueAfter5Min);
+                else {
+                    CHECK(o.ok && o.action == Action::AwaitChange && o.bound_to && *o.bound_to == "node" + std::to_string(i % 4));
+                    ++ok;
+                }
+            }
+            CHECK((int)sink.posts.size() == ok);
+            CHECK(sink.calls == 64 - 7 - 1);  // no POST for the seven pods without a node nor for the one without a namespace
+            std::sort(sink.posts.begin(), sink.posts.end());
+            CHECK(std::adjacent_find(sink.posts.begin(), sink.posts.end()) == sink.posts.end());  // every binding POSTed once
+        };
+        SlowSink serial, pooled;
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto a = post_bindings(pp, chosen, serial, 1);
+        const auto t1 = std::chrono::steady_clock::now();
+        const auto b = post_bindings(pp, chosen, pooled, 16);
+        const auto t2 = std::chrono::steady_clock::now();
+        check(a, serial);
+        check(b, pooled);
+        CHECK(serial.max_in_flight == 1);
+        CHECK(pooled.max_in_flight > 4 && pooled.max_in_flight <= 16);
+        const double ms_serial = std::chrono::duration<double, std::milli>(t1 - t0).count(), ms_pooled = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        CHECK(ms_serial >= 56 * 2.0);          // 56 POSTs one after the other
+        CHECK(ms_pooled < ms_serial / 4.0);    // 16 in flight: a quarter of that at the very most
+        for (int i = 0; i < 64; ++i) CHECK(a[i].ok == b[i].ok && a[i].error == b[i].error && a[i].bound_to == b[i].bound_to);
+        // fewer pods than workers, and an empty batch
+        SlowSink few;
+        const auto c = post_bindings({pp[0], pp[1]}, {chosen[0], chosen[1]}, few, 16);
+        CHECK(c.size() == 2 && c[0].ok && c[1].ok && few.calls == 2);
+        CHECK(post_bindings({}, {}, few, 8).empty());
     });
     run("choosers: scripted and SplitMix draws", [] {
         ScriptedChooser s;

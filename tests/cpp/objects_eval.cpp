@@ -5,13 +5,14 @@
 //
 //   objects_eval masks      <objects.json> [taints]      check_node_validity_batch: fit / feasible masks (hex rows), canonical node order
 //   objects_eval columns    <objects.json> [taints]      the encoder alone (no device): the integer columns of include/ksched.h as JSON
-//   objects_eval batch      <objects.json> <seed> [fail_every]   reconcile_batch            (src/main.rs:73-120 per pod)
+//   objects_eval batch      <objects.json> <seed> [fail_every [post_concurrency]]   reconcile_batch (src/main.rs:73-120 per pod)
 //   objects_eval sequential <objects.json> <seed> [fail_every]   reconcile_batch_sequential (8f n3, opt-in)
 // The node store is given to the host in REVERSED canonical order (the reference's store order is arbitrary, src/main.rs:56):
 // store index s <-> canonical index n - 1 - s.  Draws come from SplitMixChooser(seed) over the store order.
 #include <chrono>
 #include <cstdio>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 
 #include "../../kube_scheduler_rs_reference_amd/host/encoder.hpp"
@@ -122,7 +123,9 @@ static corev1::Node node_of(const Value &o) {
 struct RecordingSink : BindingSink {
     std::vector<std::pair<std::string, std::string>> posted;  // (namespace/name, node) in POST order
     uint32_t fail_every = 0, calls = 0;
+    std::mutex mu;  // post_concurrency > 1: several POSTs at once (their completion order is then the recorded order)
     bool create_pod_binding(const std::string &pod_name, const std::string &pod_namespace, const Binding &b) override {
+        std::lock_guard<std::mutex> lk(mu);
         ++calls;
         if (fail_every && calls % fail_every == 0) return false;  // the API server refused this POST (src/main.rs:105-108)
         posted.emplace_back(pod_namespace + "/" + pod_name, b.target_name);
@@ -250,7 +253,8 @@ int main(int argc, char **argv) {
             }
             const auto t0 = std::chrono::steady_clock::now();
             if (mode == "batch") {
-                const auto out = reconcile_batch(pp, ctx, chooser, sink);
+                const unsigned post_concurrency = argc > 5 ? (unsigned)std::strtoul(argv[5], nullptr, 0) : 1u;
+                const auto out = reconcile_batch(pp, ctx, chooser, sink, post_concurrency);
                 const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (!quiet) print_outcomes(out, sink);
                 else std::printf("\"posted_count\":%zu", sink.posted.size());

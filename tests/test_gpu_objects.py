@@ -148,6 +148,29 @@ def test_reconcile_batch_equals_oracle_restatement(tmp_path, seed, fail_every):
     assert got["incremental_equals_relist"] is True
 
 
+def test_reconcile_batch_with_overlapped_posts_equals_oracle_restatement(tmp_path):
+    """post_concurrency = 8: the POSTs of the batch overlap, as the reference's concurrent reconciles' do
+    (src/main.rs:94-103, 141-144).  Same outcome per pod, the same SET of bindings (their order is the completion order), the same
+    snapshot afterwards."""
+    pods, nodes, bound = small_cluster(0xBA7C77)
+    path = tmp_path / "objs.json"
+    write_objects(path, pods, nodes, bound)
+    got = tool("batch", path, 1777, 0, 8)
+    want, posted = R.reconcile_batch(pods, list(reversed(nodes)), bound, R.SplitMixChooser(1777), fail_every=0)
+    assert [(o["ok"], o["error"], o["bound_to"]) for o in got["outcomes"]] == [(o["ok"], o["error"], o["bound_to"]) for o in want]
+    assert sorted(tuple(x) for x in got["posted"]) == sorted(posted) and len(posted) > 8
+    assert got["incremental_equals_relist"] is True
+    by_name = {f"{p['metadata']['namespace']}/{p['metadata']['name']}": p for p in pods}
+    state = list(bound)
+    for pod_name, node in posted:
+        q = json.loads(json.dumps(by_name[pod_name]))
+        q["spec"]["nodeName"] = node
+        state.append(q)
+    for j, node in enumerate(nodes):
+        av = R.available_of(node, state)
+        assert got["avail_cpu_milli"][j] == av.cpu * 1000 and got["avail_mem_bytes"][j] == av.memory
+
+
 @pytest.mark.parametrize("seed,fail_every,tight", [(1, 0, True), (2, 4, True), (3, 0, False)])
 def test_reconcile_batch_sequential_equals_oracle_restatement(tmp_path, seed, fail_every, tight):
     pods, nodes, bound = small_cluster(0x5E0000 + seed, P=48, N=10, tight=tight)
