@@ -163,3 +163,59 @@ def test_what_the_reference_panics_on_is_an_encode_error(tmp_path, bad):
     json.dump({"name": "bad", "pods": [_obj_pod("p0", bad, "1Mi")], "nodes": [node], "bound": [], "samples": []}, open(path, "w"))
     r = columns(path, expect_fail=True)
     assert r.returncode == 1 and "objects_eval:" in r.stderr
+
+
+# ---- labels, selectors, taints, tolerations: randomly shaped small clusters --------------------------------------------------
+
+_KEYS = ["zone", "disk", "tier", "", "kubernetes.io/hostname"]
+_VALS = ["", "a", "b", "ssd", "A"]  # ("" is a value: a label present with an empty value is not an absent label)
+_label_map = st.one_of(st.none(), st.dictionaries(st.sampled_from(_KEYS), st.sampled_from(_VALS), max_size=4))
+_EFFECTS = ["NoSchedule", "NoExecute", "PreferNoSchedule"]
+_taint = st.fixed_dictionaries({"key": st.sampled_from(["dedicated", "gpu", ""]), "effect": st.sampled_from(_EFFECTS)},
+                               optional={"value": st.sampled_from(["", "x", "y"])})
+_toleration = st.fixed_dictionaries({}, optional={"key": st.sampled_from(["dedicated", "gpu", ""]), "operator": st.sampled_from(["Equal", "Exists"]),
+                                                  "value": st.sampled_from(["", "x", "y"]), "effect": st.sampled_from(_EFFECTS + [""])})
+
+
+@st.composite
+def small_cluster(draw):
+    n_nodes, n_pods = draw(st.integers(1, 5)), draw(st.integers(1, 6))
+    nodes = []
+    for i in range(n_nodes):
+        md = {"name": f"n{i}"}
+        labels = draw(_label_map)
+        if labels is not None:
+            md["labels"] = labels
+        node = {"metadata": md, "status": {"allocatable": {"cpu": str(draw(st.integers(0, 4))), "memory": f"{draw(st.integers(0, 4))}Gi"}}}
+        taints = draw(st.lists(_taint, max_size=3))
+        if taints or draw(st.booleans()):
+            node["spec"] = {"taints": taints}
+        nodes.append(node)
+    pods = []
+    for i in range(n_pods):
+        spec = {"containers": [{"name": "c", "resources": {"requests": {"cpu": f"{draw(st.integers(0, 3000))}m", "memory": f"{draw(st.integers(0, 3000))}Mi"}}}]}
+        sel = draw(_label_map)
+        if sel is not None:
+            spec["nodeSelector"] = sel
+        tols = draw(st.lists(_toleration, max_size=3))
+        if tols:
+            spec["tolerations"] = tols
+        pods.append({"metadata": {"name": f"p{i}", "namespace": "ns"}, "spec": spec})
+    return pods, nodes
+
+
+@settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(cluster=small_cluster(), use_taint=st.booleans())
+def test_random_labels_selectors_taints_tolerations_encode_to_the_oracles_masks(tmp_path, cluster, use_taint):
+    """src/predicates.rs:45-61 on label maps that are absent / empty / carry empty keys and values, selectors naming keys or values no
+    node has; extension E2 on every operator / key / value / effect combination of a toleration.  The encoder's
+    dictionary ids and taint bits, evaluated by the integer loop, must give the masks the oracle computes from the objects."""
+    pods, nodes = cluster
+    path = tmp_path / "lab.json"
+    json.dump({"name": "lab", "pods": pods, "nodes": nodes, "bound": [], "samples": []}, open(path, "w"))
+    c = columns(path, use_taint)
+    assert c["names"] == sorted(n["metadata"]["name"] for n in nodes)
+    feas, fit = masks_of_columns(c, use_taint)
+    want_feas, want_fit = expect_masks(pods, nodes, [], use_taint, cache=False)
+    assert np.array_equal(fit, want_fit)
+    assert np.array_equal(feas, want_feas), (pods, nodes)
