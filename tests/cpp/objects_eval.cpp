@@ -5,6 +5,7 @@
 //
 //   objects_eval masks      <objects.json> [taints]      check_node_validity_batch: fit / feasible masks (hex rows), canonical node order
 //   objects_eval columns    <objects.json> [taints]      the encoder alone (no device): the integer columns of include/ksched.h as JSON
+//   objects_eval events     <objects.json> [single]      snapshot + pod watch events applied incrementally (no device): `available` afterwards
 //   objects_eval batch      <objects.json> <seed> [fail_every [post_concurrency]]   reconcile_batch (src/main.rs:73-120 per pod)
 //   objects_eval sequential <objects.json> <seed> [fail_every]   reconcile_batch_sequential (8f n3, opt-in)
 // The node store is given to the host in REVERSED canonical order (the reference's store order is arbitrary, src/main.rs:56):
@@ -160,7 +161,7 @@ static void print_outcomes(const std::vector<ReconcileOutcome> &out, const Recor
 
 int main(int argc, char **argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: objects_eval masks|columns|batch|sequential <objects.json> [...]\n");
+        std::fprintf(stderr, "usage: objects_eval masks|columns|events|batch|sequential <objects.json> [...]\n");
         return 2;
     }
     try {
@@ -234,6 +235,40 @@ int main(int argc, char **argv) {
             arr32("sel_val_ids", pc.sel_val_ids); std::printf(",");
             arru64("tolerations", pc.tolerations);
             std::printf(",\"list_calls\":%llu}\n", (unsigned long long)lister->list_calls);
+            return 0;
+        }
+        if (mode == "events") {
+            // the snapshot builder's host half, no device: a snapshot built from the LISTs, then pod watch events applied
+            // incrementally.  "events": [[pod index, node name, 1 = bound | 0 = deleted], ...] over the "pods" array; every event takes a copy
+            // of the pod with spec.nodeName set.  Prints `available` after all events (what a re-LIST of the final state must give).
+            Snapshot snap(Snapshot::kEncodeOnly);
+            snap.rebuild(ctx.node_store, lister.get());
+            std::vector<corev1::Pod> moved;
+            std::vector<bool> kind;
+            for (const Value &e : doc.at("events").arr) {
+                corev1::Pod q = pods.at((size_t)e.arr.at(0).num);
+                if (!q.spec) q.spec = corev1::PodSpec{};
+                q.spec->node_name = e.arr.at(1).str;
+                moved.push_back(std::move(q));
+                kind.push_back(e.arr.at(2).num != 0);
+            }
+            size_t applied = 0;
+            const bool one_by_one = argc > 3 && std::string(argv[3]) == "single";
+            if (one_by_one) {
+                for (size_t i = 0; i < moved.size(); ++i) applied += (kind[i] ? snap.apply_bound_pod(moved[i]) : snap.apply_deleted_pod(moved[i])) ? 1 : 0;
+            } else {
+                std::vector<std::pair<const corev1::Pod *, bool>> ev;
+                for (size_t i = 0; i < moved.size(); ++i) ev.emplace_back(&moved[i], (bool)kind[i]);
+                applied = snap.apply_pod_events(ev);
+            }
+            const NodeColumns &nc = snap.columns();
+            std::printf("{\"applied\":%zu,\"names\":[", applied);
+            for (uint32_t i = 0; i < nc.n; ++i) std::printf("%s\"%s\"", i ? "," : "", nc.names[i].c_str());
+            std::printf("],\"avail_cpu_milli\":[");
+            for (uint32_t i = 0; i < nc.n; ++i) std::printf("%s%lld", i ? "," : "", (long long)nc.avail_cpu_milli[i]);
+            std::printf("],\"avail_mem_bytes\":[");
+            for (uint32_t i = 0; i < nc.n; ++i) std::printf("%s%lld", i ? "," : "", (long long)nc.avail_mem_bytes[i]);
+            std::printf("]}\n");
             return 0;
         }
         if (mode == "batch" || mode == "sequential") {

@@ -13,6 +13,10 @@ parser, dict lookups -- independent of the C++ parser; oracle.c's parser mirrors
     would panic on (src/util.rs:65,68; src/predicates.rs:29,31) or what is not an integer number of milli-cores / bytes is refused
     by the encoder (exit code 1), never silently rounded.
 
+  * randomly shaped label maps / selectors / taints / tolerations give the oracle's masks (src/predicates.rs:45-61, extension E2);
+  * pod watch events applied incrementally (Snapshot::apply_pod_events, SURVEY.md 8f n1) leave exactly the `available` a re-LIST of
+    the final state gives (src/predicates.rs:34-38).
+
 The same path through the device is tests/test_gpu_objects.py."""
 import json
 import os
@@ -219,3 +223,62 @@ def test_random_labels_selectors_taints_tolerations_encode_to_the_oracles_masks(
     want_feas, want_fit = expect_masks(pods, nodes, [], use_taint, cache=False)
     assert np.array_equal(fit, want_fit)
     assert np.array_equal(feas, want_feas), (pods, nodes)
+
+
+# ---- the snapshot builder's host half: pod watch events applied incrementally == a re-LIST ---------------------
+
+@st.composite
+def event_script(draw):
+    n_nodes, n_pods = draw(st.integers(1, 4)), draw(st.integers(1, 6))
+    nodes = [{"metadata": {"name": f"n{i}"}, "status": {"allocatable": {"cpu": str(draw(st.integers(1, 64))), "memory": f"{draw(st.integers(1, 256))}Gi"}}}
+             for i in range(n_nodes)]
+    pods = [_obj_pod(f"p{i}", draw(st.sampled_from(["250m", "1", "1500m", "0", "2e0", "0.5"])), draw(st.sampled_from(["64Mi", "1Gi", "0", "1e9", "512Ki", "3M"])))
+            for i in range(n_pods)]
+    bound = [_obj_pod(f"b{i}", "500m", "128Mi", node=f"n{draw(st.integers(0, n_nodes - 1))}") for i in range(draw(st.integers(0, 3)))]
+    # a pod may be bound, deleted, bound elsewhere ...; a node name outside the snapshot is ignored by the builder
+    events = [[draw(st.integers(0, n_pods - 1)), draw(st.sampled_from([f"n{i}" for i in range(n_nodes)] + ["elsewhere"])), draw(st.integers(0, 1))]
+              for _ in range(draw(st.integers(0, 12)))]
+    return pods, nodes, bound, events
+
+
+@settings(max_examples=100, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(script=event_script(), single=st.booleans())
+def test_incremental_pod_events_equal_a_relist_of_the_final_state(tmp_path, script, single):
+    """Snapshot::apply_pod_events / apply_bound_pod / apply_deleted_pod keep `available` current from watch events instead of one LIST
+    per evaluation (src/predicates.rs:34-38 subtracts every pod the LIST for the node returns).  After any sequence of events the
+    columns must equal allocatable - sum(requests) over the final state, as the oracle computes it from the objects -- where a
+    deleted pod ADDS its requests back even if it was never seen bound (the builder trusts its event stream; so does this test:
+    the expectation applies the same signed sum)."""
+    pods, nodes, bound, events = script
+    path = tmp_path / "ev.json"
+    json.dump({"name": "ev", "pods": pods, "nodes": nodes, "bound": bound, "samples": [], "events": events}, open(path, "w"))
+    r = subprocess.run([TOOL, "events", str(path), *(["single"] if single else [])], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1000:]
+    got = json.loads(r.stdout)
+    names = [n["metadata"]["name"] for n in nodes]
+    assert got["names"] == names
+    want_cpu = [R.available_of(n, bound).cpu * 1000 for n in nodes]
+    want_mem = [R.available_of(n, bound).memory for n in nodes]
+    applied = 0
+    for pi, node, is_bound in events:
+        if node not in names:
+            continue
+        rq = R.total_pod_resources(pods[pi])
+        j = names.index(node)
+        sign = -1 if is_bound else 1
+        want_cpu[j] += sign * rq.cpu * 1000
+        want_mem[j] += sign * rq.memory
+        applied += 1
+    assert got["applied"] == applied
+    assert [Fraction(x) for x in got["avail_cpu_milli"]] == want_cpu
+    assert [Fraction(x) for x in got["avail_mem_bytes"]] == want_mem
+    # and when every event is a bind of a distinct pod, that IS the re-LIST of the final state
+    if all(b for _, _, b in events) and len({pi for pi, _, _ in events}) == len(events):
+        state = list(bound)
+        for pi, node, _ in events:
+            q = json.loads(json.dumps(pods[pi]))
+            q["spec"]["nodeName"] = node
+            state.append(q)
+        for j, n in enumerate(nodes):
+            av = R.available_of(n, state)
+            assert Fraction(got["avail_cpu_milli"][j], 1000) == av.cpu and Fraction(got["avail_mem_bytes"][j]) == av.memory
