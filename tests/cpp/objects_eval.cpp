@@ -4,7 +4,7 @@
 // ksched_set_nodes / ksched_eval -> masks, against an INDEPENDENT parser (regex + Fraction), on whole clusters.
 //
 //   objects_eval masks      <objects.json> [taints]      check_node_validity_batch: fit / feasible masks (hex rows), canonical node order
-//   objects_eval columns    <objects.json> [taints]      the encoder alone (no device): the integer columns of include/ksched.h as JSON
+//   objects_eval columns    <objects.json> [taints] [batches=K]   the encoder alone (no device): the integer columns of include/ksched.h as JSON
 //   objects_eval events     <objects.json> [single]      snapshot + pod watch events applied incrementally (no device): `available` afterwards
 //   objects_eval batch      <objects.json> <seed> [fail_every [post_concurrency]]   reconcile_batch (src/main.rs:73-120 per pod)
 //   objects_eval sequential <objects.json> <seed> [fail_every]   reconcile_batch_sequential (8f n3, opt-in)
@@ -199,11 +199,21 @@ int main(int argc, char **argv) {
         if (mode == "columns") {
             // the wire-format step alone, no device: objects -> host/quantity.cpp + host/encoder.cpp -> the integer columns of
             // include/ksched.h (Snapshot::kEncodeOnly uploads nothing).  Runs where there is no GPU.
-            const bool taints = argc > 3 && std::string(argv[3]) == "taints";
+            bool taints = false;
+            size_t batches = 1;  // batches=K: the pods are encoded as K consecutive batches against ONE snapshot (label columns are a per-batch
+                                 // working set: a later batch may evict an earlier batch's keys); one JSON document per batch, one per line
+            for (int i = 3; i < argc; ++i) {
+                const std::string a = argv[i];
+                if (a == "taints") taints = true;
+                else if (a.rfind("batches=", 0) == 0) batches = std::max<size_t>(1, std::strtoul(a.c_str() + 8, nullptr, 0));
+            }
             Snapshot snap(Snapshot::kEncodeOnly);
             snap.rebuild(ctx.node_store, lister.get());
             if (taints) snap.enable_taints();
-            const PodColumns pc = snap.encode_pods(pp);
+            const size_t per = (pp.size() + batches - 1) / batches;
+            for (size_t b0 = 0; b0 < pp.size() || b0 == 0; b0 += std::max<size_t>(per, 1)) {
+            const std::vector<const corev1::Pod *> part(pp.begin() + (std::ptrdiff_t)b0, pp.begin() + (std::ptrdiff_t)std::min(pp.size(), b0 + std::max<size_t>(per, 1)));
+            const PodColumns pc = snap.encode_pods(part);
             const NodeColumns &nc = snap.columns();
             auto arr64 = [](const char *k, const std::vector<int64_t> &v) {
                 std::printf("\"%s\":[", k);
@@ -235,6 +245,8 @@ int main(int argc, char **argv) {
             arr32("sel_val_ids", pc.sel_val_ids); std::printf(",");
             arru64("tolerations", pc.tolerations);
             std::printf(",\"list_calls\":%llu}\n", (unsigned long long)lister->list_calls);
+            if (pp.empty()) break;
+            }
             return 0;
         }
         if (mode == "events") {

@@ -282,3 +282,45 @@ def test_incremental_pod_events_equal_a_relist_of_the_final_state(tmp_path, scri
         for j, n in enumerate(nodes):
             av = R.available_of(n, state)
             assert Fraction(got["avail_cpu_milli"][j], 1000) == av.cpu and Fraction(got["avail_mem_bytes"][j]) == av.memory
+
+
+# ---- label columns are a per-batch working set (a lifetime dictionary ran out after 32 keys) -----------------------------
+
+def test_label_columns_are_a_per_batch_working_set(tmp_path):
+    """Three consecutive batches against one snapshot, 20 distinct selector keys each (60 over the snapshot's life, KSCHED_MAX_KEYS = 32):
+    the second batch evicts what it does not use.  Every batch's columns must still give the oracle's masks; a single batch with 33
+    distinct keys is refused here (check_node_validity_batch splits such a batch into pod ranges before it reaches the encoder)."""
+    rng = np.random.default_rng(7)
+    nodes = []
+    for i in range(12):
+        labels = {f"k{j:02d}": f"v{rng.integers(0, 3)}" for j in range(60) if rng.random() < 0.7}
+        nodes.append({"metadata": {"name": f"n{i:02d}", "labels": labels}, "status": {"allocatable": {"cpu": "8", "memory": "16Gi"}}})
+    pods = []
+    for b in range(3):
+        for i in range(10):
+            keys = [f"k{j:02d}" for j in range(20 * b, 20 * b + 20) if rng.random() < 0.15] or [f"k{20 * b:02d}"]
+            pod = _obj_pod(f"p{b}{i}", "100m", "1Mi")
+            pod["spec"]["nodeSelector"] = {k: f"v{rng.integers(0, 4)}" for k in keys}  # v3: a value no node carries
+            pods.append(pod)
+        # make sure the batch really names all twenty of its keys
+        pods[-1]["spec"]["nodeSelector"] = {f"k{j:02d}": "v0" for j in range(20 * b, 20 * b + 20)}
+    path = tmp_path / "ws.json"
+    json.dump({"name": "ws", "pods": pods, "nodes": nodes, "bound": [], "samples": []}, open(path, "w"))
+    r = subprocess.run([TOOL, "columns", str(path), "batches=3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1000:]
+    docs = [json.loads(line) for line in r.stdout.splitlines()]
+    assert len(docs) == 3
+    seen = []
+    for b, c in enumerate(docs):
+        assert c["p"] == 10 and c["n_keys"] <= 32
+        assert set(f"k{j:02d}" for j in range(20 * b, 20 * b + 20)) <= set(c["keys"])
+        seen.append(set(c["keys"]))
+        feas, fit = masks_of_columns(c, False)
+        want_feas, want_fit = expect_masks(pods[10 * b: 10 * b + 10], nodes, [], False, cache=True)
+        assert np.array_equal(fit, want_fit) and np.array_equal(feas, want_feas), f"batch {b}"
+    assert not (seen[0] <= seen[1] and seen[1] <= seen[2]), "some batch must have evicted columns (60 keys over the snapshot's life, 32 columns)"
+    one = _obj_pod("wide", "100m", "1Mi")
+    one["spec"]["nodeSelector"] = {f"k{j:02d}": "v0" for j in range(33)}
+    json.dump({"name": "ws", "pods": [one], "nodes": nodes, "bound": [], "samples": []}, open(path, "w"))
+    r = columns(path, expect_fail=True)
+    assert r.returncode == 1 and "KSCHED_MAX_KEYS" in r.stderr
