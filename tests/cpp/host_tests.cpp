@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime_api.h>  // device buffers / streams for the *_device entry points of the C ABI (tests only)
 
+#include "../../kube_scheduler_rs_reference_amd/host/batcher.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/encoder.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/predicates.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/scheduler.hpp"
@@ -415,6 +416,76 @@ static void cpu_tests() {
         const auto c = post_bindings({pp[0], pp[1]}, {chosen[0], chosen[1]}, few, 16);
         CHECK(c.size() == 2 && c[0].ok && c[1].ok && few.calls == 2);
         CHECK(post_bindings({}, {}, few, 8).empty());
+    });
+    run("PodBatcher: ready_chunks semantics, one queued entry per pod, close drains (SURVEY.md 8f n2; src/main.rs:141-144)", [] {
+        auto mk = [](const std::string &name, const char *cpu) { return std::make_shared<const corev1::Pod>(pod_with(name, {container(cpu, "1Mi")})); };
+        PodBatcher b(4);
+        CHECK(b.try_next_batch().empty());
+        for (int i = 0; i < 10; ++i) CHECK(b.push(mk("p" + std::to_string(i), "100m")));
+        CHECK(b.pending() == 10);
+        CHECK(b.push(mk("p2", "900m")));  // p2 again while queued: replaces the object, keeps its place
+        CHECK(b.push(mk("p9", "700m")));
+        CHECK(b.pending() == 10 && b.coalesced() == 2);
+        auto one = b.next_batch();
+        CHECK(one.size() == 4 && *one[0]->metadata.name == "p0" && *one[2]->metadata.name == "p2");
+        CHECK(total_pod_resources(*one[2]).cpu.to_milli() == 900);  // the latest object
+        CHECK(b.push(mk("p2", "50m")));  // p2 is out of the queue now: this is a new request for it
+        CHECK(b.pending() == 7 && b.coalesced() == 2);
+        auto two = b.next_batch(), three = b.next_batch();
+        CHECK(two.size() == 4 && three.size() == 3);
+        CHECK(*three[1]->metadata.name == "p9" && total_pod_resources(*three[1]).cpu.to_milli() == 700);
+        CHECK(*three[2]->metadata.name == "p2" && total_pod_resources(*three[2]).cpu.to_milli() == 50);
+        b.close();
+        CHECK(!b.push(mk("late", "1")));
+        CHECK(b.next_batch().empty() && b.closed());
+    });
+    run("run_batches: producers and the batch loop concurrently, every pod reconciled exactly once", [] {
+        PodBatcher b(64);
+        constexpr int kProducers = 4, kPerProducer = 500;
+        std::vector<std::thread> producers;
+        for (int t = 0; t < kProducers; ++t)
+            producers.emplace_back([&b, t] {
+                for (int i = 0; i < kPerProducer; ++i) {
+                    b.push(std::make_shared<const corev1::Pod>(pod_with("t" + std::to_string(t) + "-" + std::to_string(i), {container("100m", "1Mi")})));
+                    if (i % 97 == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));  // bursts and gaps
+                }
+            });
+        std::map<std::string, int> seen;
+        size_t reconcile_calls = 0;
+        std::thread closer([&] {
+            for (auto &t : producers) t.join();
+            b.close();
+        });
+        const BatchLoopStats st = run_batches(
+            b,
+            [&](const std::vector<const corev1::Pod *> &pods) {
+                ++reconcile_calls;
+                std::vector<ReconcileOutcome> out(pods.size());
+                for (size_t i = 0; i < pods.size(); ++i)
+                    if (pods[i]->metadata.name->back() == '7') {  // "no node found" for some
+                        out[i].ok = false;
+                        out[i].error = ReconcileError::NoNodeFound;
+                        out[i].action = Action::RequeueAfter5Min;
+                    }
+                return out;
+            },
+            [&](const PodBatcher::PodPtr &pod, const ReconcileOutcome &o) {
+                ++seen[*pod->metadata.name];
+                CHECK(o.ok == (pod->metadata.name->back() != '7'));
+            });
+        closer.join();
+        CHECK(st.pods == (uint64_t)kProducers * kPerProducer && seen.size() == (size_t)kProducers * kPerProducer);
+        bool once = true;
+        for (const auto &kv : seen) once = once && kv.second == 1;
+        CHECK(once);
+        CHECK(st.batches == reconcile_calls && st.largest <= 64 && st.batches >= (uint64_t)kProducers * kPerProducer / 64);
+        CHECK(b.pending() == 0);
+        // a reconcile function that loses a pod is a programming error, reported loudly
+        PodBatcher c(8);
+        c.push(std::make_shared<const corev1::Pod>(pod_with("x", {container("1", "1Mi")})));
+        c.close();
+        CHECK_THROWS(run_batches(c, [](const std::vector<const corev1::Pod *> &) { return std::vector<ReconcileOutcome>{}; },
+                                 [](const PodBatcher::PodPtr &, const ReconcileOutcome &) {}));
     });
     run("choosers: scripted and SplitMix draws", [] {
         ScriptedChooser s;

@@ -8,14 +8,17 @@
 //   objects_eval events     <objects.json> [single]      snapshot + pod watch events applied incrementally (no device): `available` afterwards
 //   objects_eval batch      <objects.json> <seed> [fail_every [post_concurrency]]   reconcile_batch (src/main.rs:73-120 per pod)
 //   objects_eval sequential <objects.json> <seed> [fail_every]   reconcile_batch_sequential (8f n3, opt-in)
+//   objects_eval stream     <objects.json> <seed> <max_pods>     PodBatcher + run_batches + reconcile_batch: the batching reconciler end to end
 // The node store is given to the host in REVERSED canonical order (the reference's store order is arbitrary, src/main.rs:56):
 // store index s <-> canonical index n - 1 - s.  Draws come from SplitMixChooser(seed) over the store order.
 #include <chrono>
 #include <cstdio>
 #include <fstream>
+#include <map>
 #include <mutex>
 #include <sstream>
 
+#include "../../kube_scheduler_rs_reference_amd/host/batcher.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/encoder.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/predicates.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/scheduler.hpp"
@@ -161,7 +164,7 @@ static void print_outcomes(const std::vector<ReconcileOutcome> &out, const Recor
 
 int main(int argc, char **argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: objects_eval masks|columns|events|batch|sequential <objects.json> [...]\n");
+        std::fprintf(stderr, "usage: objects_eval masks|columns|events|batch|sequential|stream <objects.json> [...]\n");
         return 2;
     }
     try {
@@ -280,6 +283,35 @@ int main(int argc, char **argv) {
             for (uint32_t i = 0; i < nc.n; ++i) std::printf("%s%lld", i ? "," : "", (long long)nc.avail_cpu_milli[i]);
             std::printf("],\"avail_mem_bytes\":[");
             for (uint32_t i = 0; i < nc.n; ++i) std::printf("%s%lld", i ? "," : "", (long long)nc.avail_mem_bytes[i]);
+            std::printf("]}\n");
+            return 0;
+        }
+        if (mode == "stream") {
+            // the whole batching reconciler: pending pods -> PodBatcher (ready_chunks(max_pods)) -> run_batches ->
+            // reconcile_batch on the device -> one outcome per pod.  All pods are queued before the loop starts, so the batches are the
+            // consecutive chunks of max_pods (deterministic: the test can restate them); every batch is evaluated against the snapshot
+            // the previous batches left (reconcile_batch applies its own bindings).
+            if (argc < 5) throw std::runtime_error("usage: objects_eval stream <objects.json> <seed> <max_pods>");
+            SplitMixChooser chooser(std::strtoull(argv[3], nullptr, 0));
+            RecordingSink sink;
+            PodBatcher batcher(std::strtoul(argv[4], nullptr, 0));
+            for (const auto &p : pods) batcher.push(std::make_shared<const corev1::Pod>(p));
+            batcher.close();
+            ctx.refresh_snapshot();
+            std::map<std::string, ReconcileOutcome> by_name;
+            const BatchLoopStats st = run_batches(
+                batcher, [&](const std::vector<const corev1::Pod *> &b) { return reconcile_batch(b, ctx, chooser, sink); },
+                [&](const PodBatcher::PodPtr &pod, const ReconcileOutcome &o) { by_name[full_name(pod->metadata)] = o; });
+            std::vector<ReconcileOutcome> out;
+            for (const auto &p : pods) out.push_back(by_name.at(full_name(p.metadata)));
+            std::printf("{");
+            print_outcomes(out, sink);
+            std::printf(",\"batches\":%llu,\"largest\":%llu", (unsigned long long)st.batches, (unsigned long long)st.largest);
+            const NodeColumns &c = ctx.snapshot->columns();
+            std::printf(",\"avail_cpu_milli\":[");
+            for (uint32_t i = 0; i < c.n; ++i) std::printf("%s%lld", i ? "," : "", (long long)c.avail_cpu_milli[i]);
+            std::printf("],\"avail_mem_bytes\":[");
+            for (uint32_t i = 0; i < c.n; ++i) std::printf("%s%lld", i ? "," : "", (long long)c.avail_mem_bytes[i]);
             std::printf("]}\n");
             return 0;
         }

@@ -171,6 +171,34 @@ def test_reconcile_batch_with_overlapped_posts_equals_oracle_restatement(tmp_pat
         assert got["avail_cpu_milli"][j] == av.cpu * 1000 and got["avail_mem_bytes"][j] == av.memory
 
 
+def test_batching_reconciler_end_to_end_equals_oracle_restatement(tmp_path):
+    """PodBatcher (ready_chunks(16)) + run_batches + reconcile_batch through the device: 60 pending pods go out as
+    chunks of 16, 16, 16, 12; every chunk is evaluated against the state the earlier chunks left (their bindings count against their
+    nodes, as the reference's re-LIST per evaluation would see them, src/predicates.rs:34-38); the draws continue one chooser stream.
+    Outcome for outcome, POST for POST and the final snapshot == the oracle's restatement run chunk by chunk."""
+    pods, nodes, bound = small_cluster(0x57AEA1, P=60)
+    path = tmp_path / "objs.json"
+    write_objects(path, pods, nodes, bound)
+    got = tool("stream", path, 4242, 16)
+    assert (got["batches"], got["largest"]) == (4, 16)
+    store, chooser, state = list(reversed(nodes)), R.SplitMixChooser(4242), list(bound)
+    by_name = {f"{p['metadata']['namespace']}/{p['metadata']['name']}": p for p in pods}
+    want, posted = [], []
+    for lo in range(0, 60, 16):
+        w, po = R.reconcile_batch(pods[lo:lo + 16], store, state, chooser, fail_every=0)
+        want += w
+        posted += po
+        for pod_name, node in po:
+            q = json.loads(json.dumps(by_name[pod_name]))
+            q["spec"]["nodeName"] = node
+            state.append(q)
+    assert [(o["ok"], o["error"], o["bound_to"]) for o in got["outcomes"]] == [(o["ok"], o["error"], o["bound_to"]) for o in want]
+    assert [tuple(x) for x in got["posted"]] == posted and len(posted) > 10
+    for j, node in enumerate(nodes):
+        av = R.available_of(node, state)
+        assert got["avail_cpu_milli"][j] == av.cpu * 1000 and got["avail_mem_bytes"][j] == av.memory
+
+
 @pytest.mark.parametrize("seed,fail_every,tight", [(1, 0, True), (2, 4, True), (3, 0, False)])
 def test_reconcile_batch_sequential_equals_oracle_restatement(tmp_path, seed, fail_every, tight):
     pods, nodes, bound = small_cluster(0x5E0000 + seed, P=48, N=10, tight=tight)
