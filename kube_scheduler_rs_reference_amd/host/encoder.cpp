@@ -1,5 +1,7 @@
 #include "encoder.hpp"
 
+#include <optional>
+
 #include <algorithm>
 #include <numeric>
 #include <thread>
@@ -46,6 +48,7 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
     canonical_of_store_.assign(n, 0u);
     for (uint32_t i = 0; i < n; ++i) canonical_of_store_[order[i]] = i;
     NodeColumns c;
+    std::unordered_map<std::string, Counted> counted;
     c.n = n;
     c.names.resize(n);
     c.avail_cpu_milli.resize(n);
@@ -77,7 +80,9 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
             ++client->list_calls;
             for (const auto &p : client->list_pods_on_node(c.names[i])) {
                 try {
-                    avail -= total_pod_resources(p);
+                    const PodResources r = total_pod_resources(p);
+                    avail -= r;
+                    counted[full_name(p.metadata)] = Counted{i, r.cpu.nanos(), r.memory.nanos()};  // observe_pods() starts from the LISTs
                 } catch (const QuantityError &e) {
                     throw EncodeError("pod " + full_name(p.metadata) + ": invalid pod spec: " + e.what());
                 }
@@ -103,6 +108,7 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
     }
     c.keys = cols_.keys;  // keep the label columns that were in use
     cols_ = std::move(c);
+    counted_ = std::move(counted);
     if (taints_enabled_) intern_taints();  // the extension stays on across rebuilds once a caller has asked for it
     encode_labels();
     upload();
@@ -189,17 +195,90 @@ size_t Snapshot::apply_pod_events(const std::vector<std::pair<const corev1::Pod 
     if (touched.empty()) return 0;
     std::sort(touched.begin(), touched.end());
     touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
-    ++generation_;
-    if (dev_) {
-        std::vector<int64_t> cpu(touched.size()), mem(touched.size());
-        for (size_t i = 0; i < touched.size(); ++i) {
-            cpu[i] = cols_.avail_cpu_milli[touched[i]];
-            mem[i] = cols_.avail_mem_bytes[touched[i]];
-        }
-        dev_->check(ksched_update_nodes(dev_->handle(), (uint32_t)touched.size(), touched.data(), cpu.data(), mem.data()),
-                    "ksched_update_nodes");
-    }
+    push_rows(touched);
     return applied;
+}
+
+// the changed rows of `available` go to the device in one ksched_update_nodes (only the touched 1024-node tiles are re-indexed)
+void Snapshot::push_rows(const std::vector<uint32_t> &touched) {
+    ++generation_;
+    if (!dev_) return;  // encode-only snapshot
+    std::vector<int64_t> cpu(touched.size()), mem(touched.size());
+    for (size_t i = 0; i < touched.size(); ++i) {
+        cpu[i] = cols_.avail_cpu_milli[touched[i]];
+        mem[i] = cols_.avail_mem_bytes[touched[i]];
+    }
+    dev_->check(ksched_update_nodes(dev_->handle(), (uint32_t)touched.size(), touched.data(), cpu.data(), mem.data()), "ksched_update_nodes");
+}
+
+size_t Snapshot::observe_pods(const std::vector<std::pair<PodEvent, const corev1::Pod *>> &events) {
+    // Stage everything first (the new bookkeeping entries, the exact per-node change in nano-units), validate, then commit: an
+    // EncodeError leaves the snapshot as it was.
+    std::unordered_map<std::string, std::optional<Counted>> staged;  // key -> its entry after these events (nullopt = not counted)
+    std::map<uint32_t, std::pair<__int128, __int128>> delta;         // node -> change of available (cpu, mem) in nano-units
+    auto current = [&](const std::string &key) -> std::optional<Counted> {
+        auto st = staged.find(key);
+        if (st != staged.end()) return st->second;
+        auto it = counted_.find(key);
+        if (it == counted_.end()) return std::nullopt;
+        return it->second;
+    };
+    size_t changed = 0;
+    for (const auto &[kind, pod] : events) {
+        if (!pod) continue;
+        const std::string key = full_name(pod->metadata);
+        int idx = -1;
+        if (kind == PodEvent::Applied && pod->spec && pod->spec->node_name) idx = index_of(*pod->spec->node_name);
+        const std::optional<Counted> was = current(key);
+        if (idx < 0) {  // deleted, not bound, or bound to a node this snapshot does not hold: counted nowhere from now on
+            if (!was) continue;
+            delta[was->node].first += was->cpu_nanos;
+            delta[was->node].second += was->mem_nanos;
+            staged[key] = std::nullopt;
+            ++changed;
+            continue;
+        }
+        Counted now{(uint32_t)idx, 0, 0};
+        try {
+            const PodResources r = total_pod_resources(*pod);  // the sum the LIST loop subtracts (src/predicates.rs:37)
+            now.cpu_nanos = r.cpu.nanos();
+            now.mem_nanos = r.memory.nanos();
+        } catch (const QuantityError &e) {
+            throw EncodeError("pod " + key + ": invalid pod spec: " + e.what());
+        }
+        if (was && was->node == now.node && was->cpu_nanos == now.cpu_nanos && was->mem_nanos == now.mem_nanos) continue;  // already counted
+        if (was) {
+            delta[was->node].first += was->cpu_nanos;
+            delta[was->node].second += was->mem_nanos;
+        }
+        delta[now.node].first -= now.cpu_nanos;
+        delta[now.node].second -= now.mem_nanos;
+        staged[key] = now;
+        ++changed;
+    }
+    std::vector<uint32_t> touched;
+    std::vector<std::pair<int64_t, int64_t>> fresh;
+    for (const auto &[node, d] : delta) {
+        if (d.first == 0 && d.second == 0) continue;
+        constexpr __int128 kMilli = 1000000, kUnit = 1000000000;
+        if (d.first % kMilli != 0 || d.second % kUnit != 0)
+            throw EncodeError("node " + cols_.names[node] + ": the change is not an integer number of milli-cores / bytes");
+        const __int128 cpu = (__int128)cols_.avail_cpu_milli[node] + d.first / kMilli, mem = (__int128)cols_.avail_mem_bytes[node] + d.second / kUnit;
+        if (cpu < INT64_MIN || cpu > INT64_MAX || mem < INT64_MIN || mem > INT64_MAX)
+            throw EncodeError("node " + cols_.names[node] + ": available leaves the int64 domain");
+        touched.push_back(node);
+        fresh.emplace_back((int64_t)cpu, (int64_t)mem);
+    }
+    for (auto &[key, entry] : staged) {  // commit
+        if (entry) counted_[key] = *entry;
+        else counted_.erase(key);
+    }
+    for (size_t i = 0; i < touched.size(); ++i) {
+        cols_.avail_cpu_milli[touched[i]] = fresh[i].first;
+        cols_.avail_mem_bytes[touched[i]] = fresh[i].second;
+    }
+    if (!touched.empty()) push_rows(touched);
+    return changed;
 }
 
 bool Snapshot::apply_bound_pod(const corev1::Pod &pod) { return apply_pod_events({{&pod, true}}) == 1; }

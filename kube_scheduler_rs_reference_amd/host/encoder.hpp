@@ -11,6 +11,7 @@
 #include <set>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ksched.h"
@@ -85,6 +86,23 @@ public:
     // Many events, one device update.  second = true: bound, false: deleted.  Returns how many were applied.
     size_t apply_pod_events(const std::vector<std::pair<const corev1::Pod *, bool>> &events);
 
+    // The same bookkeeping for callers that forward a pod WATCH STREAM as it comes ("incrementally maintained from
+    // watch events"): the snapshot remembers which pods it counts against which node -- seeded by rebuild() from the LISTs -- so the
+    // calls are idempotent.  Applied = the watch's Added / Modified (the pod as it is now), Deleted = its Deleted.
+    //   Applied, spec.nodeName names a node of this snapshot : counted there with its current requests; if it was already counted with
+    //                                                         the same node and requests (a repeated or unrelated MODIFIED event, or the
+    //                                                         echo of a binding this process POSTed itself) nothing changes;
+    //   Applied, no nodeName / a node outside the snapshot    : no longer counted anywhere;
+    //   Deleted                                               : no longer counted (with the amounts that WERE counted, whatever the
+    //                                                         event's object says).
+    // One device update per call.  Returns how many events changed `available`.  Strong guarantee: on EncodeError (unparsable
+    // requests, a change that is not an integer number of milli-cores / bytes, int64 overflow) nothing has changed.
+    // apply_bound_pod / apply_deleted_pod / apply_pod_events above are the raw, untracked form (every call is applied).
+    enum class PodEvent { Applied, Deleted };
+    size_t observe_pods(const std::vector<std::pair<PodEvent, const corev1::Pod *>> &events);
+    bool observe_pod(PodEvent kind, const corev1::Pod &pod) { return observe_pods({{kind, &pod}}) == 1; }
+    size_t counted_pods() const { return counted_.size(); }
+
     // Make sure every label key in `keys` (the selector keys of ONE batch) has a column; re-uploads the label columns when the
     // column set changes.  Columns are a per-batch working set, not a lifetime dictionary: when adding the batch's keys would
     // exceed KSCHED_MAX_KEYS, the columns no pod of this batch uses are evicted.  Throws EncodeError only when one batch alone
@@ -130,6 +148,12 @@ private:
     bool any_counted_taint_ = false, taints_enabled_ = false;
     void intern_taints();
     uint64_t generation_ = 0;
+    struct Counted {
+        uint32_t node;  // canonical index
+        __int128 cpu_nanos, mem_nanos;
+    };
+    std::unordered_map<std::string, Counted> counted_;  // namespace/name -> what `available` currently holds against that pod
+    void push_rows(const std::vector<uint32_t> &touched);
 };
 
 // K8s ToleratesTaint (extension E2): does toleration `t` tolerate taint `x`?

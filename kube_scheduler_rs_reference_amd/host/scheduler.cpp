@@ -185,9 +185,10 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
     // The bindings it created then count against their nodes for the NEXT batch -- the reference gets that from re-LISTing on
     // every evaluation (src/predicates.rs:34-38); here the snapshot is patched in one device update.
     if (ctx.snapshot && !landed.empty()) {
-        std::vector<std::pair<const corev1::Pod *, bool>> events;
-        for (const auto &p : landed) events.emplace_back(&p, true);
-        ctx.snapshot->apply_pod_events(events);
+        // (observe_pods, the tracked form: when the watch later echoes these bindings as MODIFIED events they change nothing)
+        std::vector<std::pair<Snapshot::PodEvent, const corev1::Pod *>> events;
+        for (const auto &p : landed) events.emplace_back(Snapshot::PodEvent::Applied, &p);
+        ctx.snapshot->observe_pods(events);
     }
     return out;
 }
@@ -228,9 +229,9 @@ std::vector<ReconcileOutcome> reconcile_batch_sequential(const std::vector<const
             p.spec->node_name = *out[i].bound_to;
             landed.push_back(std::move(p));
         }
-        std::vector<std::pair<const corev1::Pod *, bool>> events;
-        for (const auto &p : landed) events.emplace_back(&p, true);
-        ctx.snapshot->apply_pod_events(events);
+        std::vector<std::pair<Snapshot::PodEvent, const corev1::Pod *>> events;
+        for (const auto &p : landed) events.emplace_back(Snapshot::PodEvent::Applied, &p);
+        ctx.snapshot->observe_pods(events);
         pending.swap(next);
     }
     for (size_t i : pending) out[i] = bind(*pods[i], nullptr, sink);  // still colliding after max_rounds

@@ -332,6 +332,41 @@ static void cpu_tests() {
         corev1::Pod bad = pod_with("bad", {container("lots", nullptr)}, "node-a");
         CHECK_THROWS(inc.apply_bound_pod(bad));
     });
+    run("snapshot builder: observe_pods is idempotent, follows moves, and changes nothing when it throws (SURVEY.md 8f n1)", [] {
+        std::vector<corev1::Node> nodes = {node_with("a", "8", "16Gi"), node_with("b", "8", "16Gi")};
+        auto lister = std::make_shared<StaticPodLister>();
+        lister->pods = {pod_with("old", {container("1", "1Gi")}, "a")};
+        Snapshot snap(Snapshot::kEncodeOnly);
+        snap.rebuild(nodes, lister.get());
+        using E = Snapshot::PodEvent;
+        CHECK(snap.counted_pods() == 1 && snap.columns().avail_cpu_milli[0] == 7000);
+        const corev1::Pod p1 = pod_with("p1", {container("2", "2Gi")}, "a");
+        CHECK(snap.observe_pod(E::Applied, p1));
+        CHECK(!snap.observe_pod(E::Applied, p1));  // the watch echoes the binding: nothing changes
+        CHECK(!snap.observe_pod(E::Applied, p1));
+        CHECK(snap.columns().avail_cpu_milli[0] == 5000 && snap.columns().avail_mem_bytes[0] == (16ll - 1 - 2) << 30);
+        CHECK(!snap.observe_pod(E::Applied, pod_with("old", {container("1", "1Gi")}, "a")));  // a MODIFIED event of a LISTed pod: already counted
+        const corev1::Pod moved = pod_with("p1", {container("2", "2Gi")}, "b");  // (a pod cannot move in Kubernetes; a delete + re-create under one name can look like it)
+        CHECK(snap.observe_pod(E::Applied, moved));
+        CHECK(snap.columns().avail_cpu_milli[0] == 7000 && snap.columns().avail_cpu_milli[1] == 6000);
+        CHECK(snap.observe_pod(E::Deleted, pod_with("p1", {}, nullptr)));  // the Deleted event's object need not carry the spec that was counted
+        CHECK(!snap.observe_pod(E::Deleted, moved));
+        CHECK(snap.columns().avail_cpu_milli[1] == 8000 && snap.counted_pods() == 1);
+        CHECK(!snap.observe_pod(E::Applied, pod_with("pending", {container("1", "1Gi")})));          // no nodeName: nothing to count
+        CHECK(!snap.observe_pod(E::Applied, pod_with("away", {container("1", "1Gi")}, "not-here")));  // a node outside the snapshot
+        // strong guarantee: the second event cannot be encoded -> the first one is not applied either
+        const corev1::Pod ok = pod_with("ok", {container("1", "1Gi")}, "b"), bad = pod_with("bad", {container("lots", nullptr)}, "b");
+        const auto cpu_before = snap.columns().avail_cpu_milli;
+        CHECK_THROWS(snap.observe_pods({{E::Applied, &ok}, {E::Applied, &bad}}));
+        CHECK(snap.columns().avail_cpu_milli == cpu_before && snap.counted_pods() == 1);
+        const corev1::Pod fine = pod_with("fine", {container("100n", nullptr)}, "b");  // finer than a milli-core: refused, nothing counted
+        CHECK_THROWS(snap.observe_pod(E::Applied, fine));
+        CHECK(snap.columns().avail_cpu_milli == cpu_before && snap.counted_pods() == 1);
+        // two halves of a milli-core in one call ARE an integer change
+        const corev1::Pod h1 = pod_with("h1", {container("500u", nullptr)}, "b"), h2 = pod_with("h2", {container("500u", nullptr)}, "b");
+        CHECK(snap.observe_pods({{E::Applied, &h1}, {E::Applied, &h2}}) == 2);
+        CHECK(snap.columns().avail_cpu_milli[1] == 7999 && snap.counted_pods() == 3);
+    });
     run("toleration_matches (extension E2)", [] {
         TaintId t{"k", "v", "NoSchedule"};
         corev1::Toleration a;

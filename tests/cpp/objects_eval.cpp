@@ -5,7 +5,8 @@
 //
 //   objects_eval masks      <objects.json> [taints]      check_node_validity_batch: fit / feasible masks (hex rows), canonical node order
 //   objects_eval columns    <objects.json> [taints] [batches=K]   the encoder alone (no device): the integer columns of include/ksched.h as JSON
-//   objects_eval events     <objects.json> [single]      snapshot + pod watch events applied incrementally (no device): `available` afterwards
+//   objects_eval events     <objects.json> [single | watch [single]]   snapshot + pod watch events applied incrementally (no device; watch = the tracked,
+//                                                        idempotent observe_pods): `available` afterwards
 //   objects_eval batch      <objects.json> <seed> [fail_every [post_concurrency]]   reconcile_batch (src/main.rs:73-120 per pod)
 //   objects_eval sequential <objects.json> <seed> [fail_every]   reconcile_batch_sequential (8f n3, opt-in)
 //   objects_eval stream     <objects.json> <seed> <max_pods>     PodBatcher + run_batches + reconcile_batch: the batching reconciler end to end
@@ -269,7 +270,18 @@ int main(int argc, char **argv) {
             }
             size_t applied = 0;
             const bool one_by_one = argc > 3 && std::string(argv[3]) == "single";
-            if (one_by_one) {
+            if (argc > 3 && std::string(argv[3]) == "watch") {
+                // the tracked, idempotent form: events are [pod index, node name or "" (= the pod names no node), 1 = Applied | 0 = Deleted]
+                std::vector<std::pair<Snapshot::PodEvent, const corev1::Pod *>> ev;
+                for (size_t i = 0; i < moved.size(); ++i) {
+                    if (moved[i].spec->node_name->empty()) moved[i].spec->node_name.reset();
+                    ev.emplace_back(kind[i] ? Snapshot::PodEvent::Applied : Snapshot::PodEvent::Deleted, &moved[i]);
+                }
+                const bool chunks = argc > 4 && std::string(argv[4]) == "single";
+                if (chunks) for (const auto &e : ev) applied += snap.observe_pod(e.first, *e.second) ? 1 : 0;
+                else applied = snap.observe_pods(ev);
+                applied = applied * 1000000 + snap.counted_pods();
+            } else if (one_by_one) {
                 for (size_t i = 0; i < moved.size(); ++i) applied += (kind[i] ? snap.apply_bound_pod(moved[i]) : snap.apply_deleted_pod(moved[i])) ? 1 : 0;
             } else {
                 std::vector<std::pair<const corev1::Pod *, bool>> ev;

@@ -324,3 +324,57 @@ def test_label_columns_are_a_per_batch_working_set(tmp_path):
     json.dump({"name": "ws", "pods": [one], "nodes": nodes, "bound": [], "samples": []}, open(path, "w"))
     r = columns(path, expect_fail=True)
     assert r.returncode == 1 and "KSCHED_MAX_KEYS" in r.stderr
+
+
+# ---- a pod WATCH STREAM forwarded as it comes: Snapshot::observe_pods is idempotent -----------------------------------------------
+
+@st.composite
+def watch_script(draw):
+    n_nodes, n_pods = draw(st.integers(1, 4)), draw(st.integers(1, 5))
+    nodes = [{"metadata": {"name": f"n{i}"}, "status": {"allocatable": {"cpu": str(draw(st.integers(1, 64))), "memory": f"{draw(st.integers(1, 256))}Gi"}}}
+             for i in range(n_nodes)]
+    pods = [_obj_pod(f"p{i}", draw(st.sampled_from(["250m", "1", "1500m", "0", "0.5"])), draw(st.sampled_from(["64Mi", "1Gi", "0", "1e9", "3M"])))
+            for i in range(n_pods)]
+    # some of the SAME pods are already bound when the snapshot is built (they come back from the LISTs)
+    bound = []
+    for i in range(n_pods):
+        if draw(st.booleans()):
+            q = json.loads(json.dumps(pods[i]))
+            q["spec"]["nodeName"] = f"n{draw(st.integers(0, n_nodes - 1))}"
+            bound.append(q)
+    targets = [f"n{i}" for i in range(n_nodes)] + ["", "elsewhere"]  # "" = the pod names no node (pending); elsewhere = a node outside the snapshot
+    events = [[draw(st.integers(0, n_pods - 1)), draw(st.sampled_from(targets)), draw(st.sampled_from([1, 1, 1, 0]))] for _ in range(draw(st.integers(0, 16)))]
+    return pods, nodes, bound, events
+
+
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(script=watch_script(), single=st.booleans())
+def test_a_watch_stream_forwarded_as_it_comes_keeps_available_exact(tmp_path, script, single):
+    """Added / Modified / Deleted events, repeated, out of any useful order, for pods the LISTs already returned and for pods the
+    snapshot has never seen: after every prefix the snapshot must hold allocatable - sum(requests of the pods that are bound to the
+    node NOW) -- what the reference's LIST per evaluation would return (src/predicates.rs:34-38).  The expectation is a model of the
+    API server's state (name -> node), evaluated by the oracle on the objects."""
+    pods, nodes, bound, events = script
+    path = tmp_path / "watch.json"
+    json.dump({"name": "w", "pods": pods, "nodes": nodes, "bound": bound, "samples": [], "events": events}, open(path, "w"))
+    r = subprocess.run([TOOL, "events", str(path), "watch", *(["single"] if single else [])], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1000:]
+    got = json.loads(r.stdout)
+    names = [n["metadata"]["name"] for n in nodes]
+    where = {b["metadata"]["name"]: b["spec"]["nodeName"] for b in bound}  # the API server's truth: pod -> node it is bound to
+    for pi, node, applied in events:
+        name = pods[pi]["metadata"]["name"]
+        if applied and node in names:
+            where[name] = node
+        else:  # deleted, pending again, or living on a node this snapshot does not hold
+            where.pop(name, None)
+    state = []
+    for i, p in enumerate(pods):
+        if p["metadata"]["name"] in where:
+            q = json.loads(json.dumps(p))
+            q["spec"]["nodeName"] = where[p["metadata"]["name"]]
+            state.append(q)
+    assert got["applied"] % 1000000 == len(where), "pods the snapshot counts == pods bound to its nodes"
+    for j, n in enumerate(nodes):
+        av = R.available_of(n, state)
+        assert Fraction(got["avail_cpu_milli"][j], 1000) == av.cpu and Fraction(got["avail_mem_bytes"][j]) == av.memory, (names[j], events)
