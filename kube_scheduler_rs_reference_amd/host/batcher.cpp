@@ -81,7 +81,8 @@ std::vector<PodBatcher::PodPtr> PodBatcher::try_next_batch() {
 
 BatchLoopStats run_batches(PodBatcher &batcher,
                            const std::function<std::vector<ReconcileOutcome>(const std::vector<const corev1::Pod *> &)> &reconcile,
-                           const std::function<void(const PodBatcher::PodPtr &, const ReconcileOutcome &)> &done) {
+                           const std::function<void(const PodBatcher::PodPtr &, const ReconcileOutcome &)> &done,
+                           const std::function<void(const PodBatcher::PodPtr &, const std::string &)> &failed) {
     BatchLoopStats st;
     for (;;) {
         const std::vector<PodBatcher::PodPtr> batch = batcher.next_batch();
@@ -89,7 +90,35 @@ BatchLoopStats run_batches(PodBatcher &batcher,
         std::vector<const corev1::Pod *> raw;
         raw.reserve(batch.size());
         for (const auto &p : batch) raw.push_back(p.get());
-        const std::vector<ReconcileOutcome> out = reconcile(raw);
+        std::vector<ReconcileOutcome> out;
+        bool whole = true;
+        try {
+            out = reconcile(raw);
+        } catch (const std::logic_error &) {
+            throw;  // a programming error, not a bad object
+        } catch (const std::exception &) {
+            if (!failed) throw;
+            whole = false;
+        }
+        if (!whole) {  // isolate the offender(s): the batch's pods one at a time
+            ++st.isolated_batches;
+            for (const auto &p : batch) {
+                try {
+                    const std::vector<ReconcileOutcome> one = reconcile({p.get()});
+                    if (one.size() != 1) throw std::logic_error("run_batches: the reconcile function must return one outcome per pod");
+                    done(p, one[0]);
+                } catch (const std::logic_error &) {
+                    throw;
+                } catch (const std::exception &e) {
+                    failed(p, e.what());
+                    ++st.failed_pods;
+                }
+            }
+            ++st.batches;
+            st.pods += batch.size();
+            st.largest = std::max<uint64_t>(st.largest, batch.size());
+            continue;
+        }
         if (out.size() != batch.size()) throw std::logic_error("run_batches: the reconcile function must return one outcome per pod");
         for (size_t i = 0; i < batch.size(); ++i) done(batch[i], out[i]);
         ++st.batches;

@@ -60,12 +60,20 @@ private:
 
 struct BatchLoopStats {
     uint64_t batches = 0, pods = 0, largest = 0;
+    uint64_t isolated_batches = 0, failed_pods = 0;  // batches that had to be reconciled pod by pod; pods handed to `failed`
 };
 
 // Pull batches until the batcher is closed and drained.  `reconcile` maps a batch to one outcome per pod (the product passes a
 // lambda around reconcile_batch(pods, ctx, chooser, sink, post_concurrency)); `done` receives every (pod, outcome) pair.
+//
+// A pod the host cannot encode (an unparsable quantity in its requests: the reference's `.expect("invalid pod spec")` panics on it,
+// src/util.rs:65,68) makes reconcile_batch throw for the batch it sits in, before anything is evaluated or POSTed.  With a `failed`
+// callback the loop does not give up the whole batch: it reconciles that batch's pods one at a time, hands the offender(s) to
+// `failed(pod, what)` and everybody else's outcome to `done` -- one bad object costs one batch its batching, not the other pods
+// their scheduling.  Without the callback the exception propagates to the caller (the batch's pods are then not reconciled).
 BatchLoopStats run_batches(PodBatcher &batcher,
                            const std::function<std::vector<ReconcileOutcome>(const std::vector<const corev1::Pod *> &)> &reconcile,
-                           const std::function<void(const PodBatcher::PodPtr &, const ReconcileOutcome &)> &done);
+                           const std::function<void(const PodBatcher::PodPtr &, const ReconcileOutcome &)> &done,
+                           const std::function<void(const PodBatcher::PodPtr &, const std::string &)> &failed = nullptr);
 
 }  // namespace ksched_host

@@ -515,6 +515,34 @@ static void cpu_tests() {
         CHECK(once);
         CHECK(st.batches == reconcile_calls && st.largest <= 64 && st.batches >= (uint64_t)kProducers * kPerProducer / 64);
         CHECK(b.pending() == 0);
+        // one pod the host cannot encode: its batch is reconciled pod by pod, the offender is reported, nobody else is lost
+        {
+            PodBatcher d(8);
+            for (int i = 0; i < 20; ++i) d.push(std::make_shared<const corev1::Pod>(pod_with(i == 11 ? "poison" : "q" + std::to_string(i), {container("1", "1Mi")})));
+            d.close();
+            int done_n = 0, failed_n = 0, calls = 0;
+            std::string what;
+            auto rec = [&](const std::vector<const corev1::Pod *> &pods) {
+                ++calls;
+                for (const auto *p : pods)
+                    if (*p->metadata.name == "poison") throw EncodeError("pod test/poison: invalid pod spec: 'lots'");
+                return std::vector<ReconcileOutcome>(pods.size());
+            };
+            const BatchLoopStats s2 = run_batches(
+                d, rec, [&](const PodBatcher::PodPtr &, const ReconcileOutcome &o) { done_n += o.ok ? 1 : 0; },
+                [&](const PodBatcher::PodPtr &p, const std::string &w) {
+                    ++failed_n;
+                    what = *p->metadata.name + ": " + w;
+                });
+            CHECK(done_n == 19 && failed_n == 1 && what.find("poison: pod test/poison: invalid pod spec") == 0);
+            CHECK(s2.batches == 3 && s2.pods == 20 && s2.isolated_batches == 1 && s2.failed_pods == 1);
+            CHECK(calls == 3 + 8);  // three batch calls (the second throws), then that batch's eight pods one by one
+            // without the callback the exception is the caller's
+            PodBatcher e(8);
+            e.push(std::make_shared<const corev1::Pod>(pod_with("poison", {container("1", "1Mi")})));
+            e.close();
+            CHECK_THROWS(run_batches(e, rec, [](const PodBatcher::PodPtr &, const ReconcileOutcome &) {}));
+        }
         // a reconcile function that loses a pod is a programming error, reported loudly
         PodBatcher c(8);
         c.push(std::make_shared<const corev1::Pod>(pod_with("x", {container("1", "1Mi")})));
