@@ -24,76 +24,138 @@
  * Semantics here are the Kubernetes ones (binary suffixes are exact powers of 1024); see
  * SURVEY.md section 8c for where the crate is suspected to differ (outside domain D).
  * ---------------------------------------------------------------------------------------------- */
-static int mul_check(ora_q a, ora_q b, ora_q *r) { return __builtin_mul_overflow(a, b, r) ? ORA_E_RANGE : ORA_OK; }
+/* The parser is deliberately NOT shaped like the product's (host/quantity.cpp walks the text once and scales a mantissa by
+ * a decimal exponent): here the text is first split into its five fields by a table-driven recogniser, and the value is then
+ * assembled as an exact rational  digits / 10^nfrac * mul_num / mul_den  in nano-units, reduced by gcd before every
+ * multiplication, so that the two share neither control flow nor arithmetic.  ("the same parser written twice".) */
+typedef unsigned __int128 ora_u;
+
+static ora_u gcd_u(ora_u a, ora_u b) {
+    while (b) {
+        ora_u t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+/* character classes of the recogniser */
+enum { C_SIGN, C_DIGIT, C_DOT, C_E, C_I, C_SUF, C_END, C_BAD };
+static int cls(char ch) {
+    if (ch == '+' || ch == '-') return C_SIGN;
+    if (ch >= '0' && ch <= '9') return C_DIGIT;
+    if (ch == '.') return C_DOT;
+    if (ch == 'e' || ch == 'E') return C_E;     /* exponent marker, or the decimal suffix E (10^18), or the first letter of Ei */
+    if (ch == 'i') return C_I;
+    if (ch == 'n' || ch == 'u' || ch == 'm' || ch == 'k' || ch == 'K' || ch == 'M' || ch == 'G' || ch == 'T' || ch == 'P') return C_SUF;
+    if (ch == '\0') return C_END;
+    return C_BAD;
+}
+/* states: 0 start, 1 after sign, 2 integer digits, 3 after '.', (3 loops on fraction digits), 4 after a suffix letter,
+ * 5 after 'e'/'E', 6 after the exponent's sign, 7 exponent digits, 8 after "<letter>i", 9 accept; -1 reject.
+ * A leading '.' needs digits on at least one side; that is checked on the field lengths afterwards. */
+static const signed char kNext[9][8] = {
+    /*            SIGN DIGIT DOT  E   I  SUF END BAD */
+    /* 0 start */ { 1,   2,   3, -1, -1, -1, -1, -1},
+    /* 1 sign  */ {-1,   2,   3, -1, -1, -1, -1, -1},
+    /* 2 int   */ {-1,   2,   3,  5, -1,  4,  9, -1},
+    /* 3 frac  */ {-1,   3,  -1,  5, -1,  4,  9, -1},
+    /* 4 suf   */ {-1,  -1,  -1, -1,  8, -1,  9, -1},
+    /* 5 e     */ { 6,   7,  -1, -1,  8, -1,  9, -1},   /* "1E" = 10^18, "1Ei" = 2^60, "1e3" / "1e+3" = exponent */
+    /* 6 esign */ {-1,   7,  -1, -1, -1, -1, -1, -1},
+    /* 7 edig  */ {-1,   7,  -1, -1, -1, -1,  9, -1},
+    /* 8 bin   */ {-1,  -1,  -1, -1, -1, -1,  9, -1},
+};
 
 int ora_parse_quantity(const char *s, ora_q *out) {
     if (!s || !out) return ORA_E_PARSE;
-    const char *c = s;
-    int neg = 0;
-    if (*c == '+' || *c == '-') { neg = (*c == '-'); ++c; }
-    ora_q mant = 0;
-    int ndig = 0, nfrac = 0;
-    while (*c >= '0' && *c <= '9') {
-        if (mul_check(mant, 10, &mant)) return ORA_E_RANGE;
-        mant += (*c - '0');
-        ++ndig; ++c;
+    /* 1. recognise, remembering where the fields start */
+    int state = 0, neg = 0, eneg = 0, letter = 0, binary = 0, has_exp = 0;
+    const char *int0 = NULL, *frac0 = NULL, *exp0 = NULL;
+    int nint = 0, nfrac = 0, nexp = 0;
+    for (const char *c = s;; ++c) {
+        const int k = cls(*c);
+        const int nx = kNext[state][k];
+        if (nx < 0) return ORA_E_PARSE;
+        if (nx == 1) neg = (*c == '-');
+        else if (nx == 2) { if (!nint) int0 = c; ++nint; }
+        else if (nx == 3 && k == C_DIGIT) { if (!nfrac) frac0 = c; ++nfrac; }
+        else if (nx == 4) { letter = *c; if (letter == 'K') letter = 0x100 | 'K'; /* K only exists as Ki */ }
+        else if (nx == 5) letter = (*c == 'e') ? (0x200 | 'E') : 'E';   /* a lower-case e is only ever an exponent marker */
+        else if (nx == 6) { eneg = (*c == '-'); has_exp = 1; }
+        else if (nx == 7) { if (!nexp) exp0 = c; ++nexp; has_exp = 1; }
+        else if (nx == 8) binary = 1;
+        if (nx == 9) break;
+        state = nx;
     }
-    if (*c == '.') {
-        ++c;
-        while (*c >= '0' && *c <= '9') {
-            if (mul_check(mant, 10, &mant)) return ORA_E_RANGE;
-            mant += (*c - '0');
-            ++ndig; ++nfrac; ++c;
+    if (nint + nfrac == 0) return ORA_E_PARSE;                         /* "", ".", "+", "Ki" ... */
+    if (has_exp && nexp == 0) return ORA_E_PARSE;                       /* "1e+" */
+    if (!binary && (letter & 0x100)) return ORA_E_PARSE;                /* "1K" is not a suffix; "1Ki" is */
+    if (!has_exp && (letter & 0x200)) return ORA_E_PARSE;               /* "1e", "1ei": neither the suffix E nor Ei */
+    if (binary && (letter == 'n' || letter == 'u' || letter == 'm' || letter == 'k')) return ORA_E_PARSE;  /* "1mi", "1ki" */
+    letter &= 0xFF;
+    /* 2. the multiplier of the suffix as a rational in nano-units: value = digits / 10^nfrac * num / den * 10^9 */
+    int e10 = 9, e2 = 0; /* 10^e10 * 2^e2 */
+    if (has_exp) {
+        int ev = 0;
+        for (int i = 0; i < nexp; ++i) {
+            ev = ev * 10 + (exp0[i] - '0');
+            if (ev > 100) return ORA_E_RANGE;
         }
-    }
-    if (ndig == 0) return ORA_E_PARSE;
-    int exp10 = 0;   /* decimal exponent of the suffix */
-    int bin_shift = 0; /* binary suffix = 2^bin_shift */
-    if (*c == '\0') {
-        exp10 = 0;
-    } else if ((c[0] == 'e' || c[0] == 'E') && (c[1] == '+' || c[1] == '-' || (c[1] >= '0' && c[1] <= '9'))) {
-        const char *e = c + 1;
-        int eneg = 0, ev = 0, edig = 0;
-        if (*e == '+' || *e == '-') { eneg = (*e == '-'); ++e; }
-        while (*e >= '0' && *e <= '9') { ev = ev * 10 + (*e - '0'); if (ev > 100) return ORA_E_RANGE; ++edig; ++e; }
-        if (edig == 0 || *e != '\0') return ORA_E_PARSE;
-        exp10 = eneg ? -ev : ev;
-    } else if (c[1] == 'i' && c[2] == '\0') {
-        switch (c[0]) {
-            case 'K': bin_shift = 10; break;
-            case 'M': bin_shift = 20; break;
-            case 'G': bin_shift = 30; break;
-            case 'T': bin_shift = 40; break;
-            case 'P': bin_shift = 50; break;
-            case 'E': bin_shift = 60; break;
+        e10 += eneg ? -ev : ev;
+    } else if (binary) {
+        const char *order = "KMGTPE";
+        e2 = 10 * (int)(strchr(order, letter) - order + 1);
+    } else if (letter) {
+        switch (letter) {
+            case 'n': e10 -= 9; break;
+            case 'u': e10 -= 6; break;
+            case 'm': e10 -= 3; break;
+            case 'k': e10 += 3; break;
+            case 'M': e10 += 6; break;
+            case 'G': e10 += 9; break;
+            case 'T': e10 += 12; break;
+            case 'P': e10 += 15; break;
+            case 'E': e10 += 18; break;
             default: return ORA_E_PARSE;
         }
-    } else if (c[1] == '\0') {
-        switch (c[0]) {
-            case 'n': exp10 = -9; break;
-            case 'u': exp10 = -6; break;
-            case 'm': exp10 = -3; break;
-            case 'k': exp10 = 3; break;
-            case 'M': exp10 = 6; break;
-            case 'G': exp10 = 9; break;
-            case 'T': exp10 = 12; break;
-            case 'P': exp10 = 15; break;
-            case 'E': exp10 = 18; break;
-            default: return ORA_E_PARSE;
-        }
+    }
+    e10 -= nfrac;
+    /* 3. assemble: numerator = digits * 2^e2 * 10^max(e10,0), denominator = 10^max(-e10,0); exact or out of the domain */
+    ora_u num = 0;
+    const ora_u kMax = ((ora_u)1 << 127) - 1;
+    for (int i = 0; i < nint + nfrac; ++i) {
+        const int d = (i < nint ? int0[i] : frac0[i - nint]) - '0';
+        if (num > (kMax - (ora_u)d) / 10) return ORA_E_RANGE;
+        num = num * 10 + (ora_u)d;
+    }
+    ora_u den = 1;
+    for (int i = 0; i < -e10; ++i) {
+        if (num % 10 == 0 && num != 0) num /= 10;      /* cancel as we go: the denominator never has to hold 10^k for large k */
+        else if (num == 0) break;
+        else { if (den > kMax / 10) return ORA_E_RANGE; den *= 10; }
+    }
+    if (num != 0 && e2) {  /* 2^e2 against what is left of the denominator */
+        ora_u p2 = (ora_u)1 << e2;
+        const ora_u g = gcd_u(p2, den);
+        p2 /= g;
+        den /= g;
+        if (num > kMax / p2) return ORA_E_RANGE;
+        num *= p2;
+    }
+    for (int i = 0; i < e10 && num != 0; ++i) {
+        if (num > kMax / 10) return ORA_E_RANGE;
+        num *= 10;
+    }
+    if (num != 0) {
+        const ora_u g = gcd_u(num, den);
+        num /= g;
+        den /= g;
     } else {
-        return ORA_E_PARSE;
+        den = 1;
     }
-    ora_q v = mant;
-    if (bin_shift && mul_check(v, ((ora_q)1) << bin_shift, &v)) return ORA_E_RANGE;
-    int scale = 9 + exp10 - nfrac; /* nano-units */
-    for (; scale > 0; --scale)
-        if (mul_check(v, 10, &v)) return ORA_E_RANGE;
-    for (; scale < 0; ++scale) {
-        if (v % 10 != 0) return ORA_E_RANGE; /* finer than a nano-unit: outside this oracle's exact domain */
-        v /= 10;
-    }
-    *out = neg ? -v : v;
+    if (den != 1) return ORA_E_RANGE; /* finer than a nano-unit: outside this oracle's exact domain */
+    *out = neg ? -(ora_q)num : (ora_q)num;
     return ORA_OK;
 }
 

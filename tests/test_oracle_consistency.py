@@ -67,3 +67,53 @@ def test_encoded_threads_agree():
     a = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, c.node_taints, c.req_cpu, c.req_mem, c.pod_sel, c.pod_tol, None, fl, threads=1)
     b = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, c.node_taints, c.req_cpu, c.req_mem, c.pod_sel, c.pod_tol, None, fl, threads=4)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+
+
+def test_c_and_python_quantity_parsers_agree_on_random_text():
+    """The C oracle's parser (table-driven recogniser + exact rational assembly) and the Python oracle's (regex + Fraction) are two
+    independently shaped restatements of the Kubernetes quantity grammar (the role of kube_quantity's TryFrom at src/util.rs:65,68,
+    src/predicates.rs:29,31).  On 60 000 seeded strings -- grammar-shaped ones with every suffix, exponents, signs, fractions, near
+    misses ("1K", "1e", "1ki", "1e+"), and plain noise -- they agree on which texts are quantities, on every exact value in
+    nano-units, and the C side refuses (E_RANGE) exactly the values that are not a whole number of nano-units or leave 128 bits."""
+    import random
+    import re
+    rnd = random.Random(0xC0FFEE)
+    alphabet = "0123456789" * 3 + ".+-eEinumkKMGTPi " + "x"
+    suffixes = ["", "n", "u", "m", "k", "M", "G", "T", "P", "E", "Ki", "Mi", "Gi", "Ti", "Pi", "Ei", "e3", "E3", "e-4", "E+2", "e0", "e", "ei", "K", "ki",
+                "mi", "e+", "E-", "i", "Kii", "e12", "e-12", "e30", "e100", "e101", "e-100"]
+
+    def gen():
+        if rnd.random() < 0.6:
+            sign = rnd.choice(["", "", "+", "-"])
+            ip = "".join(rnd.choice("0123456789") for _ in range(rnd.randint(0, 12)))
+            fp = rnd.choice([None, "", "".join(rnd.choice("0123456789") for _ in range(rnd.randint(1, 6)))])
+            return sign + ip + ("" if fp is None else "." + fp) + rnd.choice(suffixes)
+        return "".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 8)))
+
+    n_equal = n_invalid = n_refused = 0
+    for _ in range(60000):
+        t = gen()
+        try:
+            want, valid = R.parse_quantity(t), True
+        except R.ReferencePanic:
+            want, valid = None, False
+        try:
+            got, err = capi.parse_quantity(t), None
+        except ValueError as e:
+            got, err = None, e.args[0]
+        if not valid:
+            assert got is None and err == capi.E_PARSE, (t, got, err)
+            n_invalid += 1
+            continue
+        m = re.search(r"[eE]([+-]?\d+)$", t)
+        if m and abs(int(m.group(1))) > 100:  # the C parser caps the exponent FIELD at 100: a domain limit, not a grammar rule
+            assert got is None and err == capi.E_RANGE, (t, got, err)
+            continue
+        nanos = want * 10 ** 9
+        if nanos.denominator == 1 and abs(nanos.numerator) < 2 ** 127:
+            assert got == nanos.numerator, (t, got, nanos)
+            n_equal += 1
+        else:
+            assert got is None and err == capi.E_RANGE, (t, got, nanos, err)
+            n_refused += 1
+    assert n_equal > 20000 and n_invalid > 20000 and n_refused > 2000
