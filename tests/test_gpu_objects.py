@@ -4,7 +4,8 @@ tests/cpp/objects_eval (C++: tests/cpp/objects_eval.cpp) loads Kubernetes JSON o
 host/quantity.cpp (quantity strings -> exact i64), host/encoder.cpp (canonical order, `available` from the LISTs, label
 interning, taint bits), host/predicates.cpp / host/scheduler.cpp -- and the device (ksched_set_nodes, ksched_eval), and
 prints what came back.  The expectation is oracle/oracle_ref.py: a different parser (regex + Fraction), dict lookups, one
-per-pair evaluation at a time.  (oracle.c's parser mirrors the host's structure, so it is NOT the independent side here.)
+per-pair evaluation at a time.  (oracle.c has its own, third parser -- a table-driven recogniser + rational assembly -- checked against
+this one in tests/test_oracle_consistency.py.)
 
   * masks: the five golden object sets + a 2000 x 500 cluster with Ki/Mi spellings, 12 label keys (> 8: the kernel's overflow walk)
     and 16 taints  (row a3 of SURVEY.md section 8);

@@ -2,7 +2,7 @@
 
 `tests/cpp/objects_eval columns` runs Kubernetes JSON objects through the C++ encoder in its encode-only mode (no device, nothing
 uploaded) and prints the integer columns of include/ksched.h.  Two checks, both against oracle/oracle_ref.py (regex + Fraction
-parser, dict lookups -- independent of the C++ parser; oracle.c's parser mirrors the host's structure and is not used here):
+parser, dict lookups -- independent of the C++ parser; oracle.c's own parser is not used here):
 
   * the columns, evaluated pair by pair with the oracle's scalar loop on encoded integers (ora_eval_encoded: `req <= avail`,
     dictionary ids, taint bits -- no parsing in it), give exactly the masks the object-level oracle computes from the strings
