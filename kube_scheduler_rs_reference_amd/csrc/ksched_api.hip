@@ -247,7 +247,9 @@ void stream_forget(ksched_ctx *c, hipStream_t s) {
         }
 }
 
-// before the snapshot changes: the ctx's stream waits for everything already enqueued on the remembered streams
+// Before the snapshot changes: choose the stream that carries the change (ksched_ctx::change_stream).  One caller stream known: that
+// stream (it is behind its own evaluations by itself).  Otherwise the ctx's stream, which first waits for everything already enqueued
+// on the remembered streams.
 int snapshot_begin(ksched_ctx *c) {
     c->change_stream = c->stream;
     if (c->user_streams.size() == 1 && !c->opt_own_stream) {
@@ -281,7 +283,7 @@ int snapshot_begin(ksched_ctx *c) {
     return KSCHED_OK;
 }
 
-// after the change has been enqueued on the ctx's stream
+// after the change has been enqueued on change_stream: ev_build marks it for every other stream
 int snapshot_end(ksched_ctx *c) {
     const hipStream_t s = c->change_stream;
     HIPCHK(c, hipEventRecord(c->ev_build, s));
