@@ -4,16 +4,24 @@
     python bench.py --gpus N --steps K --warmup W [--workload C3] [--kernel auto|direct|fused] [--packed]
 
 A "step" is one pass of the hot path over one batch of synthetic pods, inputs already resident in
-HBM: the mask kernel (feasible bits for every (pod, node) pair of this rank's pod rows) + the
-sampled pick (select_node_for_pod with injected draws) and, for N > 1, the all-gather of the int32
-bindings over RCCL.  One evaluation = one (pod, node) feasibility bit.
+HBM: the feasibility mask of every (pod, node) pair of this rank's pod rows AND the sampled pick
+(select_node_for_pod with injected draws) -- on one GPU that is ONE kernel launch (the pick rides in
+the fused mask kernel, KSCHED_OPT_FUSED_PICK) -- and, for N > 1, the all-gather of the int32 bindings
+over RCCL.  One evaluation = one (pod, node) feasibility bit.
 
 Workloads (per GPU; weak scaling: rank r evaluates its own P pods against the replicated snapshot):
     C2  10k pods x 1k nodes, fit only                       BASELINE.json configs[1] (launch-bound)
-    C3  100k pods x 5k nodes, fit + nodeSelector (8 keys)   BASELINE.json configs[2]  <- default
+    C3  100k pods x 5k nodes, fit + nodeSelector (8 keys)   BASELINE.json configs[2]  <- default at EVERY N
     C3h C3 with a hostname-like label key (5 000 values)      not a BASELINE config: the high-cardinality case
     C4s 125k pods x 10k nodes, fit + sel                    configs[3] = 8 of these (1M x 10k)
     C5s 125k pods x 50k nodes, fit + sel + taints, best fit configs[4] = 8 of these (1M x 50k)
+The default workload is the same at every N (the driver computes scaling from the per-N values: a workload that
+changed with N would read as scaling); for N > 1 the line also carries `config.configs3_strong`, the strong-scaling
+leg BASELINE.json's configs[3] describes (1M pods x 10k nodes split N ways).
+
+L3-proof: the timed loop rotates its output over enough mask buffers to exceed the 256 MiB Infinity Cache
+(`config.mask_rotation`), so a step's stores cannot be absorbed by the cache holding the previous step's mask; the
+in-place figure (one buffer rewritten every step) is reported next to it (`config.in_place`).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant (mask) kernel: algorithmic bytes
 per launch / its mean HIP-event duration, measured live in this run on the launch stream: events on
@@ -37,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 HBM_COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling, same table
+L3_BYTES = 256 << 20        # Infinity Cache (MALL), same guide
 
 WORKLOADS = {
     # name: (config, P per GPU, N, flags, pick, description)
@@ -106,14 +115,109 @@ def cpu_baseline(c, flags_names, budget_s=12.0):
     }
 
 
+def rotation_for(mask_bytes: int, want: bool) -> int:
+    """Mask buffers the timed loop rotates over: enough that their total exceeds the Infinity Cache by a quarter (a step's
+    stores then cannot land in lines the cache still holds from the step that last wrote the same buffer)."""
+    if not want or mask_bytes <= 0:
+        return 1
+    return int(max(1, min(12, -(-(L3_BYTES * 5 // 4) // mask_bytes))))
+
+
+class SingleRig:
+    """One workload on one GPU, strictly sequential steps on the current stream (the N = 1 form): used for the secondary figures
+    of the default line (`config.other_workloads`, `config.in_place`) -- same code path as the graded loop, its own evaluator."""
+
+    def __init__(self, torch, L, synth, Evaluator, dev, name, kernel="auto", fused_pick=1, packed=False, debug=0):
+        cfg, P, N, flag_names, pick, desc = WORKLOADS[name]
+        self.torch, self.name, self.desc, self.P, self.N, self.flag_names, self.pick = torch, name, desc, P, N, flag_names, pick
+        c = synth.make_config(cfg, P=P, N=N)
+        self.c = c
+        self.flags = sum(getattr(L, f) for f in flag_names) | (L.PICK_SAMPLED if pick == "sampled" else L.PICK_BESTFIT)
+        self.taint = "TAINT" in flag_names
+        ev = Evaluator(dev.index)
+        ev.set_kernel(kernel)
+        ev.set_option(L.OPT_FUSED_PICK, fused_pick)
+        if debug:
+            ev.set_option(L.OPT_DEBUG, debug)
+        ev.set_nodes(**c.node_columns())
+        self.ev = ev
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+        self.d = (t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32) if c.n_keys else None,
+                  t(c.pod_tol, np.int64) if self.taint else None, t(c.samples, np.int32) if pick == "sampled" else None)
+        self.out = torch.full((P,), -1, dtype=torch.int32, device=dev)
+        self.packed = packed
+
+    def loop(self, rotate: bool, mask: bool = True):
+        ev, torch = self.ev, self.torch
+        if not mask:
+            run = ev.bind_eval_device(*self.d, self.flags, out_feasible=None, out_bindings=[self.out])
+            return (lambda: run(0, 0)), 0, None
+        m0 = ev.alloc_mask(self.P, pitched=not self.packed)
+        R = rotation_for(int(m0.stride(0)) * 8 * self.P, rotate)
+        masks = [m0] + [ev.alloc_mask(self.P, pitched=not self.packed) for _ in range(R - 1)]
+        run = ev.bind_eval_device(*self.d, self.flags, out_feasible=masks, out_bindings=[self.out])
+        k = [0]
+
+        def step():
+            run(0, k[0] % R)
+            k[0] += 1
+        return step, R, masks
+
+    def measure(self, steps: int, samples: int, rotate: bool = True):
+        torch, ev = self.torch, self.ev
+        step, R, masks = self.loop(rotate)
+        for _ in range(max(8, 2 * R)):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ev.set_timing(True, every=1)
+        for _ in range(samples):
+            step()
+        torch.cuda.synchronize()
+        ev.kernel_time_ms()
+        for _ in range(samples):
+            step()
+        torch.cuda.synchronize()
+        us = np.sort(ev.kernel_time_samples(samples * 2) * 1e3)
+        ev.set_timing(False)
+        kern, pick_how = ev.last_kernel, ev.last_pick
+        del masks
+        # the pick alone: a bindings-only request (sampled: k_select_sampled; best fit: the two best-fit stages); no mask kernel runs
+        bstep, _, _ = self.loop(False, mask=False)
+        for _ in range(8):
+            bstep()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            bstep()
+        torch.cuda.synchronize()
+        pick_us = (time.perf_counter() - t1) / steps * 1e6
+        n_keys = self.c.n_keys if "SEL" in self.flag_names else 0
+        alg = algorithmic_bytes(self.P, self.N, n_keys, self.taint)
+        avg = float(us.mean()) if us.size else 0.0
+        return {"workload": self.desc, "value": float(self.P) * self.N * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps,
+                "mask_rotation": R, "kernel": kern, "pick": self.pick, "pick_in_mask_launch": pick_how == "fused",
+                "mask_kernel_us": avg, "mask_kernel_median_us": float(np.median(us)) if us.size else None,
+                "mask_kernel_frac": (alg / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS) if avg > 0 else None,
+                "step_frac": alg / (el / steps) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": alg, "pick_alone_us_per_step": pick_us,
+                "pick_alone_note": "a bindings-only request of the same batch (no mask kernel): launch-to-launch time of the pick by itself"}
+
+    def close(self):
+        self.ev.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: C3 on one GPU (configs[2], the largest single-GPU configuration); C4s for N > 1 (8 GPUs x C4s == configs[3], "
-                         "1M pods x 10k nodes)")
+                    help="default: C3 per GPU at every N (configs[2], the largest single-GPU configuration; weak scaling)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "fused"])
     ap.add_argument("--pods", type=int, default=None, help="override pods per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,19 +225,28 @@ def main():
     ap.add_argument("--packed", action="store_true",
                     help="mask rows packed at W words (default: rows pitched to ksched_mask_pitch(n) = W rounded up to 128 B)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (timing experiments; results invalid)")
+    ap.add_argument("--fused-pick", type=int, default=1, choices=[0, 1],
+                    help="1 (default): the sampled pick rides in the fused mask launch (one kernel per step); 0: its own launch ahead of it")
+    ap.add_argument("--no-rotate", action="store_true",
+                    help="rewrite ONE mask buffer every step (the Infinity Cache then absorbs part of the stores at C3 / C4s); the default "
+                         "rotates over enough buffers to exceed it and reports the in-place figure as config.in_place")
+    ap.add_argument("--no-others", action="store_true",
+                    help="N = 1, default workload: skip config.other_workloads (C4s, C5s measured in the same process, a few hundred ms) "
+                         "and config.in_place")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip config.configs3_strong (1M pods x 10k nodes split N ways)")
+    ap.add_argument("--repeats", type=int, default=4, help="further timed regions of K steps after the graded one (config.repeat_ms_per_step)")
     ap.add_argument("--depth", type=int, default=None,
                     help="buffer slots in flight (bindings, and masks with two streams).  Default: 1 on one GPU (strictly sequential steps "
                          "on one stream); 2 for N > 1, where the all-gather is asynchronous and overlaps the kernels of the following steps")
     ap.add_argument("--ramp-ms", type=float, default=60.0,
                     help="after the W warm-up steps keep stepping (untimed) until this many ms have passed: the GPU's clocks ramp over "
-                         "tens of milliseconds, and a 5-step warm-up of 26 us steps ends long before that")
+                         "tens of milliseconds, and a 5-step warm-up of 20 us steps ends long before that (reported as `ramp_steps`)")
     ap.add_argument("--kernel-samples", type=int, default=64,
                     help="post-pass after the timed region: this many further steps with HIP events on EVERY mask kernel dispatch "
                          "(roofline.avg_kernel_us = their mean; min / median reported).  Events cost launch gap, not kernel time, so "
                          "they are kept out of the timed steps")
     ap.add_argument("--gather-every", type=int, default=None,
-                    help="N > 1: one all-gather per this many steps (their bindings share a buffer).  Default 4: an RCCL call costs tens "
-                         "of microseconds of host and launch time whatever its size -- the same order as a step's kernels")
+                    help="N > 1: one all-gather per this many steps (their bindings share a buffer).  Default 1 (one per batch)")
     ap.add_argument("--torch-gather", action="store_true",
                     help="N > 1: all-gather with torch.distributed.all_gather_into_tensor instead of the C ABI's communicator "
                          "(ksched_allgather_bindings); A/B only, the default is the ABI")
@@ -143,14 +256,10 @@ def main():
     ap.add_argument("--refresh-nodes", type=int, default=8)
     ap.add_argument("--overlap-leg", action="store_true",
                     help="N = 1: after the graded loop, time the same K steps with two batches in flight on two streams and report it as "
-                         "config.two_batches_in_flight.  Off by default: its mask kernel launches run next to pick kernels and would mix "
-                         "into the rocprofv3 per-kernel average of the default command, which has to agree with roofline.avg_kernel_us")
+                         "config.two_batches_in_flight")
     ap.add_argument("--one-stream", action="store_true", help="N > 1: keep pick, all-gather (side stream) and mask kernel off the two-stream pipe")
     ap.add_argument("--two-stream", action="store_true",
-                    help="with --depth >= 2: mask kernels on one HIP stream, pick kernels (+ all-gather) on another (ksched_pipe).  The picks "
-                         "do not read the mask, so the two streams need no ordering between them: +25 %% evals/s at C3 and in the N > 1 path; "
-                         "the mask kernel then shares the chip with pick kernels and its own duration grows by 6-10 %%, which is why the "
-                         "default keeps one stream and a clean per-kernel roofline number (profiles/r01_h5_ab_streams.txt)")
+                    help="with --depth >= 2: mask kernels on one HIP stream, pick kernels (+ all-gather) on another (ksched_pipe)")
     args = ap.parse_args()
 
     import torch
@@ -178,22 +287,83 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    if args.workload is None:
-        args.workload = "C4s" if world > 1 else "C3"
+    default_workload = args.workload is None
+    if default_workload:
+        args.workload = "C3"  # at EVERY N: the driver's scaling figures compare like with like
     cfg, P_gpu, N, flag_names, pick, desc = WORKLOADS[args.workload]
     if args.pods:
         P_gpu = args.pods
-    P_total = P_gpu * world
-    c = synth.make_config(cfg, P=P_total, N=N)  # same seeded cluster on every rank; each takes its rows
-    flags = sum(getattr(L, f) for f in flag_names)
-    flags |= L.PICK_SAMPLED if pick == "sampled" else L.PICK_BESTFIT
-    taint = "TAINT" in flag_names
 
-    ev = Evaluator(local_rank)
-    ev.set_kernel(args.kernel)
-    if args.debug:
-        ev.set_option(L.OPT_DEBUG, args.debug)
-    ev.set_nodes(**c.node_columns())
+    def sync():
+        # drain this rank's streams first (so the barrier's collective never interleaves with all-gathers still in flight on the
+        # ABI's communicator), then barrier + synchronize
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x: float) -> float:
+        if not multi:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    class Rig:
+        """This rank's shard of one P_total x N workload: evaluator, resident inputs, loops."""
+
+        def __init__(self, cfg, P_total, N, flag_names, pick):
+            self.P_total, self.N, self.flag_names, self.pick = P_total, N, flag_names, pick
+            c = synth.make_config(cfg, P=P_total, N=N)  # same seeded cluster on every rank; each takes its rows
+            self.c = c
+            flags = sum(getattr(L, f) for f in flag_names)
+            flags |= L.PICK_SAMPLED if pick == "sampled" else L.PICK_BESTFIT
+            self.flags = flags
+            self.taint = "TAINT" in flag_names
+            ev = Evaluator(local_rank)
+            ev.set_kernel(args.kernel)
+            ev.set_option(L.OPT_FUSED_PICK, args.fused_pick)
+            if args.debug:
+                ev.set_option(L.OPT_DEBUG, args.debug)
+            ev.set_nodes(**c.node_columns())
+            self.ev = ev
+            self.lo, self.hi, _ = shard_bounds(P_total, world, rank)
+            lo, hi = self.lo, self.hi
+            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+            self.d_cpu, self.d_mem = t(c.req_cpu[lo:hi], np.int64), t(c.req_mem[lo:hi], np.int64)
+            self.d_sel = t(c.pod_sel[:, lo:hi], np.int32) if c.n_keys else None
+            self.d_tol = t(c.pod_tol[lo:hi], np.int64) if self.taint else None
+            self.d_smp = t(c.samples[lo:hi], np.int32) if pick == "sampled" else None
+            self.comm, self.comm_note = None, None
+
+        def make_comm(self):
+            """ksched_comm_create: the C ABI's RCCL communicator.  Its creation is collective; if it fails on ANY rank (e.g. no
+            usable librccl for dlopen) every rank falls back to torch's collective together, and the JSON line says so."""
+            if not multi or args.torch_gather:
+                return
+            try:
+                self.comm = AbiComm(self.ev)
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                self.comm, ok, self.comm_note = None, 0, f"AbiComm failed on rank {rank}: {e}"
+            okt = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 0:
+                if self.comm is not None:
+                    self.comm.close()
+                self.comm = None
+                self.comm_note = self.comm_note or "AbiComm failed on another rank"
+                args.torch_gather = True
+
+        def close(self):
+            if self.comm is not None:
+                self.comm.close()
+            self.ev.close()
+
+    rig = Rig(cfg, P_gpu * world, N, flag_names, pick)
+    rig.make_comm()
+    ev, c, flags, taint = rig.ev, rig.c, rig.flags, rig.taint
+    P_total, lo, hi = rig.P_total, rig.lo, rig.hi
     depth = args.depth if args.depth else (2 if multi else 1)
     pipelined = depth > 1 and not args.no_mask
     # N > 1: ONE all-gather per batch by default -- what north_star describes ("an RCCL allgather of the resulting bindings").
@@ -204,75 +374,83 @@ def main():
         # N > 1 default: ksched_pipe -- mask kernels on one stream; pick -> all-gather -> pick -> ... on the other.  The gather is
         # ordered behind its pick by the stream itself (no event per step) and overlaps the next batches' mask kernels.
         args.two_stream = True
-    comm, comm_note = None, None
-    if multi and not args.torch_gather:
-        # ksched_comm_create: the C ABI's RCCL communicator.  Its creation is collective; if it fails on ANY rank (e.g. no usable
-        # librccl for dlopen) every rank falls back to torch's collective together, and the JSON line says so.
-        try:
-            comm = AbiComm(ev)
-            ok = 1
-        except Exception as e:  # noqa: BLE001
-            comm, ok, comm_note = None, 0, f"AbiComm failed on rank {rank}: {e}"
-        okt = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        if int(okt.item()) == 0:
-            if comm is not None:
-                comm.close()
-            comm = None
-            comm_note = comm_note or "AbiComm failed on another rank"
-            args.torch_gather = True
-    lo, hi, _ = shard_bounds(P_total, world, rank)
-    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
-    d_cpu, d_mem = t(c.req_cpu[lo:hi], np.int64), t(c.req_mem[lo:hi], np.int64)
-    d_sel = t(c.pod_sel[:, lo:hi], np.int32) if c.n_keys else None
-    d_tol = t(c.pod_tol[lo:hi], np.int64) if taint else None
-    d_smp = t(c.samples[lo:hi], np.int32) if pick == "sampled" else None
     W = ev.W
 
     class Loop:
         """One configuration of the step loop: scheduler (sharding + gather), buffers, pre-marshalled launches."""
 
-        def __init__(self, G, depth=depth, two_stream=None):
+        def __init__(self, rig, G, depth=depth, two_stream=None, rotate=True):
+            ev = rig.ev
+            n_loc = rig.hi - rig.lo
             pipelined = depth > 1 and not args.no_mask
             two_stream = args.two_stream if two_stream is None else two_stream
             self.G, self.depth, self.pipelined = G, depth, pipelined
             self.pipe = ev.pipe(depth * G) if (pipelined and two_stream) else None
-            self.sched = (PipelinedScheduler(P_total, dev, depth=depth, pipe=self.pipe, gather_always=multi, gather_every=G, comm=comm)
-                          if pipelined else ShardedScheduler(P_total, dev, comm=comm))
+            self.sched = (PipelinedScheduler(rig.P_total, dev, depth=depth, pipe=self.pipe, gather_always=multi, gather_every=G, comm=rig.comm)
+                          if pipelined else ShardedScheduler(rig.P_total, dev, comm=rig.comm))
             sched = self.sched
-            n_masks = depth * G if self.pipe is not None else 1
-            self.masks = [None if args.no_mask else ev.alloc_mask(hi - lo, pitched=not args.packed) for _ in range(n_masks)]
+            probe = None if args.no_mask else ev.alloc_mask(n_loc, pitched=not args.packed)
+            mask_bytes = 0 if probe is None else int(probe.stride(0) if n_loc > 1 else ev.W) * 8 * n_loc
+            # rotation: the sequential loop cycles its output over R buffers (> 256 MiB together); the pipe already owns
+            # depth * G masks and takes further ones until the same total is reached
+            want_rot = rotate and not args.no_rotate and not args.no_mask
+            R = rotation_for(mask_bytes, want_rot)
+            if self.pipe is not None:
+                n_masks = depth * G
+                self.R = n_masks
+            else:
+                n_masks = R
+                self.R = R
+            self.masks = [None] if args.no_mask else [probe] + [ev.alloc_mask(n_loc, pitched=not args.packed) for _ in range(n_masks - 1)]
+            self.mask_bytes = mask_bytes
             if pipelined:  # one binding buffer per (slot, step of the slot's gather group)
                 slot_outs = {(k, g): sched.binding_buffer(k, g) for k in range(depth) for g in range(G)}
             else:
-                slot_outs = {(0, 0): sched.local[: hi - lo]}
+                slot_outs = {(0, 0): sched.local[: n_loc]}
             keys = sorted(slot_outs)
-            # sequential form: pick kernel + mask kernel on one stream, one (pre-marshalled) library call per step
-            bound = ev.bind_eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=self.masks[0], out_bindings=[slot_outs[k] for k in keys])
+            # sequential form: ONE (pre-marshalled) library call per step on one stream
+            bound = ev.bind_eval_device(rig.d_cpu, rig.d_mem, rig.d_sel, rig.d_tol, rig.d_smp, rig.flags,
+                                        out_feasible=None if args.no_mask else (self.masks if self.pipe is None else self.masks[0]),
+                                        out_bindings=[slot_outs[k] for k in keys])
             index_of = {slot_outs[k].data_ptr(): i for i, k in enumerate(keys)}
             submit = None
             if self.pipe is not None:  # pre-marshalled ksched_pipe_submit: mask kernel -> the pipe's mask stream, pick -> its pick stream
-                submit = self.pipe.bind(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, self.masks, [slot_outs[k] for k in keys])  # pipe slot = k * G + g
+                submit = self.pipe.bind(rig.d_cpu, rig.d_mem, rig.d_sel, rig.d_tol, rig.d_smp, rig.flags, self.masks, [slot_outs[k] for k in keys])  # pipe slot = k * G + g
+            n_rot = max(1, self.R) if self.pipe is None and not args.no_mask else 1
+            k_rot = [0]
 
             def local_eval(binding_out):
-                bound(index_of[binding_out.data_ptr()])
+                bound(index_of[binding_out.data_ptr()], k_rot[0] % n_rot)
+                k_rot[0] += 1
 
             def run(slot, binding_out):  # pipelined form: bindings and masks are per slot
                 if submit is not None:
                     submit(slot)
                 else:
-                    bound(index_of[binding_out.data_ptr()])
+                    bound(index_of[binding_out.data_ptr()], k_rot[0] % n_rot)
+                    k_rot[0] += 1
             self.step = (lambda: sched.step(run)) if pipelined else (lambda: sched.step(local_eval))
 
         def drain(self):
             if self.pipelined:
                 self.sched.drain()
 
+        def timed(self, steps):
+            """exactly `steps` steps between barrier + synchronize pairs; MAX over ranks"""
+            sync()
+            t0 = time.perf_counter()
+            last = None
+            for _ in range(steps):
+                last = self.step()
+            self.drain()
+            sync()
+            return max_over_ranks(time.perf_counter() - t0), last
+
         def close(self):
             if self.pipe is not None:
                 self.pipe.close()
 
-    loop = Loop(gather_every)
+    loop = Loop(rig, gather_every)
     sched, pipe = loop.sched, loop.pipe
     d_mask = loop.masks[0]
     pitch = int(d_mask.stride(0)) if d_mask is not None else W
@@ -293,14 +471,6 @@ def main():
                 refresh["calls"] += 1
         return loop.step()
 
-    def sync():
-        # drain this rank's streams first (so the barrier's collective never interleaves with all-gathers still in flight on the
-        # ABI's communicator), then barrier + synchronize
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     if args.refresh_every > 0:
         # The HIP runtime stalls ONCE per process for ~37 ms around its ~600th snapshot update (profiles/r02_m_snapshot_stream.txt);
         # get past that point before anything is timed, or it lands in the timed region of some --refresh-every / --steps combinations.
@@ -310,8 +480,9 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         last = one_step()
-    # clock ramp (untimed, part of the warm-up): step until about --ramp-ms have passed.  The step count is agreed across ranks
-    # (MAX) so that every rank issues the same collectives.
+
+    # clock ramp (untimed, reported as `ramp_steps`): step until about --ramp-ms have passed.  The step count is agreed across
+    # ranks (MAX) so that every rank issues the same collectives.
     def burst(k):
         t_b = time.perf_counter()
         for _ in range(k):
@@ -337,101 +508,146 @@ def main():
     if pipelined:
         sched.drain()
     sync()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     bindings = (last.wait() if pipelined else last).clone()
-    if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # further regions of the same K steps: how much one region of K steps moves from run to run (the graded one is the first)
+    repeats = []
+    for _ in range(max(0, args.repeats)):
+        sync()
+        t_r = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        if pipelined:
+            sched.drain()
+        sync()
+        repeats.append(max_over_ranks(time.perf_counter() - t_r) / args.steps * 1e3)
     # ---- post-pass: the same steps with HIP events on every mask kernel dispatch (per-kernel roofline number) ----------
-    ev.set_timing(True, every=1)
-    for _ in range(max(1, args.kernel_samples)):  # first round: creates the event pool (host work), discarded
-        one_step()
-    if pipelined:
-        sched.drain()
-    sync()
-    ev.kernel_time_ms()  # reset
-    for _ in range(max(1, args.kernel_samples)):
-        one_step()
-    if pipelined:
-        sched.drain()
-    sync()
-    samples_us = np.sort(ev.kernel_time_samples(max(1, args.kernel_samples) * 2) * 1e3)
-    ev.set_timing(False)
+
+    def kernel_events(step_fn, drain_fn, ev_, n):
+        ev_.set_timing(True, every=1)
+        for _ in range(max(1, n)):  # first round: creates the event pool (host work), discarded
+            step_fn()
+        drain_fn()
+        sync()
+        ev_.kernel_time_ms()  # reset
+        for _ in range(max(1, n)):
+            step_fn()
+        drain_fn()
+        sync()
+        us = np.sort(ev_.kernel_time_samples(max(1, n) * 2) * 1e3)
+        ev_.set_timing(False)
+        return us
+    samples_us = kernel_events(one_step, loop.drain, ev, args.kernel_samples)
     launches = int(samples_us.shape[0])
     kern_ms = float(samples_us.sum()) * 1e-3
+    kernel_name, pick_how = ev.last_kernel, ev.last_pick
+
+    # ---- N = 1: the in-place figure next to the rotated one (ONE mask buffer rewritten every step: what round 2 timed) -------
+    in_place = None
+    if not multi and not pipelined and not args.no_mask and loop.R > 1 and not args.no_others:
+        try:
+            lp = Loop(rig, 1, rotate=False)
+            for _ in range(64):
+                lp.step()
+            e_ip, _ = lp.timed(args.steps)
+            us_ip = kernel_events(lp.step, lp.drain, ev, args.kernel_samples)
+            alg_ip = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint)
+            in_place = {"value": float(P_total) * N * args.steps / e_ip, "ms_per_step": e_ip / args.steps * 1e3, "steps": args.steps,
+                        "mask_kernel_us": float(us_ip.mean()), "mask_kernel_frac": alg_ip / (float(us_ip.mean()) * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "note": f"one {lp.mask_bytes / 2**20:.0f} MiB mask buffer rewritten every step: the 256 MiB Infinity Cache still holds "
+                                "the previous step's lines, and write counters count fabric requests -- not the L3-proof figure"}
+            lp.close()
+        except Exception as e:  # noqa: BLE001 -- a secondary figure must never take the graded line down with it
+            in_place = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- N > 1, second number: the same K steps with ONE all-gather per 4 steps (fewer, larger collectives) ------------
     alt = None
     if multi and pipelined and args.gather_every is None:
         loop.drain()
-        loop_alt = Loop(4)
+        loop_alt = Loop(rig, 4)
         for _ in range(32):
             loop_alt.step()
         loop_alt.drain()
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            loop_alt.step()
-        loop_alt.drain()
-        sync()
-        e_alt = time.perf_counter() - t1
-        tt = torch.tensor([e_alt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        e_alt = float(tt.item())
+        e_alt, _ = loop_alt.timed(args.steps)
         alt = {"value": float(P_total) * N * args.steps / e_alt, "ms_per_step": e_alt / args.steps * 1e3, "steps": args.steps}
         loop_alt.close()
 
-    # ---- N = 1, second number: the same K steps with TWO batches in flight on two streams (ksched_pipe: mask kernels on one stream,
-    # picks on the other; the picks do not read the mask).  The primary number stays the strictly sequential loop: there the mask
-    # kernel has the chip to itself, and its duration -- the roofline figure -- is the one rocprofv3 reports for the same command.
+    # ---- N = 1, second number: the same K steps with TWO batches in flight on two streams (ksched_pipe) -------------------
     overlapped = None
     if not multi and not pipelined and not args.no_mask and args.refresh_every == 0 and args.overlap_leg:
         try:
             loop.drain()
-            loop_ov = Loop(1, depth=2, two_stream=True)
+            loop_ov = Loop(rig, 1, depth=2, two_stream=True)
             for _ in range(64):
                 loop_ov.step()
             loop_ov.drain()
-            sync()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                last_ov = loop_ov.step()
-            loop_ov.drain()
-            sync()
-            e_ov = time.perf_counter() - t1
+            e_ov, last_ov = loop_ov.timed(args.steps)
             same = bool(torch.equal(last_ov.wait(), bindings))
             overlapped = {"value": float(P_total) * N * args.steps / e_ov, "ms_per_step": e_ov / args.steps * 1e3, "steps": args.steps,
                           "steps_in_flight": 2, "two_stream": True, "bindings_equal_sequential": same,
-                          "note": "pick of batch i+1 overlaps the mask kernel of batch i; mask kernel durations are longer here, so this is not the roofline leg"}
+                          "note": "pick of batch i+1 (its own kernel on the second stream) overlaps the mask kernel of batch i"}
             loop_ov.close()
-        except Exception as e:  # noqa: BLE001 -- a secondary figure must never take the graded line down with it
+        except Exception as e:  # noqa: BLE001
             overlapped = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- N > 1, reference point: this rank's own shard with NO exchange (same kernels, same pipe, no collective), K steps ------
     # per-GPU rate of the same workload without the all-gather: value / (N x min over ranks of this) is the cost of the exchange
-    solo = None
-    if multi and pipelined:
-        loop.drain()
-        k_steps = [None]
-        def solo_steps(n):
-            for j in range(n):
-                if loop.pipe is not None:
-                    k_steps[0](j % (depth * loop.G))
-                else:
-                    loop.step()
-        if loop.pipe is not None:
-            outs = [loop.sched.binding_buffer(k, g) for k in range(depth) for g in range(loop.G)]
-            k_steps[0] = loop.pipe.bind(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, loop.masks, outs)
-            solo_steps(32)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            solo_steps(args.steps)
-            torch.cuda.synchronize()
-            e_solo = time.perf_counter() - t2
-            ts = torch.tensor([e_solo], dtype=torch.float64, device=dev)
-            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-            solo = {"per_gpu_value_max_time": float(hi - lo) * N * args.steps / float(ts.item()), "ms_per_step": float(ts.item()) / args.steps * 1e3,
-                    "note": "each rank alone: the same ksched_pipe steps on its shard, no all-gather; slowest rank"}
+    def solo_rate(lp, rg):
+        if lp.pipe is None:
+            return None
+        lp.drain()
+        outs = [lp.sched.binding_buffer(k, g) for k in range(lp.depth) for g in range(lp.G)]
+        sub = lp.pipe.bind(rg.d_cpu, rg.d_mem, rg.d_sel, rg.d_tol, rg.d_smp, rg.flags, lp.masks, outs)
+        nslot = lp.depth * lp.G
+        for j in range(32):
+            sub(j % nslot)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for j in range(args.steps):
+            sub(j % nslot)
+        torch.cuda.synchronize()
+        e_solo = max_over_ranks(time.perf_counter() - t2)
+        return {"per_gpu_value_max_time": float(rg.hi - rg.lo) * rg.N * args.steps / e_solo, "ms_per_step": e_solo / args.steps * 1e3,
+                "note": "each rank alone: the same ksched_pipe steps on its shard, no all-gather; slowest rank"}
+    solo = solo_rate(loop, rig) if (multi and pipelined) else None
+
+    # ---- N > 1: the strong-scaling leg BASELINE.json's configs[3] describes: 1M pods x 10k nodes split N ways ----------------
+    strong = None
+    if multi and pipelined and default_workload and not args.no_strong_leg:
+        try:
+            loop.drain()
+            cfg4, _, N4, fn4, pick4, _ = WORKLOADS["C4s"]
+            rig4 = Rig(cfg4, 1_000_000, N4, fn4, pick4)
+            rig4.comm = rig.comm  # one communicator per process is enough (same ranks, same device)
+            lp4 = Loop(rig4, 1)
+            for _ in range(16):
+                lp4.step()
+            lp4.drain()
+            k4 = max(20, min(args.steps, 400))
+            e4, _ = lp4.timed(k4)
+            s4 = solo_rate(lp4, rig4)
+            strong = {"workload": f"configs[3]: 1M pods x 10k nodes, pod rows split {world} ways ({rig4.hi - rig4.lo} pods on this rank), "
+                                  "one all-gather of the 1M bindings per batch", "scaling": "strong", "pods_total": 1_000_000, "nodes": N4,
+                      "value": 1e6 * N4 * k4 / e4, "ms_per_step": e4 / k4 * 1e3, "steps": k4, "no_allgather": s4}
+            lp4.close()
+            rig4.comm = None
+            rig4.close()
+        except Exception as e:  # noqa: BLE001
+            strong = {"error": f"{type(e).__name__}: {e}"}
+
+    # ---- N = 1, default workload: C4s and C5s in the same process (their own evaluators; the graded loop is over) -------------
+    others = None
+    if not multi and default_workload and not args.no_others and not args.no_mask and args.refresh_every == 0 and not args.pods:
+        others = {}
+        for name in ("C4s", "C5s"):
+            try:
+                r = SingleRig(torch, L, synth, Evaluator, dev, name, kernel=args.kernel, fused_pick=args.fused_pick, packed=args.packed, debug=args.debug)
+                others[name] = r.measure(steps=100 if name == "C5s" else 200, samples=24)
+                r.close()
+                del r
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                others[name] = {"error": f"{type(e).__name__}: {e}"}
 
     # sanity inside the bench: the fraction of pods the last timed step bound (a degenerate workload would show 0 or 1)
     bound_frac = float((bindings >= 0).float().mean().item())
@@ -449,23 +665,36 @@ def main():
         if os.path.exists(tpath):
             try:
                 doc = json.load(open(tpath))
-                rec = doc.get(f"{args.workload}:{ev.last_kernel}")
+                rec = doc.get(f"{args.workload}:{kernel_name}")
                 traffic = rec["hbm_bytes_per_launch"] if rec else None
                 if rec:
                     traffic_source = f"profiles/pmc_traffic.json ({doc.get('_session', 'session unnamed')}): separate rocprofv3 --pmc passes, not this run"
             except Exception:
                 traffic = None
+        step_s = elapsed / args.steps
+        per_gpu_solo = solo["per_gpu_value_max_time"] if solo else None
         out = {
             "metric": "pod x node predicate evals/s", "value": value, "unit": "evals/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": args.steps, "warmup": args.warmup, "ramp_steps": ramp_steps,
+            "untimed_steps_before_timed_region": args.warmup + ramp_steps, "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": desc, "pods_per_gpu": P_gpu, "pods_total": P_total, "nodes": N,
                        "predicates": "+".join(flag_names), "pick": pick, "mask_written": not args.no_mask,
                        "mask_row_pitch_words": pitch, "mask_words": W,
-                       "kernel": ev.last_kernel, "steps_in_flight": depth if pipelined else 1, "two_stream": pipe is not None,
+                       "kernel": kernel_name, "pick_launch": pick_how,
+                       "kernels_per_step": (1 if pick_how == "fused" else None),
+                       "mask_rotation": loop.R, "mask_rotation_bytes": loop.R * loop.mask_bytes,
+                       "mask_rotation_note": (f"the loop writes {loop.R} mask buffers of {loop.mask_bytes / 2**20:.0f} MiB in turn "
+                                              f"({loop.R * loop.mask_bytes / 2**20:.0f} MiB > the 256 MiB Infinity Cache)" if loop.R > 1 else
+                                              "one mask buffer" + (" (already larger than the 256 MiB Infinity Cache)" if loop.mask_bytes > L3_BYTES else "")),
+                       "step_frac_of_hbm_peak": (alg / step_s / 1e9 / HBM_PEAK_GBS) if world == 1 else None,
+                       "repeat_ms_per_step": repeats, "in_place": in_place, "other_workloads": others,
+                       "steps_in_flight": depth if pipelined else 1, "two_stream": pipe is not None,
                        "steps_per_allgather": gather_every if (pipelined and multi) else (1 if multi else None),
                        "allgather": (("torch.distributed.all_gather_into_tensor" if args.torch_gather else "ksched_allgather_bindings (C ABI, ncclAllGather on the pick's stream)") if multi else None),
-                       "two_batches_in_flight": overlapped, "allgather_every_4": alt, "no_allgather": solo, "allgather_fallback": comm_note,
+                       "two_batches_in_flight": overlapped, "allgather_every_4": alt, "no_allgather": solo, "allgather_fallback": rig.comm_note,
+                       "scaling_efficiency_vs_no_allgather": (value / (world * per_gpu_solo) if per_gpu_solo else None),
+                       "configs3_strong": strong,
                        "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
                        "allgather(int32 bindings)" if world > 1 else "single GPU",
                        "bound_fraction": bound_frac,
@@ -474,12 +703,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
-                         "kernel": f"mask kernel ({ev.last_kernel})", "algorithmic_bytes_per_launch": alg,
+                         "kernel": f"mask kernel ({kernel_name}" + (", the sampled pick rides in it)" if pick_how == "fused" else ")"),
+                         "algorithmic_bytes_per_launch": alg,
                          "avg_kernel_us": avg_kernel_s * 1e6, "median_kernel_us": float(np.median(samples_us)) if launches else None,
                          "min_kernel_us": float(samples_us[0]) if launches else None, "max_kernel_us": float(samples_us[-1]) if launches else None,
                          "launches_timed": int(launches),
                          "timing": f"HIP events on every mask kernel dispatch of a post-pass of {launches} steps after the timed region "
-                                   f"(clock ramp {ramp_steps} untimed steps >= {args.ramp_ms:.0f} ms before it)",
+                                   f"(clock ramp {ramp_steps} untimed steps >= {args.ramp_ms:.0f} ms before it); outputs rotate over {loop.R} mask buffer(s)",
                          "mask_kernel_evals_per_s": (hi - lo) * N / avg_kernel_s if avg_kernel_s > 0 else 0.0},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -490,9 +720,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     loop.close()
-    if comm is not None:
-        comm.close()
-    ev.close()
+    rig.close()
     if rank == 0:
         import ctypes
         try:

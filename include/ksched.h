@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define KSCHED_ABI_VERSION 2u
+#define KSCHED_ABI_VERSION 3u
 
 /* at most this many label-key columns per batch */
 #define KSCHED_MAX_KEYS 32u
@@ -116,6 +116,16 @@ extern "C" {
  * caller streams, onto the ctx's own stream, ordered against the callers' streams by events.  1 = always the ctx's own stream.
  * Same results either way: every evaluation sees the snapshot that was current when it was enqueued. */
 #define KSCHED_OPT_SNAPSHOT_STREAM 8
+/* KSCHED_OPT_FUSED_PICK: 1 (default) = when an evaluation asks for the feasibility mask AND the sampled pick and the fused mask
+ * kernel runs, the pick rides in that launch (select_node_for_pod, src/main.rs:51-71, evaluated for the batch's pods by a few
+ * waves of every block while the block's tile is staged): ONE kernel per step.  0 = the pick is its own launch ahead of the
+ * mask kernel (k_select_sampled).  Same bindings either way: both run the same per-pod code on the same node records. */
+#define KSCHED_OPT_FUSED_PICK 9
+/* KSCHED_OPT_FAULT: test hook for the "nothing unwinds across this boundary" rule.  value = kind | (skip << 8): after `skip`
+ * further fault points (the places where a call enters the library's C++: snapshot calls, evaluations, explain, checksum) the
+ * next one throws inside the call -- kind 1: std::bad_alloc, kind 2: std::runtime_error -- once.  That call must come back with
+ * KSCHED_E_NOMEM / KSCHED_E_INVAL and ksched_last_error set; the process must not terminate.  0 = off (default). */
+#define KSCHED_OPT_FAULT 10
 
 typedef struct ksched_ctx ksched_ctx;
 
@@ -328,6 +338,9 @@ int ksched_trace_read(ksched_ctx *ctx, uint64_t *out, uint32_t max_blocks);
 int ksched_index_checksum(ksched_ctx *ctx, uint64_t *out /* [2] */);
 /* name of the mask kernel variant the last ksched_eval* used ("direct", "indexed", ...) */
 const char *ksched_last_kernel(const ksched_ctx *ctx);
+/* how the pick of the last ksched_eval* ran: "fused" (it rode in the fused mask launch, KSCHED_OPT_FUSED_PICK), "select" (its own
+ * launch testing the drawn candidates), "bestfit-rows", "from-mask" (KSCHED_OPT_PICK_FROM_MASK / no bitmap index), "none" */
+const char *ksched_last_pick(const ksched_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KSCHED_LIB") or os.path.join(_PKG_DIR, "libksched_hip.so")
 
 # --- constants mirrored from include/ksched.h --------------------------------------------------
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_KEYS = 32
 MAX_ATTEMPTS = 64
 SEL_NEVER = 0xFFFFFFFF
@@ -50,6 +50,8 @@ OPT_PICK_FROM_MASK = 5
 OPT_INDEX_BUILD = 6
 OPT_BESTFIT_STAGES = 7
 OPT_SNAPSHOT_STREAM = 8
+OPT_FUSED_PICK = 9
+OPT_FAULT = 10
 TRACE_WORDS = 8
 KERNEL_AUTO = 0
 KERNEL_DIRECT = 1
@@ -98,6 +100,7 @@ SYMBOLS = {
     "ksched_index_checksum": (C.c_int, [_vp, _vp]),
     "ksched_trace_read": (C.c_int, [_vp, _vp, C.c_uint32]),
     "ksched_last_kernel": (C.c_char_p, [_vp]),
+    "ksched_last_pick": (C.c_char_p, [_vp]),
 }
 
 _lib = None

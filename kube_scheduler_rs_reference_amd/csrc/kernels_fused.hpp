@@ -43,6 +43,7 @@
 #include <type_traits>
 
 #include "kernarg.hpp"
+#include "kernels_direct.hpp"  // SelectArgs, select_one_pod: the sampled pick that rides in this kernel's fill (PICK)
 #include "tile_index.hpp"
 
 // Build-time variants (tools/build_variants.sh builds one library per setting for A/B timing; the shipped library
@@ -82,6 +83,7 @@ struct FusedArgs {
     uint32_t list_col[kMaxListKeys];                 // their label columns
     uint32_t debug;
     uint32_t has_tol;  // tolerations were given (g_ptol is not null)
+    uint32_t pick_ppb, pick_waves;  // PICK: pods whose sampled pick one block carries, and how many of its waves carry them (the others stage)
     uint64_t *trace;  // diagnostics: per-block phase timestamps (100 MHz), or nullptr
 };
 
@@ -118,19 +120,27 @@ typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 
 // LIST: the snapshot keeps some label keys as per-tile sorted lists (high-cardinality keys, tile_index.hpp).  A separate
 // instantiation, so that snapshots without such keys run exactly the code they ran before.
-template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST = false>
+// PICK: the sampled pick of select_node_for_pod (src/main.rs:51-71) rides in this launch: the (chunk, tile) blocks share the
+// batch's pods evenly, and while a block's tile is being staged its first `pick_waves` waves run select_one_pod
+// (kernels_direct.hpp: the drawn candidates tested from the 64-byte node records, exactly what k_select_sampled does) for the
+// block's pods instead of issuing staging pieces -- the pick's chain of dependent memory round trips overlaps the fill, which
+// every block has to sit through anyway, and a step is ONE kernel.  The pick does not read the mask and the mask code below is
+// the same with and without it.
+template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST = false, bool PICK = false>
 __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     const uint64_t *__restrict__ g_tables, const uint64_t *__restrict__ g_aux, const int64_t *__restrict__ g_pcpu,
     const int64_t *__restrict__ g_pmem, const uint32_t *__restrict__ g_psel, const uint64_t *__restrict__ g_ptol,
-    uint64_t *__restrict__ out_feas, uint64_t *__restrict__ out_fit, const uint8_t *__restrict__ g_list, const FusedArgs a) {
+    uint64_t *__restrict__ out_feas, uint64_t *__restrict__ out_fit, const uint8_t *__restrict__ g_list, const FusedArgs a,
+    const SelectArgs sa) {
     static_assert(!LIST || SEL, "list keys only exist with the selector predicate");
-    kernarg_warm<9 * 8 + sizeof(FusedArgs)>();  // the prologue makes four dependent groups of argument loads (kernarg.hpp)
+    static_assert(!PICK || (!LIST && !WANT_FIT), "the pick rides only in the plain mask variants");
+    kernarg_warm<9 * 8 + sizeof(FusedArgs) + (PICK ? sizeof(SelectArgs) : 0)>();  // the prologue makes four dependent groups of argument loads (kernarg.hpp)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t b = blockIdx.x;
     // (chunk, tile) pairs in chunk-major order are dealt to the XCDs in contiguous runs: XCD x = block id % 8
     // (observed dispatch order; speed only) takes pairs [x * run, (x + 1) * run), so the tile-blocks of one
     // pod range sit on one XCD (at most one seam per XCD boundary) and share its L2.
-    uint32_t tile, chunk;
+    uint32_t tile, chunk, lin;  // lin = chunk * tiles + tile: the block's number among the launch's live blocks
     if (!(a.debug & 32u)) {
         const uint32_t l = (b & 7u) * a.run + (b >> 3);
         if ((b >> 3) >= a.run) return;
@@ -140,15 +150,41 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             tile -= a.tiles;
             ++chunk;
         }
+        lin = l;
     } else {  // experiment: plain round-robin of (tile, chunk) pairs
         tile = b % a.tiles;
         chunk = b / a.tiles;
+        lin = chunk * a.tiles + tile;
     }
     if (chunk >= a.chunks) return;
 
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar control flow below
-    const bool tracer = a.trace && threadIdx.x == 0;
+    // PICK: which waves of the block carry the pick (wave-uniform).  Default: the first `pick_waves` (they are launched first, so
+    // the pick's chain of round trips gets a head start); debug bit 0x10000 gives it to the last ones instead (A/B).
+    const uint32_t pick_waves = PICK ? a.pick_waves : 0u;
+    uint32_t tid = threadIdx.x;
+    bool pick_wave = false;
+    if constexpr (PICK) {
+        // The pick runs HERE, ahead of everything the mask code keeps in registers: select_one_pod holds up to five 48-byte
+        // candidates per lane, and next to the main loop's per-lane invariants that would not fit the 128 VGPRs of a 1024-thread
+        // block (it spilled when it sat at the loop's first trip).  The `tid` the rest of the kernel derives its per-lane values
+        // from passes through an asm statement placed after the pick, so none of them can be computed (and live) before it.
+        const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const uint32_t pick_rank = (a.debug & 0x10000u) ? (kFusedWaves - 1u - wave0) : wave0;
+        pick_wave = pick_rank < pick_waves;
+        if (pick_wave) {
+            // this block's share of the batch's pods: [lin * ppb, (lin + 1) * ppb), 64 at a time over the pick waves
+            const uint32_t base = lin * a.pick_ppb;
+            const uint32_t end = min(a.p, base + a.pick_ppb);
+            for (uint32_t pod = base + pick_rank * 64u + (threadIdx.x & 63u); pod < end; pod += pick_waves * 64u)
+                sa.binding[pod] = select_one_pod<5, 1>(sa, pod);  // src/main.rs:53-66: first feasible draw wins, none -> -1
+        }
+        asm volatile("" : "+v"(tid) : : "memory");
+    }
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar control flow below
+    const uint32_t stage_rank = (PICK && !(a.debug & 0x10000u)) ? wave - pick_waves : wave;  // of a staging wave among the staging waves
+    const uint32_t stage_waves = kFusedWaves - pick_waves;
+    const bool tracer = a.trace && tid == 0;
     auto stamp = [&](uint32_t i) {
         if (tracer) a.trace[(size_t)b * 8u + i] = wall_clock64();
     };
@@ -594,18 +630,31 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             // (global_load_lds_dwordx4: per-lane global address, LDS destination = wave-uniform base + lane*16)
             auto stage = [&](const void *gsrc, uint32_t lds_off, uint32_t bytes) {
                 const uint8_t *g = static_cast<const uint8_t *>(gsrc);
-                for (uint32_t off = wave * 1024u; off < bytes; off += kFusedWaves * 1024u) {
+                for (uint32_t off = stage_rank * 1024u; off < bytes; off += stage_waves * 1024u) {
                     if (off + lane * 16u < bytes)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off + lane * 16u),
                                                          (__attribute__((address_space(3))) void *)(lds + lds_off + off), 16, 0, 0);
                 }
             };
-            if (FIT) stage(g_aux + (size_t)tile * kAuxWords, a.off_aux, kAuxWords * 8u);  // needed first (phase 1)
-            if (LIST) stage(g_list + (size_t)tile * a.nlist * kListBytes, a.off_list, a.nlist * kListBytes);
-            if (!(a.debug & 8u)) stage(g_tables + (size_t)tile * a.rows * kTileWords, 0u, a.rows * 128u);
+            if (!pick_wave) {
+                if (FIT) stage(g_aux + (size_t)tile * kAuxWords, a.off_aux, kAuxWords * 8u);  // needed first (phase 1)
+                if (LIST) stage(g_list + (size_t)tile * a.nlist * kListBytes, a.off_list, a.nlist * kListBytes);
+                if (!(a.debug & 8u)) stage(g_tables + (size_t)tile * a.rows * kTileWords, 0u, a.rows * 128u);
+            }
             if (!(a.debug & 128u)) stamp(1);
+            // everything this wave has in flight lands before the barrier: its staging pieces and the first round's operand loads
+            // (a pick wave issues no staging piece whose wait would cover them)
+            if (PICK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (!(a.debug & 128u)) stamp(2);
+            if (a.debug & 0x300000u) {
+                // experiment (debug bits 20 / 21): issue priority by wave quartet (waves w, w+4, w+8, w+12 share a SIMD), so that one
+                // wave per SIMD gets through its first rank searches -- and to its first stores -- ahead of the other three
+                const uint32_t q = wave >> 2;
+                if (q == 0u) __builtin_amdgcn_s_setprio(3);
+                else if (q == 1u) __builtin_amdgcn_s_setprio(2);
+                else if (q == 2u) __builtin_amdgcn_s_setprio(1);
+            }
         }
         if (have_prev) {
             // ============ phase 2 of the previous round: 8 lanes per pod, 2 words per lane ===========
@@ -731,6 +780,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if (!stamped4) stamp(4);
+            if ((a.debug & 0x200000u) && !stamped4) __builtin_amdgcn_s_setprio(0);  // (bit 21: the priority only up to the first stores)
             stamped4 = true;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -792,20 +842,22 @@ struct FusedLaunch {
     const uint64_t *ptol;
     uint64_t *out_feas, *out_fit;
     hipEvent_t ev_start, ev_stop;  // optional: attached to the dispatch itself (exact kernel duration)
+    const SelectArgs *pick;        // the sampled pick that rides in the launch (PICK), or nullptr
 };
 
-template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST>
+template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST, bool PICK = false>
 inline hipError_t launch_fused_k(const FusedLaunch &q, const FusedArgs &a) {
-    auto kern = k_eval_fused<FIT, SEL, TAINT, WANT_FIT, LIST>;
+    auto kern = k_eval_fused<FIT, SEL, TAINT, WANT_FIT, LIST, PICK>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds);
     if (e != hipSuccess) return e;
     const IndexedSnapshot &s = *q.snap;
+    const SelectArgs sa = q.pick ? *q.pick : SelectArgs{};
     if (q.ev_start || q.ev_stop)
         hipExtLaunchKernelGGL(kern, q.grid, dim3(kFusedThreads), q.lds, q.stream, q.ev_start, q.ev_stop, 0, s.d_tables, s.d_aux, q.pcpu,
-                              q.pmem, q.psel, q.ptol, q.out_feas, q.out_fit, (const uint8_t *)s.d_list, a);
+                              q.pmem, q.psel, q.ptol, q.out_feas, q.out_fit, (const uint8_t *)s.d_list, a, sa);
     else
         hipLaunchKernelGGL(kern, q.grid, dim3(kFusedThreads), q.lds, q.stream, s.d_tables, s.d_aux, q.pcpu, q.pmem, q.psel, q.ptol,
-                           q.out_feas, q.out_fit, (const uint8_t *)s.d_list, a);
+                           q.out_feas, q.out_fit, (const uint8_t *)s.d_list, a, sa);
     return hipGetLastError();
 }
 
@@ -814,7 +866,14 @@ inline hipError_t launch_fused_t(bool want_fit, bool list, const FusedLaunch &q,
     if constexpr (SEL) {
         if (list) return want_fit ? launch_fused_k<FIT, SEL, TAINT, true, true>(q, a) : launch_fused_k<FIT, SEL, TAINT, false, true>(q, a);
     }
+    if (q.pick && !want_fit) return launch_fused_k<FIT, SEL, TAINT, false, false, true>(q, a);
     return want_fit ? launch_fused_k<FIT, SEL, TAINT, true, false>(q, a) : launch_fused_k<FIT, SEL, TAINT, false, false>(q, a);
+}
+
+// can this request's sampled pick ride in the fused launch?  (plain variants only: no second mask, no list keys)
+inline bool fused_pick_applicable(const IndexedSnapshot &s, uint32_t flags, bool want_fit, uint32_t p) {
+    const bool list = (flags & KSCHED_SEL) && s.lay.nkeys && s.lay.nlist > 0;
+    return s.built && !want_fit && !list && p < (1u << 31);
 }
 
 inline bool fused_applicable(const IndexedSnapshot &s, uint32_t flags) {
@@ -826,7 +885,7 @@ inline bool fused_applicable(const IndexedSnapshot &s, uint32_t flags) {
 inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                             const uint64_t *ptol, uint32_t flags, uint64_t *out_feas, uint64_t *out_fit, uint32_t pitch, hipStream_t stream,
                             uint32_t debug = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint64_t *trace = nullptr,
-                            uint32_t trace_blocks = 0) {
+                            uint32_t trace_blocks = 0, const SelectArgs *pick = nullptr) {
     const IndexedLayout &l = s.lay;
     FusedArgs a{};
     a.W = l.W;
@@ -860,7 +919,14 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     // more than one round (64 pods) per wave needs.
     const uint32_t blocks_per_cu = std::max(1u, std::min(kLdsBudget / lds, 2048u / kFusedThreads));
     const uint32_t rounds = (a.units + 7u) / 8u;
-    const uint32_t want = (rounds + kFusedWaves - 1u) / kFusedWaves;  // chunks that give every wave one round
+    // chunks that give every wave one round; small batches whose pick rides along are cut finer (a block's time is its fill plus
+    // ONE round either way, and the pick's pods spread over more CUs).  debug bits 18-19: A/B of that divisor (0: default).
+    uint32_t per_block = kFusedWaves;
+    if (pick) per_block = 4u;
+    if (((debug >> 18) & 3u) == 1u) per_block = kFusedWaves;
+    if (((debug >> 18) & 3u) == 2u) per_block = 4u;
+    if (((debug >> 18) & 3u) == 3u) per_block = 1u;
+    const uint32_t want = (rounds + per_block - 1u) / per_block;
     a.chunks = std::max(1u, std::min((256u * blocks_per_cu) / l.tiles, want));
     a.unit_q = a.units / a.chunks;
     a.unit_rem = a.units % a.chunks;
@@ -871,8 +937,13 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     a.trace = (trace && grid.x <= trace_blocks) ? trace : nullptr;
     const bool want_fit = (flags & KSCHED_WANT_FIT_MASK) && out_fit;
     const int sel = do_sel ? 1 : 0, tnt = do_taint ? 1 : 0, fit = do_fit ? 1 : 0;
-    const FusedLaunch q{grid, lds, stream, &s, pcpu, pmem, psel, ptol, out_feas, out_fit, ev_start, ev_stop};
     const bool list = do_sel && l.nlist > 0;
+    if (pick && (want_fit || list)) pick = nullptr;  // (the caller checks fused_pick_applicable first; never a silent drop of the pick)
+    if (pick) {
+        a.pick_ppb = (p + total - 1u) / total;
+        a.pick_waves = std::max(1u, std::min(8u, (a.pick_ppb + 63u) / 64u));
+    }
+    const FusedLaunch q{grid, lds, stream, &s, pcpu, pmem, psel, ptol, out_feas, out_fit, ev_start, ev_stop, pick};
     a.nlist = list ? l.nlist : 0u;
     a.list_mask8 = 0;
     for (uint32_t j = 0; j < a.nlist; ++j) {

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <numeric>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -134,11 +135,14 @@ struct ksched_ctx {
     uint32_t opt_debug = 0;
     bool opt_trace = false;
     bool opt_pick_from_mask = false;
+    bool opt_fused_pick = true;   // KSCHED_OPT_FUSED_PICK: the sampled pick rides in the fused mask launch
+    uint32_t fault_kind = 0, fault_skip = 0;  // KSCHED_OPT_FAULT (test hook of the no-unwind rule)
     int opt_bestfit_stages = 0;  // KSCHED_OPT_BESTFIT_STAGES: 0 auto, 1 one stage, 2 two stages
     int opt_index_build = 0;  // KSCHED_OPT_INDEX_BUILD: 0 = device kernels (default), 1 = host spec (tile_index.hpp)
     DevBuf<uint64_t> trace;
     uint32_t trace_blocks_last = 0;
     const char *last_kernel = "none";
+    const char *last_pick = "none";  // how the latest evaluation's pick ran (ksched_last_pick)
 
     // timing
     struct EvPair {
@@ -149,6 +153,39 @@ struct ksched_ctx {
 };
 
 namespace {
+
+// ---- nothing unwinds across the C ABI (include/ksched.h "Conventions") -----------------------------------------------------
+// Every extern "C" body below is a function-try-block ending in KSCHED_ABI_CATCH: the library's own C++ (std::vector,
+// std::string, std::mutex, rocPRIM) may throw -- std::bad_alloc above all -- and an exception leaving an extern "C" function
+// called from Rust or C is an abort.  bad_alloc -> KSCHED_E_NOMEM, anything else -> KSCHED_E_INVAL, text in ksched_last_error.
+int abi_caught(ksched_ctx *c, int code, const char *what) noexcept {
+    if (c) {
+        try {  // (the body's lock_guard was released by the unwinding)
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->last_error.assign("exception inside the library: ");
+            c->last_error.append(what ? what : "?");
+        } catch (...) {  // no memory for the text either: the code alone has to do
+        }
+    }
+    return code;
+}
+#define KSCHED_ABI_CATCH(CTX)                                                                          \
+    catch (const std::bad_alloc &) { return abi_caught((CTX), KSCHED_E_NOMEM, "std::bad_alloc"); }      \
+    catch (const std::exception &e_) { return abi_caught((CTX), KSCHED_E_INVAL, e_.what()); }           \
+    catch (...) { return abi_caught((CTX), KSCHED_E_INVAL, "unknown exception"); }
+
+// KSCHED_OPT_FAULT: the test hook.  Called (with the ctx's mutex held) at the points where the library's C++ is entered.
+void fault_point(ksched_ctx *c) {
+    if (!c->fault_kind) return;
+    if (c->fault_skip) {
+        --c->fault_skip;
+        return;
+    }
+    const uint32_t kind = c->fault_kind;
+    c->fault_kind = 0;  // one shot
+    if (kind == 1u) throw std::bad_alloc();
+    throw std::runtime_error("injected fault (KSCHED_OPT_FAULT)");
+}
 
 int fail_hip(ksched_ctx *c, hipError_t e, const char *what) {
     char buf[256];
@@ -637,14 +674,28 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         if ((pick_s || pick_b) && out_binding) HIPCHK(c, hipMemsetAsync(out_binding, 0xFF, (size_t)p * sizeof(int32_t), s));
         return KSCHED_OK;
     }
-    // The sampled pick tests only the drawn candidates, from the columns: it does not need the mask, so it goes
-    // first (nothing waits on a mask kernel) and a bindings-only request launches no mask kernel at all.
-    // KSCHED_OPT_PICK_FROM_MASK restores the mask-reading pick (same results; kept as a cross-check).
+    fault_point(c);
+    // kernel choice: fused (one launch over the bitmap index) when the snapshot has an index that fits LDS, else the
+    // always-applicable direct kernel; KSCHED_OPT_KERNEL can force one.
+    const bool want_mask = out_feas || out_fit;
+    const bool can_fused = fused_applicable(c->idx, flags);
+    int kern = c->opt_kernel;
+    if (kern == KSCHED_KERNEL_AUTO) kern = can_fused ? KSCHED_KERNEL_FUSED : KSCHED_KERNEL_DIRECT;
+    // The sampled pick tests only the drawn candidates, from the node records: it does not need the mask.  When a mask is
+    // asked for too and the fused kernel runs, the pick RIDES in that launch (KSCHED_OPT_FUSED_PICK, kernels_fused.hpp "PICK":
+    // a step is one kernel); otherwise it is its own launch, first (nothing waits on a mask kernel), and a bindings-only
+    // request launches no mask kernel at all.  KSCHED_OPT_PICK_FROM_MASK restores the mask-reading pick (a cross-check).
     const bool select_direct = pick_s && !c->opt_pick_from_mask;
-    if (select_direct) {
+    const bool pick_rides = select_direct && want_mask && c->opt_fused_pick && kern == KSCHED_KERNEL_FUSED && can_fused &&
+                            fused_pick_applicable(c->idx, flags, (flags & KSCHED_WANT_FIT_MASK) && out_fit, p);
+    SelectArgs ride{};
+    if (pick_rides) ride = make_select_args(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_binding);
+    c->last_pick = "none";
+    if (select_direct && !pick_rides) {
         int rcs = launch_select(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_binding, s);
         if (rcs) return rcs;
-        if (!out_feas && !out_fit) return KSCHED_OK;
+        c->last_pick = "select";
+        if (!want_mask) return KSCHED_OK;
     }
     // The best-fit pick likewise: from bitmaps kept in best-fit order (k_pick_bestfit_rows), no mask involved.
     const bool bestfit_rows = pick_b && !c->opt_pick_from_mask && c->bf_rows_built;
@@ -742,6 +793,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
             }
         }
         HIPCHK(c, hipGetLastError());
+        c->last_pick = "bestfit-rows";
         if (!out_feas && !out_fit) return KSCHED_OK;
     }
     uint64_t *feas = out_feas;
@@ -751,14 +803,9 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         feas = c->scratch_mask.ptr;
     }
 
-    // kernel choice is needed before timing: the fused kernel carries its events on the dispatch
-    // packet itself (hipExtLaunchKernel), the multi-launch paths are bracketed by stream events.
+    // (the fused kernel carries its timing events on the dispatch packet itself -- hipExtLaunchKernel --, the multi-launch
+    // paths are bracketed by stream events)
     int rc;
-    // kernel choice: fused (one launch over the bitmap index) when the snapshot has an index that
-    // fits LDS, else the always-applicable direct kernel; KSCHED_OPT_KERNEL can force one.
-    const bool can_fused = fused_applicable(c->idx, flags);
-    int kern = c->opt_kernel;
-    if (kern == KSCHED_KERNEL_AUTO) kern = can_fused ? KSCHED_KERNEL_FUSED : KSCHED_KERNEL_DIRECT;
     if (kern == KSCHED_KERNEL_FUSED && !can_fused) {
         c->last_error = "fused kernel not applicable to this snapshot/request: " + (c->index_reason.empty() ? std::string("the bitmap index does not fit LDS") : c->index_reason);
         return KSCHED_E_UNSUPPORTED;
@@ -781,9 +828,10 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         }
         hipError_t e = run_fused(c->idx, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, pitch, s, c->opt_debug,
                                  timed ? c->ev_pool[slot].a : nullptr, timed ? c->ev_pool[slot].b : nullptr,
-                                 c->opt_trace ? c->trace.ptr : nullptr, kTraceBlocks);
+                                 c->opt_trace ? c->trace.ptr : nullptr, kTraceBlocks, pick_rides ? &ride : nullptr);
         if (e != hipSuccess) return fail_hip(c, e, "run_fused");
         c->last_kernel = "fused";
+        if (pick_rides) c->last_pick = "fused";
         rc = KSCHED_OK;
     } else {
         rc = run_direct(c, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, pitch, s);
@@ -791,7 +839,8 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     if (rc) return rc;
     if (timed && kern != KSCHED_KERNEL_FUSED) HIPCHK(c, hipEventRecord(c->ev_pool[slot].b, s));
 
-    if (select_direct || bestfit_rows || !(pick_s || pick_b)) return KSCHED_OK;
+    if (select_direct || bestfit_rows || !(pick_s || pick_b)) return KSCHED_OK;  // (a riding pick is a select_direct one)
+    c->last_pick = "from-mask";
     return launch_pick(c, p, feas, pitch, pmem, samples, attempts, flags, out_binding, s);
 }
 
@@ -837,7 +886,7 @@ const char *ksched_strerror(int code) {
     }
 }
 
-int ksched_create(ksched_ctx **out, int device_id) {
+int ksched_create(ksched_ctx **out, int device_id) try {
     if (!out) return KSCHED_E_INVAL;
     *out = nullptr;
     int count = 0;
@@ -860,9 +909,9 @@ int ksched_create(ksched_ctx **out, int device_id) {
     c->change_stream = c->stream;
     *out = c;
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH(nullptr)
 
-void ksched_destroy(ksched_ctx *c) {
+void ksched_destroy(ksched_ctx *c) try {
     if (!c) return;
     {
         DeviceGuard g(c->device);
@@ -886,14 +935,16 @@ void ksched_destroy(ksched_ctx *c) {
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
+} catch (...) {  // nothing unwinds across the C ABI
 }
 
 const char *ksched_last_error(const ksched_ctx *c) { return c ? c->last_error.c_str() : ""; }
 uint32_t ksched_num_nodes(const ksched_ctx *c) { return (c && c->have_nodes) ? c->n : 0; }
 uint32_t ksched_num_keys(const ksched_ctx *c) { return (c && c->have_nodes) ? c->nkeys : 0; }
 const char *ksched_last_kernel(const ksched_ctx *c) { return c ? c->last_kernel : "none"; }
+const char *ksched_last_pick(const ksched_ctx *c) { return c ? c->last_pick : "none"; }
 
-int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
+int ksched_set_option(ksched_ctx *c, int option, int64_t value) try {
     if (!c) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     switch (option) {
@@ -927,22 +978,31 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) {
             if (value != 0 && value != 1) return KSCHED_E_INVAL;
             c->opt_own_stream = value == 1;
             return KSCHED_OK;
+        case KSCHED_OPT_FUSED_PICK:
+            if (value != 0 && value != 1) return KSCHED_E_INVAL;
+            c->opt_fused_pick = value == 1;
+            return KSCHED_OK;
+        case KSCHED_OPT_FAULT:  // low byte: 0 off, 1 std::bad_alloc, 2 std::runtime_error; bits 8..: fault points to pass first
+            if (value < 0 || (value & 0xFF) > 2 || value > 0xFFFFFF) return KSCHED_E_INVAL;
+            c->fault_kind = (uint32_t)(value & 0xFF);
+            c->fault_skip = (uint32_t)(value >> 8);
+            return KSCHED_OK;
 
         default:
             return KSCHED_E_INVAL;
     }
-}
+} KSCHED_ABI_CATCH(c)
 
-int ksched_forget_stream(ksched_ctx *c, void *hip_stream) {
+int ksched_forget_stream(ksched_ctx *c, void *hip_stream) try {
     if (!c) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     stream_forget(c, (hipStream_t)hip_stream);
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH(c)
 
 int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_t *mem, const uint32_t *lab,
-                     uint32_t n_keys, const uint64_t *taints) {
+                     uint32_t n_keys, const uint64_t *taints) try {
     if (!c) return KSCHED_E_INVAL;
     if (n > 0 && (!cpu || !mem)) return KSCHED_E_INVAL;
     if (n_keys > KSCHED_MAX_KEYS) return KSCHED_E_INVAL;
@@ -962,7 +1022,8 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     if (!g.ok) return KSCHED_E_HIP;
-    c->have_nodes = false;  // stays false if anything below fails: a half-built snapshot is never evaluated
+    c->have_nodes = false;  // stays false if anything below fails (or throws): a half-built snapshot is never evaluated
+    fault_point(c);
     // evaluations already enqueued on the caller's streams read the previous snapshot: the ctx's stream waits for them
     // (events; the host does not)
     if (int rc = snapshot_begin(c)) return rc;
@@ -984,11 +1045,21 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     HIPCHK(c, c->bf_cpu.reserve(n));
     HIPCHK(c, c->cpu_sorted.reserve((size_t)n + 8));
     hipStream_t s = c->change_stream;  // (snapshot_begin chose it)
+    // the per-tile bitmap index: layout on the host (it fixes kernel arguments and LDS sizes), contents on the device
+    IndexedLayout l{};
+    const char *why = "";
+    const bool indexed = indexed_plan(l, n, n_keys, lab_max, all_taints, &why);
+    uint32_t meta[72] = {};
+    if (indexed) indexed_meta(l, meta);
+    // the caller's arrays (and the index's meta words) -> pinned staging -> asynchronous copies on the chosen stream; nothing is
+    // copied from pageable or stack memory, so the call never waits for work already queued on that stream
+    const size_t b_col = (size_t)n * 8, b_lab = (size_t)n * n_keys * 4, b_taint = taints ? b_col : 0, b_meta = indexed ? sizeof meta : 0;
+    const size_t o_meta = 2 * b_col + b_lab + b_taint;
+    uint8_t *h = nullptr;
+    if (n > 0 || b_meta) {
+        if (int rc = stage_reserve(c, o_meta + b_meta, &h)) return rc;
+    }
     if (n > 0) {
-        // the caller's arrays -> pinned staging -> asynchronous copies on the ctx's stream
-        const size_t b_col = (size_t)n * 8, b_lab = (size_t)n * n_keys * 4, b_taint = taints ? b_col : 0;
-        uint8_t *h = nullptr;
-        if (int rc = stage_reserve(c, 2 * b_col + b_lab + b_taint, &h)) return rc;
         memcpy(h, cpu, b_col);
         memcpy(h + b_col, mem, b_col);
         if (b_lab) memcpy(h + 2 * b_col, lab, b_lab);
@@ -997,23 +1068,23 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
         HIPCHK(c, hipMemcpyAsync(c->nmem.ptr, h + b_col, b_col, hipMemcpyHostToDevice, s));
         if (b_lab) HIPCHK(c, hipMemcpyAsync(c->nlab.ptr, h + 2 * b_col, b_lab, hipMemcpyHostToDevice, s));
         if (b_taint) HIPCHK(c, hipMemcpyAsync(c->ntaint.ptr, h + 2 * b_col + b_lab, b_taint, hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipEventRecord(c->ev_stage, s));
+    }
+    if (indexed) {
+        hipError_t e = indexed_reserve(c->idx, l);
+        if (e != hipSuccess) return fail_hip(c, e, "indexed_reserve");
+        memcpy(h + o_meta, meta, b_meta);
+        HIPCHK(c, hipMemcpyAsync(c->idx.d_lab_meta, h + o_meta, b_meta, hipMemcpyHostToDevice, s));
+    }
+    if (h) HIPCHK(c, hipEventRecord(c->ev_stage, s));  // the last copy out of the staging block
+    if (n > 0) {
         hipLaunchKernelGGL(k_build_nrec, dim3((n + 255u) / 256u), dim3(256), 0, s, (const int64_t *)c->ncpu.ptr, (const int64_t *)c->nmem.ptr,
                            taints ? (const uint64_t *)c->ntaint.ptr : nullptr, (const uint32_t *)c->nlab.ptr, n_keys, c->nrec.ptr, n);
         HIPCHK(c, hipGetLastError());
     }
-    // the per-tile bitmap index: layout on the host (it fixes kernel arguments and LDS sizes), contents on the device
-    IndexedLayout l{};
-    const char *why = "";
-    if (indexed_plan(l, n, n_keys, lab_max, all_taints, &why)) {
-        hipError_t e = indexed_reserve(c->idx, l);
-        if (e != hipSuccess) return fail_hip(c, e, "indexed_reserve");
-        uint32_t meta[72];
-        indexed_meta(l, meta);
-        HIPCHK(c, hipMemcpyAsync(c->idx.d_lab_meta, meta, sizeof meta, hipMemcpyHostToDevice, s));  // pageable and small: staged before the call returns
+    if (indexed) {
         c->idx.lay = l;
         if (c->opt_index_build == 1) {
-            e = indexed_build_host(c->idx, l, cpu, mem, lab, taints, s);
+            hipError_t e = indexed_build_host(c->idx, l, cpu, mem, lab, taints, s);
             if (e != hipSuccess) return fail_hip(c, e, "indexed_build_host");
         } else {
             if (int rc = launch_build_named(c)) return rc;
@@ -1028,9 +1099,9 @@ int ksched_set_nodes(ksched_ctx *c, uint32_t n, const int64_t *cpu, const int64_
     if (int rc = snapshot_end(c)) return rc;
     c->have_nodes = true;
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH(c)
 
-int ksched_update_nodes(ksched_ctx *c, uint32_t count, const uint32_t *node_index, const int64_t *cpu, const int64_t *mem) {
+int ksched_update_nodes(ksched_ctx *c, uint32_t count, const uint32_t *node_index, const int64_t *cpu, const int64_t *mem) try {
     if (!c) return KSCHED_E_INVAL;
     if (count > 0 && (!node_index || !cpu || !mem)) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -1040,6 +1111,7 @@ int ksched_update_nodes(ksched_ctx *c, uint32_t count, const uint32_t *node_inde
     if (count == 0) return KSCHED_OK;
     DeviceGuard g(c->device);
     if (!g.ok) return KSCHED_E_HIP;
+    fault_point(c);  // (nothing has changed yet: an exception up to snapshot_begin leaves the snapshot as it was)
     // a node listed twice takes its last values: keep the last occurrence of every index (the patch kernel's threads are unordered)
     std::vector<uint32_t> keep;
     if (count > 1) {
@@ -1113,12 +1185,12 @@ int ksched_update_nodes(ksched_ctx *c, uint32_t count, const uint32_t *node_inde
     c->bf_dirty = true;  // the best-fit order is rebuilt by the next PICK_BESTFIT request, not here
     if (int rc = snapshot_end(c)) return fail(rc);
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH(c)
 
 int ksched_eval_device_pitched(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                                const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags,
                                uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, uint32_t mask_pitch_words,
-                               void *hip_stream) {
+                               void *hip_stream) try {
     if (!c) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->have_nodes) return KSCHED_E_STATE;
@@ -1129,14 +1201,14 @@ int ksched_eval_device_pitched(ksched_ctx *c, uint32_t p, const int64_t *pcpu, c
     if (!g.ok) return KSCHED_E_HIP;
     return eval_on_device(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_feas, out_fit, out_binding,
                           mask_pitch_words, (hipStream_t)hip_stream);
-}
+} KSCHED_ABI_CATCH(c)
 
 int ksched_eval_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                        const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags,
-                       uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, void *hip_stream) {
+                       uint64_t *out_feas, uint64_t *out_fit, int32_t *out_binding, void *hip_stream) try {
     return ksched_eval_device_pitched(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_feas, out_fit, out_binding,
                                       ksched_mask_words(ksched_num_nodes(c)), hip_stream);
-}
+} KSCHED_ABI_CATCH(c)
 
 uint32_t ksched_mask_pitch(uint32_t n_nodes) { return (ksched_mask_words(n_nodes) + 15u) & ~15u; }
 
@@ -1147,7 +1219,7 @@ struct ksched_pipe {
     std::vector<hipEvent_t> mask_done, pick_done;
 };
 
-int ksched_pipe_create(ksched_ctx *c, uint32_t depth, ksched_pipe **out) {
+int ksched_pipe_create(ksched_ctx *c, uint32_t depth, ksched_pipe **out) try {
     if (!c || !out || depth == 0 || depth > 16) return KSCHED_E_INVAL;
     *out = nullptr;
     DeviceGuard g(c->device);
@@ -1169,9 +1241,9 @@ int ksched_pipe_create(ksched_ctx *c, uint32_t depth, ksched_pipe **out) {
     }
     *out = q;
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH(c)
 
-void ksched_pipe_destroy(ksched_pipe *q) {
+void ksched_pipe_destroy(ksched_pipe *q) try {
     if (!q) return;
     {
         DeviceGuard g(q->ctx->device);
@@ -1188,13 +1260,14 @@ void ksched_pipe_destroy(ksched_pipe *q) {
         if (q->s_pick) (void)hipStreamDestroy(q->s_pick);
     }
     delete q;
+} catch (...) {  // nothing unwinds across the C ABI
 }
 
 void *ksched_pipe_stream(ksched_pipe *q, int which) { return q ? (void *)(which == 0 ? q->s_mask : q->s_pick) : nullptr; }
 
 int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                        const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, uint64_t *mask,
-                       uint32_t mask_pitch_words, int32_t *binding) {
+                       uint32_t mask_pitch_words, int32_t *binding) try {
     if (!q || slot >= q->depth) return KSCHED_E_INVAL;
     ksched_ctx *c = q->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -1228,9 +1301,9 @@ int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t 
     }
     HIPCHK(c, hipEventRecord(q->pick_done[slot], q->s_pick));
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH((q ? q->ctx : nullptr))
 
-int ksched_pipe_wait(ksched_pipe *q, uint32_t slot, void *hip_stream) {
+int ksched_pipe_wait(ksched_pipe *q, uint32_t slot, void *hip_stream) try {
     if (!q || slot >= q->depth) return KSCHED_E_INVAL;
     ksched_ctx *c = q->ctx;
     DeviceGuard g(c->device);
@@ -1238,9 +1311,9 @@ int ksched_pipe_wait(ksched_pipe *q, uint32_t slot, void *hip_stream) {
     if (hip_stream) HIPCHK(c, hipStreamWaitEvent((hipStream_t)hip_stream, q->pick_done[slot], 0));
     else HIPCHK(c, hipEventSynchronize(q->pick_done[slot]));
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH((q ? q->ctx : nullptr))
 
-int ksched_pipe_wait_mask(ksched_pipe *q, uint32_t slot, void *hip_stream) {
+int ksched_pipe_wait_mask(ksched_pipe *q, uint32_t slot, void *hip_stream) try {
     if (!q || slot >= q->depth) return KSCHED_E_INVAL;
     ksched_ctx *c = q->ctx;
     std::lock_guard<std::mutex> lk(c->mu);  // (ksched_pipe_submit records the same events)
@@ -1252,10 +1325,10 @@ int ksched_pipe_wait_mask(ksched_pipe *q, uint32_t slot, void *hip_stream) {
     if (hip_stream) HIPCHK(c, hipStreamWaitEvent((hipStream_t)hip_stream, q->mask_done[slot], 0));
     else HIPCHK(c, hipEventSynchronize(q->mask_done[slot]));
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH((q ? q->ctx : nullptr))
 
 int ksched_pick_device(ksched_ctx *c, uint32_t p, const uint64_t *feasible, uint32_t mask_pitch_words, const int64_t *req_mem_bytes,
-                       const uint32_t *samples, uint32_t attempts, uint32_t flags, int32_t *out_binding, void *hip_stream) {
+                       const uint32_t *samples, uint32_t attempts, uint32_t flags, int32_t *out_binding, void *hip_stream) try {
     if (!c) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->have_nodes) return KSCHED_E_STATE;
@@ -1273,11 +1346,11 @@ int ksched_pick_device(ksched_ctx *c, uint32_t p, const uint64_t *feasible, uint
         return KSCHED_OK;
     }
     return launch_pick(c, p, feasible, mask_pitch_words, req_mem_bytes, samples, attempts, flags, out_binding, s);
-}
+} KSCHED_ABI_CATCH(c)
 
 int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                 const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, uint64_t *out_feas,
-                uint64_t *out_fit, int32_t *out_binding) {
+                uint64_t *out_fit, int32_t *out_binding) try {
     if (!c) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->have_nodes) return KSCHED_E_STATE;
@@ -1337,9 +1410,9 @@ int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *p
     if (pick && out_binding) HIPCHK(c, hipMemcpyAsync(out_binding, d_bind, (size_t)p * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH(c)
 
-int ksched_reason(const uint64_t *feasible_row, const uint64_t *fit_row, uint32_t node, uint32_t flags) {
+int ksched_reason(const uint64_t *feasible_row, const uint64_t *fit_row, uint32_t node, uint32_t flags) try {
     if (!feasible_row) return KSCHED_E_INVAL;
     const uint32_t w = node >> 6, b = node & 63u;
     if ((feasible_row[w] >> b) & 1ull) return KSCHED_REASON_OK;
@@ -1349,10 +1422,10 @@ int ksched_reason(const uint64_t *feasible_row, const uint64_t *fit_row, uint32_
     if ((flags & KSCHED_TAINT) && !(flags & KSCHED_SEL)) return KSCHED_REASON_TAINT_NOT_TOLERATED;
     // both extension and selector active: the two masks cannot tell them apart
     return KSCHED_REASON_NODE_SELECTOR_MISMATCH;
-}
+} KSCHED_ABI_CATCH(nullptr)
 
 int ksched_explain(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel, const uint64_t *ptol,
-                   uint32_t count, const uint32_t *pair_pod, const uint32_t *pair_node, uint32_t flags, int32_t *out_reason) {
+                   uint32_t count, const uint32_t *pair_pod, const uint32_t *pair_node, uint32_t flags, int32_t *out_reason) try {
     if (!c) return KSCHED_E_INVAL;
     if (flags & ~(KSCHED_FIT | KSCHED_SEL | KSCHED_TAINT)) return KSCHED_E_INVAL;
     if (count > 0 && (!pair_pod || !pair_node || !out_reason)) return KSCHED_E_INVAL;
@@ -1364,6 +1437,7 @@ int ksched_explain(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     if (count == 0) return KSCHED_OK;
     DeviceGuard g(c->device);
     if (!g.ok) return KSCHED_E_HIP;
+    fault_point(c);
     hipStream_t s = c->stream;
     if (int rce = stream_enter(c, s)) return rce;  // behind the latest snapshot change, whichever stream carried it
     const bool use_fit = flags & KSCHED_FIT;
@@ -1409,7 +1483,7 @@ int ksched_explain(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     HIPCHK(c, hipMemcpyAsync(out_reason, c->xreason.ptr, (size_t)count * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH(c)
 
 // ---- multi-GPU: RCCL all-gather of the bindings (comm_rccl.hpp) --------------------------------------------------
 
@@ -1430,11 +1504,22 @@ int comm_unavailable() {
     g_comm_error = rccl_api().error;
     return KSCHED_E_RCCL;
 }
+int comm_caught(int code, const char *what) noexcept {
+    try {
+        g_comm_error = std::string("exception inside the library: ") + (what ? what : "?");
+    } catch (...) {
+    }
+    return code;
+}
+#define KSCHED_ABI_CATCH_COMM                                                                 \
+    catch (const std::bad_alloc &) { return comm_caught(KSCHED_E_NOMEM, "std::bad_alloc"); }  \
+    catch (const std::exception &e_) { return comm_caught(KSCHED_E_INVAL, e_.what()); }        \
+    catch (...) { return comm_caught(KSCHED_E_INVAL, "unknown exception"); }
 }  // namespace
 
 const char *ksched_comm_last_error(void) { return g_comm_error.c_str(); }
 
-int ksched_comm_unique_id(uint8_t *id) {
+int ksched_comm_unique_id(uint8_t *id) try {
     if (!id) return KSCHED_E_INVAL;
     RcclApi &api = rccl_api();
     if (!api.ok) return comm_unavailable();
@@ -1444,9 +1529,9 @@ int ksched_comm_unique_id(uint8_t *id) {
     if (r != ncclSuccess) return comm_fail("ncclGetUniqueId", r);
     memcpy(id, &u, sizeof u);
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH_COMM
 
-int ksched_comm_create(ksched_ctx *c, const uint8_t *id, int rank, int nranks, ksched_comm **out) {
+int ksched_comm_create(ksched_ctx *c, const uint8_t *id, int rank, int nranks, ksched_comm **out) try {
     if (!c || !id || !out || nranks <= 0 || rank < 0 || rank >= nranks) return KSCHED_E_INVAL;
     *out = nullptr;
     RcclApi &api = rccl_api();
@@ -1467,9 +1552,9 @@ int ksched_comm_create(ksched_ctx *c, const uint8_t *id, int rank, int nranks, k
     q->nranks = nranks;
     *out = q;
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH_COMM
 
-int ksched_comm_create_local(ksched_ctx *const *ctxs, int n, ksched_comm **out) {
+int ksched_comm_create_local(ksched_ctx *const *ctxs, int n, ksched_comm **out) try {
     if (!ctxs || !out || n <= 0 || n > 64) return KSCHED_E_INVAL;
     for (int i = 0; i < n; ++i) {
         out[i] = nullptr;
@@ -1499,9 +1584,9 @@ int ksched_comm_create_local(ksched_ctx *const *ctxs, int n, ksched_comm **out) 
         out[i] = q;
     }
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH_COMM
 
-void ksched_comm_destroy(ksched_comm *q) {
+void ksched_comm_destroy(ksched_comm *q) try {
     if (!q) return;
     RcclApi &api = rccl_api();
     if (api.ok && q->comm) {
@@ -1509,12 +1594,13 @@ void ksched_comm_destroy(ksched_comm *q) {
         (void)api.CommDestroy(q->comm);
     }
     delete q;
+} catch (...) {  // nothing unwinds across the C ABI
 }
 
 int ksched_comm_rank(const ksched_comm *q) { return q ? q->rank : -1; }
 int ksched_comm_size(const ksched_comm *q) { return q ? q->nranks : 0; }
 
-int ksched_allgather_bindings(ksched_comm *q, const int32_t *local, int32_t *gathered, uint32_t count_per_rank, void *hip_stream) {
+int ksched_allgather_bindings(ksched_comm *q, const int32_t *local, int32_t *gathered, uint32_t count_per_rank, void *hip_stream) try {
     if (!q || !q->comm) return KSCHED_E_INVAL;
     if (count_per_rank > 0 && (!local || !gathered)) return KSCHED_E_INVAL;
     if (count_per_rank == 0) return KSCHED_OK;
@@ -1524,10 +1610,10 @@ int ksched_allgather_bindings(ksched_comm *q, const int32_t *local, int32_t *gat
     if (!g.ok) return KSCHED_E_HIP;
     ncclResult_t r = api.AllGather(local, gathered, count_per_rank, ncclInt32, q->comm, (hipStream_t)hip_stream);
     return r == ncclSuccess ? KSCHED_OK : comm_fail("ncclAllGather", r);
-}
+} KSCHED_ABI_CATCH_COMM
 
 int ksched_allgather_bindings_local(ksched_comm *const *comms, int n, const int32_t *const *local, int32_t *const *gathered,
-                                    uint32_t count_per_rank, void *const *hip_streams) {
+                                    uint32_t count_per_rank, void *const *hip_streams) try {
     if (!comms || n <= 0 || !local || !gathered) return KSCHED_E_INVAL;
     for (int i = 0; i < n; ++i)
         if (!comms[i] || !comms[i]->comm || (count_per_rank > 0 && (!local[i] || !gathered[i]))) return KSCHED_E_INVAL;
@@ -1546,15 +1632,16 @@ int ksched_allgather_bindings_local(ksched_comm *const *comms, int n, const int3
     r = api.GroupEnd();
     if (first != ncclSuccess) return comm_fail("ncclAllGather", first);
     return r == ncclSuccess ? KSCHED_OK : comm_fail("ncclGroupEnd", r);
-}
+} KSCHED_ABI_CATCH_COMM
 
-int ksched_index_checksum(ksched_ctx *c, uint64_t *out) {
+int ksched_index_checksum(ksched_ctx *c, uint64_t *out) try {
     if (!c || !out) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->have_nodes) return KSCHED_E_STATE;
     out[0] = out[1] = 0;
     if (!c->idx.built) return KSCHED_OK;
     DeviceGuard g(c->device);
+    fault_point(c);
     const IndexedLayout &l = c->idx.lay;
     std::vector<uint64_t> tab((size_t)l.tiles * l.rows * kTileWords), aux((size_t)l.tiles * kAuxWords);
     HIPCHK(c, hipEventSynchronize(c->ev_build));  // the latest snapshot change, whichever stream carried it
@@ -1574,9 +1661,9 @@ int ksched_index_checksum(ksched_ctx *c, uint64_t *out) {
     out[0] = fnv(tab);
     out[1] = fnv(aux) ^ (lists.empty() ? 0ull : fnv(lists) * 0x9E3779B97F4A7C15ull);
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH(c)
 
-int ksched_trace_read(ksched_ctx *c, uint64_t *out, uint32_t max_blocks) {
+int ksched_trace_read(ksched_ctx *c, uint64_t *out, uint32_t max_blocks) try {
     if (!c || !out) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->trace.ptr) return 0;
@@ -1585,9 +1672,9 @@ int ksched_trace_read(ksched_ctx *c, uint64_t *out, uint32_t max_blocks) {
     const uint32_t nb = std::min<uint32_t>(max_blocks, 8192u);
     HIPCHK(c, hipMemcpy(out, c->trace.ptr, (size_t)nb * KSCHED_TRACE_WORDS * 8, hipMemcpyDeviceToHost));
     return (int)nb;
-}
+} KSCHED_ABI_CATCH(c)
 
-int ksched_kernel_time_ms(ksched_ctx *c, double *total_ms, uint64_t *launches) {
+int ksched_kernel_time_ms(ksched_ctx *c, double *total_ms, uint64_t *launches) try {
     if (!c) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -1602,9 +1689,9 @@ int ksched_kernel_time_ms(ksched_ctx *c, double *total_ms, uint64_t *launches) {
     if (launches) *launches = c->ev_used;
     c->ev_used = 0;
     return KSCHED_OK;
-}
+} KSCHED_ABI_CATCH(c)
 
-int ksched_kernel_time_samples(ksched_ctx *c, double *out_ms, uint32_t cap) {
+int ksched_kernel_time_samples(ksched_ctx *c, double *out_ms, uint32_t cap) try {
     if (!c || (cap > 0 && !out_ms)) return KSCHED_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -1617,6 +1704,6 @@ int ksched_kernel_time_samples(ksched_ctx *c, double *out_ms, uint32_t cap) {
     }
     c->ev_used = 0;
     return (int)n;
-}
+} KSCHED_ABI_CATCH(c)
 
 }  // extern "C"

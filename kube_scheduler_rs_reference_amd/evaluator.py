@@ -129,6 +129,11 @@ class Evaluator:
         return self._lib.ksched_last_kernel(self._h).decode()
 
     @property
+    def last_pick(self) -> str:
+        """How the latest evaluation's pick ran: "fused" (inside the mask launch), "select", "bestfit-rows", "from-mask", "none"."""
+        return self._lib.ksched_last_pick(self._h).decode()
+
+    @property
     def W(self) -> int:
         return mask_words(self.n)
 
@@ -242,15 +247,16 @@ class Evaluator:
 
     def bind_eval_device(self, req_cpu_milli, req_mem_bytes, sel_val_ids=None, tolerations=None, samples=None, flags: int = L.FIT,
                          out_feasible=None, out_fit=None, out_bindings=(), stream=None):
-        """Pre-marshal eval_device for a steady-state loop whose inputs stay in place: validates once (through eval_device's
-        own checks on the first binding buffer) and returns run(i) that enqueues the evaluation writing out_bindings[i].
-        Saves the per-call tensor checks and pointer conversions (tens of microseconds of Python per step)."""
+        """Pre-marshal eval_device for a steady-state loop whose inputs stay in place: validates once and returns run(i, m=0)
+        that enqueues the evaluation writing out_bindings[i] (and, when `out_feasible` is a LIST of equally shaped masks, the
+        mask out_feasible[m]: a loop can rotate its output over several buffers).  Saves the per-call tensor checks and pointer
+        conversions (tens of microseconds of Python per step)."""
         import torch
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
         p, W = int(req_cpu_milli.shape[0]), self.W
         outs = list(out_bindings) or [None]
-        # one checked call's worth of validation, without launching anything: reuse eval_device's argument checks
+        masks = list(out_feasible) if isinstance(out_feasible, (list, tuple)) else [out_feasible]
         for t, dt in ((req_cpu_milli, (torch.int64,)), (req_mem_bytes, (torch.int64,))):
             if not t.is_cuda or t.device.index != self.device or not t.is_contiguous() or t.dtype not in dt or tuple(t.shape) != (p,):
                 raise ValueError("bind_eval_device: request columns must be contiguous int64 [p] CUDA tensors on this device")
@@ -259,22 +265,27 @@ class Evaluator:
         for b in outs:
             if b is not None and (b.dtype != torch.int32 or tuple(b.shape) != (p,) or not b.is_contiguous()):
                 raise ValueError("out_bindings must be contiguous int32 [p] CUDA tensors")
-        pitch = W
-        for m in (out_feasible, out_fit):
+        pitch = None
+        for m in masks + [out_fit]:
             if m is not None:
                 if tuple(m.shape) != (p, W) or (W and m.stride(1) != 1):
                     raise ValueError(f"mask must be a [{p}, {W}] view with unit column stride")
-                pitch = int(m.stride(0)) if p > 1 else W
+                mp = int(m.stride(0)) if p > 1 else W
+                if pitch is not None and mp != pitch:
+                    raise ValueError("every mask of one bound evaluation must have the same row pitch")
+                pitch = mp
+        if pitch is None:
+            pitch = W
         attempts = _attempts(samples, flags, p)
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        head = (self._h, p, ptr(req_cpu_milli), ptr(req_mem_bytes), ptr(sel_val_ids), ptr(tolerations), ptr(samples), attempts, flags,
-                ptr(out_feasible), ptr(out_fit))
+        head = (self._h, p, ptr(req_cpu_milli), ptr(req_mem_bytes), ptr(sel_val_ids), ptr(tolerations), ptr(samples), attempts, flags)
+        mids = [(ptr(m), ptr(out_fit)) for m in masks]
         tails = [(ptr(b), pitch, C.c_void_p(stream.cuda_stream)) for b in outs]
-        keep = (req_cpu_milli, req_mem_bytes, sel_val_ids, tolerations, samples, out_feasible, out_fit, outs)
+        keep = (req_cpu_milli, req_mem_bytes, sel_val_ids, tolerations, samples, masks, out_fit, outs)
         fn, check = self._lib.ksched_eval_device_pitched, self._check
 
-        def run(i: int = 0, _keep=keep):
-            rc = fn(*head, *tails[i])
+        def run(i: int = 0, m: int = 0, _keep=keep):
+            rc = fn(*head, *mids[m], *tails[i])
             if rc:
                 check(rc, "ksched_eval_device_pitched")
         return run

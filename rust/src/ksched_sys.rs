@@ -17,7 +17,7 @@ pub struct ksched_comm {
     _private: [u8; 0],
 }
 
-pub const KSCHED_ABI_VERSION: u32 = 2;
+pub const KSCHED_ABI_VERSION: u32 = 3;
 pub const KSCHED_MAX_KEYS: u32 = 32;
 pub const KSCHED_MAX_ATTEMPTS: u32 = 64;
 pub const KSCHED_SEL_NEVER: u32 = 0xFFFF_FFFF;
@@ -52,6 +52,8 @@ pub const KSCHED_OPT_PICK_FROM_MASK: c_int = 5;
 pub const KSCHED_OPT_INDEX_BUILD: c_int = 6;
 pub const KSCHED_OPT_BESTFIT_STAGES: c_int = 7;
 pub const KSCHED_OPT_SNAPSHOT_STREAM: c_int = 8;
+pub const KSCHED_OPT_FUSED_PICK: c_int = 9;
+pub const KSCHED_OPT_FAULT: c_int = 10;
 
 extern "C" {
     // ---- lifetime
@@ -132,4 +134,5 @@ extern "C" {
     pub fn ksched_index_checksum(ctx: *mut ksched_ctx, out: *mut u64) -> c_int;
     pub fn ksched_trace_read(ctx: *mut ksched_ctx, out: *mut u64, max_blocks: u32) -> c_int;
     pub fn ksched_last_kernel(ctx: *const ksched_ctx) -> *const c_char;
+    pub fn ksched_last_pick(ctx: *const ksched_ctx) -> *const c_char;
 }

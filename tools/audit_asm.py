@@ -4,8 +4,8 @@
 The kernel loads its per-pod operands with inline-asm global loads that the compiler's s_waitcnt
 bookkeeping does not see, and waits for them with a hand-counted `s_waitcnt vmcnt(N)` statement
 (kernels_fused.hpp, "pod operands").  That is only sound if, for every instantiation,
-  1. no VGPR is spilled and no scratch is used (a spill could move an operand register before
-     its data has landed),
+  1. no VGPR is spilled and no scratch instruction is issued (a spill could move an operand register
+     before its data has landed),
   2. no instruction between an operand load and the counted wait reads or writes the load's
      destination registers (no compiler copy of a register that is still in flight),
   3. exactly the expected number of vector-memory instructions sits between the last operand
@@ -63,8 +63,11 @@ def audit_kernel(name: str, lines: list[str], meta: dict) -> list[str]:
     errs = []
     if meta.get("vgpr_spill", 0):
         errs.append(f"vgpr_spill_count = {meta['vgpr_spill']}")
-    if meta.get("scratch", 0):
-        errs.append(f"private_segment_fixed_size = {meta['scratch']}")
+    # scratch: a frame the back end reserved but never touches (SGPR-spill bookkeeping: seen as 36 bytes in the PICK variants
+    # without SEL) moves no register; any scratch / buffer instruction in the body does
+    scratch_ops = [ln.strip() for ln in lines if re.match(r"\s*(scratch_|buffer_(load|store))", ln)]
+    if meta.get("scratch", 0) and scratch_ops:
+        errs.append(f"private_segment_fixed_size = {meta['scratch']} with {len(scratch_ops)} scratch instructions, e.g. {scratch_ops[0]}")
     # collect asm statements
     in_asm = False
     loads, waits = [], []  # (line index, dest regs) / (line index, n)
