@@ -126,6 +126,12 @@ extern "C" {
  * next one throws inside the call -- kind 1: std::bad_alloc, kind 2: std::runtime_error -- once.  That call must come back with
  * KSCHED_E_NOMEM / KSCHED_E_INVAL and ksched_last_error set; the process must not terminate.  0 = off (default). */
 #define KSCHED_OPT_FAULT 10
+/* KSCHED_OPT_PIPE_MODE: how ksched_pipe_submit spreads a batch over the pipe's two streams.  0 (default) = split: the mask kernel
+ * on the mask stream, the pick (and whatever the caller enqueues behind it, e.g. the all-gather of the bindings) on the pick
+ * stream.  1 = alternate: the WHOLE evaluation of a slot -- one launch when the pick rides in the mask kernel -- goes onto stream
+ * (slot mod 2): consecutive batches overlap at their edges (the next launch's blocks fill while the previous one's last blocks
+ * still store).  Same results either way; ksched_pipe_wait / ksched_pipe_wait_mask order a consumer behind the slot's work. */
+#define KSCHED_OPT_PIPE_MODE 11
 
 typedef struct ksched_ctx ksched_ctx;
 

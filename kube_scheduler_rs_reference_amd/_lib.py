@@ -52,6 +52,7 @@ OPT_BESTFIT_STAGES = 7
 OPT_SNAPSHOT_STREAM = 8
 OPT_FUSED_PICK = 9
 OPT_FAULT = 10
+OPT_PIPE_MODE = 11
 TRACE_WORDS = 8
 KERNEL_AUTO = 0
 KERNEL_DIRECT = 1

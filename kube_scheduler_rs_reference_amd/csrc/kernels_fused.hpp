@@ -172,11 +172,14 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         const uint32_t pick_rank = (a.debug & 0x10000u) ? (kFusedWaves - 1u - wave0) : wave0;
         pick_wave = pick_rank < pick_waves;
         if (pick_wave) {
+            const uint64_t t_in = (a.trace && threadIdx.x == 0u) ? wall_clock64() : 0ull;  // diagnostics (KSCHED_OPT_TRACE)
             // this block's share of the batch's pods: [lin * ppb, (lin + 1) * ppb), 64 at a time over the pick waves
             const uint32_t base = lin * a.pick_ppb;
             const uint32_t end = min(a.p, base + a.pick_ppb);
             for (uint32_t pod = base + pick_rank * 64u + (threadIdx.x & 63u); pod < end; pod += pick_waves * 64u)
                 sa.binding[pod] = select_one_pod<5, 1>(sa, pod);  // src/main.rs:53-66: first feasible draw wins, none -> -1
+            if (a.trace && threadIdx.x == 0u)  // trace word 7, bits 8..: wave 0's entry -> its picks issued, in 10 ns ticks (bits 0..7: XCC id)
+                atomicOr((unsigned long long *)&a.trace[(size_t)b * 8u + 7u], (unsigned long long)((wall_clock64() - t_in) << 8));
         }
         asm volatile("" : "+v"(tid) : : "memory");
     }
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar control flow below
     const uint32_t stage_rank = (PICK && !(a.debug & 0x10000u)) ? wave - pick_waves : wave;  // of a staging wave among the staging waves
     const uint32_t stage_waves = kFusedWaves - pick_waves;
-    const bool tracer = a.trace && tid == 0;
+    const bool tracer = a.trace && tid == (PICK ? (kFusedWaves - 1u) * 64u : 0u);  // (PICK: wave 0 carries picks; trace a staging wave)
     auto stamp = [&](uint32_t i) {
         if (tracer) a.trace[(size_t)b * 8u + i] = wall_clock64();
     };
@@ -647,14 +650,6 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             if (PICK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (!(a.debug & 128u)) stamp(2);
-            if (a.debug & 0x300000u) {
-                // experiment (debug bits 20 / 21): issue priority by wave quartet (waves w, w+4, w+8, w+12 share a SIMD), so that one
-                // wave per SIMD gets through its first rank searches -- and to its first stores -- ahead of the other three
-                const uint32_t q = wave >> 2;
-                if (q == 0u) __builtin_amdgcn_s_setprio(3);
-                else if (q == 1u) __builtin_amdgcn_s_setprio(2);
-                else if (q == 2u) __builtin_amdgcn_s_setprio(1);
-            }
         }
         if (have_prev) {
             // ============ phase 2 of the previous round: 8 lanes per pod, 2 words per lane ===========
@@ -780,7 +775,6 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if (!stamped4) stamp(4);
-            if ((a.debug & 0x200000u) && !stamped4) __builtin_amdgcn_s_setprio(0);  // (bit 21: the priority only up to the first stores)
             stamped4 = true;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -828,7 +822,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     if (tracer) {
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        a.trace[(size_t)b * 8u + 7u] = xcc;
+        atomicOr((unsigned long long *)&a.trace[(size_t)b * 8u + 7u], (unsigned long long)(xcc & 0xFFu));
     }
 }
 

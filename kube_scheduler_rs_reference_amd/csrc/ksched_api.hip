@@ -136,6 +136,7 @@ struct ksched_ctx {
     bool opt_trace = false;
     bool opt_pick_from_mask = false;
     bool opt_fused_pick = true;   // KSCHED_OPT_FUSED_PICK: the sampled pick rides in the fused mask launch
+    int opt_pipe_mode = 0;        // KSCHED_OPT_PIPE_MODE: 0 split (mask stream / pick stream), 1 alternate (whole steps, stream = slot % 2)
     uint32_t fault_kind = 0, fault_skip = 0;  // KSCHED_OPT_FAULT (test hook of the no-unwind rule)
     int opt_bestfit_stages = 0;  // KSCHED_OPT_BESTFIT_STAGES: 0 auto, 1 one stage, 2 two stages
     int opt_index_build = 0;  // KSCHED_OPT_INDEX_BUILD: 0 = device kernels (default), 1 = host spec (tile_index.hpp)
@@ -982,6 +983,10 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) try {
             if (value != 0 && value != 1) return KSCHED_E_INVAL;
             c->opt_fused_pick = value == 1;
             return KSCHED_OK;
+        case KSCHED_OPT_PIPE_MODE:
+            if (value != 0 && value != 1) return KSCHED_E_INVAL;
+            c->opt_pipe_mode = (int)value;
+            return KSCHED_OK;
         case KSCHED_OPT_FAULT:  // low byte: 0 off, 1 std::bad_alloc, 2 std::runtime_error; bits 8..: fault points to pass first
             if (value < 0 || (value & 0xFF) > 2 || value > 0xFFFFFF) return KSCHED_E_INVAL;
             c->fault_kind = (uint32_t)(value & 0xFF);
@@ -1217,6 +1222,7 @@ struct ksched_pipe {
     uint32_t depth = 0;
     hipStream_t s_mask = nullptr, s_pick = nullptr;
     std::vector<hipEvent_t> mask_done, pick_done;
+    std::vector<hipStream_t> slot_stream;  // the stream that carries the slot's mask kernel (alternate mode: also its pick)
 };
 
 int ksched_pipe_create(ksched_ctx *c, uint32_t depth, ksched_pipe **out) try {
@@ -1230,6 +1236,7 @@ int ksched_pipe_create(ksched_ctx *c, uint32_t depth, ksched_pipe **out) try {
     q->depth = depth;
     bool ok = hipStreamCreateWithFlags(&q->s_mask, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&q->s_pick, hipStreamNonBlocking) == hipSuccess;
+    q->slot_stream.assign(depth, nullptr);
     for (uint32_t i = 0; ok && i < 2 * depth; ++i) {
         hipEvent_t e;
         ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -1283,7 +1290,18 @@ int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t 
     // best fit: bitmaps kept in best-fit order), so the two streams need no ordering at all: each is in order by itself
     // (mask kernels of successive batches on one, picks on the other), which also covers the reuse of a slot's buffers.
     const bool pick_reads_mask = c->opt_pick_from_mask || ((pick & KSCHED_PICK_BESTFIT) && !bf_rows_expected(c));
+    if (c->opt_pipe_mode == 1 && !pick_reads_mask) {
+        // alternate: the whole evaluation of the slot on one of the two streams (ONE launch when the pick rides in the mask
+        // kernel); a slot always comes back to the same stream, so the reuse of its buffers is ordered by the stream itself
+        hipStream_t st = (slot & 1u) ? q->s_pick : q->s_mask;
+        q->slot_stream[slot] = st;
+        rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, mask, nullptr, binding, mask_pitch_words, st);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(q->pick_done[slot], st));
+        return KSCHED_OK;
+    }
     hipStream_t sm = q->s_mask;
+    q->slot_stream[slot] = sm;
     if (pick_reads_mask) HIPCHK(c, hipStreamWaitEvent(sm, q->pick_done[slot], 0));  // the slot's mask may be overwritten once its pick has run
     rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, nullptr, 0, flags & ~pick, mask, nullptr, nullptr, mask_pitch_words, sm);
     if (rc) return rc;
@@ -1321,7 +1339,7 @@ int ksched_pipe_wait_mask(ksched_pipe *q, uint32_t slot, void *hip_stream) try {
     if (!g.ok) return KSCHED_E_HIP;
     // The mask stream is in order: "everything enqueued on it so far" contains the slot's latest mask kernel.  Recorded here, on
     // demand, so that the submit path carries no event for consumers that never read the masks.
-    HIPCHK(c, hipEventRecord(q->mask_done[slot], q->s_mask));
+    HIPCHK(c, hipEventRecord(q->mask_done[slot], q->slot_stream[slot] ? q->slot_stream[slot] : q->s_mask));
     if (hip_stream) HIPCHK(c, hipStreamWaitEvent((hipStream_t)hip_stream, q->mask_done[slot], 0));
     else HIPCHK(c, hipEventSynchronize(q->mask_done[slot]));
     return KSCHED_OK;

@@ -54,6 +54,7 @@ pub const KSCHED_OPT_BESTFIT_STAGES: c_int = 7;
 pub const KSCHED_OPT_SNAPSHOT_STREAM: c_int = 8;
 pub const KSCHED_OPT_FUSED_PICK: c_int = 9;
 pub const KSCHED_OPT_FAULT: c_int = 10;
+pub const KSCHED_OPT_PIPE_MODE: c_int = 11;
 
 extern "C" {
     // ---- lifetime

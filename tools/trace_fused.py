@@ -11,7 +11,7 @@ from bench import WORKLOADS
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="C3"); ap.add_argument("--pods", type=int, default=None)
 ap.add_argument("--profile", action="store_true", help="library built with -DKSCHED_PROFILE=1: trace words 1..4 are wave 0's cycle totals");
-ap.add_argument("--debug", type=int, default=0); ap.add_argument("--packed", action="store_true"); ap.add_argument("--nodes", type=int, default=None); ap.add_argument("--kill", type=int, default=0, help="make the last K nodes infeasible")
+ap.add_argument("--pick", action="store_true", help="with the sampled pick riding in the launch (KSCHED_OPT_FUSED_PICK)"); ap.add_argument("--debug", type=int, default=0); ap.add_argument("--packed", action="store_true"); ap.add_argument("--nodes", type=int, default=None); ap.add_argument("--kill", type=int, default=0, help="make the last K nodes infeasible")
 a = ap.parse_args()
 cfg, P, N, flag_names, pick, desc = WORKLOADS[a.workload]
 P = a.pods or P
@@ -29,15 +29,23 @@ d_cpu, d_mem = t(c.req_cpu, np.int64), t(c.req_mem, np.int64)
 d_sel = t(c.pod_sel, np.int32) if c.n_keys else None
 d_tol = t(c.pod_tol, np.int64) if "TAINT" in flag_names else None
 mask = ev.alloc_mask(P, pitched=not a.packed)
+d_smp = d_out = None
+if a.pick:
+    flags |= L.PICK_SAMPLED
+    d_smp = t(c.samples, np.int32); d_out = torch.empty((P,), dtype=torch.int32, device=dev)
 for i in range(5):
-    ev.eval_device(d_cpu, d_mem, d_sel, d_tol, None, flags, out_feasible=mask)
+    ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=mask, out_binding=d_out)
 torch.cuda.synchronize()
 ev.set_option(L.OPT_TRACE, 1)
-ev.eval_device(d_cpu, d_mem, d_sel, d_tol, None, flags, out_feasible=mask)
+ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=mask, out_binding=d_out)
 torch.cuda.synchronize()
 tr = ev.trace_read()
 live = tr[:, 0] > 0
 tr = tr[live]
+pick_done = (tr[:, 7] >> np.uint64(8)).astype(np.float64) * 0.01  # wave 0: entry -> picks done (us); 0 without a riding pick
+tr[:, 7] &= np.uint64(0xFF)
+if a.pick:
+    print(f"pick: {ev.last_pick}; wave 0 entry -> its picks done: median {np.median(pick_done):.2f} p90 {np.percentile(pick_done, 90):.2f} max {pick_done.max():.2f} us (includes its wait at the block's barrier)")
 if a.profile:
     p2, wt, p1, rounds = (tr[:, i].astype(np.float64) for i in (1, 2, 3, 4))
     life = (tr[:, 6].astype(np.float64) - tr[:, 0].astype(np.float64)) * 0.01  # us, block entry -> drained
