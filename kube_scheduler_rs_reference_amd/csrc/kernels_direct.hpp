@@ -429,6 +429,9 @@ struct BestfitRowsArgs {
     // snapshots with list keys (tile_index.hpp): pods that constrain one are collected for k_pick_bestfit_listed
     uint32_t nlist, list_col[2];
     uint32_t *listed_list, *listed_count;
+    // 8-positions-per-bit summaries of `rows` (kernels_build.hpp k_bf_sum), [rows][Ws]: the second stage scans these
+    const uint64_t *sum;
+    uint32_t Ws;
 };
 
 // first i in [0, n) with arr[i] >= key (n if none), by the whole wave: 64-ary search, three rounds for n <= 262144
@@ -599,6 +602,105 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
     if (lane == 0) q.binding[wave] = b;
 }
 
+// Best fit, second stage over the row SUMMARIES (k_bf_sum: one bit per 8 best-fit positions).  The pods that reach the second
+// stage are the ones whose AND of rows is sparse -- several selective label keys, a cpu request few nodes can hold, or no
+// feasible node at all (4 % of the C5 pods: the scan runs to the end of the snapshot) -- and scanning every word of every row
+// for them moved ~400 MB per batch at the C5 shard.  Here a lane ANDs the pod's summary words (512 positions per word, 32 768 per
+// wave round), which is a superset of the bytes where the AND of the full rows can have a bit, and only those candidate bytes of
+// the full rows are looked at, lowest first.  Same result as bestfit_rows_scan by construction: the first position >= the
+// hand-over point whose bit is set in every row the pod ANDs and whose cpu fits; every position is either ruled out by a zero
+// summary bit (its byte is zero in some row) or examined.
+__device__ __forceinline__ int32_t bestfit_coarse_scan(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane, uint32_t start, uint32_t r, uint32_t w_first,
+                                                       int64_t req_c, uint64_t tol, const uint32_t (&sel)[8]) {
+    uint32_t r_hi = q.row_valid, r_lo = q.row_valid;
+    if (q.do_fit) {
+        r_hi = q.row_cpu0 + (r + q.q - 1u) / q.q;  // only nodes that fit
+        r_lo = q.row_cpu0 + r / q.q;               // every node that fits
+    }
+    uint32_t lrow[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) lrow[k] = (sel[k] <= q.lab_max8[k]) ? q.lab_base8[k] + sel[k] - 1u : q.row_zero;
+    // AND of the pod's rows at index `at` of a table whose rows are `pitch` words apart: the summaries (with the "every node that
+    // fits" cpu row: a superset) or the full rows (base only; the cpu rows are applied by the caller)
+    auto and_rows = [&](const uint64_t *tab, uint32_t pitch, uint32_t at) -> uint64_t {
+        uint64_t x = tab[(size_t)q.row_valid * pitch + at];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+            if (sel[k] != 0u) x &= tab[(size_t)lrow[k] * pitch + at];
+        for (uint32_t k = 8; k < q.nkeys; ++k) {
+            const uint32_t s = q.psel[(size_t)k * q.p + pod];
+            if (s != 0u) x &= tab[(size_t)((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero) * pitch + at];
+        }
+        if (q.do_taint)
+            for (uint32_t g = 0; g < q.ngroups; ++g) x &= tab[(size_t)(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * pitch + at];
+        return x;
+    };
+    const uint32_t p0 = max(start, w_first * 64u);  // first position not yet looked at (w_first > start >> 6: a multiple of 64)
+    if (p0 >= q.n) return -1;
+    const uint32_t j_first = p0 >> 9;  // summary word of p0
+    for (uint32_t jb = j_first; jb < q.Ws; jb += 64u) {
+        const uint32_t j = jb + lane;
+        uint64_t S = 0;
+        if (j < q.Ws) {
+            S = and_rows(q.sum, q.Ws, j);
+            if (q.do_fit) S &= q.sum[(size_t)r_lo * q.Ws + j];
+            if (j == j_first) S &= ~0ull << ((p0 >> 3) & 63u);  // bytes before p0
+        }
+        uint32_t found = 0xFFFFFFFFu;
+        while (true) {
+            const bool active = S != 0ull && found == 0xFFFFFFFFu;
+            if (__ballot(active) == 0ull) break;
+            if (active) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(S);
+                S &= S - 1ull;
+                const uint32_t fw = j * 8u + (b >> 3), sh = (b & 7u) * 8u;  // the candidate byte: word fw of the full rows, bits [sh, sh + 8)
+                if (fw < q.Wbf) {
+                    const uint64_t base = and_rows(q.rows, q.Wbf, fw);
+                    const uint64_t hi = q.do_fit ? q.rows[(size_t)r_hi * q.Wbf + fw] : ~0ull, lo = q.do_fit ? q.rows[(size_t)r_lo * q.Wbf + fw] : ~0ull;
+                    uint64_t byte_mask = 0xFFull << sh;
+                    if (fw == (start >> 6)) byte_mask &= ~0ull << (start & 63u);  // (only when the hand-over point is inside start's word)
+                    const uint64_t sure = base & hi & byte_mask;
+                    uint64_t cand = (base & lo & byte_mask);
+                    while (cand) {
+                        const uint32_t bb = (uint32_t)__builtin_ctzll(cand);
+                        const uint32_t i = fw * 64u + bb;
+                        if (((sure >> bb) & 1ull) || req_c <= q.bf_cpu[i]) {
+                            found = i;
+                            break;
+                        }
+                        cand &= cand - 1ull;
+                    }
+                }
+            }
+            // a hit in lane L settles the round once no lane below L has candidates left; lanes above L can stop looking
+            const uint64_t hit = __ballot(found != 0xFFFFFFFFu);
+            if (hit) {
+                const uint32_t L = (uint32_t)__builtin_ctzll(hit);
+                if (lane > L) S = 0ull;
+            }
+        }
+        const uint64_t hit = __ballot(found != 0xFFFFFFFFu);
+        if (hit) {  // lanes hold ascending summary words: the lowest lane with a hit holds the best-fit node
+            const uint32_t first = (uint32_t)__shfl((int)found, __builtin_ctzll(hit), 64);
+            return (int32_t)q.bf_order[first];
+        }
+    }
+    return -1;
+}
+
+// one short-lived wave per pod the first stage handed over (its 64-byte record carries everything the first stage had in registers)
+__global__ __launch_bounds__(256) void k_pick_bestfit_coarse(const BestfitRowsArgs q) {
+    kernarg_warm<sizeof(BestfitRowsArgs)>();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= *q.pod_count) return;
+    const uint4 *rec = reinterpret_cast<const uint4 *>(q.pod_list) + (size_t)wave * 4u;
+    const uint4 h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
+    const uint32_t sel[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const int32_t b = bestfit_coarse_scan(q, h.x, lane, h.y, h.z, h.w, (int64_t)(((uint64_t)o.w << 32) | o.z), ((uint64_t)o.y << 32) | o.x, sel);
+    if (lane == 0) q.binding[h.x] = b;
+}
+
 // Best fit, first stage, ONE LANE PER POD.  The wave-per-pod kernel above spends a whole wave's chain of dependent round trips on
 // every pod (rank searches -> rows -> winner; 135 us for 125k pods at the C5 shard, occupancy x latency bound), although the
 // answer almost always sits in the first word of candidates: the pick is the first set bit, at or after `start`, of the AND of a
@@ -653,6 +755,11 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
     }
     int32_t found = -1;
     bool undecided = start < q.n;
+    // a required value no node carries (KSCHED_SEL_NEVER, or an id beyond the key's largest): the pod's AND of rows is empty --
+    // no node, and no scan to the end of the snapshot to find that out (1 % of the constrained keys in the C5 workload)
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k)
+        if (sel[k] != 0u && sel[k] > q.lab_max8[k]) undecided = false;
     if (undecided) {
         const uint32_t r_hi = q.do_fit ? q.row_cpu0 + (r + q.q - 1u) / q.q : q.row_valid;  // only nodes that fit
         const uint32_t r_lo = q.do_fit ? q.row_cpu0 + r / q.q : q.row_valid;               // every node that fits

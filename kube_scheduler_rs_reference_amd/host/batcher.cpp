@@ -94,9 +94,10 @@ BatchLoopStats run_batches(PodBatcher &batcher,
         bool whole = true;
         try {
             out = reconcile(raw);
-        } catch (const std::logic_error &) {
-            throw;  // a programming error, not a bad object
-        } catch (const std::exception &) {
+        } catch (const PodEncodeError &) {
+            // a pod of the batch cannot be encoded: thrown by Snapshot::encode_pods, i.e. before anything of the batch was evaluated
+            // or POSTed -- the ONE failure after which the batch's pods may be reconciled again, one at a time.  Every other
+            // exception propagates: once bindings may have been created, re-reconciling the batch would POST them a second time.
             if (!failed) throw;
             whole = false;
         }
@@ -107,9 +108,7 @@ BatchLoopStats run_batches(PodBatcher &batcher,
                     const std::vector<ReconcileOutcome> one = reconcile({p.get()});
                     if (one.size() != 1) throw std::logic_error("run_batches: the reconcile function must return one outcome per pod");
                     done(p, one[0]);
-                } catch (const std::logic_error &) {
-                    throw;
-                } catch (const std::exception &e) {
+                } catch (const PodEncodeError &e) {
                     failed(p, e.what());
                     ++st.failed_pods;
                 }

@@ -71,6 +71,8 @@ struct BatchLoopStats {
 // callback the loop does not give up the whole batch: it reconciles that batch's pods one at a time, hands the offender(s) to
 // `failed(pod, what)` and everybody else's outcome to `done` -- one bad object costs one batch its batching, not the other pods
 // their scheduling.  Without the callback the exception propagates to the caller (the batch's pods are then not reconciled).
+// Only that exception (PodEncodeError, thrown by Snapshot::encode_pods) is answered this way: any other one may come from AFTER
+// the batch's POSTs, where reconciling the pods again would create their bindings a second time -- it propagates.
 BatchLoopStats run_batches(PodBatcher &batcher,
                            const std::function<std::vector<ReconcileOutcome>(const std::vector<const corev1::Pod *> &)> &reconcile,
                            const std::function<void(const PodBatcher::PodPtr &, const ReconcileOutcome &)> &done,

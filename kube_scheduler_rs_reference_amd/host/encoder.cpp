@@ -24,6 +24,7 @@ Snapshot::Snapshot(int device) {
 
 DeviceEvaluator &Snapshot::device() {
     if (!dev_) throw EncodeError("this Snapshot was created encode-only (no device): evaluation is not possible");
+    if (device_stale_) upload();  // an earlier device call failed after the host state had been committed: bring the device back in line
     return *dev_;
 }
 
@@ -38,15 +39,16 @@ bool toleration_matches(const corev1::Toleration &t, const TaintId &x) {
 }
 
 void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client, bool with_resources) {
+    // Everything is staged in locals and committed at the end: an EncodeError (a node or a LISTed pod that cannot be encoded, more
+    // than 64 distinct taints with the extension on) leaves the snapshot -- host bookkeeping AND device -- exactly as it was.
     const uint32_t n = (uint32_t)nodes.size();
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         return corev1::name_any(nodes[a].metadata) < corev1::name_any(nodes[b].metadata);
     });
-    store_of_canonical_ = order;
-    canonical_of_store_.assign(n, 0u);
-    for (uint32_t i = 0; i < n; ++i) canonical_of_store_[order[i]] = i;
+    std::vector<uint32_t> canonical_of_store(n, 0u);
+    for (uint32_t i = 0; i < n; ++i) canonical_of_store[order[i]] = i;
     NodeColumns c;
     std::unordered_map<std::string, Counted> counted;
     c.n = n;
@@ -54,10 +56,10 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
     c.avail_cpu_milli.resize(n);
     c.avail_mem_bytes.resize(n);
     c.taints.assign(n, 0);
-    node_labels_.assign(n, {});
-    node_has_labels_.assign(n, false);
-    node_taints_raw_.assign(n, {});
-    any_counted_taint_ = false;
+    std::vector<corev1::StringMap> labels(n);
+    std::vector<bool> has_labels(n, false);
+    std::vector<std::vector<TaintId>> taints_raw(n);
+    bool any_taint = false;
     for (uint32_t i = 0; i < n; ++i) {
         const corev1::Node &node = nodes[order[i]];
         c.names[i] = corev1::name_any(node.metadata);
@@ -95,49 +97,61 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
             throw EncodeError("node " + c.names[i] + ": outside the exact integer domain: " + e.what());
         }
         if (node.metadata.labels) {
-            node_labels_[i] = *node.metadata.labels;
-            node_has_labels_[i] = true;
+            labels[i] = *node.metadata.labels;
+            has_labels[i] = true;
         }
         if (node.spec && node.spec->taints) {
             for (const auto &t : *node.spec->taints) {
                 if (t.effect != "NoSchedule" && t.effect != "NoExecute") continue;  // PreferNoSchedule never filters
-                node_taints_raw_[i].emplace_back(t.key, t.value.value_or(""), t.effect);
-                any_counted_taint_ = true;
+                taints_raw[i].emplace_back(t.key, t.value.value_or(""), t.effect);
+                any_taint = true;
             }
         }
     }
+    std::map<TaintId, uint32_t> ids;
+    if (taints_enabled_) intern_taints_into(taints_raw, ids, c.taints);  // throws BEFORE anything is committed; the extension stays on across rebuilds
+    // ---- commit (nothing below throws an EncodeError about the INPUT; a failing device call is remembered, see upload()) ----
     c.keys = cols_.keys;  // keep the label columns that were in use
     cols_ = std::move(c);
     counted_ = std::move(counted);
-    if (taints_enabled_) intern_taints();  // the extension stays on across rebuilds once a caller has asked for it
+    store_of_canonical_ = std::move(order);
+    canonical_of_store_ = std::move(canonical_of_store);
+    node_labels_ = std::move(labels);
+    node_has_labels_ = std::move(has_labels);
+    node_taints_raw_ = std::move(taints_raw);
+    any_counted_taint_ = any_taint;
+    if (taints_enabled_) taint_ids_ = std::move(ids);
     encode_labels();
     upload();
 }
 
 // Extension E2: (key, value, effect) triples -> bit positions, at most 64 per snapshot.
-void Snapshot::intern_taints() {
-    taint_ids_.clear();
-    std::fill(cols_.taints.begin(), cols_.taints.end(), 0ull);
-    for (uint32_t i = 0; i < cols_.n; ++i)
-        for (const TaintId &id : node_taints_raw_[i]) {
-            auto it = taint_ids_.find(id);
-            if (it == taint_ids_.end()) {
-                if (taint_ids_.size() >= 64) {
-                    taint_ids_.clear();
-                    std::fill(cols_.taints.begin(), cols_.taints.end(), 0ull);
-                    taints_enabled_ = false;
-                    throw EncodeError("taint extension: more than 64 distinct NoSchedule/NoExecute taints in one snapshot");
-                }
-                it = taint_ids_.emplace(id, (uint32_t)taint_ids_.size()).first;
+void Snapshot::intern_taints_into(const std::vector<std::vector<TaintId>> &raw, std::map<TaintId, uint32_t> &ids, std::vector<uint64_t> &column) {
+    ids.clear();
+    column.assign(raw.size(), 0ull);
+    for (size_t i = 0; i < raw.size(); ++i)
+        for (const TaintId &id : raw[i]) {
+            auto it = ids.find(id);
+            if (it == ids.end()) {
+                if (ids.size() >= 64) throw EncodeError("taint extension: more than 64 distinct NoSchedule/NoExecute taints in one snapshot");
+                it = ids.emplace(id, (uint32_t)ids.size()).first;
             }
-            cols_.taints[i] |= 1ull << it->second;
+            column[i] |= 1ull << it->second;
         }
+}
+
+void Snapshot::intern_taints() {
+    std::map<TaintId, uint32_t> ids;
+    std::vector<uint64_t> column;
+    intern_taints_into(node_taints_raw_, ids, column);  // (throws before anything changes)
+    taint_ids_ = std::move(ids);
+    cols_.taints = std::move(column);
 }
 
 void Snapshot::enable_taints() {
     if (taints_enabled_) return;
+    intern_taints();  // "more than 64 distinct taints" leaves the extension off and the snapshot unchanged
     taints_enabled_ = true;
-    intern_taints();
     if (!taint_ids_.empty()) upload();
 }
 
@@ -161,10 +175,12 @@ void Snapshot::encode_labels() {
 void Snapshot::upload() {
     ++generation_;
     if (!dev_) return;  // encode-only snapshot (host tests of the wire-format step)
+    device_stale_ = true;  // until the call below has succeeded: the host columns are ahead of the device
     dev_->check(ksched_set_nodes(dev_->handle(), cols_.n, cols_.avail_cpu_milli.data(), cols_.avail_mem_bytes.data(),
                                  cols_.n_keys ? cols_.label_val_ids.data() : nullptr, cols_.n_keys,
                                  (taints_enabled_ && !taint_ids_.empty()) ? cols_.taints.data() : nullptr),
                 "ksched_set_nodes");
+    device_stale_ = false;
 }
 
 size_t Snapshot::apply_pod_events(const std::vector<std::pair<const corev1::Pod *, bool>> &events) {
@@ -203,12 +219,21 @@ size_t Snapshot::apply_pod_events(const std::vector<std::pair<const corev1::Pod 
 void Snapshot::push_rows(const std::vector<uint32_t> &touched) {
     ++generation_;
     if (!dev_) return;  // encode-only snapshot
+    if (device_stale_) {  // the device missed an earlier change: the whole snapshot goes up, these rows with it
+        upload();
+        return;
+    }
+    // The callers have committed their bookkeeping (counted_, cols_) by now.  If the device call fails the rows never arrived
+    // (and the C ABI refuses evaluations until the next ksched_set_nodes): remember it, so that the next evaluation -- or the
+    // next change -- uploads everything instead of trusting a device that is behind the host for good.
+    device_stale_ = true;
     std::vector<int64_t> cpu(touched.size()), mem(touched.size());
     for (size_t i = 0; i < touched.size(); ++i) {
         cpu[i] = cols_.avail_cpu_milli[touched[i]];
         mem[i] = cols_.avail_mem_bytes[touched[i]];
     }
     dev_->check(ksched_update_nodes(dev_->handle(), (uint32_t)touched.size(), touched.data(), cpu.data(), mem.data()), "ksched_update_nodes");
+    device_stale_ = false;
 }
 
 size_t Snapshot::observe_pods(const std::vector<std::pair<PodEvent, const corev1::Pod *>> &events) {
@@ -335,7 +360,7 @@ PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
                 pc.req_cpu_milli[i] = r.cpu.to_milli();
                 pc.req_mem_bytes[i] = r.memory.to_units();
             } catch (const QuantityError &e) {
-                throw EncodeError("pod " + full_name(pod.metadata) + ": invalid pod spec: " + e.what());
+                throw PodEncodeError("pod " + full_name(pod.metadata) + ": invalid pod spec: " + e.what());
             }
             if (pod.spec && pod.spec->node_selector) {
                 for (const auto &[k, v] : *pod.spec->node_selector) {  // src/predicates.rs:48-53
@@ -367,13 +392,13 @@ PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
             pool.emplace_back([&, t] {
                 try {
                     encode_range((uint32_t)((uint64_t)pc.p * t / nthreads), (uint32_t)((uint64_t)pc.p * (t + 1) / nthreads));
-                } catch (const std::exception &e) {
+                } catch (const PodEncodeError &e) {
                     errors[t] = e.what();
-                }
+                }  // (anything else -- std::bad_alloc, a logic error -- is not a bad pod: it terminates, as it would on one thread)
             });
         for (auto &th : pool) th.join();
         for (const auto &e : errors)
-            if (!e.empty()) throw EncodeError(e);  // the lowest pod range's error, like the sequential walk would have raised first
+            if (!e.empty()) throw PodEncodeError(e);  // the lowest pod range's error, like the sequential walk would have raised first
     }
     return pc;
 }

@@ -23,6 +23,12 @@ namespace ksched_host {
 struct EncodeError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
+// A POD of a batch cannot be encoded (unparsable requests, a value outside the exact integer domain -- where the reference's
+// .expect("invalid pod spec") panics, src/util.rs:65,68).  Thrown by Snapshot::encode_pods only, i.e. BEFORE anything of the
+// batch has been evaluated or POSTed: the one failure a batching caller may answer by retrying the batch's pods one at a time.
+struct PodEncodeError : EncodeError {
+    using EncodeError::EncodeError;
+};
 
 // RAII over the C ABI handle.
 class DeviceEvaluator {
@@ -132,6 +138,9 @@ public:
     DeviceEvaluator &device();
     const std::map<TaintId, uint32_t> &taint_ids() const { return taint_ids_; }
     uint64_t generation() const { return generation_; }
+    // A device call failed after the host columns had been committed (ksched_set_nodes / ksched_update_nodes returned an error):
+    // the device may hold an older snapshot.  The next device() -- every evaluation goes through it -- uploads everything again.
+    bool device_stale() const { return device_stale_; }
 
 private:
     void encode_labels();
@@ -145,8 +154,9 @@ private:
     std::vector<std::map<std::string, uint32_t>> value_ids_;  // per column: value string -> id (1..)
     std::map<TaintId, uint32_t> taint_ids_;                 // NoSchedule / NoExecute taints -> bit (filled by enable_taints)
     std::vector<std::vector<TaintId>> node_taints_raw_;     // canonical order: the node's counted taints, un-interned
-    bool any_counted_taint_ = false, taints_enabled_ = false;
+    bool any_counted_taint_ = false, taints_enabled_ = false, device_stale_ = false;
     void intern_taints();
+    static void intern_taints_into(const std::vector<std::vector<TaintId>> &raw, std::map<TaintId, uint32_t> &ids, std::vector<uint64_t> &column);
     uint64_t generation_ = 0;
     struct Counted {
         uint32_t node;  // canonical index

@@ -188,7 +188,15 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
         // (observe_pods, the tracked form: when the watch later echoes these bindings as MODIFIED events they change nothing)
         std::vector<std::pair<Snapshot::PodEvent, const corev1::Pod *>> events;
         for (const auto &p : landed) events.emplace_back(Snapshot::PodEvent::Applied, &p);
-        ctx.snapshot->observe_pods(events);
+        // The bindings EXIST by now: whatever happens to the snapshot update, the caller gets `out` (an exception here would make
+        // a batching caller lose the outcomes, or worse reconcile -- and POST -- the batch again).  A device failure leaves the
+        // snapshot marked stale (it uploads everything before the next evaluation); a bookkeeping failure (int64 overflow of
+        // `available`) drops the snapshot, so that the next batch starts from fresh LISTs.
+        try {
+            ctx.snapshot->observe_pods(events);
+        } catch (const EncodeError &) {
+            if (!ctx.snapshot->device_stale()) ctx.snapshot.reset();
+        }
     }
     return out;
 }

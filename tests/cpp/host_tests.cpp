@@ -367,6 +367,44 @@ static void cpu_tests() {
         CHECK(snap.observe_pods({{E::Applied, &h1}, {E::Applied, &h2}}) == 2);
         CHECK(snap.columns().avail_cpu_milli[1] == 7999 && snap.counted_pods() == 3);
     });
+    run("snapshot builder: a rebuild that throws leaves the snapshot as it was (commit at the end)", [] {
+        // 5 nodes with taints enabled; then a rebuild of 2 nodes carrying 65 distinct taints: "more than 64" -- thrown BEFORE anything is
+        // committed (it used to come after the columns had been replaced: host n = 2, device still 5 nodes)
+        std::vector<corev1::Node> five;
+        for (int i = 0; i < 5; ++i) five.push_back(node_with("n" + std::to_string(i), "4", "1000"));
+        corev1::NodeSpec one;
+        one.taints = std::vector<corev1::Taint>{{"dedicated", std::string("gpu"), "NoSchedule"}};
+        five[2].spec = one;
+        five[1].metadata.labels = corev1::StringMap{{"zone", "z1"}};
+        Snapshot snap(Snapshot::kEncodeOnly);
+        snap.rebuild(five, nullptr);
+        snap.enable_taints();
+        corev1::Pod asks = test_pod("zone", "z1");
+        snap.encode_pods({&asks});
+        const NodeColumns before = snap.columns();
+        const uint64_t gen = snap.generation();
+        std::vector<corev1::Node> two = {node_with("a", "1", "1"), node_with("b", "1", "1")};
+        corev1::NodeSpec many;
+        many.taints = std::vector<corev1::Taint>{};
+        for (int t = 0; t < 65; ++t) many.taints->push_back({"k" + std::to_string(t), std::nullopt, "NoSchedule"});
+        two[1].spec = many;
+        CHECK_THROWS(snap.rebuild(two, nullptr));
+        const NodeColumns &after = snap.columns();
+        CHECK(after.n == 5 && after.names == before.names && after.avail_cpu_milli == before.avail_cpu_milli && after.taints == before.taints);
+        CHECK(after.label_val_ids == before.label_val_ids && after.keys == before.keys && snap.generation() == gen && snap.taints_enabled());
+        CHECK(snap.index_of("n3") == 3 && snap.index_of("a") == -1 && snap.store_index(4) == 4);
+        const PodColumns pc = snap.encode_pods({&asks});  // still encodes against the five nodes' dictionaries
+        CHECK(pc.n_keys == 1 && pc.sel_val_ids[0] == 1u);
+        // a node that cannot be encoded: the same
+        std::vector<corev1::Node> bad = {node_with("x", "lots", "1")};
+        CHECK_THROWS(snap.rebuild(bad, nullptr));
+        CHECK(snap.columns().n == 5 && snap.index_of("n0") == 0);
+        // enable_taints that fails leaves the extension off (and can be retried after the cluster changed)
+        Snapshot s2(Snapshot::kEncodeOnly);
+        s2.rebuild(two, nullptr);
+        CHECK_THROWS(s2.enable_taints());
+        CHECK(!s2.taints_enabled() && s2.taint_ids().empty());
+    });
     run("toleration_matches (extension E2)", [] {
         TaintId t{"k", "v", "NoSchedule"};
         corev1::Toleration a;
@@ -525,7 +563,7 @@ static void cpu_tests() {
             auto rec = [&](const std::vector<const corev1::Pod *> &pods) {
                 ++calls;
                 for (const auto *p : pods)
-                    if (*p->metadata.name == "poison") throw EncodeError("pod test/poison: invalid pod spec: 'lots'");
+                    if (*p->metadata.name == "poison") throw PodEncodeError("pod test/poison: invalid pod spec: 'lots'");  // what Snapshot::encode_pods throws
                 return std::vector<ReconcileOutcome>(pods.size());
             };
             const BatchLoopStats s2 = run_batches(
@@ -542,6 +580,22 @@ static void cpu_tests() {
             e.push(std::make_shared<const corev1::Pod>(pod_with("poison", {container("1", "1Mi")})));
             e.close();
             CHECK_THROWS(run_batches(e, rec, [](const PodBatcher::PodPtr &, const ReconcileOutcome &) {}));
+            // Any OTHER exception is not "a pod could not be encoded, nothing was POSTed": it may come from after the batch's POSTs
+            // (a device failure while the batch's own bindings are applied to the snapshot).  The loop must NOT reconcile -- and
+            // POST -- the batch's pods a second time: the exception is the caller's, and the reconcile function ran once.
+            PodBatcher f(8);
+            for (int i = 0; i < 5; ++i) f.push(std::make_shared<const corev1::Pod>(pod_with("r" + std::to_string(i), {container("1", "1Mi")})));
+            f.close();
+            int calls2 = 0, failed2 = 0;
+            CHECK_THROWS(run_batches(
+                f,
+                [&](const std::vector<const corev1::Pod *> &pods) -> std::vector<ReconcileOutcome> {
+                    ++calls2;
+                    (void)pods;
+                    throw EncodeError("ksched_update_nodes: HIP runtime error (after the POSTs)");
+                },
+                [](const PodBatcher::PodPtr &, const ReconcileOutcome &) {}, [&](const PodBatcher::PodPtr &, const std::string &) { ++failed2; }));
+            CHECK(calls2 == 1 && failed2 == 0);
         }
         // a reconcile function that loses a pod is a programming error, reported loudly
         PodBatcher c(8);
@@ -827,6 +881,42 @@ static void gpu_tests() {
         CHECK(a.feasible == b.feasible && a.fit == b.fit && a.binding == b.binding);
         CHECK(a.feasible_count(2) < a.feasible_count(0));  // the events mattered
         CHECK(std::static_pointer_cast<StaticPodLister>(inc.client)->list_calls == 1500);  // no LIST after the first build
+    });
+
+    run("a device failure after the host commit: the snapshot is stale, the next evaluation uploads everything (KSCHED_OPT_FAULT)", [] {
+        std::vector<corev1::Node> nodes;
+        for (int i = 0; i < 40; ++i) nodes.push_back(node_with("node-" + std::string(i < 10 ? "0" : "") + std::to_string(i), "4", "8589934592"));
+        std::vector<corev1::Pod> probes = {pod_with("mid", {container("2500m", "1")}), pod_with("small", {container("500m", "1")})};
+        std::vector<const corev1::Pod *> pp = {&probes[0], &probes[1]};
+        Context ctx = make_ctx(nodes);
+        ctx.refresh_snapshot();
+        const predicates::BatchValidity before = predicates::check_node_validity_batch(pp, ctx, false, 0);
+        CHECK(before.feasible_count(0) == 40);
+        // the watch reports a pod on node-07; the device update fails inside the library (an injected std::bad_alloc -> KSCHED_E_NOMEM)
+        corev1::Pod landed = pod_with("l0", {container("2", "1")}, "node-07");
+        CHECK(ksched_set_option(ctx.snapshot->device().handle(), KSCHED_OPT_FAULT, 1) == KSCHED_OK);
+        CHECK_THROWS(ctx.snapshot->observe_pod(Snapshot::PodEvent::Applied, landed));
+        CHECK(ctx.snapshot->device_stale());
+        CHECK(ctx.snapshot->counted_pods() == 1);  // the host bookkeeping is committed (the echo of this event will change nothing) ...
+        CHECK(ctx.snapshot->observe_pods({{Snapshot::PodEvent::Applied, &landed}}) == 0);
+        // ... and the device catches up before the next evaluation: node-07 no longer holds the 2.5-core pod
+        const predicates::BatchValidity after = predicates::check_node_validity_batch(pp, ctx, false, 0);
+        CHECK(!ctx.snapshot->device_stale());
+        CHECK(after.feasible_count(0) == 39 && after.feasible_count(1) == 40);
+        Context fresh = make_ctx(nodes, {landed});
+        fresh.refresh_snapshot();
+        const predicates::BatchValidity want = predicates::check_node_validity_batch(pp, fresh, false, 0);
+        CHECK(after.feasible == want.feasible);
+        // reconcile_batch keeps its outcomes when the snapshot update after the POSTs fails (the bindings exist by then)
+        RecordingSink sink;
+        SplitMixChooser rng(9);
+        std::vector<corev1::Pod> batch = {pod_with("b0", {container("100m", "1")}), pod_with("b1", {container("100m", "1")})};
+        CHECK(ksched_set_option(ctx.snapshot->device().handle(), KSCHED_OPT_FAULT, 1 | (1 << 8)) == KSCHED_OK);  // skip the evaluation's fault point, hit the update's
+        const std::vector<ReconcileOutcome> out = reconcile_batch({&batch[0], &batch[1]}, ctx, rng, sink);
+        CHECK(out.size() == 2 && out[0].ok && out[1].ok && sink.posts.size() == 2);
+        CHECK(ctx.snapshot && ctx.snapshot->device_stale());
+        const predicates::BatchValidity later = predicates::check_node_validity_batch(pp, ctx, false, 0);  // uploads, then evaluates
+        CHECK(!ctx.snapshot->device_stale() && later.feasible_count(1) == 40);
     });
 
     run("reconcile_batch_sequential: in-batch capacity accounting never over-commits (8f n3, opt-in)", [] {

@@ -1,0 +1,69 @@
+"""Second stage of the best-fit pick over the row summaries (k_pick_bestfit_coarse, one summary bit per 8 best-fit positions)
+against the oracle and against the second stage over the full rows (KSCHED_OPT_DEBUG bit 11): pods whose AND of rows is
+sparse -- several selective label keys, a value no node carries, a cpu request only a handful of nodes can hold, no feasible
+node at all -- at snapshot sizes where the summaries span several wave rounds, with every hand-over point of the first stage."""
+import numpy as np
+import pytest
+
+from kube_scheduler_rs_reference_amd import FIT, PICK_BESTFIT, SEL, SEL_NEVER, TAINT, _lib, synth
+from oracle import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def want_of(c, sel, req_cpu, req_mem, flags):
+    return capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, c.node_taints, req_cpu, req_mem, sel, c.pod_tol, None, flags | PICK_BESTFIT)[2]
+
+
+@pytest.mark.parametrize("N", [700, 5_000, 40_000, 70_001])
+def test_coarse_second_stage_equals_full_rows_equals_oracle(evaluator, N):
+    ev = evaluator
+    P = 3000
+    c = synth.make_cluster(P, N, n_keys=8, n_taints=16, seed=1000 + N)
+    rng = np.random.default_rng(N)
+    sel = c.pod_sel.copy()
+    req_cpu, req_mem = c.req_cpu.copy(), c.req_mem.copy()
+    card = c.node_labels.max(axis=1)
+    # sparse ANDs: every third pod constrains the three most selective keys with values nodes do carry
+    for k in (5, 6, 7):
+        sel[k, ::3] = rng.integers(1, int(card[k]) + 1, size=sel[k, ::3].shape)
+    sel[7, 1::50] = SEL_NEVER                      # a value no node carries
+    sel[6, 2::50] = np.uint32(int(card[6]) + 7)    # an id beyond the key's largest
+    req_cpu[3::11] = np.sort(c.avail_cpu)[-3]       # only the few largest nodes can hold these
+    req_cpu[4::97] = c.avail_cpu.max() + 1         # nothing can
+    req_mem[5::89] = c.avail_mem.max() + 1
+    ev.set_nodes(**c.node_columns())
+    try:
+        for flags in (FIT | SEL | TAINT, FIT | SEL, SEL | TAINT, FIT):
+            want = want_of(c, sel, req_cpu, req_mem, flags)
+            for stages in (2, 1):
+                ev.set_option(_lib.OPT_BESTFIT_STAGES, stages)
+                for dbg in ((0, 0x800, 1 << 12, (1 << 12) | 0x800, 2 << 12, 15 << 12) if stages == 2 else (0,)):  # bit 11: full rows; bits 12-15: hand-over after this many words
+                    ev.set_option(_lib.OPT_DEBUG, dbg)
+                    r = ev.eval(req_cpu, req_mem, sel, c.pod_tol, None, flags | PICK_BESTFIT, want_mask=False)
+                    assert np.array_equal(r.binding, want), (N, flags, stages, hex(dbg), int((r.binding != want).sum()))
+        assert (want_of(c, sel, req_cpu, req_mem, FIT | SEL | TAINT) == -1).sum() > P // 100  # the case this test is about exists
+    finally:
+        ev.set_option(_lib.OPT_DEBUG, 0)
+        ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
+
+
+def test_coarse_second_stage_after_snapshot_updates(evaluator):
+    """ksched_update_nodes marks the best-fit structures stale: rows AND their summaries are rebuilt by the next pick."""
+    ev = evaluator
+    c = synth.make_cluster(2000, 9000, n_keys=8, n_taints=16, seed=77)
+    rng = np.random.default_rng(5)
+    cpu, mem = c.avail_cpu.copy(), c.avail_mem.copy()
+    ev.set_nodes(cpu, mem, c.node_labels, c.node_taints)
+    ev.set_option(_lib.OPT_BESTFIT_STAGES, 2)
+    try:
+        for step in range(3):
+            want = capi.eval_encoded(cpu, mem, c.node_labels, c.node_taints, c.req_cpu, c.req_mem, c.pod_sel, c.pod_tol, None, FIT | SEL | TAINT | PICK_BESTFIT)[2]
+            r = ev.eval(c.req_cpu, c.req_mem, c.pod_sel, c.pod_tol, None, FIT | SEL | TAINT | PICK_BESTFIT, want_mask=False)
+            assert np.array_equal(r.binding, want), step
+            idx = rng.choice(c.N, size=400, replace=False).astype(np.uint32)
+            cpu[idx] = rng.integers(0, 64_000, size=idx.size)
+            mem[idx] = rng.integers(0, 1 << 37, size=idx.size)
+            ev.update_nodes(idx, cpu[idx], mem[idx])
+    finally:
+        ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
