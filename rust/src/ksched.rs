@@ -12,8 +12,7 @@
 //   * nodes in canonical order = ascending metadata.name; column index == mask bit.
 //   * label values -> dense dictionary ids per key (1..), 0 = key absent on the node; a selector value that no node
 //     carries -> KSCHED_SEL_NEVER.  Exact interning, never a hash.
-#![allow(dead_code)]
-use std::collections::{BTreeMap, BTreeSet};
+use std::collections::{BTreeMap, BTreeSet, HashMap};
 use std::ffi::CStr;
 use std::sync::Arc;
 
@@ -58,6 +57,8 @@ impl Evaluator {
             // KSCHED_E_NODEVICE: there is no CPU fallback by design
             return Err(KschedError { code: rc, message: strerror(rc) });
         }
+        // every entry point and constant of the binding, resolved against the library that was actually linked
+        tracing::debug!("ksched ABI {}: {} entry points, {} constants bound", sys::KSCHED_ABI_VERSION, sys::symbol_table().len(), sys::constant_table().len());
         return Ok(Evaluator(h));
     }
 
@@ -231,31 +232,69 @@ pub struct Snapshot {
     pub avail_cpu_milli: Vec<i64>,
     pub avail_mem_bytes: Vec<i64>,
     pub keys: Vec<String>,            // label column k <-> key
+    avail_cpu_nanos: Vec<i128>,       // the same columns, exact (a pod event moves them by the pod's exact requests)
+    avail_mem_nanos: Vec<i128>,
     value_ids: Vec<BTreeMap<String, u32>>,
     labels: Vec<Option<BTreeMap<String, String>>>, // canonical order
     label_val_ids: Vec<u32>,          // [n_keys][n]
+    touched: BTreeSet<u32>,           // rows changed since the device last saw them (-> ksched_update_nodes)
+    on_device: Option<Vec<String>>,   // the label keys the device's copy was uploaded with; None = nothing uploaded yet
+}
+
+/// What `available` currently holds against one pod: the pod's node and its exact requests (twin of the C++ host mirror's
+/// Snapshot::Counted, host/encoder.hpp).
+#[derive(Clone, Debug, PartialEq, Eq)]
+pub struct Counted {
+    pub node_name: String,
+    pub cpu_nanos: i128,
+    pub mem_nanos: i128,
+}
+
+/// One event of the pod watch (kube::runtime::watcher::Event::{Applied, Deleted}).
+pub enum PodEvent<'a> {
+    Applied(&'a corev1::Pod),
+    Deleted(&'a corev1::Pod),
+}
+
+fn pod_key(pod: &corev1::Pod) -> String {
+    return match &pod.metadata.namespace {
+        Some(ns) => format!("{}/{}", ns, pod.metadata.name.clone().unwrap_or_default()),
+        None => pod.metadata.name.clone().unwrap_or_default(),
+    };
 }
 
 impl Snapshot {
     /// `nodes` in any order (the reflector store's), `all_pods` = every pod of the cluster (one LIST for the whole batch
     /// instead of one per evaluation, src/predicates.rs:34).  Err where the reference panics: allocatable lacking cpu or
-    /// memory (src/predicates.rs:29-31), unparsable quantities.
+    /// memory (src/predicates.rs:29-31), unparsable quantities.  (Test builds: the running scheduler builds from the watch's table.)
+    #[cfg(test)]
     pub fn build(nodes: &[Arc<corev1::Node>], all_pods: &[corev1::Pod]) -> Result<Snapshot, String> {
+        let mut counted: HashMap<String, Counted> = HashMap::new();
+        for p in all_pods {
+            if let Some(corev1::PodSpec { node_name: Some(nn), .. }) = &p.spec {
+                let (c, m) = total_pod_resources_nanos(p)?;
+                counted.insert(pod_key(p), Counted { node_name: nn.clone(), cpu_nanos: c, mem_nanos: m });
+            }
+        }
+        return Snapshot::build_from_counted(nodes, &counted);
+    }
+
+    /// The same from the table the pod watch maintains (ClusterState): available[n] = allocatable[n] - sum of what is counted
+    /// against n (src/predicates.rs:27-38; every phase counts: the reference applies no phase filter).
+    pub fn build_from_counted(nodes: &[Arc<corev1::Node>], counted: &HashMap<String, Counted>) -> Result<Snapshot, String> {
         let n = nodes.len();
         let mut order: Vec<usize> = (0..n).collect();
         let name_of = |i: usize| nodes[i].metadata.name.clone().unwrap_or_default();
         order.sort_by(|&a, &b| name_of(a).cmp(&name_of(b)).then(a.cmp(&b)));
         let names: Vec<String> = order.iter().map(|&i| name_of(i)).collect();
-        // requests of the bound pods, summed per node name (every phase counts: no phase filter in the reference)
         let mut used: BTreeMap<&str, (i128, i128)> = BTreeMap::new();
-        for p in all_pods {
-            if let Some(corev1::PodSpec { node_name: Some(nn), .. }) = &p.spec {
-                let (c, m) = total_pod_resources_nanos(p)?;
-                let e = used.entry(nn.as_str()).or_insert((0, 0));
-                e.0 += c;
-                e.1 += m;
-            }
+        for c in counted.values() {
+            let e = used.entry(c.node_name.as_str()).or_insert((0, 0));
+            e.0 += c.cpu_nanos;
+            e.1 += c.mem_nanos;
         }
+        let mut avail_cpu_nanos = Vec::with_capacity(n);
+        let mut avail_mem_nanos = Vec::with_capacity(n);
         let mut avail_cpu_milli = Vec::with_capacity(n);
         let mut avail_mem_bytes = Vec::with_capacity(n);
         let mut labels = Vec::with_capacity(n);
@@ -274,9 +313,49 @@ impl Snapshot {
             }
             avail_cpu_milli.push(nanos_to_i64(cpu, 1_000_000, "milli-cores")?);
             avail_mem_bytes.push(nanos_to_i64(mem, 1_000_000_000, "bytes")?);
+            avail_cpu_nanos.push(cpu);
+            avail_mem_nanos.push(mem);
             labels.push(node.metadata.labels.clone());
         }
-        return Ok(Snapshot { names, store_index: order, avail_cpu_milli, avail_mem_bytes, keys: Vec::new(), value_ids: Vec::new(), labels, label_val_ids: Vec::new() });
+        return Ok(Snapshot {
+            names,
+            store_index: order,
+            avail_cpu_milli,
+            avail_mem_bytes,
+            keys: Vec::new(),
+            avail_cpu_nanos,
+            avail_mem_nanos,
+            value_ids: Vec::new(),
+            labels,
+            label_val_ids: Vec::new(),
+            touched: BTreeSet::new(),
+            on_device: None,
+        });
+    }
+
+    /// canonical index of a node name, or None when the snapshot does not hold the node
+    pub fn index_of(&self, node_name: &str) -> Option<u32> {
+        return self.names.binary_search_by(|n| n.as_str().cmp(node_name)).ok().map(|i| i as u32);
+    }
+
+    /// A pod appeared on / left `node_name`: available moves by its exact requests (sign = -1: now counted, +1: no longer).
+    /// The row goes to the device with the next evaluation (ksched_update_nodes).  Err (nothing changed) when the result is
+    /// not a whole number of milli-cores / bytes or leaves i64.  Ok(false): the node is not in this snapshot.
+    fn shift(&mut self, node_name: &str, sign: i128, cpu_nanos: i128, mem_nanos: i128) -> Result<bool, String> {
+        let i = match self.index_of(node_name) {
+            Some(i) => i as usize,
+            None => return Ok(false),
+        };
+        let cpu = self.avail_cpu_nanos[i] + sign * cpu_nanos;
+        let mem = self.avail_mem_nanos[i] + sign * mem_nanos;
+        let cpu_milli = nanos_to_i64(cpu, 1_000_000, "milli-cores")?;
+        let mem_bytes = nanos_to_i64(mem, 1_000_000_000, "bytes")?;
+        self.avail_cpu_nanos[i] = cpu;
+        self.avail_mem_nanos[i] = mem;
+        self.avail_cpu_milli[i] = cpu_milli;
+        self.avail_mem_bytes[i] = mem_bytes;
+        self.touched.insert(i as u32);
+        return Ok(true);
     }
 
     pub fn n(&self) -> u32 {
@@ -305,7 +384,9 @@ impl Snapshot {
         return Ok(());
     }
 
-    /// Encode `pods` against this snapshot and upload the snapshot's columns for the batch's selector keys.
+    /// Encode `pods` against this snapshot and bring the device's copy up to date: a full ksched_set_nodes when the batch's
+    /// selector keys differ from the ones the device holds (or nothing is there yet), otherwise only the rows pod events have
+    /// changed since the last call (ksched_update_nodes), otherwise nothing.
     pub fn encode_and_upload(&mut self, ev: &Evaluator, pods: &[&corev1::Pod]) -> Result<PodColumns, String> {
         let mut keys = BTreeSet::new();
         for p in pods {
@@ -315,16 +396,32 @@ impl Snapshot {
                 }
             }
         }
-        self.encode_labels(&keys)?;
+        let wanted: Vec<String> = keys.iter().cloned().collect();
         let n = self.n();
+        if self.on_device.as_ref() != Some(&wanted) {
+            self.encode_labels(&keys)?;
+            let n_keys = self.keys.len() as u32;
+            let rc = unsafe {
+                sys::ksched_set_nodes(
+                    ev.raw(), n, self.avail_cpu_milli.as_ptr(), self.avail_mem_bytes.as_ptr(),
+                    if n_keys > 0 { self.label_val_ids.as_ptr() } else { std::ptr::null() }, n_keys, std::ptr::null(),
+                )
+            };
+            ev.check(rc, "ksched_set_nodes").map_err(|e| e.to_string())?;
+            self.on_device = Some(wanted);
+            self.touched.clear();
+        } else if !self.touched.is_empty() {
+            let idx: Vec<u32> = self.touched.iter().cloned().collect();
+            let cpu: Vec<i64> = idx.iter().map(|&i| self.avail_cpu_milli[i as usize]).collect();
+            let mem: Vec<i64> = idx.iter().map(|&i| self.avail_mem_bytes[i as usize]).collect();
+            let rc = unsafe { sys::ksched_update_nodes(ev.raw(), idx.len() as u32, idx.as_ptr(), cpu.as_ptr(), mem.as_ptr()) };
+            if rc != sys::KSCHED_OK {
+                self.on_device = None; // the library refuses evaluations until the next ksched_set_nodes: upload everything next time
+            }
+            ev.check(rc, "ksched_update_nodes").map_err(|e| e.to_string())?;
+            self.touched.clear();
+        }
         let n_keys = self.keys.len() as u32;
-        let rc = unsafe {
-            sys::ksched_set_nodes(
-                ev.raw(), n, self.avail_cpu_milli.as_ptr(), self.avail_mem_bytes.as_ptr(),
-                if n_keys > 0 { self.label_val_ids.as_ptr() } else { std::ptr::null() }, n_keys, std::ptr::null(),
-            )
-        };
-        ev.check(rc, "ksched_set_nodes").map_err(|e| e.to_string())?;
         let p = pods.len();
         let mut cols = PodColumns { p: p as u32, n_keys, req_cpu_milli: vec![0; p], req_mem_bytes: vec![0; p], sel_val_ids: vec![0u32; self.keys.len() * p] };
         for (i, pod) in pods.iter().enumerate() {
@@ -345,7 +442,9 @@ impl Snapshot {
     }
 }
 
-/// Both masks (+ optional bindings) of one batch, pod-major, node bit = canonical index.
+/// Both masks (+ optional bindings) of one batch, pod-major, node bit = canonical index.  (Test builds: device_parity.rs compares
+/// every pair with this crate's own predicates; the running scheduler only needs the bindings, ClusterState::pick_batch.)
+#[cfg(test)]
 pub struct BatchValidity {
     pub p: u32,
     pub n: u32,
@@ -355,6 +454,7 @@ pub struct BatchValidity {
     pub binding: Vec<i32>,
 }
 
+#[cfg(test)]
 impl BatchValidity {
     pub fn is_valid(&self, pod: u32, node: u32) -> bool {
         return (self.feasible[(pod * self.words + (node >> 6)) as usize] >> (node & 63)) & 1 == 1;
@@ -368,6 +468,7 @@ impl BatchValidity {
 
 /// check_node_validity (src/predicates.rs:63-77) for every (pod, node) pair in ONE device call, optionally with the
 /// sampled pick of select_node_for_pod (src/main.rs:51-71): `samples` = [p][attempts] canonical node indices.
+#[cfg(test)]
 pub fn eval_batch(ev: &Evaluator, snap: &mut Snapshot, pods: &[&corev1::Pod], samples: Option<(&[u32], u32)>) -> Result<BatchValidity, String> {
     let cols = snap.encode_and_upload(ev, pods)?;
     let n = snap.n();
@@ -400,4 +501,160 @@ pub fn eval_batch(ev: &Evaluator, snap: &mut Snapshot, pods: &[&corev1::Pod], sa
     };
     ev.check(rc, "ksched_eval").map_err(|e| e.to_string())?;
     return Ok(out);
+}
+
+// ---- the cluster as the watches see it (SURVEY.md section 8f n1 + n2) ----------------------------------------------------
+
+/// Twin of the C++ host mirror's watch-fed snapshot (host/encoder.cpp Snapshot::observe_pods) and of its batch selection
+/// (host/scheduler.cpp select_nodes_for_pods).  The pod WATCH keeps a table of what is counted against which node, so the
+/// reference's one LIST per evaluation (src/predicates.rs:34) becomes: no LIST at all after the watch's initial one.  The
+/// device-resident snapshot is built from the node store + that table when the node set changes, and follows pod events row
+/// by row in between.
+pub struct ClusterState {
+    counted: HashMap<String, Counted>, // namespace/name -> what `available` holds against that pod
+    snapshot: Option<Snapshot>,
+    node_fingerprint: Vec<(String, String)>, // (name, resourceVersion) of the nodes the snapshot was built from, store order
+    synced: bool,                            // the pod watch has delivered its initial LIST
+}
+
+impl ClusterState {
+    pub fn new() -> ClusterState {
+        return ClusterState { counted: HashMap::new(), snapshot: None, node_fingerprint: Vec::new(), synced: false };
+    }
+
+    pub fn is_synced(&self) -> bool {
+        return self.synced;
+    }
+
+    pub fn counted_pods(&self) -> usize {
+        return self.counted.len();
+    }
+
+    /// watcher::Event::Restarted: the watch (re)LISTed every pod.  The table is rebuilt; the snapshot follows at the next batch.
+    pub fn resync(&mut self, pods: &[corev1::Pod]) {
+        self.counted.clear();
+        for p in pods {
+            if let Some(corev1::PodSpec { node_name: Some(nn), .. }) = &p.spec {
+                match total_pod_resources_nanos(p) {
+                    Ok((c, m)) => {
+                        self.counted.insert(pod_key(p), Counted { node_name: nn.clone(), cpu_nanos: c, mem_nanos: m });
+                    },
+                    Err(e) => tracing::warn!("pod {} is not counted against {}: {}", pod_key(p), nn, e),
+                }
+            }
+        }
+        self.snapshot = None;
+        self.synced = true;
+    }
+
+    /// watcher::Event::Applied / Deleted, and the bindings this process POSTs itself.  Idempotent: a repeated MODIFIED event, or the
+    /// watch's echo of a binding already registered here, changes nothing.  Returns whether `available` changed.
+    pub fn observe(&mut self, event: PodEvent<'_>) -> Result<bool, String> {
+        let (pod, applied) = match event {
+            PodEvent::Applied(p) => (p, true),
+            PodEvent::Deleted(p) => (p, false),
+        };
+        let key = pod_key(pod);
+        let now: Option<Counted> = match (&pod.spec, applied) {
+            (Some(corev1::PodSpec { node_name: Some(nn), .. }), true) => {
+                let (c, m) = total_pod_resources_nanos(pod)?;
+                Some(Counted { node_name: nn.clone(), cpu_nanos: c, mem_nanos: m })
+            },
+            _ => None,
+        };
+        let was: Option<Counted> = self.counted.get(&key).cloned();
+        if was == now {
+            return Ok(false);
+        }
+        let mut rebuild = false;
+        if let Some(snap) = self.snapshot.as_mut() {
+            // a shift that cannot be represented (not a whole milli-core / byte, i64 overflow) drops the snapshot: the next batch
+            // rebuilds it from the table, where the same condition is reported against the node
+            if let Some(w) = &was {
+                rebuild |= snap.shift(&w.node_name, 1, w.cpu_nanos, w.mem_nanos).is_err();
+            }
+            if let Some(nw) = &now {
+                rebuild |= snap.shift(&nw.node_name, -1, nw.cpu_nanos, nw.mem_nanos).is_err();
+            }
+        }
+        if rebuild {
+            self.snapshot = None;
+        }
+        match now {
+            Some(c) => {
+                self.counted.insert(key, c);
+            },
+            None => {
+                self.counted.remove(&key);
+            },
+        }
+        return Ok(true);
+    }
+
+    fn snapshot_for(&mut self, nodes: &[Arc<corev1::Node>]) -> Result<&mut Snapshot, String> {
+        let fingerprint: Vec<(String, String)> = nodes
+            .iter()
+            .map(|n| (n.metadata.name.clone().unwrap_or_default(), n.metadata.resource_version.clone().unwrap_or_default()))
+            .collect();
+        if self.snapshot.is_none() || fingerprint != self.node_fingerprint {
+            self.snapshot = Some(Snapshot::build_from_counted(nodes, &self.counted)?);
+            self.node_fingerprint = fingerprint;
+        }
+        return Ok(self.snapshot.as_mut().expect("snapshot was just built"));
+    }
+
+    /// select_node_for_pod (src/main.rs:51-71) for a batch of pending pods in ONE device call: `draws` holds `attempts` indices
+    /// into `nodes` (the store's own order; u32::MAX = no draw: empty store) per pod, made up front by the caller; the first
+    /// feasible draw wins.  Returns the chosen index into `nodes` per pod, -1 = none (NoNodeFound in reconcile).  A pod whose
+    /// requests cannot be encoded (the reference's .expect("invalid pod spec") panics on it) gets -1 and a warning; the other
+    /// pods of the batch are evaluated as usual.
+    pub fn pick_batch(&mut self, ev: &Evaluator, nodes: &[Arc<corev1::Node>], pods: &[Arc<corev1::Pod>], draws: &[u32], attempts: u32) -> Result<Vec<i32>, String> {
+        if draws.len() != pods.len() * attempts as usize {
+            return Err("draws must hold attempts indices per pod".into());
+        }
+        let mut chosen = vec![-1i32; pods.len()];
+        if nodes.is_empty() || pods.is_empty() {
+            return Ok(chosen); // choose() on an empty store yields None on every attempt (src/main.rs:56,70)
+        }
+        let snap = self.snapshot_for(nodes)?;
+        let mut canonical_of_store = vec![0u32; nodes.len()];
+        for (canonical, &store) in snap.store_index.iter().enumerate() {
+            canonical_of_store[store] = canonical as u32;
+        }
+        // the pods that can be encoded, and their draws in canonical column indices
+        let mut which: Vec<usize> = Vec::with_capacity(pods.len());
+        for (i, p) in pods.iter().enumerate() {
+            match total_pod_resources_nanos(p).and_then(|(c, m)| nanos_to_i64(c, 1_000_000, "milli-cores").and(nanos_to_i64(m, 1_000_000_000, "bytes"))) {
+                Ok(_) => which.push(i),
+                Err(e) => tracing::warn!("pod {} cannot be scheduled: {}", pod_key(p), e),
+            }
+        }
+        if which.is_empty() {
+            return Ok(chosen);
+        }
+        let refs: Vec<&corev1::Pod> = which.iter().map(|&i| pods[i].as_ref()).collect();
+        let mut samples: Vec<u32> = Vec::with_capacity(which.len() * attempts as usize);
+        for &i in &which {
+            for a in 0..attempts as usize {
+                let d = draws[i * attempts as usize + a];
+                samples.push(if (d as usize) < nodes.len() { canonical_of_store[d as usize] } else { u32::MAX });
+            }
+        }
+        let cols = snap.encode_and_upload(ev, &refs)?;
+        let mut binding = vec![-1i32; which.len()];
+        let rc = unsafe {
+            sys::ksched_eval(
+                ev.raw(), cols.p, cols.req_cpu_milli.as_ptr(), cols.req_mem_bytes.as_ptr(),
+                if cols.n_keys > 0 { cols.sel_val_ids.as_ptr() } else { std::ptr::null() }, std::ptr::null(), samples.as_ptr(), attempts,
+                sys::KSCHED_FIT | sys::KSCHED_SEL | sys::KSCHED_PICK_SAMPLED, std::ptr::null_mut(), std::ptr::null_mut(), binding.as_mut_ptr(),
+            )
+        };
+        ev.check(rc, "ksched_eval").map_err(|e| e.to_string())?;
+        for (j, &i) in which.iter().enumerate() {
+            if binding[j] >= 0 {
+                chosen[i] = snap.store_index[binding[j] as usize] as i32;
+            }
+        }
+        return Ok(chosen);
+    }
 }

@@ -1,7 +1,7 @@
-// src/ksched_sys.rs -- mechanical binding of include/ksched.h (ABI version 2): one `extern "C"` item per symbol the
+// src/ksched_sys.rs -- mechanical binding of include/ksched.h (ABI version 3): one `extern "C"` item per symbol the
 // header declares, same order.  Nothing here allocates or panics.  tests/test_abi_symbols.py (in the ksched repository)
 // checks this list against the header and the shared library's exports.
-#![allow(non_camel_case_types, dead_code)]
+#![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)]
@@ -136,4 +136,91 @@ extern "C" {
     pub fn ksched_trace_read(ctx: *mut ksched_ctx, out: *mut u64, max_blocks: u32) -> c_int;
     pub fn ksched_last_kernel(ctx: *const ksched_ctx) -> *const c_char;
     pub fn ksched_last_pick(ctx: *const ksched_ctx) -> *const c_char;
+}
+
+/// Every entry point of the binding with its address in the library that was linked: building the table makes the linker
+/// resolve all of them (a stale libksched_hip.so fails at link time, not at the first call of a rarely used function).
+pub fn symbol_table() -> Vec<(&'static str, usize)> {
+    return vec![
+        ("ksched_create", ksched_create as usize),
+        ("ksched_destroy", ksched_destroy as usize),
+        ("ksched_abi_version", ksched_abi_version as usize),
+        ("ksched_strerror", ksched_strerror as usize),
+        ("ksched_last_error", ksched_last_error as usize),
+        ("ksched_mask_words", ksched_mask_words as usize),
+        ("ksched_set_option", ksched_set_option as usize),
+        ("ksched_set_nodes", ksched_set_nodes as usize),
+        ("ksched_update_nodes", ksched_update_nodes as usize),
+        ("ksched_forget_stream", ksched_forget_stream as usize),
+        ("ksched_num_nodes", ksched_num_nodes as usize),
+        ("ksched_num_keys", ksched_num_keys as usize),
+        ("ksched_eval", ksched_eval as usize),
+        ("ksched_eval_device", ksched_eval_device as usize),
+        ("ksched_eval_device_pitched", ksched_eval_device_pitched as usize),
+        ("ksched_mask_pitch", ksched_mask_pitch as usize),
+        ("ksched_pick_device", ksched_pick_device as usize),
+        ("ksched_pipe_create", ksched_pipe_create as usize),
+        ("ksched_pipe_destroy", ksched_pipe_destroy as usize),
+        ("ksched_pipe_submit", ksched_pipe_submit as usize),
+        ("ksched_pipe_wait", ksched_pipe_wait as usize),
+        ("ksched_pipe_wait_mask", ksched_pipe_wait_mask as usize),
+        ("ksched_pipe_stream", ksched_pipe_stream as usize),
+        ("ksched_reason", ksched_reason as usize),
+        ("ksched_explain", ksched_explain as usize),
+        ("ksched_comm_unique_id", ksched_comm_unique_id as usize),
+        ("ksched_comm_create", ksched_comm_create as usize),
+        ("ksched_comm_create_local", ksched_comm_create_local as usize),
+        ("ksched_comm_destroy", ksched_comm_destroy as usize),
+        ("ksched_comm_rank", ksched_comm_rank as usize),
+        ("ksched_comm_size", ksched_comm_size as usize),
+        ("ksched_allgather_bindings", ksched_allgather_bindings as usize),
+        ("ksched_allgather_bindings_local", ksched_allgather_bindings_local as usize),
+        ("ksched_comm_last_error", ksched_comm_last_error as usize),
+        ("ksched_kernel_time_ms", ksched_kernel_time_ms as usize),
+        ("ksched_kernel_time_samples", ksched_kernel_time_samples as usize),
+        ("ksched_index_checksum", ksched_index_checksum as usize),
+        ("ksched_trace_read", ksched_trace_read as usize),
+        ("ksched_last_kernel", ksched_last_kernel as usize),
+        ("ksched_last_pick", ksched_last_pick as usize),
+    ];
+}
+
+/// Every constant of the binding (tests/test_rust_overlay.py in the ksched repository compares the values with include/ksched.h).
+pub fn constant_table() -> Vec<(&'static str, i64)> {
+    return vec![
+        ("KSCHED_ABI_VERSION", KSCHED_ABI_VERSION as i64),
+        ("KSCHED_MAX_KEYS", KSCHED_MAX_KEYS as i64),
+        ("KSCHED_MAX_ATTEMPTS", KSCHED_MAX_ATTEMPTS as i64),
+        ("KSCHED_SEL_NEVER", KSCHED_SEL_NEVER as i64),
+        ("KSCHED_COMM_ID_BYTES", KSCHED_COMM_ID_BYTES as i64),
+        ("KSCHED_OK", KSCHED_OK as i64),
+        ("KSCHED_E_INVAL", KSCHED_E_INVAL as i64),
+        ("KSCHED_E_NODEVICE", KSCHED_E_NODEVICE as i64),
+        ("KSCHED_E_HIP", KSCHED_E_HIP as i64),
+        ("KSCHED_E_NOMEM", KSCHED_E_NOMEM as i64),
+        ("KSCHED_E_STATE", KSCHED_E_STATE as i64),
+        ("KSCHED_E_UNSUPPORTED", KSCHED_E_UNSUPPORTED as i64),
+        ("KSCHED_E_RCCL", KSCHED_E_RCCL as i64),
+        ("KSCHED_FIT", KSCHED_FIT as i64),
+        ("KSCHED_SEL", KSCHED_SEL as i64),
+        ("KSCHED_TAINT", KSCHED_TAINT as i64),
+        ("KSCHED_PICK_SAMPLED", KSCHED_PICK_SAMPLED as i64),
+        ("KSCHED_PICK_BESTFIT", KSCHED_PICK_BESTFIT as i64),
+        ("KSCHED_WANT_FIT_MASK", KSCHED_WANT_FIT_MASK as i64),
+        ("KSCHED_REASON_OK", KSCHED_REASON_OK as i64),
+        ("KSCHED_REASON_NOT_ENOUGH_RESOURCES", KSCHED_REASON_NOT_ENOUGH_RESOURCES as i64),
+        ("KSCHED_REASON_NODE_SELECTOR_MISMATCH", KSCHED_REASON_NODE_SELECTOR_MISMATCH as i64),
+        ("KSCHED_REASON_TAINT_NOT_TOLERATED", KSCHED_REASON_TAINT_NOT_TOLERATED as i64),
+        ("KSCHED_OPT_KERNEL", KSCHED_OPT_KERNEL as i64),
+        ("KSCHED_OPT_TIMING", KSCHED_OPT_TIMING as i64),
+        ("KSCHED_OPT_DEBUG", KSCHED_OPT_DEBUG as i64),
+        ("KSCHED_OPT_TRACE", KSCHED_OPT_TRACE as i64),
+        ("KSCHED_OPT_PICK_FROM_MASK", KSCHED_OPT_PICK_FROM_MASK as i64),
+        ("KSCHED_OPT_INDEX_BUILD", KSCHED_OPT_INDEX_BUILD as i64),
+        ("KSCHED_OPT_BESTFIT_STAGES", KSCHED_OPT_BESTFIT_STAGES as i64),
+        ("KSCHED_OPT_SNAPSHOT_STREAM", KSCHED_OPT_SNAPSHOT_STREAM as i64),
+        ("KSCHED_OPT_FUSED_PICK", KSCHED_OPT_FUSED_PICK as i64),
+        ("KSCHED_OPT_FAULT", KSCHED_OPT_FAULT as i64),
+        ("KSCHED_OPT_PIPE_MODE", KSCHED_OPT_PIPE_MODE as i64),
+    ];
 }

@@ -1,6 +1,13 @@
 """The Rust overlay (rust/) cannot be compiled here (no cargo / rustc).  What can be checked without a toolchain:
   * src/ksched_sys.rs declares exactly the functions include/ksched.h declares (and nothing else), with as many arguments;
-  * its constants carry the header's values;
+  * its constants carry the header's values; its self-check tables list every function and constant it declares;
+  * every `sys::` item src/ksched.rs uses is declared there;
+  * no `dead_code` allowance anywhere: the batched pick is wired into the running binary, not parked;
+  * every file (and every patched file) has balanced brackets once comments, strings and char literals are stripped;
+  * every k8s-openapi field the overlay touches is one the reference's own sources use, or is in the short list below of
+    fields of the pinned k8s-openapi 0.18 (Cargo.lock:681-682) -- a typo in a field name fails here, not at a maintainer's desk;
+  * the wiring itself: under `--features ksched` select_node_for_pod goes through the batch task, main() spawns the batch
+    task and the pod watch, Context carries the two fields, reconcile's POST is the reference's own text;
   * the patches apply cleanly to the reference checkout (only where /root/reference exists: this container, not the GPU box).
 """
 import os
@@ -62,3 +69,141 @@ def test_patches_apply_cleanly_to_the_reference(tmp_path):
     assert not list(out.rglob("*.rej")) and not list(out.rglob("*.orig"))
     for f in ("build.rs", "src/ksched.rs", "src/ksched_sys.rs", "src/predicates/parity_dump.rs", "src/predicates/device_parity.rs"):
         assert (out / f).exists(), f
+
+
+RUST_DIR = os.path.join(ROOT, "rust")
+
+
+def rust_sources():
+    out = {}
+    for base, _, files in os.walk(RUST_DIR):
+        for f in files:
+            if f.endswith((".rs", ".patch", ".sh", ".md")):
+                out[os.path.relpath(os.path.join(base, f), RUST_DIR)] = open(os.path.join(base, f)).read()
+    return out
+
+
+def strip_rust(text):
+    """comments, string literals and char literals out (lifetimes like <'a> stay: they hold no brackets)"""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r'b?"(?:\\.|[^"\\])*"', '""', text, flags=re.S)
+    text = re.sub(r"b?'(?:\\.|[^'\\])'", "''", text)
+    return text
+
+
+def balanced(text):
+    pairs = {")": "(", "]": "[", "}": "{"}
+    stack = []
+    for ch in strip_rust(text):
+        if ch in "([{":
+            stack.append(ch)
+        elif ch in pairs:
+            if not stack or stack.pop() != pairs[ch]:
+                return False
+    return not stack
+
+
+def test_no_dead_code_allowance_anywhere():
+    for name, text in rust_sources().items():
+        if name.endswith((".rs", ".patch")):
+            assert "dead_code" not in text, f"rust/{name} still carries a dead_code allowance"
+
+
+def test_every_sys_item_used_is_declared_and_listed():
+    sys_rs = open(SYS_RS).read()
+    declared = set(re.findall(r"pub fn (ksched_\w+)", sys_rs)) | set(re.findall(r"pub const (KSCHED_\w+)", sys_rs)) | \
+        set(re.findall(r"pub struct (ksched_\w+)", sys_rs)) | {"symbol_table", "constant_table"}
+    used = set(re.findall(r"\bsys::(\w+)", open(os.path.join(RUST_DIR, "src", "ksched.rs")).read()))
+    assert used and used <= declared, f"used but not declared in ksched_sys.rs: {sorted(used - declared)}"
+    for patch in ("0001-predicates-fits-seam-and-batch.patch",):
+        for item in re.findall(r"crate::ksched_sys::(\w+)", open(os.path.join(RUST_DIR, "patches", patch)).read()):
+            assert item in declared, item
+    # the self-check tables name every function / constant exactly once
+    fn_tab = re.search(r"pub fn symbol_table\(\).*?\n    \];", sys_rs, flags=re.S).group(0)
+    const_tab = re.search(r"pub fn constant_table\(\).*?\n    \];", sys_rs, flags=re.S).group(0)
+    assert sorted(re.findall(r'\("(ksched_\w+)", \1 as usize\)', fn_tab)) == sorted(rust_functions())
+    assert sorted(re.findall(r'\("(KSCHED_\w+)", \1 as i64\)', const_tab)) == sorted(re.findall(r"pub const (KSCHED_\w+):", sys_rs))
+
+
+def test_brackets_balance_in_every_rust_file():
+    for name, text in rust_sources().items():
+        if name.endswith(".rs"):
+            assert balanced(text), f"rust/{name}: unbalanced brackets"
+
+
+# k8s-openapi 0.18 (v1_26) fields the overlay touches beyond the ones the reference's own sources already use.
+PINNED_API_FIELDS = {
+    "resource_version": "ObjectMeta::resource_version: Option<String>",
+}
+
+
+def overlay_field_uses(text):
+    """every field ACCESS (`.name` not followed by a call) and every field named in a struct pattern (`name: Some(`, `name: None`)"""
+    fields = set(re.findall(r"(?<![.\d])\.([a-z_][a-z0-9_]*)\b(?!\s*[(:!])", text))  # (not the `..` of a range)
+    fields |= set(re.findall(r"\b([a-z_][a-z0-9_]*):\s*(?:Some\(|None\b)", text))
+    return fields - {"await"}
+
+
+def overlay_own_fields(text):
+    """fields of the structs the overlay declares itself"""
+    own = set()
+    for body in re.findall(r"\bstruct\s+\w+(?:<[^>]*>)?\s*\{(.*?)\n\}", text, flags=re.S):
+        own |= set(re.findall(r"(?:pub\s+)?([a-z_][a-z0-9_]*)\s*:", body))
+    return own
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="/root/reference is not on this box (GPU box)")
+def test_k8s_fields_are_the_reference_own_or_pinned():
+    ref_text = "".join(open(os.path.join(base, f)).read() for base, _, files in os.walk(os.path.join(REFERENCE, "src")) for f in files if f.endswith(".rs"))
+    srcs = rust_sources()
+    used, own = set(), set()
+    for name in ("src/ksched.rs", "src/predicates/device_parity.rs", "src/predicates/parity_dump.rs", "patches/0002-main-batch-task-and-pod-watch.patch"):
+        text = srcs[name]
+        if name.endswith(".patch"):
+            text = "\n".join(ln[1:] for ln in text.splitlines() if ln.startswith("+") and not ln.startswith("+++"))
+        used |= overlay_field_uses(strip_rust(text))
+        own |= overlay_own_fields(strip_rust(text))
+    own |= set(re.findall(r"^\+\s+pub (\w+):", srcs["patches/0004-context-ksched-fields.patch"], flags=re.M))  # the fields Context gains
+    assert {"node_name", "node_selector", "containers", "requests", "resources", "allocatable", "labels", "name", "namespace", "resource_version"} <= used
+    # what is neither a field of the overlay's own structs nor an identifier the reference's sources use must be in the pinned list
+    unknown = sorted(f for f in used - own if not re.search(r"\b%s\b" % re.escape(f), ref_text) and f not in PINNED_API_FIELDS)
+    assert unknown == [], f"fields neither the overlay's own, nor in the reference's sources, nor in the pinned list: {unknown}"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="/root/reference is not on this box (GPU box)")
+def test_the_batched_pick_is_wired_into_the_running_binary(tmp_path):
+    """VERDICT r2 "a binding that routes the running binary to the device": with --features ksched the Controller's reconcile gets its node
+    from the batch task (ready_chunks -> ClusterState::pick_batch -> ksched_eval), `available` comes from the pod watch, and the POST
+    below the pick is the reference's own text."""
+    if not shutil.which("patch"):
+        pytest.skip("no `patch` binary")
+    out = tmp_path / "scheduler-v0"
+    subprocess.check_call(["bash", os.path.join(ROOT, "rust", "apply.sh"), REFERENCE, str(out)], stdout=subprocess.DEVNULL)
+    main_rs = (out / "src" / "main.rs").read_text()
+    util_rs = (out / "src" / "util.rs").read_text()
+    for f in ("src/main.rs", "src/util.rs", "src/predicates.rs", "src/ksched.rs", "src/ksched_sys.rs"):
+        assert balanced((out / f).read_text()), f
+    ref_main = open(os.path.join(REFERENCE, "src", "main.rs")).read()
+    # both forms of select_node_for_pod exist, one per feature state; reconcile calls it with the reference's own expression
+    assert '#[cfg(not(feature = "ksched"))]\nasync fn select_node_for_pod(pod: &corev1::Pod, ctx: &Context) -> Option<corev1::Node>' in main_rs
+    assert '#[cfg(feature = "ksched")]\nasync fn select_node_for_pod(pod: &Arc<corev1::Pod>, ctx: &Context) -> Option<corev1::Node>' in main_rs
+    assert strip_rust(main_rs).count("select_node_for_pod(&pod, &ctx).await") == 1 and "select_node_for_pod(&pod, &ctx).await" in ref_main
+    # the batch task: ready_chunks -> one device call per batch -> replies; spawned from main(); the pod watch too
+    for needle in ("requests.ready_chunks(MAX_BATCH)", "state.pick_batch(&evaluator_b, &nodes_b, &pods, &draws, ATTEMPTS)", "tokio::task::spawn_blocking",
+                   "tokio::spawn(run_pick_batches(pick_requests, node_store.clone(), cluster.clone(), evaluator));",
+                   "tokio::spawn(watch_bound_pods(client.clone(), cluster.clone()));", "watcher::Event::Applied(pod)", "watcher::Event::Deleted(pod)",
+                   "watcher::Event::Restarted(pods)", "ctx.picker.unbounded_send((pod.clone(), reply))"):
+        assert needle in main_rs, needle
+    assert "picker: futures::channel::mpsc::UnboundedSender<crate::PickRequest>" in util_rs and "cluster: std::sync::Arc<std::sync::Mutex<crate::ksched::ClusterState>>" in util_rs
+    # no LIST per batch any more
+    assert "Api::<corev1::Pod>::all" not in main_rs and ".list(" not in main_rs
+    # the binding POST of reconcile (src/main.rs:83-103) is the reference's text, line for line
+    post = ref_main[ref_main.index("        let pod_name = pod.name_any();"):ref_main.index("                match ctx.client.send(req_body).await {")]
+    assert post in main_rs
+    # what the overlay's ksched.rs offers is what main.rs calls
+    ksched_rs = (out / "src" / "ksched.rs").read_text()
+    for item in ("pub fn pick_batch(", "pub fn observe(", "pub fn resync(", "pub fn is_synced(", "pub fn counted_pods(", "pub enum PodEvent", "pub struct ClusterState"):
+        assert item in ksched_rs, item
+    for call in re.findall(r"\bksched::(\w+)", main_rs):
+        assert re.search(r"pub (?:struct|enum|fn|type) %s\b" % call, ksched_rs), call
