@@ -353,3 +353,162 @@ def reconcile_batch_sequential(pods: Sequence[dict], store: Sequence[dict], all_
     for i in pending:
         outcomes[i] = {"ok": False, "error": "no-node-found", "bound_to": None}
     return outcomes, sink[2], rounds, conflicts, state
+
+
+# ---- second reading: kube_quantity 0.6.1 AS RECALLED (SURVEY.md section 8c hazard list) ----------------------------------------------
+#
+# NOT a restatement of code on disk: the crate is an un-vendored dependency (Cargo.lock:787-797) and nothing here can build or run it.
+# This class writes down what the surveyor RECALLS of its internals, so that the unpinned half of the parity claim is BRACKETED: for
+# every quantity spelling, tests/test_quantity_readings.py states whether exact Kubernetes semantics (parse_quantity above: what the
+# product and both oracles implement) and this reading agree.  Where they agree, a run of the real reference (rust/pin_parity.sh)
+# cannot tell them apart and the parity claim holds under either; where they differ, the committed fixtures carry BOTH expectations
+# and the day someone runs the reference the answer is a one-line diff.
+#
+# The recollection (crate `kube_quantity`, struct ParsedQuantity { value: rust_decimal::Decimal, scale, format }):
+#   * parse: sign? digits [. digits] suffix; suffix in  n u m "" k M G T P E  -> DecimalSI, Ki Mi Gi Ti Pi Ei -> BinarySI, scale index
+#     n=-3 u=-2 m=-1 ""=0 k/Ki=1 M/Mi=2 G/Gi=3 T/Ti=4 P/Pi=5 E/Ei=6.  Exponent forms (1e3, 1E3) are NOT accepted by 0.6.1.
+#   * a += b, a -= b, a <= b all first bring b to a's FORMAT -- b.value *= Decimal::from_f32((1024/1000)^b.scale) (DecimalSI <- BinarySI) or
+#     (1000/1024)^b.scale (BinarySI <- DecimalSI), the power computed in f32 -- then both to the SMALLER scale, multiplying the larger-scale
+#     side by Decimal::from_f32(base^diff), base 1000 or 1024 by that side's format, again in f32; the result keeps a's format.
+#   * Decimal::from_f32 keeps 7 significant decimal digits (rust_decimal's FromPrimitive for f32).
+# Consequences: Ki (1.024) and Mi (1.048576) factors survive f32 + 7 digits exactly; Gi (1.073741824 -> 1.073742), Ti, Pi, Ei do not,
+# and neither do decimal scale steps of 10^12 and beyond.  Because PodResources::new() seeds "0" (DecimalSI, src/util.rs:25-26), every
+# BinarySI REQUEST is converted on its way into the sum; a node's allocatable is ASSIGNED (src/predicates.rs:29-31) and keeps its own
+# format, so `available` may be BinarySI and the pods subtracted from it are converted the other way.
+import decimal as _decimal
+import struct as _struct
+
+_KQ_CTX = _decimal.Context(prec=60)  # (rust_decimal: 96-bit mantissa, 28 fractional digits; nothing here comes near either limit)
+_KQ_SCALE = {"n": -3, "u": -2, "m": -1, "": 0, "k": 1, "M": 2, "G": 3, "T": 4, "P": 5, "E": 6, "Ki": 1, "Mi": 2, "Gi": 3, "Ti": 4, "Pi": 5, "Ei": 6}
+_KQ_RE = re.compile(r"^([+-]?)(\d+)(?:\.(\d+))?(Ki|Mi|Gi|Ti|Pi|Ei|[numkMGTPE]?)$")
+
+
+def _f32(x: float) -> float:
+    return _struct.unpack("f", _struct.pack("f", x))[0]
+
+
+def _powi_f32(base: float, n: int) -> float:
+    """f32::powi: repeated multiplication in f32 (what llvm.powi lowers to for small integer exponents); negative n = 1 / powi(-n)."""
+    r = _f32(1.0)
+    b = _f32(base)
+    for _ in range(abs(n)):
+        r = _f32(r * b)
+    return _f32(1.0 / r) if n < 0 else r
+
+
+def _decimal_from_f32(x: float) -> "_decimal.Decimal":
+    """rust_decimal Decimal::from_f32: the f32's value rounded to 7 significant decimal digits."""
+    if x == 0:
+        return _decimal.Decimal(0)
+    return _KQ_CTX.create_decimal(_decimal.Context(prec=7, rounding=_decimal.ROUND_HALF_EVEN).create_decimal(repr(float(x))))
+
+
+class KubeQuantity061:
+    """One ParsedQuantity as recalled: (value, scale index, binary format?)."""
+
+    __slots__ = ("value", "scale", "binary")
+
+    def __init__(self, value, scale: int, binary: bool):
+        self.value, self.scale, self.binary = _decimal.Decimal(value), scale, binary
+
+    @staticmethod
+    def parse(s: str) -> "KubeQuantity061":
+        if not isinstance(s, str):
+            raise ReferencePanic(f"quantity is not a string: {s!r}")
+        m = _KQ_RE.match(s)
+        if not m:
+            raise ReferencePanic(f"kube_quantity 0.6.1 (as recalled) does not parse {s!r}")  # try_into().expect(...)
+        sign, ip, fp, suf = m.group(1), m.group(2), m.group(3) or "", m.group(4)
+        v = _decimal.Decimal((1 if sign == "-" else 0, tuple(int(c) for c in (ip + fp).lstrip("0") or "0"), -len(fp)))
+        return KubeQuantity061(v, _KQ_SCALE[suf], suf.endswith("i"))
+
+    def copy(self) -> "KubeQuantity061":
+        return KubeQuantity061(self.value, self.scale, self.binary)
+
+    # -- the two normalisations every operator runs on (clones of) its operands
+    @staticmethod
+    def _normalize_formats(lhs: "KubeQuantity061", rhs: "KubeQuantity061"):
+        if lhs.binary == rhs.binary:
+            return
+        ratio = _f32(1000.0) / _f32(1024.0) if lhs.binary else _f32(1024.0) / _f32(1000.0)
+        rhs.value = _KQ_CTX.multiply(rhs.value, _decimal_from_f32(_powi_f32(_f32(ratio), rhs.scale)))
+        rhs.binary = lhs.binary
+
+    @staticmethod
+    def _normalize_scales(lhs: "KubeQuantity061", rhs: "KubeQuantity061"):
+        if lhs.scale == rhs.scale:
+            return
+        big, small = (rhs, lhs) if rhs.scale > lhs.scale else (lhs, rhs)
+        base = 1024.0 if big.binary else 1000.0
+        big.value = _KQ_CTX.multiply(big.value, _decimal_from_f32(_powi_f32(base, big.scale - small.scale)))
+        big.scale = small.scale
+
+    def _with(self, other: "KubeQuantity061"):
+        lhs, rhs = self.copy(), other.copy()
+        KubeQuantity061._normalize_formats(lhs, rhs)
+        KubeQuantity061._normalize_scales(lhs, rhs)
+        return lhs, rhs
+
+    def add_assign(self, other: "KubeQuantity061"):
+        lhs, rhs = self._with(other)
+        self.value, self.scale, self.binary = _KQ_CTX.add(lhs.value, rhs.value), lhs.scale, lhs.binary
+
+    def sub_assign(self, other: "KubeQuantity061"):
+        lhs, rhs = self._with(other)
+        self.value, self.scale, self.binary = _KQ_CTX.subtract(lhs.value, rhs.value), lhs.scale, lhs.binary
+
+    def le(self, other: "KubeQuantity061") -> bool:
+        lhs, rhs = self._with(other)
+        return lhs.value <= rhs.value
+
+    def in_units(self) -> Fraction:
+        """the quantity's value in cores / bytes under THIS reading's own conversion to scale "" (for printing and comparing)"""
+        probe = KubeQuantity061(0, 0, False)
+        probe.add_assign(self)  # = how a request enters the accumulator seeded "0" (src/util.rs:25-26,65,68)
+        return Fraction(str(probe.value)) * Fraction(1000) ** probe.scale
+
+
+def kq061_total_pod_resources(pod: dict):
+    """src/util.rs:54-75 under the recalled arithmetic: two accumulators seeded "0" (DecimalSI)."""
+    cpu, mem = KubeQuantity061.parse("0"), KubeQuantity061.parse("0")
+    spec = pod.get("spec")
+    if spec is not None:
+        for c in spec.get("containers") or []:
+            resources = c.get("resources")
+            requests = resources.get("requests") if resources is not None else None
+            if requests is not None:
+                if "cpu" in requests:
+                    cpu.add_assign(KubeQuantity061.parse(requests["cpu"]))
+                if "memory" in requests:
+                    mem.add_assign(KubeQuantity061.parse(requests["memory"]))
+    return cpu, mem
+
+
+def kq061_can_pod_fit(pod: dict, node: dict, pods_on_node: Sequence[dict]) -> bool:
+    """src/predicates.rs:20-43 under the recalled arithmetic (allocatable ASSIGNED, so `available` keeps the node's format)."""
+    acpu, amem = KubeQuantity061.parse("0"), KubeQuantity061.parse("0")
+    status = node.get("status")
+    allocatable = status.get("allocatable") if status is not None else None
+    if allocatable is not None:
+        if "cpu" not in allocatable or "memory" not in allocatable:
+            raise ReferencePanic("allocatable lacks cpu/memory (BTreeMap index panics, src/predicates.rs:29-31)")
+        acpu, amem = KubeQuantity061.parse(allocatable["cpu"]), KubeQuantity061.parse(allocatable["memory"])
+    for p in pods_on_node:
+        c, m = kq061_total_pod_resources(p)
+        acpu.sub_assign(c)
+        amem.sub_assign(m)
+    rc, rm = kq061_total_pod_resources(pod)
+    return rc.le(acpu) and rm.le(amem)
+
+
+def kq061_fit_matrix(pods: Sequence[dict], nodes: Sequence[dict], all_pods: Sequence[dict]):
+    """fit bit of every (pod, node) pair under the recalled reading; a pair on which it would panic (an unparsable spelling) is None."""
+    lists = [list_pods_on_node(all_pods, node_name(n)) for n in nodes]
+    out = []
+    for p in pods:
+        for i, n in enumerate(nodes):
+            try:
+                out.append(kq061_can_pod_fit(p, n, lists[i]))
+            except ReferencePanic:
+                out.append(None)
+    return out

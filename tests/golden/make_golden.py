@@ -90,6 +90,79 @@ def hazard_case():
     return pods, nodes, bound, samples
 
 
+def typical_case():
+    """Hand-built: the spellings real manifests and kubelets use -- cpu "500m" / "2" / "0.5", memory "128Mi" / "1Gi" / "512Mi",
+    allocatable "32779148Ki" / "7910m" -- including pods that fit a node EXACTLY (where a reading that inflates Gi by 1.6e-7 shows)."""
+    allocs = [("8", "32779148Ki"), ("7910m", "32779148Ki"), ("4", "16Gi"), ("3920m", "15031Mi"), ("16", "64Gi"), ("2", "4Gi"),
+              ("96", "196608Mi"), ("1", "2Gi"), ("32", "128Gi"), ("8", "31Gi"), ("4", "8G"), ("64", "256Gi")]
+    nodes = [{"metadata": {"name": f"ty-node-{i:02d}", "labels": {"pool": "gp" if i % 3 else "hm", "kubernetes.io/os": "linux"}},
+              "status": {"allocatable": {"cpu": c, "memory": m}}} for i, (c, m) in enumerate(allocs)]
+    reqs = [("500m", "1Gi"), ("500m", "512Mi"), ("250m", "128Mi"), ("100m", "64Mi"), ("1", "2Gi"), ("2", "4Gi"), ("4", "16Gi"), ("4", "8G"),
+            ("0.5", "1Gi"), ("1500m", "3Gi"), ("8", "32779148Ki"), ("7910m", "32779148Ki"), ("16", "64Gi"), ("3920m", "15031Mi"),
+            ("32", "128Gi"), ("1", "2147483648"), ("2", "4294967296"), ("1", "2147483649"), ("64", "256Gi"), ("8", "31Gi"),
+            ("10m", "16Mi"), ("50m", "100M"), ("2", "1500Mi"), ("1", "1G"), ("3", "6Gi"), ("6", "24Gi"), ("12", "48Gi"), ("200m", "256Mi"),
+            ("1", "1.5Gi"), ("750m", "768Mi"), ("4", "17179869184"), ("4", "17179869185"), ("16", "68719476736"), ("16", "68719476737"),
+            ("96", "196608Mi"), ("96", "192Gi"), ("2", "4000Mi"), ("1", "1025Mi"), ("8", "16Gi"), ("4", "7Gi")]
+    pods = [{"metadata": {"name": f"ty-pod-{i:02d}", "namespace": "ty"},
+             "spec": {"containers": [{"name": "app", "resources": {"requests": {"cpu": c, "memory": m}}}]}}
+            for i, (c, m) in enumerate(reqs)]
+    pods[5]["spec"]["containers"].append({"name": "sidecar", "resources": {"requests": {"cpu": "100m", "memory": "128Mi"}}})
+    pods[9]["spec"]["nodeSelector"] = {"pool": "hm"}
+    pods[20]["spec"]["nodeSelector"] = {"kubernetes.io/os": "linux"}
+    bound = [{"metadata": {"name": "ty-bound-0", "namespace": "ty"},
+              "spec": {"nodeName": "ty-node-04", "containers": [{"name": "c", "resources": {"requests": {"cpu": "4", "memory": "16Gi"}}}]}},
+             {"metadata": {"name": "ty-bound-1", "namespace": "ty"},
+              "spec": {"nodeName": "ty-node-00", "containers": [{"name": "c", "resources": {"requests": {"cpu": "1500m", "memory": "6Gi"}}}]}},
+             {"metadata": {"name": "ty-bound-2", "namespace": "ty"},
+              "spec": {"nodeName": "ty-node-08", "containers": [{"name": "c", "resources": {"requests": {"cpu": "30", "memory": "120Gi"}}}]}}]
+    samples = np.array([[(i * 5 + t * 7) % len(nodes) for t in range(R.ATTEMPTS)] for i in range(len(pods))], dtype=np.uint32)
+    return pods, nodes, bound, samples
+
+
+SPELLINGS = ["0", "1", "2", "500m", "250m", "100m", "10m", "1500m", "7910m", "0.5", "1.5", "64Mi", "128Mi", "512Mi", "768Mi", "1025Mi", "15031Mi", "196608Mi",
+             "32779148Ki", "1Gi", "2Gi", "4Gi", "16Gi", "31Gi", "64Gi", "256Gi", "1.5Gi", "1Ti", "0.5Ti", "1Pi", "1G", "8G", "100M", "1k", "1T", "10E",
+             "1073741824", "17179869184", "1n", "100u", "1e3", "1E3", "129e6", "5.", "+5", "-5m"]
+
+
+def dump_readings(name, pods, nodes, bound):
+    """Both expectations of the fit mask: exact Kubernetes semantics (what the product implements) and kube_quantity 0.6.1 as
+    recalled (oracle_ref.KubeQuantity061).  ref_<name>.json of a real reference run is compared with both (tests/test_quantity_readings.py)."""
+    P, N = len(pods), len(nodes)
+    _, fit = R.eval_matrix(pods, nodes, bound)
+    kq = R.kq061_fit_matrix(pods, nodes, bound)
+    exact_bits = np.array(fit, dtype=bool).reshape(P, N)
+    kq_bits = np.array([bool(x) for x in kq], dtype=bool).reshape(P, N)  # (a pair the recalled parser would panic on counts as infeasible: parity_dump.rs does the same)
+    panics = [[i // N, i % N] for i, x in enumerate(kq) if x is None]
+    differ = [[int(p), int(n)] for p, n in np.argwhere(exact_bits != kq_bits)]
+    doc = {"name": name, "p": P, "n": N, "fit_exact_kubernetes": hex_rows(pack_mask(exact_bits)), "fit_kube_quantity_0_6_1_as_recalled": hex_rows(pack_mask(kq_bits)),
+           "pairs_where_the_readings_differ": differ, "pairs_the_recalled_parser_rejects": panics,
+           "source": "oracle/oracle_ref.py: eval_matrix (exact Fractions) and kq061_fit_matrix (Decimal + f32 scale factors, 7 significant digits)"}
+    with open(os.path.join(HERE, name + "_readings.json"), "w") as f:
+        json.dump(doc, f, separators=(",", ":"), sort_keys=True)
+        f.write("\n")
+    return len(differ), len(panics)
+
+
+def dump_spellings():
+    rows = []
+    for s in SPELLINGS:
+        try:
+            a = R.parse_quantity(s)
+            exact = f"{a.numerator}/{a.denominator}" if a.denominator != 1 else str(a.numerator)
+        except R.ReferencePanic:
+            exact = "rejected"
+        try:
+            b = R.KubeQuantity061.parse(s).in_units()
+            kq = f"{b.numerator}/{b.denominator}" if b.denominator != 1 else str(b.numerator)
+        except R.ReferencePanic:
+            kq = "rejected"
+        rows.append({"spelling": s, "exact_kubernetes": exact, "kube_quantity_0_6_1_as_recalled": kq, "agree": exact == kq})
+    with open(os.path.join(HERE, "quantity_readings.json"), "w") as f:
+        json.dump({"note": "value of the spelling as a request entering the accumulator seeded \"0\" (src/util.rs:25-26,65,68), in cores / bytes",
+                   "rows": rows}, f, indent=1)
+        f.write("\n")
+
+
 def main():
     # object-only cases
     c = synth.make_cluster(P=60, N=40, n_keys=8, n_taints=0, seed=0x5EED0303, binary_suffixes=True)
@@ -99,6 +172,12 @@ def main():
     pods, nodes, bound, samples = hazard_case()
     dump_objects("hazard_gi_24x10", pods, nodes, bound, samples, "OUTSIDE D: Gi/Ti/exponent/fractional spellings (hazard list, SURVEY.md 8c)")
     dump_expected("hazard_gi_24x10", pods, nodes, bound, samples, use_taint=False)
+    print("hazard_gi_24x10: readings differ on %d pairs, the recalled parser rejects %d" % dump_readings("hazard_gi_24x10", pods, nodes, bound))
+    pods, nodes, bound, samples = typical_case()
+    dump_objects("typical_specs_40x12", pods, nodes, bound, samples, "typical real spellings (500m / 1Gi / 512Mi / 32779148Ki): Gi and above are OUTSIDE D")
+    dump_expected("typical_specs_40x12", pods, nodes, bound, samples, use_taint=False)
+    print("typical_specs_40x12: readings differ on %d pairs, the recalled parser rejects %d" % dump_readings("typical_specs_40x12", pods, nodes, bound))
+    dump_spellings()
     for name, kw in CASES.items():
         c = synth.make_cluster(**kw)
         pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()
