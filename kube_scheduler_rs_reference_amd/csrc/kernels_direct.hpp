@@ -432,6 +432,8 @@ struct BestfitRowsArgs {
     // 8-positions-per-bit summaries of `rows` (kernels_build.hpp k_bf_sum), [rows][Ws]: the second stage scans these
     const uint64_t *sum;
     uint32_t Ws;
+    uint32_t *zero_next;  // the counters of the NEXT two-stage call (three slots in rotation): zeroed here, so that no call pays a memset launch
+    uint32_t coarse_max;  // most candidate bytes per wave round the summary scan looks at itself; more -> the pod continues on the full rows
 };
 
 // first i in [0, n) with arr[i] >= key (n if none), by the whole wave: 64-ary search, three rounds for n <= 262144
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
         const uint4 *rec = reinterpret_cast<const uint4 *>(q.pod_list) + (size_t)wave * 4u;
         const uint4 h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
         const uint32_t sel[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const int32_t b = bestfit_rows_scan(q, h.x, lane, h.y, h.z, h.w, (int64_t)(((uint64_t)o.w << 32) | o.z), ((uint64_t)o.y << 32) | o.x, sel);
+        const int32_t b = bestfit_rows_scan(q, h.x, lane, h.y, h.z, h.w & 0x7FFFFFFFu, (int64_t)(((uint64_t)o.w << 32) | o.z), ((uint64_t)o.y << 32) | o.x, sel);
         if (lane == 0) q.binding[h.x] = b;
         return;
     }
@@ -602,8 +604,11 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
     if (lane == 0) q.binding[wave] = b;
 }
 
-// Best fit, second stage over the row SUMMARIES (k_bf_sum: one bit per 8 best-fit positions).  The pods that reach the second
-// stage are the ones whose AND of rows is sparse -- several selective label keys, a cpu request few nodes can hold, or no
+// Best fit, second stage over the row SUMMARIES (k_bf_sum: one bit per 8 best-fit positions), for the pods the first stage flags
+// as sparse (it saw no candidate at all in its words); the others continue on the full rows (bestfit_rows_scan): with a
+// candidate every few positions, reading whole words beats looking at candidate bytes one per lane and trip (session r3c / r3d:
+// summaries for every handed-over pod 135 us per batch at the C5 shard, 105 us with a per-round switch, full rows 98 us).  The sparse ones
+// are the ones whose AND of rows is sparse -- several selective label keys, a cpu request few nodes can hold, or no
 // feasible node at all (4 % of the C5 pods: the scan runs to the end of the snapshot) -- and scanning every word of every row
 // for them moved ~400 MB per batch at the C5 shard.  Here a lane ANDs the pod's summary words (512 positions per word, 32 768 per
 // wave round), which is a superset of the bytes where the AND of the full rows can have a bit, and only those candidate bytes of
@@ -646,6 +651,14 @@ __device__ __forceinline__ int32_t bestfit_coarse_scan(const BestfitRowsArgs &q,
             if (q.do_fit) S &= q.sum[(size_t)r_lo * q.Ws + j];
             if (j == j_first) S &= ~0ull << ((p0 >> 3) & 63u);  // bytes before p0
         }
+        // Adaptive: the summaries pay off when the AND is SPARSE (a handful of candidate bytes in 32 768 positions).  When many bytes
+        // are candidates the pod's first feasible node is near, and looking at candidates one byte per lane and trip costs more than
+        // reading whole words: that pod continues on the full rows from here (session r3c: summaries alone, 135 us per batch at
+        // the C5 shard against 98 us on the full rows).
+        uint32_t cands = (uint32_t)__popcll(S);
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1) cands += (uint32_t)__shfl_xor((int)cands, d, 64);
+        if (cands > q.coarse_max) return bestfit_rows_scan(q, pod, lane, start, r, max(w_first, jb * 8u), req_c, tol, sel);
         uint32_t found = 0xFFFFFFFFu;
         while (true) {
             const bool active = S != 0ull && found == 0xFFFFFFFFu;
@@ -697,7 +710,11 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_coarse(const BestfitRowsAr
     const uint4 *rec = reinterpret_cast<const uint4 *>(q.pod_list) + (size_t)wave * 4u;
     const uint4 h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
     const uint32_t sel[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const int32_t b = bestfit_coarse_scan(q, h.x, lane, h.y, h.z, h.w, (int64_t)(((uint64_t)o.w << 32) | o.z), ((uint64_t)o.y << 32) | o.x, sel);
+    const int64_t req_c = (int64_t)(((uint64_t)o.w << 32) | o.z);
+    const uint64_t tol = ((uint64_t)o.y << 32) | o.x;
+    const uint32_t w_first = h.w & 0x7FFFFFFFu;
+    // the first stage's hint (bit 31): sparse AND -> the summaries; a candidate was seen near the start -> the full rows
+    const int32_t b = (h.w >> 31) ? bestfit_coarse_scan(q, h.x, lane, h.y, h.z, w_first, req_c, tol, sel) : bestfit_rows_scan(q, h.x, lane, h.y, h.z, w_first, req_c, tol, sel);
     if (lane == 0) q.binding[h.x] = b;
 }
 
@@ -712,6 +729,10 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_coarse(const BestfitRowsAr
 __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArgs q) {
     kernarg_warm<sizeof(BestfitRowsArgs)>();
     const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pod == 0u && q.zero_next) {  // (the slot after this call's: its last users finished two calls ago, its next ones start after this kernel)
+        q.zero_next[0] = 0u;
+        q.zero_next[1] = 0u;
+    }
     if (pod >= q.p) return;
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
     if (q.nlist && q.psel) {  // a list key has no bitmap rows: a pod that constrains one is picked from the key's sorted lists instead
@@ -754,6 +775,7 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
         r = min(r, q.n);
     }
     int32_t found = -1;
+    uint32_t w0_flag = 0;
     bool undecided = start < q.n;
     // a required value no node carries (KSCHED_SEL_NEVER, or an id beyond the key's largest): the pod's AND of rows is empty --
     // no node, and no scan to the end of the snapshot to find that out (1 % of the constrained keys in the C5 workload)
@@ -767,6 +789,7 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) lrow[k] = (sel[k] <= q.lab_max8[k]) ? q.lab_base8[k] + sel[k] - 1u : q.row_zero;
         const uint32_t w0 = start >> 6;
+        uint32_t seen = 0;  // positions in the words looked at that pass selector, taints and the coarse cpu row (before the exact cpu test)
         for (uint32_t t = 0; t < q.lane_words && undecided; ++t) {
             const uint32_t w = w0 + t;
             if (w >= q.Wbf) {
@@ -788,6 +811,7 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
             if (t == 0) base &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
             const uint64_t sure = q.do_fit ? (base & hi) : base;
             uint64_t cand = q.do_fit ? (sure | (base & lo & ~hi)) : base;
+            seen += (uint32_t)__popcll(cand);
             while (cand) {
                 const uint32_t b = (uint32_t)__builtin_ctzll(cand);
                 const uint32_t i = w * 64u + b;
@@ -800,10 +824,14 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
             }
             if (undecided && w + 1u >= q.Wbf) undecided = false;  // that was the last word: no feasible node
         }
+        // Hand-over hint: not ONE candidate in the (up to 512) positions looked at -> the pod's AND of rows is sparse (several
+        // selective keys, a cpu request few nodes hold, or no feasible node at all: those scan to the end of the snapshot) -> the second
+        // stage scans the row SUMMARIES for it; otherwise a feasible node is near and the full rows are read (bit 31 of the record's word 3)
+        if (undecided && seen == 0u && q.sum != nullptr) w0_flag = 0x80000000u;
     }
     if (undecided) {  // the wave-per-pod kernel scans on behind the words looked at here
         uint4 *rec = reinterpret_cast<uint4 *>(q.fallback_list) + (size_t)atomicAdd(q.fallback_count, 1u) * 4u;
-        rec[0] = make_uint4(pod, start, r, (start >> 6) + q.lane_words);
+        rec[0] = make_uint4(pod, start, r, ((start >> 6) + q.lane_words) | w0_flag);
         rec[1] = make_uint4((uint32_t)tol, (uint32_t)(tol >> 32), (uint32_t)(uint64_t)req_c, (uint32_t)((uint64_t)req_c >> 32));
         rec[2] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
         rec[3] = make_uint4(sel[4], sel[5], sel[6], sel[7]);

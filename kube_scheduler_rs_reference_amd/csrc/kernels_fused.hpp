@@ -176,8 +176,16 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             // this block's share of the batch's pods: [lin * ppb, (lin + 1) * ppb), 64 at a time over the pick waves
             const uint32_t base = lin * a.pick_ppb;
             const uint32_t end = min(a.p, base + a.pick_ppb);
-            for (uint32_t pod = base + pick_rank * 64u + (threadIdx.x & 63u); pod < end; pod += pick_waves * 64u)
-                sa.binding[pod] = select_one_pod<5, 1>(sa, pod);  // src/main.rs:53-66: first feasible draw wins, none -> -1
+            const uint32_t eager = (a.debug >> 8) & 3u;  // A/B of the number of eagerly fetched draws (same bits as the stand-alone kernel)
+            for (uint32_t pod = base + pick_rank * 64u + (threadIdx.x & 63u); pod < end; pod += pick_waves * 64u) {
+                // src/main.rs:53-66: first feasible draw wins, none -> -1
+                int32_t bnd;
+                if (eager == 1u) bnd = select_one_pod<5, 3>(sa, pod);
+                else if (eager == 2u) bnd = select_one_pod<5, 5>(sa, pod);
+                else if (eager == 3u) bnd = select_one_pod<5, 2>(sa, pod);
+                else bnd = select_one_pod<5, 1>(sa, pod);
+                sa.binding[pod] = bnd;
+            }
             if (a.trace && threadIdx.x == 0u)  // trace word 7, bits 8..: wave 0's entry -> its picks issued, in 10 ns ticks (bits 0..7: XCC id)
                 atomicOr((unsigned long long *)&a.trace[(size_t)b * 8u + 7u], (unsigned long long)((wall_clock64() - t_in) << 8));
         }

@@ -75,7 +75,9 @@ struct ksched_ctx {
     uint32_t bf_n1 = 0, bf_n2 = 0;
     DevBuf<int64_t> bf_levels;       // 8-ary level arrays of bf_mem / cpu_sorted (k_pick_bestfit_lanes)
     uint32_t bf_nlev = 0, bf_lvl_half = 0, bf_lvl_off[6] = {};
-    DevBuf<uint32_t> bf_fallback;    // counter (16 bytes), then one uint4 per pod the lane-per-pod pick hands to the wave-per-pod kernel
+    DevBuf<uint32_t> bf_fallback;    // 3 x 2 counters in rotation (64-byte header), then one 64-byte record per pod the lane-per-pod pick hands over, then the listed pods
+    uint32_t bf_slot = 0;            // which of the three counter pairs the next two-stage pick uses (the call before zeroed it)
+    size_t bf_fallback_zeroed_cap = 0;
     DevBuf<uint64_t> bf_rows;        // [rows][Wbf] bitmaps over best-fit positions (k_pick_bestfit_rows); built with the tile index
     DevBuf<uint64_t> bf_sum;         // [rows][Ws] their 8-positions-per-bit summaries (k_pick_bestfit_coarse)
     uint32_t bf_Ws = 0;
@@ -765,25 +767,39 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
                 return KSCHED_E_UNSUPPORTED;
             }
             if (int rsc = scratch_enter(c, s)) return rsc;
-            HIPCHK(c, c->bf_fallback.reserve(16 * ((size_t)p + 1) + p));  // [2 counters, padding to 64 bytes][64-byte hand-over record x p][listed pods x p]
-            HIPCHK(c, hipMemsetAsync(c->bf_fallback.ptr, 0, 8, s));
+            HIPCHK(c, c->bf_fallback.reserve(16 * ((size_t)p + 1) + p));  // [3 x 2 counters, padding to 64 bytes][64-byte hand-over record x p][listed pods x p]
+            if (c->bf_fallback_zeroed_cap != c->bf_fallback.cap) {  // a fresh allocation: the header once; from then on every call zeroes the next call's pair
+                HIPCHK(c, hipMemsetAsync(c->bf_fallback.ptr, 0, 64, s));
+                c->bf_fallback_zeroed_cap = c->bf_fallback.cap;
+                c->bf_slot = 0;
+            }
+            uint32_t *const ctr = c->bf_fallback.ptr + 4u * c->bf_slot;
+            q.zero_next = c->bf_fallback.ptr + 4u * ((c->bf_slot + 1u) % 3u);
             q.lvl = c->bf_levels.ptr;
             q.nlev = c->bf_nlev;
             q.lvl_half = c->bf_lvl_half;
             for (uint32_t k = 0; k < 6; ++k) q.lvl_off[k] = c->bf_lvl_off[k];
-            q.fallback_count = c->bf_fallback.ptr;
+            q.fallback_count = ctr;
             q.fallback_list = c->bf_fallback.ptr + 16;
             q.nlist = lists ? l.nlist : 0u;
             for (uint32_t j = 0; j < q.nlist; ++j) q.list_col[j] = l.list_col[j];
-            q.listed_count = c->bf_fallback.ptr + 1;
+            q.listed_count = ctr + 1;
             q.listed_list = c->bf_fallback.ptr + 16 * ((size_t)p + 1);
+            q.sum = (c->opt_debug & 0x800u) ? nullptr : c->bf_sum.ptr;  // (bit 11: no summaries -- every handed-over pod on the full rows)
+            q.Ws = c->bf_Ws;
             q.lane_words = ((c->opt_debug >> 12) & 15u) ? ((c->opt_debug >> 12) & 15u) : 8u;  // KSCHED_OPT_DEBUG bits 12-15: A/B of the hand-over point (8 words = 512 candidates measured best at the C5 shard)
             hipLaunchKernelGGL(k_pick_bestfit_lanes, dim3((p + 255) / 256), dim3(256), 0, s, q);
+            HIPCHK(c, hipGetLastError());
+            c->bf_slot = (c->bf_slot + 1u) % 3u;  // (only once the kernel that zeroes the next pair is on its way)
             BestfitRowsArgs q2 = q;
             q2.pod_list = q.fallback_list;
             q2.pod_count = q.fallback_count;
             q2.sum = c->bf_sum.ptr;
             q2.Ws = c->bf_Ws;
+            {   // KSCHED_OPT_DEBUG bits 24-25: A/B of the sparse / dense switch of the summary scan
+                static const uint32_t kMax[4] = {64u, 16u, 256u, 1024u};
+                q2.coarse_max = kMax[(c->opt_debug >> 24) & 3u];
+            }
             if (c->opt_debug & 0x800u)  // KSCHED_OPT_DEBUG bit 11: the second stage over the full rows (A/B; same bindings)
                 hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q2);
             else

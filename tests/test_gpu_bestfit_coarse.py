@@ -38,7 +38,8 @@ def test_coarse_second_stage_equals_full_rows_equals_oracle(evaluator, N):
             want = want_of(c, sel, req_cpu, req_mem, flags)
             for stages in (2, 1):
                 ev.set_option(_lib.OPT_BESTFIT_STAGES, stages)
-                for dbg in ((0, 0x800, 1 << 12, (1 << 12) | 0x800, 2 << 12, 15 << 12) if stages == 2 else (0,)):  # bit 11: full rows; bits 12-15: hand-over after this many words
+                # bit 11: full rows; bits 12-15: hand-over after this many words; bits 24-25: sparse / dense switch of the summary scan (16 / 256 / 1024 candidate bytes)
+                for dbg in ((0, 0x800, 1 << 12, (1 << 12) | 0x800, 2 << 12, 15 << 12, 1 << 24, (3 << 24) | (1 << 12), 2 << 24) if stages == 2 else (0,)):
                     ev.set_option(_lib.OPT_DEBUG, dbg)
                     r = ev.eval(req_cpu, req_mem, sel, c.pod_tol, None, flags | PICK_BESTFIT, want_mask=False)
                     assert np.array_equal(r.binding, want), (N, flags, stages, hex(dbg), int((r.binding != want).sum()))
