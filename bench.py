@@ -63,12 +63,15 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes(P, N, n_keys, taint, masks=1):
-    """SURVEY.md section 8d for the mask kernel: every input column read once, every mask word written once."""
+def algorithmic_bytes(P, N, n_keys, taint, masks=1, pick_attempts=0):
+    """`P*b_pod + N*b_node + P*W*8*m + P*4`, every input column read once, every output written once.
+    b_pod = 16 (fit) + 4 per label key + 8 (tolerations) + 4 per draw when the sampled pick runs IN this kernel (`pick_attempts`:
+    the launch then also reads the pod's injected draws and writes its int32 binding); without a riding pick the kernel neither
+    reads draws nor writes bindings and both terms are left out."""
     W = (N + 63) // 64
-    b_pod = 16 + 4 * n_keys + (8 if taint else 0)
+    b_pod = 16 + 4 * n_keys + (8 if taint else 0) + 4 * pick_attempts
     b_node = 16 + 4 * n_keys + (8 if taint else 0)
-    return P * b_pod + N * b_node + P * W * 8 * masks
+    return P * b_pod + N * b_node + P * W * 8 * masks + (P * 4 if pick_attempts else 0)
 
 
 def cpu_baseline(c, flags_names, budget_s=12.0):
@@ -197,7 +200,7 @@ class SingleRig:
         torch.cuda.synchronize()
         pick_us = (time.perf_counter() - t1) / steps * 1e6
         n_keys = self.c.n_keys if "SEL" in self.flag_names else 0
-        alg = algorithmic_bytes(self.P, self.N, n_keys, self.taint)
+        alg = algorithmic_bytes(self.P, self.N, n_keys, self.taint, pick_attempts=int(self.c.samples.shape[1]) if (pick_how == "fused" and self.pick == "sampled") else 0)
         avg = float(us.mean()) if us.size else 0.0
         return {"workload": self.desc, "value": float(self.P) * self.N * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps,
                 "mask_rotation": R, "kernel": kern, "pick": self.pick, "pick_in_mask_launch": pick_how == "fused",
@@ -551,7 +554,8 @@ def main():
                 lp.step()
             e_ip, _ = lp.timed(args.steps)
             us_ip = kernel_events(lp.step, lp.drain, ev, min(16, args.kernel_samples))
-            alg_ip = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint)
+            alg_ip = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint,
+                                       pick_attempts=int(c.samples.shape[1]) if (ev.last_pick == "fused" and pick == "sampled") else 0)
             in_place = {"value": float(P_total) * N * args.steps / e_ip, "ms_per_step": e_ip / args.steps * 1e3, "steps": args.steps,
                         "mask_kernel_us": float(us_ip.mean()), "mask_kernel_frac": alg_ip / (float(us_ip.mean()) * 1e-6) / 1e9 / HBM_PEAK_GBS,
                         "note": f"one {lp.mask_bytes / 2**20:.0f} MiB mask buffer rewritten every step: the 256 MiB Infinity Cache still holds "
@@ -588,7 +592,8 @@ def main():
             loop_ov.drain()
             e_ov, last_ov = loop_ov.timed(args.steps)
             same = bool(torch.equal(last_ov.wait(), bindings))
-            alg_ov = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint)
+            alg_ov = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint,
+                                       pick_attempts=int(c.samples.shape[1]) if (ev.last_pick == "fused" and pick == "sampled") else 0)
             overlapped = {"value": float(P_total) * N * args.steps / e_ov, "ms_per_step": e_ov / args.steps * 1e3, "steps": args.steps,
                           "streams": 2, "mask_buffers": d_ov, "pick_launch": ev.last_pick, "bindings_equal_sequential": same,
                           "step_frac_of_hbm_peak": alg_ov / (e_ov / args.steps) / 1e9 / HBM_PEAK_GBS,
@@ -665,7 +670,9 @@ def main():
         evals = float(P_total) * N * args.steps
         value = evals / elapsed
         avg_kernel_s = (kern_ms / max(launches, 1)) * 1e-3
-        alg = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint)
+        attempts_in_kernel = int(c.samples.shape[1]) if (pick_how == "fused" and pick == "sampled") else 0
+        alg = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint, pick_attempts=attempts_in_kernel)
+        alg_mask_only = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint)
         achieved = alg / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         # HBM traffic per launch comes from SEPARATE rocprofv3 --pmc passes (tools/gpu_pmc.sh -> tools/pmc_traffic.py), not from
         # this run: the counters cannot be collected inside a timing run.  The file names the session it was measured in.
@@ -697,6 +704,7 @@ def main():
                                               f"({loop.R * loop.mask_bytes / 2**20:.0f} MiB > the 256 MiB Infinity Cache)" if loop.R > 1 else
                                               "one mask buffer" + (" (already larger than the 256 MiB Infinity Cache)" if loop.mask_bytes > L3_BYTES else "")),
                        "step_frac_of_hbm_peak": (alg / step_s / 1e9 / HBM_PEAK_GBS) if world == 1 else None,
+                       "step_frac_note": "algorithmic bytes of one step (mask + draws + bindings) / ms_per_step / 8 TB/s",
                        "repeat_ms_per_step": repeats, "in_place": in_place, "other_workloads": others,
                        "steps_in_flight": depth if pipelined else 1, "two_stream": pipe is not None,
                        "steps_per_allgather": gather_every if (pipelined and multi) else (1 if multi else None),
@@ -714,6 +722,9 @@ def main():
                          "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                          "kernel": f"mask kernel ({kernel_name}" + (", the sampled pick rides in it)" if pick_how == "fused" else ")"),
                          "algorithmic_bytes_per_launch": alg,
+                         "algorithmic_bytes_note": ("SURVEY.md 8d: P*b_pod + N*b_node + P*W*8 + P*4 with b_pod = 16 + 4*keys"
+                                                    + (" + 8" if taint else "") + (f" + 4*{attempts_in_kernel} (the pod's draws: the sampled pick runs in this launch and writes the "
+                                                       f"P*4 bindings); mask-only terms alone: {alg_mask_only}" if attempts_in_kernel else "; no pick in this launch: no draws, no bindings")),
                          "avg_kernel_us": avg_kernel_s * 1e6, "median_kernel_us": float(np.median(samples_us)) if launches else None,
                          "min_kernel_us": float(samples_us[0]) if launches else None, "max_kernel_us": float(samples_us[-1]) if launches else None,
                          "launches_timed": int(launches),

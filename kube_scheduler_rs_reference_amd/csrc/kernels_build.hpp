@@ -375,30 +375,6 @@ __global__ __launch_bounds__(256) void k_bf_rows(const BfRowsArgs a) {
     }
 }
 
-// Summary of the best-fit rows, 8 positions per bit: bit b of sum[r][j] = "byte (b % 8) of word (8 j + b / 8) of row r is not zero"
-// (one summary word covers 512 best-fit positions).  The AND of a pod's summary words is a superset of the bytes where the AND of
-// its rows can have a bit: the second stage of the best-fit pick (k_pick_bestfit_coarse, kernels_direct.hpp) scans the summaries
-// and looks only at those bytes of the full rows.
-struct BfSumArgs {
-    const uint64_t *rows;  // [nrows][Wbf]
-    uint64_t *sum;         // [nrows][Ws], Ws = ceil(Wbf / 8)
-    uint32_t nrows, Wbf, Ws;
-};
-__global__ __launch_bounds__(256) void k_bf_sum(const BfSumArgs a) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.nrows * a.Ws) return;
-    const uint32_t r = t / a.Ws, j = t - r * a.Ws;
-    uint64_t out = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 8; ++w) {
-        const uint32_t fw = j * 8u + w;
-        const uint64_t x = fw < a.Wbf ? a.rows[(size_t)r * a.Wbf + fw] : 0ull;
-#pragma unroll
-        for (uint32_t by = 0; by < 8; ++by) out |= (((x >> (8u * by)) & 0xFFull) != 0ull) ? (1ull << (w * 8u + by)) : 0ull;
-    }
-    a.sum[(size_t)r * a.Ws + j] = out;
-}
-
 // 8-ary level arrays of the two sorted columns (k_pick_bestfit_lanes): level k, entry j = last element of block j of 8^k entries
 struct BfLevelsArgs {
     const int64_t *bf_mem, *cpu_sorted;

@@ -429,11 +429,8 @@ struct BestfitRowsArgs {
     // snapshots with list keys (tile_index.hpp): pods that constrain one are collected for k_pick_bestfit_listed
     uint32_t nlist, list_col[2];
     uint32_t *listed_list, *listed_count;
-    // 8-positions-per-bit summaries of `rows` (kernels_build.hpp k_bf_sum), [rows][Ws]: the second stage scans these
-    const uint64_t *sum;
-    uint32_t Ws;
+    uint32_t lane_pair;   // k_pick_bestfit_lanes: 1 = two candidate words per trip
     uint32_t *zero_next;  // the counters of the NEXT two-stage call (three slots in rotation): zeroed here, so that no call pays a memset launch
-    uint32_t coarse_max;  // most candidate bytes per wave round the summary scan looks at itself; more -> the pod continues on the full rows
 };
 
 // first i in [0, n) with arr[i] >= key (n if none), by the whole wave: 64-ary search, three rounds for n <= 262144
@@ -595,127 +592,13 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
         const uint4 *rec = reinterpret_cast<const uint4 *>(q.pod_list) + (size_t)wave * 4u;
         const uint4 h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
         const uint32_t sel[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const int32_t b = bestfit_rows_scan(q, h.x, lane, h.y, h.z, h.w & 0x7FFFFFFFu, (int64_t)(((uint64_t)o.w << 32) | o.z), ((uint64_t)o.y << 32) | o.x, sel);
+        const int32_t b = bestfit_rows_scan(q, h.x, lane, h.y, h.z, h.w, (int64_t)(((uint64_t)o.w << 32) | o.z), ((uint64_t)o.y << 32) | o.x, sel);
         if (lane == 0) q.binding[h.x] = b;
         return;
     }
     if (wave >= q.p) return;
     const int32_t b = bestfit_rows_one_pod(q, wave, lane);
     if (lane == 0) q.binding[wave] = b;
-}
-
-// Best fit, second stage over the row SUMMARIES (k_bf_sum: one bit per 8 best-fit positions), for the pods the first stage flags
-// as sparse (it saw no candidate at all in its words); the others continue on the full rows (bestfit_rows_scan): with a
-// candidate every few positions, reading whole words beats looking at candidate bytes one per lane and trip (session r3c / r3d:
-// summaries for every handed-over pod 135 us per batch at the C5 shard, 105 us with a per-round switch, full rows 98 us).  The sparse ones
-// are the ones whose AND of rows is sparse -- several selective label keys, a cpu request few nodes can hold, or no
-// feasible node at all (4 % of the C5 pods: the scan runs to the end of the snapshot) -- and scanning every word of every row
-// for them moved ~400 MB per batch at the C5 shard.  Here a lane ANDs the pod's summary words (512 positions per word, 32 768 per
-// wave round), which is a superset of the bytes where the AND of the full rows can have a bit, and only those candidate bytes of
-// the full rows are looked at, lowest first.  Same result as bestfit_rows_scan by construction: the first position >= the
-// hand-over point whose bit is set in every row the pod ANDs and whose cpu fits; every position is either ruled out by a zero
-// summary bit (its byte is zero in some row) or examined.
-__device__ __forceinline__ int32_t bestfit_coarse_scan(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane, uint32_t start, uint32_t r, uint32_t w_first,
-                                                       int64_t req_c, uint64_t tol, const uint32_t (&sel)[8]) {
-    uint32_t r_hi = q.row_valid, r_lo = q.row_valid;
-    if (q.do_fit) {
-        r_hi = q.row_cpu0 + (r + q.q - 1u) / q.q;  // only nodes that fit
-        r_lo = q.row_cpu0 + r / q.q;               // every node that fits
-    }
-    uint32_t lrow[8];
-#pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) lrow[k] = (sel[k] <= q.lab_max8[k]) ? q.lab_base8[k] + sel[k] - 1u : q.row_zero;
-    // AND of the pod's rows at index `at` of a table whose rows are `pitch` words apart: the summaries (with the "every node that
-    // fits" cpu row: a superset) or the full rows (base only; the cpu rows are applied by the caller)
-    auto and_rows = [&](const uint64_t *tab, uint32_t pitch, uint32_t at) -> uint64_t {
-        uint64_t x = tab[(size_t)q.row_valid * pitch + at];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k)
-            if (sel[k] != 0u) x &= tab[(size_t)lrow[k] * pitch + at];
-        for (uint32_t k = 8; k < q.nkeys; ++k) {
-            const uint32_t s = q.psel[(size_t)k * q.p + pod];
-            if (s != 0u) x &= tab[(size_t)((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero) * pitch + at];
-        }
-        if (q.do_taint)
-            for (uint32_t g = 0; g < q.ngroups; ++g) x &= tab[(size_t)(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * pitch + at];
-        return x;
-    };
-    const uint32_t p0 = max(start, w_first * 64u);  // first position not yet looked at (w_first > start >> 6: a multiple of 64)
-    if (p0 >= q.n) return -1;
-    const uint32_t j_first = p0 >> 9;  // summary word of p0
-    for (uint32_t jb = j_first; jb < q.Ws; jb += 64u) {
-        const uint32_t j = jb + lane;
-        uint64_t S = 0;
-        if (j < q.Ws) {
-            S = and_rows(q.sum, q.Ws, j);
-            if (q.do_fit) S &= q.sum[(size_t)r_lo * q.Ws + j];
-            if (j == j_first) S &= ~0ull << ((p0 >> 3) & 63u);  // bytes before p0
-        }
-        // Adaptive: the summaries pay off when the AND is SPARSE (a handful of candidate bytes in 32 768 positions).  When many bytes
-        // are candidates the pod's first feasible node is near, and looking at candidates one byte per lane and trip costs more than
-        // reading whole words: that pod continues on the full rows from here (session r3c: summaries alone, 135 us per batch at
-        // the C5 shard against 98 us on the full rows).
-        uint32_t cands = (uint32_t)__popcll(S);
-#pragma unroll
-        for (uint32_t d = 32; d >= 1; d >>= 1) cands += (uint32_t)__shfl_xor((int)cands, d, 64);
-        if (cands > q.coarse_max) return bestfit_rows_scan(q, pod, lane, start, r, max(w_first, jb * 8u), req_c, tol, sel);
-        uint32_t found = 0xFFFFFFFFu;
-        while (true) {
-            const bool active = S != 0ull && found == 0xFFFFFFFFu;
-            if (__ballot(active) == 0ull) break;
-            if (active) {
-                const uint32_t b = (uint32_t)__builtin_ctzll(S);
-                S &= S - 1ull;
-                const uint32_t fw = j * 8u + (b >> 3), sh = (b & 7u) * 8u;  // the candidate byte: word fw of the full rows, bits [sh, sh + 8)
-                if (fw < q.Wbf) {
-                    const uint64_t base = and_rows(q.rows, q.Wbf, fw);
-                    const uint64_t hi = q.do_fit ? q.rows[(size_t)r_hi * q.Wbf + fw] : ~0ull, lo = q.do_fit ? q.rows[(size_t)r_lo * q.Wbf + fw] : ~0ull;
-                    uint64_t byte_mask = 0xFFull << sh;
-                    if (fw == (start >> 6)) byte_mask &= ~0ull << (start & 63u);  // (only when the hand-over point is inside start's word)
-                    const uint64_t sure = base & hi & byte_mask;
-                    uint64_t cand = (base & lo & byte_mask);
-                    while (cand) {
-                        const uint32_t bb = (uint32_t)__builtin_ctzll(cand);
-                        const uint32_t i = fw * 64u + bb;
-                        if (((sure >> bb) & 1ull) || req_c <= q.bf_cpu[i]) {
-                            found = i;
-                            break;
-                        }
-                        cand &= cand - 1ull;
-                    }
-                }
-            }
-            // a hit in lane L settles the round once no lane below L has candidates left; lanes above L can stop looking
-            const uint64_t hit = __ballot(found != 0xFFFFFFFFu);
-            if (hit) {
-                const uint32_t L = (uint32_t)__builtin_ctzll(hit);
-                if (lane > L) S = 0ull;
-            }
-        }
-        const uint64_t hit = __ballot(found != 0xFFFFFFFFu);
-        if (hit) {  // lanes hold ascending summary words: the lowest lane with a hit holds the best-fit node
-            const uint32_t first = (uint32_t)__shfl((int)found, __builtin_ctzll(hit), 64);
-            return (int32_t)q.bf_order[first];
-        }
-    }
-    return -1;
-}
-
-// one short-lived wave per pod the first stage handed over (its 64-byte record carries everything the first stage had in registers)
-__global__ __launch_bounds__(256) void k_pick_bestfit_coarse(const BestfitRowsArgs q) {
-    kernarg_warm<sizeof(BestfitRowsArgs)>();
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wave >= *q.pod_count) return;
-    const uint4 *rec = reinterpret_cast<const uint4 *>(q.pod_list) + (size_t)wave * 4u;
-    const uint4 h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
-    const uint32_t sel[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const int64_t req_c = (int64_t)(((uint64_t)o.w << 32) | o.z);
-    const uint64_t tol = ((uint64_t)o.y << 32) | o.x;
-    const uint32_t w_first = h.w & 0x7FFFFFFFu;
-    // the first stage's hint (bit 31): sparse AND -> the summaries; a candidate was seen near the start -> the full rows
-    const int32_t b = (h.w >> 31) ? bestfit_coarse_scan(q, h.x, lane, h.y, h.z, w_first, req_c, tol, sel) : bestfit_rows_scan(q, h.x, lane, h.y, h.z, w_first, req_c, tol, sel);
-    if (lane == 0) q.binding[h.x] = b;
 }
 
 // Best fit, first stage, ONE LANE PER POD.  The wave-per-pod kernel above spends a whole wave's chain of dependent round trips on
@@ -775,7 +658,6 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
         r = min(r, q.n);
     }
     int32_t found = -1;
-    uint32_t w0_flag = 0;
     bool undecided = start < q.n;
     // a required value no node carries (KSCHED_SEL_NEVER, or an id beyond the key's largest): the pod's AND of rows is empty --
     // no node, and no scan to the end of the snapshot to find that out (1 % of the constrained keys in the C5 workload)
@@ -789,49 +671,65 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) lrow[k] = (sel[k] <= q.lab_max8[k]) ? q.lab_base8[k] + sel[k] - 1u : q.row_zero;
         const uint32_t w0 = start >> 6;
-        uint32_t seen = 0;  // positions in the words looked at that pass selector, taints and the coarse cpu row (before the exact cpu test)
-        for (uint32_t t = 0; t < q.lane_words && undecided; ++t) {
-            const uint32_t w = w0 + t;
-            if (w >= q.Wbf) {
-                undecided = false;  // ran off the end: no feasible node
-                break;
-            }
-            uint64_t base = q.rows[(size_t)q.row_valid * q.Wbf + w];
-            const uint64_t hi = q.rows[(size_t)r_hi * q.Wbf + w], lo = q.rows[(size_t)r_lo * q.Wbf + w];
+        // the rows of word `w` (clamped: a word past the end reads as empty), all loads of one word in flight together
+        struct Word {
+            uint64_t base, hi, lo;
+        };
+        auto load_word = [&](uint32_t w) -> Word {
+            const bool in = w < q.Wbf;
+            const uint32_t wc = in ? w : q.Wbf - 1u;
+            Word x;
+            x.base = q.rows[(size_t)q.row_valid * q.Wbf + wc];
+            x.hi = q.rows[(size_t)r_hi * q.Wbf + wc];
+            x.lo = q.rows[(size_t)r_lo * q.Wbf + wc];
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k)
-                if (sel[k] != 0u) base &= q.rows[(size_t)lrow[k] * q.Wbf + w];
+                if (sel[k] != 0u) x.base &= q.rows[(size_t)lrow[k] * q.Wbf + wc];
             for (uint32_t k = 8; k < q.nkeys; ++k) {
                 const uint32_t s = q.psel[(size_t)k * q.p + pod];
-                if (s != 0u) base &= q.rows[(size_t)((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero) * q.Wbf + w];
+                if (s != 0u) x.base &= q.rows[(size_t)((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero) * q.Wbf + wc];
             }
             if (q.do_taint)
                 for (uint32_t g = 0; g < q.ngroups; ++g)
-                    base &= q.rows[(size_t)(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * q.Wbf + w];
-            if (t == 0) base &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
-            const uint64_t sure = q.do_fit ? (base & hi) : base;
-            uint64_t cand = q.do_fit ? (sure | (base & lo & ~hi)) : base;
-            seen += (uint32_t)__popcll(cand);
+                    x.base &= q.rows[(size_t)(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * q.Wbf + wc];
+            if (!in) x.base = 0ull;
+            return x;
+        };
+        // first candidate of word `w` that fits (sure bits at once, the others by their exact cpu); returns whether one was found
+        auto take_word = [&](uint32_t w, Word x) -> bool {
+            const uint64_t sure = q.do_fit ? (x.base & x.hi) : x.base;
+            uint64_t cand = q.do_fit ? (sure | (x.base & x.lo & ~x.hi)) : x.base;
             while (cand) {
                 const uint32_t b = (uint32_t)__builtin_ctzll(cand);
                 const uint32_t i = w * 64u + b;
                 if (((sure >> b) & 1ull) || req_c <= q.bf_cpu[i]) {
                     found = (int32_t)q.bf_order[i];
-                    undecided = false;
-                    break;
+                    return true;
                 }
                 cand &= cand - 1ull;
             }
-            if (undecided && w + 1u >= q.Wbf) undecided = false;  // that was the last word: no feasible node
+            return false;
+        };
+        // TWO words per trip: both words' row loads are in flight together, so a lane that needs all its words makes half as many
+        // dependent round trips (a wave runs as long as its slowest lane, and one pod in five needs every word it may look at)
+        const uint32_t per_trip = q.lane_pair ? 2u : 1u;  // (KSCHED_OPT_DEBUG bit 11: one word per trip, the round-2 form -- A/B)
+        for (uint32_t t = 0; t < q.lane_words && undecided; t += per_trip) {
+            const uint32_t w = w0 + t;
+            if (w >= q.Wbf) {
+                undecided = false;  // ran off the end: no feasible node
+                break;
+            }
+            Word x0 = load_word(w);
+            const bool second = per_trip == 2u && t + 1u < q.lane_words;  // (an odd hand-over point: the last trip looks at one word)
+            Word x1 = second ? load_word(w + 1u) : Word{0ull, 0ull, 0ull};
+            if (t == 0) x0.base &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
+            if (take_word(w, x0) || (second && take_word(w + 1u, x1))) undecided = false;
+            if (undecided && w + (second ? 2u : 1u) >= q.Wbf) undecided = false;  // those were the last words: no feasible node
         }
-        // Hand-over hint: not ONE candidate in the (up to 512) positions looked at -> the pod's AND of rows is sparse (several
-        // selective keys, a cpu request few nodes hold, or no feasible node at all: those scan to the end of the snapshot) -> the second
-        // stage scans the row SUMMARIES for it; otherwise a feasible node is near and the full rows are read (bit 31 of the record's word 3)
-        if (undecided && seen == 0u && q.sum != nullptr) w0_flag = 0x80000000u;
     }
     if (undecided) {  // the wave-per-pod kernel scans on behind the words looked at here
         uint4 *rec = reinterpret_cast<uint4 *>(q.fallback_list) + (size_t)atomicAdd(q.fallback_count, 1u) * 4u;
-        rec[0] = make_uint4(pod, start, r, ((start >> 6) + q.lane_words) | w0_flag);
+        rec[0] = make_uint4(pod, start, r, (start >> 6) + q.lane_words);
         rec[1] = make_uint4((uint32_t)tol, (uint32_t)(tol >> 32), (uint32_t)(uint64_t)req_c, (uint32_t)((uint64_t)req_c >> 32));
         rec[2] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
         rec[3] = make_uint4(sel[4], sel[5], sel[6], sel[7]);

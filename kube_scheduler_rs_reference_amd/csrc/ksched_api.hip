@@ -79,8 +79,6 @@ struct ksched_ctx {
     uint32_t bf_slot = 0;            // which of the three counter pairs the next two-stage pick uses (the call before zeroed it)
     size_t bf_fallback_zeroed_cap = 0;
     DevBuf<uint64_t> bf_rows;        // [rows][Wbf] bitmaps over best-fit positions (k_pick_bestfit_rows); built with the tile index
-    DevBuf<uint64_t> bf_sum;         // [rows][Ws] their 8-positions-per-bit summaries (k_pick_bestfit_coarse)
-    uint32_t bf_Ws = 0;
     bool bf_rows_built = false;
     uint32_t bf_row_cpu0 = 0, bf_q = 1;
     // the best-fit structures are built lazily, by the first PICK_BESTFIT request after the snapshot changed
@@ -502,19 +500,6 @@ int build_bestfit(ksched_ctx *c) {
         r.levels = levels;
         hipLaunchKernelGGL(k_bf_rows, dim3((Wbf + 3u) / 4u), dim3(256), 0, s, r);
         HIPCHK(c, hipGetLastError());
-        {   // the rows' summaries (one bit per 8 positions) for the second stage of the pick
-            const uint32_t Ws = (Wbf + 7u) / 8u;
-            HIPCHK(c, c->bf_sum.reserve((size_t)rows * Ws));
-            BfSumArgs sa{};
-            sa.rows = c->bf_rows.ptr;
-            sa.sum = c->bf_sum.ptr;
-            sa.nrows = rows;
-            sa.Wbf = Wbf;
-            sa.Ws = Ws;
-            hipLaunchKernelGGL(k_bf_sum, dim3((rows * Ws + 255u) / 256u), dim3(256), 0, s, sa);
-            HIPCHK(c, hipGetLastError());
-            c->bf_Ws = Ws;
-        }
         c->bf_row_cpu0 = named;
         c->bf_q = q;
         c->bf_rows_built = true;
@@ -785,25 +770,15 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
             for (uint32_t j = 0; j < q.nlist; ++j) q.list_col[j] = l.list_col[j];
             q.listed_count = ctr + 1;
             q.listed_list = c->bf_fallback.ptr + 16 * ((size_t)p + 1);
-            q.sum = (c->opt_debug & 0x800u) ? nullptr : c->bf_sum.ptr;  // (bit 11: no summaries -- every handed-over pod on the full rows)
-            q.Ws = c->bf_Ws;
-            q.lane_words = ((c->opt_debug >> 12) & 15u) ? ((c->opt_debug >> 12) & 15u) : 8u;  // KSCHED_OPT_DEBUG bits 12-15: A/B of the hand-over point (8 words = 512 candidates measured best at the C5 shard)
+            q.lane_words = ((c->opt_debug >> 12) & 15u) ? ((c->opt_debug >> 12) & 15u) : 8u;
+            q.lane_pair = (c->opt_debug & 0x800u) ? 0u : 1u;  // KSCHED_OPT_DEBUG bits 12-15: A/B of the hand-over point (8 words = 512 candidates measured best at the C5 shard)
             hipLaunchKernelGGL(k_pick_bestfit_lanes, dim3((p + 255) / 256), dim3(256), 0, s, q);
             HIPCHK(c, hipGetLastError());
             c->bf_slot = (c->bf_slot + 1u) % 3u;  // (only once the kernel that zeroes the next pair is on its way)
             BestfitRowsArgs q2 = q;
             q2.pod_list = q.fallback_list;
             q2.pod_count = q.fallback_count;
-            q2.sum = c->bf_sum.ptr;
-            q2.Ws = c->bf_Ws;
-            {   // KSCHED_OPT_DEBUG bits 24-25: A/B of the sparse / dense switch of the summary scan
-                static const uint32_t kMax[4] = {64u, 16u, 256u, 1024u};
-                q2.coarse_max = kMax[(c->opt_debug >> 24) & 3u];
-            }
-            if (c->opt_debug & 0x800u)  // KSCHED_OPT_DEBUG bit 11: the second stage over the full rows (A/B; same bindings)
-                hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q2);
-            else
-                hipLaunchKernelGGL(k_pick_bestfit_coarse, dim3((p + 3) / 4), dim3(256), 0, s, q2);
+            hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q2);
             if (lists) {
                 BestfitListedArgs la{};
                 la.lists = c->idx.d_list;
@@ -954,7 +929,7 @@ void ksched_destroy(ksched_ctx *c) try {
         DeviceGuard g(c->device);
         (void)hipDeviceSynchronize();
         c->ncpu.release(); c->nmem.release(); c->nrec.release(); c->nlab.release(); c->ntaint.release();
-        c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release(); c->bf_cpu.release(); c->cpu_sorted.release(); c->bf_rows.release(); c->bf_sum.release(); c->bf_samples.release(); c->bf_levels.release(); c->bf_fallback.release();
+        c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release(); c->bf_cpu.release(); c->cpu_sorted.release(); c->bf_rows.release(); c->bf_samples.release(); c->bf_levels.release(); c->bf_fallback.release();
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
         c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release(); c->xpairs.release(); c->xreason.release();
         c->scratch_mask.release(); c->trace.release();

@@ -1,7 +1,7 @@
-"""Second stage of the best-fit pick over the row summaries (k_pick_bestfit_coarse, one summary bit per 8 best-fit positions)
-against the oracle and against the second stage over the full rows (KSCHED_OPT_DEBUG bit 11): pods whose AND of rows is
-sparse -- several selective label keys, a value no node carries, a cpu request only a handful of nodes can hold, no feasible
-node at all -- at snapshot sizes where the summaries span several wave rounds, with every hand-over point of the first stage."""
+"""The best-fit pick on the pods that are hard for it -- the AND of their rows is sparse: several selective label keys, a value no
+node carries (decided in the first stage without a scan), a cpu request only a handful of nodes can hold, no feasible node at all
+(the scan runs to the end of the snapshot) -- at snapshot sizes where the scan spans several wave rounds, one and two stages, every
+hand-over point of the first stage; all against the oracle."""
 import numpy as np
 import pytest
 
@@ -16,7 +16,7 @@ def want_of(c, sel, req_cpu, req_mem, flags):
 
 
 @pytest.mark.parametrize("N", [700, 5_000, 40_000, 70_001])
-def test_coarse_second_stage_equals_full_rows_equals_oracle(evaluator, N):
+def test_sparse_and_infeasible_pods_one_and_two_stages(evaluator, N):
     ev = evaluator
     P = 3000
     c = synth.make_cluster(P, N, n_keys=8, n_taints=16, seed=1000 + N)
@@ -38,8 +38,8 @@ def test_coarse_second_stage_equals_full_rows_equals_oracle(evaluator, N):
             want = want_of(c, sel, req_cpu, req_mem, flags)
             for stages in (2, 1):
                 ev.set_option(_lib.OPT_BESTFIT_STAGES, stages)
-                # bit 11: full rows; bits 12-15: hand-over after this many words; bits 24-25: sparse / dense switch of the summary scan (16 / 256 / 1024 candidate bytes)
-                for dbg in ((0, 0x800, 1 << 12, (1 << 12) | 0x800, 2 << 12, 15 << 12, 1 << 24, (3 << 24) | (1 << 12), 2 << 24) if stages == 2 else (0,)):
+                # bits 12-15: hand-over after this many words; bit 11: one candidate word per trip of the first stage instead of two
+                for dbg in ((0, 0x800, 1 << 12, 2 << 12, 3 << 12, (3 << 12) | 0x800, 15 << 12) if stages == 2 else (0,)):
                     ev.set_option(_lib.OPT_DEBUG, dbg)
                     r = ev.eval(req_cpu, req_mem, sel, c.pod_tol, None, flags | PICK_BESTFIT, want_mask=False)
                     assert np.array_equal(r.binding, want), (N, flags, stages, hex(dbg), int((r.binding != want).sum()))
@@ -49,8 +49,9 @@ def test_coarse_second_stage_equals_full_rows_equals_oracle(evaluator, N):
         ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
 
 
-def test_coarse_second_stage_after_snapshot_updates(evaluator):
-    """ksched_update_nodes marks the best-fit structures stale: rows AND their summaries are rebuilt by the next pick."""
+def test_two_stage_pick_after_snapshot_updates_many_calls(evaluator):
+    """ksched_update_nodes marks the best-fit structures stale; the hand-over counters rotate over three slots (each call zeroes
+    the next call's pair instead of a memset launch): many consecutive two-stage calls stay == oracle."""
     ev = evaluator
     c = synth.make_cluster(2000, 9000, n_keys=8, n_taints=16, seed=77)
     rng = np.random.default_rng(5)
@@ -58,7 +59,7 @@ def test_coarse_second_stage_after_snapshot_updates(evaluator):
     ev.set_nodes(cpu, mem, c.node_labels, c.node_taints)
     ev.set_option(_lib.OPT_BESTFIT_STAGES, 2)
     try:
-        for step in range(3):
+        for step in range(7):
             want = capi.eval_encoded(cpu, mem, c.node_labels, c.node_taints, c.req_cpu, c.req_mem, c.pod_sel, c.pod_tol, None, FIT | SEL | TAINT | PICK_BESTFIT)[2]
             r = ev.eval(c.req_cpu, c.req_mem, c.pod_sel, c.pod_tol, None, FIT | SEL | TAINT | PICK_BESTFIT, want_mask=False)
             assert np.array_equal(r.binding, want), step
