@@ -200,10 +200,10 @@ class SingleRig:
         torch.cuda.synchronize()
         pick_us = (time.perf_counter() - t1) / steps * 1e6
         n_keys = self.c.n_keys if "SEL" in self.flag_names else 0
-        alg = algorithmic_bytes(self.P, self.N, n_keys, self.taint, pick_attempts=int(self.c.samples.shape[1]) if (pick_how == "fused" and self.pick == "sampled") else 0)
+        alg = algorithmic_bytes(self.P, self.N, n_keys, self.taint, pick_attempts=int(self.c.samples.shape[1]) if (pick_how.startswith("fused") and self.pick == "sampled") else 0)
         avg = float(us.mean()) if us.size else 0.0
         return {"workload": self.desc, "value": float(self.P) * self.N * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps,
-                "mask_rotation": R, "kernel": kern, "pick": self.pick, "pick_in_mask_launch": pick_how == "fused",
+                "mask_rotation": R, "kernel": kern, "pick": self.pick, "pick_in_mask_launch": pick_how.startswith("fused"),
                 "mask_kernel_us": avg, "mask_kernel_median_us": float(np.median(us)) if us.size else None,
                 "mask_kernel_frac": (alg / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS) if avg > 0 else None,
                 "step_frac": alg / (el / steps) / 1e9 / HBM_PEAK_GBS,
@@ -228,8 +228,9 @@ def main():
     ap.add_argument("--packed", action="store_true",
                     help="mask rows packed at W words (default: rows pitched to ksched_mask_pitch(n) = W rounded up to 128 B)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (timing experiments; results invalid)")
-    ap.add_argument("--fused-pick", type=int, default=1, choices=[0, 1],
-                    help="1 (default): the sampled pick rides in the fused mask launch (one kernel per step); 0: its own launch ahead of it")
+    ap.add_argument("--fused-pick", type=int, default=1, choices=[0, 1, 2, 3],
+                    help="1 (default): the sampled pick rides in the fused mask launch (one kernel per step), in the form the library chooses; "
+                         "0: its own launch ahead of it; 2: rides as waves of the fill; 3: rides as tile tests in phase 1 (KSCHED_OPT_FUSED_PICK)")
     ap.add_argument("--no-rotate", action="store_true",
                     help="rewrite ONE mask buffer every step (the Infinity Cache then absorbs part of the stores at C3 / C4s); the default "
                          "rotates over enough buffers to exceed it and reports the in-place figure as config.in_place")
@@ -555,7 +556,7 @@ def main():
             e_ip, _ = lp.timed(args.steps)
             us_ip = kernel_events(lp.step, lp.drain, ev, min(16, args.kernel_samples))
             alg_ip = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint,
-                                       pick_attempts=int(c.samples.shape[1]) if (ev.last_pick == "fused" and pick == "sampled") else 0)
+                                       pick_attempts=int(c.samples.shape[1]) if (ev.last_pick.startswith("fused") and pick == "sampled") else 0)
             in_place = {"value": float(P_total) * N * args.steps / e_ip, "ms_per_step": e_ip / args.steps * 1e3, "steps": args.steps,
                         "mask_kernel_us": float(us_ip.mean()), "mask_kernel_frac": alg_ip / (float(us_ip.mean()) * 1e-6) / 1e9 / HBM_PEAK_GBS,
                         "note": f"one {lp.mask_bytes / 2**20:.0f} MiB mask buffer rewritten every step: the 256 MiB Infinity Cache still holds "
@@ -593,7 +594,7 @@ def main():
             e_ov, last_ov = loop_ov.timed(args.steps)
             same = bool(torch.equal(last_ov.wait(), bindings))
             alg_ov = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint,
-                                       pick_attempts=int(c.samples.shape[1]) if (ev.last_pick == "fused" and pick == "sampled") else 0)
+                                       pick_attempts=int(c.samples.shape[1]) if (ev.last_pick.startswith("fused") and pick == "sampled") else 0)
             overlapped = {"value": float(P_total) * N * args.steps / e_ov, "ms_per_step": e_ov / args.steps * 1e3, "steps": args.steps,
                           "streams": 2, "mask_buffers": d_ov, "pick_launch": ev.last_pick, "bindings_equal_sequential": same,
                           "step_frac_of_hbm_peak": alg_ov / (e_ov / args.steps) / 1e9 / HBM_PEAK_GBS,
@@ -670,7 +671,7 @@ def main():
         evals = float(P_total) * N * args.steps
         value = evals / elapsed
         avg_kernel_s = (kern_ms / max(launches, 1)) * 1e-3
-        attempts_in_kernel = int(c.samples.shape[1]) if (pick_how == "fused" and pick == "sampled") else 0
+        attempts_in_kernel = int(c.samples.shape[1]) if (pick_how.startswith("fused") and pick == "sampled") else 0
         alg = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint, pick_attempts=attempts_in_kernel)
         alg_mask_only = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint)
         achieved = alg / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
@@ -698,7 +699,7 @@ def main():
                        "predicates": "+".join(flag_names), "pick": pick, "mask_written": not args.no_mask,
                        "mask_row_pitch_words": pitch, "mask_words": W,
                        "kernel": kernel_name, "pick_launch": pick_how,
-                       "kernels_per_step": (1 if pick_how == "fused" else None),
+                       "kernels_per_step": (1 if pick_how.startswith("fused") else None),
                        "mask_rotation": loop.R, "mask_rotation_bytes": loop.R * loop.mask_bytes,
                        "mask_rotation_note": (f"the loop writes {loop.R} mask buffers of {loop.mask_bytes / 2**20:.0f} MiB in turn "
                                               f"({loop.R * loop.mask_bytes / 2**20:.0f} MiB > the 256 MiB Infinity Cache)" if loop.R > 1 else
@@ -720,7 +721,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
-                         "kernel": f"mask kernel ({kernel_name}" + (", the sampled pick rides in it)" if pick_how == "fused" else ")"),
+                         "kernel": f"mask kernel ({kernel_name}" + (", the sampled pick rides in it)" if pick_how.startswith("fused") else ")"),
                          "algorithmic_bytes_per_launch": alg,
                          "algorithmic_bytes_note": ("SURVEY.md 8d: P*b_pod + N*b_node + P*W*8 + P*4 with b_pod = 16 + 4*keys"
                                                     + (" + 8" if taint else "") + (f" + 4*{attempts_in_kernel} (the pod's draws: the sampled pick runs in this launch and writes the "

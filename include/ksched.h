@@ -117,9 +117,12 @@ extern "C" {
  * Same results either way: every evaluation sees the snapshot that was current when it was enqueued. */
 #define KSCHED_OPT_SNAPSHOT_STREAM 8
 /* KSCHED_OPT_FUSED_PICK: 1 (default) = when an evaluation asks for the feasibility mask AND the sampled pick and the fused mask
- * kernel runs, the pick rides in that launch (select_node_for_pod, src/main.rs:51-71, evaluated for the batch's pods by a few
- * waves of every block while the block's tile is staged): ONE kernel per step.  0 = the pick is its own launch ahead of the
- * mask kernel (k_select_sampled).  Same bindings either way: both run the same per-pod code on the same node records. */
+ * kernel runs, the pick rides in that launch (select_node_for_pod, src/main.rs:51-71): ONE kernel per step.  Two forms, chosen by
+ * the request: tile tests -- every block tests the drawn candidates that lie in its own tile against the bitmap rows it holds in
+ * LDS, the blocks of a pod combine through one atomic per pod (ATTEMPTS = 5 draws, no taint predicate, at most eight label
+ * keys) -- or, otherwise, a few waves of every block test the pods' candidates from the node records while the block's tile is
+ * staged.  0 = the pick is its own launch ahead of the mask kernel (k_select_sampled); 2 = rides, always as waves of the fill;
+ * 3 = rides as tile tests or the call fails with KSCHED_E_UNSUPPORTED.  Same bindings in every form. */
 #define KSCHED_OPT_FUSED_PICK 9
 /* KSCHED_OPT_FAULT: test hook for the "nothing unwinds across this boundary" rule.  value = kind | (skip << 8): after `skip`
  * further fault points (the places where a call enters the library's C++: snapshot calls, evaluations, explain, checksum) the
@@ -344,8 +347,9 @@ int ksched_trace_read(ksched_ctx *ctx, uint64_t *out, uint32_t max_blocks);
 int ksched_index_checksum(ksched_ctx *ctx, uint64_t *out /* [2] */);
 /* name of the mask kernel variant the last ksched_eval* used ("direct", "indexed", ...) */
 const char *ksched_last_kernel(const ksched_ctx *ctx);
-/* how the pick of the last ksched_eval* ran: "fused" (it rode in the fused mask launch, KSCHED_OPT_FUSED_PICK), "select" (its own
- * launch testing the drawn candidates), "bestfit-rows", "from-mask" (KSCHED_OPT_PICK_FROM_MASK / no bitmap index), "none" */
+/* how the pick of the last ksched_eval* ran: "fused-tile" / "fused" (it rode in the fused mask launch as tile tests / as waves of
+ * the fill, KSCHED_OPT_FUSED_PICK), "select" (its own launch testing the drawn candidates), "bestfit-rows", "from-mask"
+ * (KSCHED_OPT_PICK_FROM_MASK / no bitmap index), "none" */
 const char *ksched_last_pick(const ksched_ctx *ctx);
 
 #ifdef __cplusplus

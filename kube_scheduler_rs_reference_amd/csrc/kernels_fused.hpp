@@ -83,14 +83,18 @@ struct FusedArgs {
     uint32_t list_col[kMaxListKeys];                 // their label columns
     uint32_t debug;
     uint32_t has_tol;  // tolerations were given (g_ptol is not null)
-    uint32_t pick_ppb, pick_waves;  // PICK: pods whose sampled pick one block carries, and how many of its waves carry them (the others stage)
+    uint32_t pick_ppb, pick_waves;  // PICK == 1: pods whose sampled pick one block carries, and how many of its waves carry them (the others stage)
+    uint64_t *pick_acc;             // PICK == 2: [p + 1] per-pod accumulators (count << 32 | feasible-draw bits), all zero between launches
+    uint32_t off_park;              // PICK == 2: LDS byte offset of the per-wave park of the round's draws
     uint64_t *trace;  // diagnostics: per-block phase timestamps (100 MHz), or nullptr
 };
 
 // LDS carve-up: [rows * 128 : bitmap rows][aux block: 2 search trees + 2 cnt tables (FIT)]
 //               per wave x 64 pods: [16 B fit record (FIT)][16 B label rows 1..8 (SEL)][8 B taint rows (TAINT)]
 //               [nlist * 6 KiB: the tile's list keys][per wave x 64 pods: 16 B list record]   (snapshots with list keys only)
-inline uint32_t fused_lds_bytes(const IndexedLayout &l, bool fit, bool sel, bool taint, FusedArgs *a = nullptr) {
+constexpr uint32_t kPickAttempts = 5;  // draws per pod the tile-test pick (PICK == 2) handles: ATTEMPTS of src/main.rs:49
+constexpr uint32_t kPickParkBytes = kFusedWaves * kPickAttempts * 64u * 4u;
+inline uint32_t fused_lds_bytes(const IndexedLayout &l, bool fit, bool sel, bool taint, FusedArgs *a = nullptr, bool park = false) {
     uint32_t off = l.rows * 128u;
     const uint32_t off_aux = off;
     if (fit) off += kAuxWords * 8u;
@@ -104,7 +108,10 @@ inline uint32_t fused_lds_bytes(const IndexedLayout &l, bool fit, bool sel, bool
     if (sel && l.nlist) off += l.nlist * kListBytes;
     const uint32_t off_lrec = off;
     if (sel && l.nlist) off += kFusedWaves * 64u * kListRecBytes;
+    const uint32_t off_park = off;
+    if (park) off += kPickParkBytes;
     if (a) {
+        a->off_park = off_park;
         a->off_list = off_list;
         a->off_lrec = off_lrec;
         a->off_aux = off_aux;
@@ -126,7 +133,18 @@ typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 // block's pods instead of issuing staging pieces -- the pick's chain of dependent memory round trips overlaps the fill, which
 // every block has to sit through anyway, and a step is ONE kernel.  The pick does not read the mask and the mask code below is
 // the same with and without it.
-template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST = false, bool PICK = false>
+//
+// PICK == 2, the tile-test pick: a drawn candidate that lies in the block's tile is tested against the bitmap rows the block has in
+// LDS anyway -- the (pod, node) bit the block is about to write into the mask, read straight from the rows phase 1 has just named --
+// so no node record is fetched and no wave is taken off the staging.  Every (chunk, tile) block sees all five draws of its
+// chunk's pods and tests the ones that fall into its tile (lane = pod, phase 1); what it found goes into the pod's 64-bit
+// accumulator with ONE returning atomic add per pod and block: bits 0..4 = "draw i is feasible" (a draw lies in exactly one tile,
+// so the blocks' bit sets are disjoint and the add is an OR), bits 32.. = how many blocks have contributed.  The block whose add
+// returns tiles - 1 is the pod's last contributor: it holds every bit, takes the lowest set one (first feasible draw wins,
+// src/main.rs:61-65), writes the binding -- the drawn node, from the draws it parked in LDS -- and zeroes the accumulator for the next
+// launch.  The atomic is issued at the top of the NEXT trip and awaited by that trip's counted wait, like the operand loads: its
+// return registers are in flight inside one trip only.
+template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST = false, int PICK = 0>
 __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     const uint64_t *__restrict__ g_tables, const uint64_t *__restrict__ g_aux, const int64_t *__restrict__ g_pcpu,
     const int64_t *__restrict__ g_pmem, const uint32_t *__restrict__ g_psel, const uint64_t *__restrict__ g_ptol,
@@ -134,6 +152,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     const SelectArgs sa) {
     static_assert(!LIST || SEL, "list keys only exist with the selector predicate");
     static_assert(!PICK || (!LIST && !WANT_FIT), "the pick rides only in the plain mask variants");
+    static_assert(PICK != 2 || !TAINT, "the tile-test pick is built for the reference's two predicates");
     kernarg_warm<9 * 8 + sizeof(FusedArgs) + (PICK ? sizeof(SelectArgs) : 0)>();  // the prologue makes four dependent groups of argument loads (kernarg.hpp)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t b = blockIdx.x;
@@ -160,10 +179,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
 
     // PICK: which waves of the block carry the pick (wave-uniform).  Default: the first `pick_waves` (they are launched first, so
     // the pick's chain of round trips gets a head start); debug bit 0x10000 gives it to the last ones instead (A/B).
-    const uint32_t pick_waves = PICK ? a.pick_waves : 0u;
+    const uint32_t pick_waves = PICK == 1 ? a.pick_waves : 0u;
     uint32_t tid = threadIdx.x;
     bool pick_wave = false;
-    if constexpr (PICK) {
+    if constexpr (PICK == 1) {
         // The pick runs HERE, ahead of everything the mask code keeps in registers: select_one_pod holds up to five 48-byte
         // candidates per lane, and next to the main loop's per-lane invariants that would not fit the 128 VGPRs of a 1024-thread
         // block (it spilled when it sat at the loop's first trip).  The `tid` the rest of the kernel derives its per-lane values
@@ -193,9 +212,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     }
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar control flow below
-    const uint32_t stage_rank = (PICK && !(a.debug & 0x10000u)) ? wave - pick_waves : wave;  // of a staging wave among the staging waves
+    const uint32_t stage_rank = (PICK == 1 && !(a.debug & 0x10000u)) ? wave - pick_waves : wave;  // of a staging wave among the staging waves
     const uint32_t stage_waves = kFusedWaves - pick_waves;
-    const bool tracer = a.trace && tid == (PICK ? (kFusedWaves - 1u) * 64u : 0u);  // (PICK: wave 0 carries picks; trace a staging wave)
+    const bool tracer = a.trace && tid == (PICK == 1 ? (kFusedWaves - 1u) * 64u : 0u);  // (PICK == 1: wave 0 carries picks; trace a staging wave)
     auto stamp = [&](uint32_t i) {
         if (tracer) a.trace[(size_t)b * 8u + i] = wall_clock64();
     };
@@ -217,8 +236,19 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     int64_t rc = 0, rm = 0;
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
     uint64_t tol = 0;
+    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;  // PICK == 2: the pod's five draws
+    uint64_t ar = 0;                                  // PICK == 2: what the pod's accumulator held before this block's add
     auto issue_ops = [&](uint32_t pod) {
         const uint32_t pc = min(pod, a.p - 1u);  // clamp: lanes past the end read a valid row and are masked later
+        if constexpr (PICK == 2) {
+            static_assert(kPickAttempts == 5, "five draw registers");
+            const uint32_t *dp = sa.samples + (size_t)pc * kPickAttempts;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(d0) : "v"(dp) : "memory");
+            asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(d1) : "v"(dp) : "memory");
+            asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(d2) : "v"(dp) : "memory");
+            asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(d3) : "v"(dp) : "memory");
+            asm volatile("global_load_dword %0, %1, off offset:16" : "=v"(d4) : "v"(dp) : "memory");
+        }
         if (FIT) {
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rc) : "v"(g_pcpu + pc) : "memory");
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rm) : "v"(g_pmem + pc) : "memory");
@@ -251,6 +281,13 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
 #define KSCHED_WAIT_OPS(N)                                                                                                            \
     asm volatile("s_waitcnt vmcnt(%c11)"                                                                                              \
                  : "+v"(rc), "+v"(rm), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7), "+v"(tol)  \
+                 : "n"(N)                                                                                                             \
+                 : "memory")
+    // the same with the tile-test pick's in-flight registers: the five draws and the accumulator's returned value
+#define KSCHED_WAIT_OPS_PICK(N)                                                                                                       \
+    asm volatile("s_waitcnt vmcnt(%c17)"                                                                                              \
+                 : "+v"(rc), "+v"(rm), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7), "+v"(tol), \
+                   "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(ar)                                                     \
                  : "n"(N)                                                                                                             \
                  : "memory")
     // aux block of the tile: [tree cpu 1024][tree mem 1024][cnt cpu kCntEntries][cnt mem kCntEntries] (8-byte words)
@@ -479,7 +516,11 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     // ---- phase 1: lane = pod pod0 + lane (branch-free); returns the overflow ballot ---------------
     bool extra_any = false, list_any = false;
     uint32_t list_bound = 0;
+    uint32_t pick_bits = 0;  // PICK == 2: which of the pod's draws this block found feasible in its tile (the round that was just prepared)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32 *const s_park = (lds_u32 *)(lds + a.off_park) + wave * (kPickAttempts * 64u);  // the round's draws, [draw][lane]
     auto phase1 = [&](uint32_t pod0) -> uint64_t {
+        uint2 cnt_c = make_uint2(0u, 0u), cnt_m = make_uint2(0u, 0u);  // cnt[rank] of cpu / memory: one row number per sub-tile
         if (FIT) {
             // r = #sorted values < req: two interleaved descents of the tile's implicit search trees.  The sorted
             // arrays are stored in breadth-first (Eytzinger) order (tile_index.hpp): the candidates of one level are
@@ -502,6 +543,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             // cnt[rank]: for each sub-tile, how many of its nodes sit below the request = the row {lr >= cnt} to read
             const uint2 cc = s_cnt_cpu[lc], cm = s_cnt_mem[lm];
             s_fit[lane] = make_uint4(cc.x, cc.y, cm.x, cm.y);
+            cnt_c = cc;
+            cnt_m = cm;
         }
         const uint32_t rv = a.row_valid * 128u;  // offsets, not row numbers, from here on
         uint32_t cnt = 0;
@@ -601,6 +644,37 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                 t[g] = (g < a.ngroups) ? (a.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * 128u : rv;
             s_trow[lane] = make_uint2(t[0] | (t[1] << 16), t[2] | (t[3] << 16));
         }
+        if constexpr (PICK == 2) {
+            // The tile-test pick: check_node_validity(pod, candidate) (src/predicates.rs:63-77) for the draws that fall into THIS
+            // tile, read from the rows phase 2 is about to AND for the same pod: bit (l % 32) of word (l / 32) of every row the pod's
+            // records name -- the fit rows of both resources by the candidate's sub-tile, the eight selector slots (unconstrained
+            // slots name the all-valid row) -- is exactly the feasible bit this block writes for (pod, candidate).
+            const uint4 slots = SEL ? s_lab[lane] : make_uint4(0u, 0u, 0u, 0u);  // (read back after this lane's own scatter stores: LDS operations of a wave execute in order)
+            const uint32_t dv[kPickAttempts] = {d0, d1, d2, d3, d4};
+            uint32_t bits = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kPickAttempts; ++i) {
+                const uint32_t l = dv[i] - tile * (uint32_t)kTileNodes;  // in this tile <=> l < 1024 (unsigned; a draw >= n lies in no tile, or on padding bits, which are zero in every row)
+                if (l < (uint32_t)kTileNodes) {
+                    const uint32_t wofs = (l >> 5) << 2, sub = l >> 7;
+                    auto word = [&](uint32_t off) -> uint32_t { return *(lds_u32 *)(lds + off + wofs); };
+                    uint32_t v;
+                    if (FIT) {
+                        const uint32_t sh = (sub & 3u) * 8u;
+                        const uint32_t bc = ((sub < 4u ? cnt_c.x : cnt_c.y) >> sh) & 0xFFu, bm = ((sub < 4u ? cnt_m.x : cnt_m.y) >> sh) & 0xFFu;
+                        v = word((a.row_cpu + bc) * 128u) & word((a.row_cpu + (uint32_t)kFitRows + bm) * 128u);  // src/predicates.rs:42, both resources
+                    } else {
+                        v = word(rv);
+                    }
+                    if (SEL)  // src/predicates.rs:45-61
+                        v &= word(slots.x & 0xFFFFu) & word(slots.x >> 16) & word(slots.y & 0xFFFFu) & word(slots.y >> 16) & word(slots.z & 0xFFFFu) &
+                             word(slots.z >> 16) & word(slots.w & 0xFFFFu) & word(slots.w >> 16);
+                    bits |= ((v >> (l & 31u)) & 1u) << i;
+                }
+                s_park[i * 64u + lane] = dv[i];  // the pod's last contributor reads the winning draw's node from here, one trip later
+            }
+            pick_bits = bits;
+        }
         extra_any = __ballot(cnt > 4u) != 0ull;  // some pod of the round needs label rows 5..8
         const uint64_t over = __ballot(cnt > 8u || (LIST && lmax > kListCap));  // more than eight row keys constrained, or a long list range
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -633,7 +707,31 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     do {                 \
     } while (0)
 #endif
+    // PICK == 2: this block's word for the pods of the round prepared in the previous trip goes into their accumulators; the value
+    // that comes back says whether this block was a pod's last contributor (lanes past the end add nothing to a spare slot)
+    // (`nu` = units of that round: its pods are lanes [0, 8 nu); phase 1 prepares 64 lanes whatever the round holds, and the lanes past a
+    // short round's end are pods of the NEXT wave's range -- they contribute there, not here)
+    auto pick_contribute = [&](uint32_t pod0, uint32_t nu) {
+        const uint32_t pod = pod0 + lane;
+        const bool live = lane < nu * 8u && pod < a.p;
+        // (a lane that contributes nothing adds 0 to its own pod's slot -- or to the spare slot past the end --: all lanes to ONE spare
+        // slot serialised 20 000 atomics on one address, 278 us per launch at C3, session r3g2)
+        uint64_t *const slot = a.pick_acc + min(pod, a.p);
+        const uint64_t delta = live ? ((1ull << 32) | (uint64_t)pick_bits) : 0ull;
+        asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0 sc1" : "=v"(ar) : "v"(slot), "v"(delta) : "memory");
+    };
+    auto pick_decide = [&](uint32_t pod0, uint32_t nu) {
+        const uint32_t pod = pod0 + lane;
+        if (lane < nu * 8u && pod < a.p && (uint32_t)(ar >> 32) == a.tiles - 1u) {  // every tile's block has contributed: this lane decides the pod
+            const uint32_t all = ((uint32_t)ar | pick_bits) & ((1u << kPickAttempts) - 1u);
+            int32_t bnd = -1;  // no drawn candidate is feasible: None -> NoNodeFound (src/main.rs:70,117)
+            if (all) bnd = (int32_t)s_park[(uint32_t)__builtin_ctz(all) * 64u + lane];  // first feasible draw wins (src/main.rs:61-65)
+            sa.binding[pod] = bnd;
+            a.pick_acc[pod] = 0ull;  // ready for the next launch (nobody else touches the slot any more in this one)
+        }
+    };
     while (true) {
+        if (PICK == 2 && have_prev) pick_contribute(prev_u * 8u, prev_nu);
         if (more) issue_ops(u * 8u + lane);
         if ((a.debug & 128u) && have_prev && !stamped4) stamp(1);  // experiment: after the 2nd round's operand loads were issued
         if (first) {
@@ -655,7 +753,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             if (!(a.debug & 128u)) stamp(1);
             // everything this wave has in flight lands before the barrier: its staging pieces and the first round's operand loads
             // (a pick wave issues no staging piece whose wait would cover them)
-            if (PICK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (PICK == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (!(a.debug & 128u)) stamp(2);
         }
@@ -795,7 +893,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             ++prof_rounds;
 #endif
             // operands of round u have landed; up to kFastStores younger stores may be in flight
-            KSCHED_WAIT_OPS(kFastStores);
+            if constexpr (PICK == 2) {
+                KSCHED_WAIT_OPS_PICK(kFastStores);
+                if (have_prev) pick_decide(prev_u * 8u, prev_nu);  // (before phase 1 overwrites the park and pick_bits)
+            } else {
+                KSCHED_WAIT_OPS(kFastStores);
+            }
             KSCHED_PROF(prof_wait);
             prev_over = phase1(u * 8u);
             KSCHED_PROF(prof_p1);
@@ -809,10 +912,15 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             u += 8u;
             more = u < u_hi;
         }
+        if (PICK == 2 && !had_more && have_prev) {  // the wave's last round: nothing else is in flight behind its atomic
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ar) : : "memory");
+            pick_decide(prev_u * 8u, prev_nu);
+        }
         first = false;
         if (!had_more) break;
     }
 #undef KSCHED_WAIT_OPS
+#undef KSCHED_WAIT_OPS_PICK
     if (a.trace && lane == 0) {  // every wave: latest loop end / drain of the block
         atomicMax((unsigned long long *)&a.trace[(size_t)b * 8u + 5u], (unsigned long long)wall_clock64());
         __builtin_amdgcn_s_waitcnt(0);  // all counters to zero: this wave's stores have been acknowledged
@@ -845,9 +953,10 @@ struct FusedLaunch {
     uint64_t *out_feas, *out_fit;
     hipEvent_t ev_start, ev_stop;  // optional: attached to the dispatch itself (exact kernel duration)
     const SelectArgs *pick;        // the sampled pick that rides in the launch (PICK), or nullptr
+    int pick_form;                 // 1 = by waves of the fill (select_one_pod), 2 = tile tests in phase 1
 };
 
-template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST, bool PICK = false>
+template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST, int PICK = 0>
 inline hipError_t launch_fused_k(const FusedLaunch &q, const FusedArgs &a) {
     auto kern = k_eval_fused<FIT, SEL, TAINT, WANT_FIT, LIST, PICK>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds);
@@ -868,7 +977,12 @@ inline hipError_t launch_fused_t(bool want_fit, bool list, const FusedLaunch &q,
     if constexpr (SEL) {
         if (list) return want_fit ? launch_fused_k<FIT, SEL, TAINT, true, true>(q, a) : launch_fused_k<FIT, SEL, TAINT, false, true>(q, a);
     }
-    if (q.pick && !want_fit) return launch_fused_k<FIT, SEL, TAINT, false, false, true>(q, a);
+    if (q.pick && !want_fit) {
+        if constexpr (!TAINT) {
+            if (q.pick_form == 2) return launch_fused_k<FIT, SEL, TAINT, false, false, 2>(q, a);
+        }
+        return launch_fused_k<FIT, SEL, TAINT, false, false, 1>(q, a);
+    }
     return want_fit ? launch_fused_k<FIT, SEL, TAINT, true, false>(q, a) : launch_fused_k<FIT, SEL, TAINT, false, false>(q, a);
 }
 
@@ -876,6 +990,15 @@ inline hipError_t launch_fused_t(bool want_fit, bool list, const FusedLaunch &q,
 inline bool fused_pick_applicable(const IndexedSnapshot &s, uint32_t flags, bool want_fit, uint32_t p) {
     const bool list = (flags & KSCHED_SEL) && s.lay.nkeys && s.lay.nlist > 0;
     return s.built && !want_fit && !list && p < (1u << 31);
+}
+// ... and as the tile-test form (PICK == 2)?  ATTEMPTS draws per pod, the reference's two predicates, at most eight label keys
+// (a pod's selector then fits the eight slots of its record), and room in LDS for the per-wave park of the draws
+inline bool fused_tile_pick_applicable(const IndexedSnapshot &s, uint32_t flags, uint32_t attempts, bool have_psel) {
+    const IndexedLayout &l = s.lay;
+    if (attempts != kPickAttempts || ((flags & KSCHED_TAINT) && l.ngroups)) return false;
+    const bool sel = (flags & KSCHED_SEL) && have_psel && l.nkeys;
+    if (sel && l.nkeys > 8u) return false;
+    return fused_lds_bytes(l, flags & KSCHED_FIT, sel, false, nullptr, true) <= kLdsBudget;
 }
 
 inline bool fused_applicable(const IndexedSnapshot &s, uint32_t flags) {
@@ -887,7 +1010,7 @@ inline bool fused_applicable(const IndexedSnapshot &s, uint32_t flags) {
 inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                             const uint64_t *ptol, uint32_t flags, uint64_t *out_feas, uint64_t *out_fit, uint32_t pitch, hipStream_t stream,
                             uint32_t debug = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint64_t *trace = nullptr,
-                            uint32_t trace_blocks = 0, const SelectArgs *pick = nullptr) {
+                            uint32_t trace_blocks = 0, const SelectArgs *pick = nullptr, int pick_form = 1, uint64_t *pick_acc = nullptr) {
     const IndexedLayout &l = s.lay;
     FusedArgs a{};
     a.W = l.W;
@@ -915,7 +1038,9 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     const bool do_fit = flags & KSCHED_FIT;
     const bool do_sel = (flags & KSCHED_SEL) && psel && l.nkeys;
     const bool do_taint = (flags & KSCHED_TAINT) && l.ngroups;
-    const uint32_t lds = fused_lds_bytes(l, do_fit, do_sel, do_taint, &a);
+    const bool tile_pick = pick && pick_form == 2;
+    const uint32_t lds = fused_lds_bytes(l, do_fit, do_sel, do_taint, &a, tile_pick);
+    a.pick_acc = pick_acc;
 
     // chunks: as many pod ranges as keep every block resident at once (256 CUs x blocks per CU), but no
     // more than one round (64 pods) per wave needs.
@@ -940,12 +1065,13 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     const bool want_fit = (flags & KSCHED_WANT_FIT_MASK) && out_fit;
     const int sel = do_sel ? 1 : 0, tnt = do_taint ? 1 : 0, fit = do_fit ? 1 : 0;
     const bool list = do_sel && l.nlist > 0;
-    if (pick && (want_fit || list)) pick = nullptr;  // (the caller checks fused_pick_applicable first; never a silent drop of the pick)
+    if (pick && (want_fit || list)) return hipErrorInvalidValue;  // (the caller checks fused_pick_applicable first: a pick is never dropped silently)
+    if (tile_pick && (!pick_acc || do_taint || (do_sel && l.nkeys > 8u) || pick->attempts != kPickAttempts || lds > kLdsBudget)) return hipErrorInvalidValue;
     if (pick) {
         a.pick_ppb = (p + total - 1u) / total;
         a.pick_waves = std::max(1u, std::min(8u, (a.pick_ppb + 63u) / 64u));
     }
-    const FusedLaunch q{grid, lds, stream, &s, pcpu, pmem, psel, ptol, out_feas, out_fit, ev_start, ev_stop, pick};
+    const FusedLaunch q{grid, lds, stream, &s, pcpu, pmem, psel, ptol, out_feas, out_fit, ev_start, ev_stop, pick, pick_form};
     a.nlist = list ? l.nlist : 0u;
     a.list_mask8 = 0;
     for (uint32_t j = 0; j < a.nlist; ++j) {

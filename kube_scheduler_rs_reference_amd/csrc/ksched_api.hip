@@ -137,7 +137,15 @@ struct ksched_ctx {
     uint32_t opt_debug = 0;
     bool opt_trace = false;
     bool opt_pick_from_mask = false;
-    bool opt_fused_pick = true;   // KSCHED_OPT_FUSED_PICK: the sampled pick rides in the fused mask launch
+    int opt_fused_pick = 1;       // KSCHED_OPT_FUSED_PICK: 0 = the pick is its own launch, 1 = it rides in the fused mask launch (the form is chosen
+                                  // by the request), 2 = ... only as waves of the fill, 3 = ... only as tile tests
+    // per-pod accumulators of the tile-test pick (kernels_fused.hpp PICK == 2): all zero between launches (the kernel zeroes what it
+    // used); one buffer per stream evaluations are enqueued on, so that launches on different streams may overlap
+    struct PickAcc {
+        hipStream_t s;
+        DevBuf<uint64_t> buf;
+    };
+    std::vector<PickAcc> pick_acc;
     int opt_pipe_mode = 0;        // KSCHED_OPT_PIPE_MODE: 0 split (mask stream / pick stream), 1 alternate (whole steps, stream = slot % 2)
     uint32_t fault_kind = 0, fault_skip = 0;  // KSCHED_OPT_FAULT (test hook of the no-unwind rule)
     int opt_bestfit_stages = 0;  // KSCHED_OPT_BESTFIT_STAGES: 0 auto, 1 one stage, 2 two stages
@@ -273,6 +281,13 @@ int scratch_enter(ksched_ctx *c, hipStream_t s) {
 }
 
 void stream_forget(ksched_ctx *c, hipStream_t s) {
+    for (size_t i = 0; i < c->pick_acc.size(); ++i)
+        if (c->pick_acc[i].s == s) {  // (its launches are ordered before whatever the caller does to the stream next: freeing is safe after a sync there;
+                                      // hipFree synchronises the device itself)
+            c->pick_acc[i].buf.release();
+            c->pick_acc.erase(c->pick_acc.begin() + (std::ptrdiff_t)i);
+            break;
+        }
     if (c->scratch_owned && c->scratch_stream == s) {  // its last use of the scratch buffers stays ordered: as an event
         c->scratch_ev_pending = hipEventRecord(c->ev_scratch, s) == hipSuccess;
         if (!c->scratch_ev_pending) (void)hipGetLastError();
@@ -692,7 +707,37 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     const bool pick_rides = select_direct && want_mask && c->opt_fused_pick && kern == KSCHED_KERNEL_FUSED && can_fused &&
                             fused_pick_applicable(c->idx, flags, (flags & KSCHED_WANT_FIT_MASK) && out_fit, p);
     SelectArgs ride{};
-    if (pick_rides) ride = make_select_args(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_binding);
+    int ride_form = 1;
+    uint64_t *ride_acc = nullptr;
+    if (pick_rides) {
+        ride = make_select_args(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_binding);
+        // the form: tile tests in phase 1 (no node records fetched, no wave taken off the staging) where the request allows it, else
+        // waves of the fill running select_one_pod
+        const bool tile_ok = fused_tile_pick_applicable(c->idx, flags, attempts, psel != nullptr);
+        // Which form when both apply: the tile tests cost every (pod, tile) pair five draw loads and a handful of LDS reads, the waves
+        // of the fill cost every block a longer fill.  Measured (session r3g3, rotated outputs, step): 5 tiles (C3) 19.8 us against 21.6;
+        // 10 tiles (the C4 shard) 45.3 us against 42.1; 1 tile (C2) 7.1 us against 6.8.
+        const bool tile_pays = c->idx.lay.tiles >= 2u && c->idx.lay.tiles <= 6u;
+        if (((c->opt_fused_pick == 1 && tile_pays) || c->opt_fused_pick == 3) && tile_ok) {
+            ksched_ctx::PickAcc *pa = nullptr;
+            for (auto &x : c->pick_acc)
+                if (x.s == s) pa = &x;
+            if (!pa) {
+                c->pick_acc.emplace_back();
+                pa = &c->pick_acc.back();
+                pa->s = s;
+            }
+            if (pa->buf.cap < (size_t)p + 1) {  // (re)allocated: zero once; from then on the kernel leaves every slot it used at zero
+                HIPCHK(c, pa->buf.reserve((size_t)p + 1));
+                HIPCHK(c, hipMemsetAsync(pa->buf.ptr, 0, ((size_t)p + 1) * 8, s));
+            }
+            ride_form = 2;
+            ride_acc = pa->buf.ptr;
+        } else if (c->opt_fused_pick == 3) {
+            c->last_error = "the tile-test pick is not applicable to this request (attempts != 5, taints, more than eight label keys, or no room in LDS)";
+            return KSCHED_E_UNSUPPORTED;
+        }
+    }
     c->last_pick = "none";
     if (select_direct && !pick_rides) {
         int rcs = launch_select(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, out_binding, s);
@@ -840,10 +885,10 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         }
         hipError_t e = run_fused(c->idx, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, pitch, s, c->opt_debug,
                                  timed ? c->ev_pool[slot].a : nullptr, timed ? c->ev_pool[slot].b : nullptr,
-                                 c->opt_trace ? c->trace.ptr : nullptr, kTraceBlocks, pick_rides ? &ride : nullptr);
+                                 c->opt_trace ? c->trace.ptr : nullptr, kTraceBlocks, pick_rides ? &ride : nullptr, ride_form, ride_acc);
         if (e != hipSuccess) return fail_hip(c, e, "run_fused");
         c->last_kernel = "fused";
-        if (pick_rides) c->last_pick = "fused";
+        if (pick_rides) c->last_pick = ride_form == 2 ? "fused-tile" : "fused";
         rc = KSCHED_OK;
     } else {
         rc = run_direct(c, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, pitch, s);
@@ -935,6 +980,7 @@ void ksched_destroy(ksched_ctx *c) try {
         c->scratch_mask.release(); c->trace.release();
         c->by_cpu.release(); c->cpurank.release(); c->iota.release(); c->sort_keys.release(); c->sort_tmp.release(); c->d_stage.release();
         if (c->h_stage) (void)hipHostFree(c->h_stage);
+        for (auto &x : c->pick_acc) x.buf.release();
         for (auto &u : c->user_streams) (void)hipEventDestroy(u.ev);
         if (c->ev_build) (void)hipEventDestroy(c->ev_build);
         if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
@@ -991,8 +1037,8 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) try {
             c->opt_own_stream = value == 1;
             return KSCHED_OK;
         case KSCHED_OPT_FUSED_PICK:
-            if (value != 0 && value != 1) return KSCHED_E_INVAL;
-            c->opt_fused_pick = value == 1;
+            if (value < 0 || value > 3) return KSCHED_E_INVAL;
+            c->opt_fused_pick = (int)value;
             return KSCHED_OK;
         case KSCHED_OPT_PIPE_MODE:
             if (value != 0 && value != 1) return KSCHED_E_INVAL;

@@ -130,7 +130,7 @@ class Evaluator:
 
     @property
     def last_pick(self) -> str:
-        """How the latest evaluation's pick ran: "fused" (inside the mask launch), "select", "bestfit-rows", "from-mask", "none"."""
+        """How the latest evaluation's pick ran: "fused-tile" / "fused" (inside the mask launch), "select", "bestfit-rows", "from-mask", "none"."""
         return self._lib.ksched_last_pick(self._h).decode()
 
     @property

@@ -32,7 +32,7 @@ def test_default_line_contract(built):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["launches_timed"] == 16
     # C3, 8 label keys; the sampled pick rides in the launch: + 20 B of draws per pod read, + 4 B of binding per pod written
-    assert c["pick_launch"] == "fused" and c["kernels_per_step"] == 1
+    assert c["pick_launch"] in ("fused", "fused-tile") and c["kernels_per_step"] == 1
     assert r["algorithmic_bytes_per_launch"] == 100_000 * (48 + 20) + 5_000 * 48 + 100_000 * 79 * 8 + 100_000 * 4
     assert c["mask_rotation"] >= 5 and c["mask_rotation_bytes"] > 256 * 2**20, "the timed loop must not rewrite a mask the Infinity Cache still holds"
     assert d["ramp_steps"] >= 16 and d["untimed_steps_before_timed_region"] == d["warmup"] + d["ramp_steps"]

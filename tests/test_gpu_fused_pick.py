@@ -20,7 +20,9 @@ def oracle_eval(c, flags):
 
 
 def run(ev, c, flags, ride):
-    ev.set_option(_lib.OPT_FUSED_PICK, 1 if ride else 0)
+    """ride: False / 0 = the pick is its own launch; True / 1 = it rides, the library chooses the form; 2 = as waves of the fill
+    (select_one_pod on the node records); 3 = as tile tests in phase 1 (KSCHED_E_UNSUPPORTED where that form does not apply)"""
+    ev.set_option(_lib.OPT_FUSED_PICK, int(ride))
     try:
         pc = c.pod_columns()
         r = ev.eval(pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], pc["tolerations"], pc["samples"], flags)
@@ -30,7 +32,7 @@ def run(ev, c, flags, ride):
 
 
 @pytest.mark.parametrize("P,N,attempts", [(1, 1, 5), (63, 65, 5), (300, 200, 5), (1000, 4097, 5), (5000, 1000, 1), (4099, 2500, 8),
-                                          (2500, 700, 11), (20_000, 5_000, 5), (70_000, 1_100, 5)])
+                                          (2500, 700, 11), (20_000, 5_000, 5), (70_000, 1_100, 5), (3_000, 12_000, 5), (130, 40_000, 5)])
 @pytest.mark.parametrize("flags", [FIT, FIT | SEL, FIT | SEL | TAINT, SEL, 0])
 def test_riding_pick_equals_standalone_pick_equals_oracle(evaluator, P, N, attempts, flags):
     ev = evaluator
@@ -39,13 +41,25 @@ def test_riding_pick_equals_standalone_pick_equals_oracle(evaluator, P, N, attem
         c = synth.make_cluster(P, N, n_keys=8, n_taints=16, seed=P * 31 + N * 7 + attempts, attempts=attempts)
         ev.set_nodes(**c.node_columns())
         f = flags | PICK_SAMPLED
-        a, how_a, kern_a = run(ev, c, f, ride=True)
-        b, how_b, _ = run(ev, c, f, ride=False)
         feas, _, bind = oracle_eval(c, f)
-        assert kern_a == "fused" and how_a == "fused" and how_b == "select"
-        assert np.array_equal(a.binding, bind), "riding pick vs oracle"
-        assert np.array_equal(b.binding, bind), "stand-alone pick vs oracle"
-        assert np.array_equal(a.feasible, feas) and np.array_equal(b.feasible, feas), "the mask does not notice the pick"
+        # the tile-test form: ATTEMPTS draws, the reference's two predicates (a taint predicate no node's taints make active is none)
+        tile_ok = attempts == 5 and not ((flags & TAINT) and c.node_taints.any())
+        a, how_a, kern_a = run(ev, c, f, ride=1)
+        assert kern_a == "fused" and how_a == ("fused-tile" if (tile_ok and 1024 < N <= 6 * 1024) else "fused")  # (the library picks the tile form from two to six tiles)
+        w, how_w, _ = run(ev, c, f, ride=2)
+        b, how_b, _ = run(ev, c, f, ride=0)
+        assert how_w == "fused" and how_b == "select"
+        for r, what in ((a, "riding pick (form chosen by the library)"), (w, "riding pick, waves of the fill"), (b, "stand-alone pick")):
+            assert np.array_equal(r.binding, bind), what + " vs oracle"
+            assert np.array_equal(r.feasible, feas), what + ": the mask does not notice the pick"
+        if tile_ok:
+            for rep in range(3):  # the accumulators are left at zero by every launch: the same call again gives the same bindings
+                t, how_t, _ = run(ev, c, f, ride=3)
+                assert how_t == "fused-tile" and np.array_equal(t.binding, bind) and np.array_equal(t.feasible, feas), rep
+        else:
+            with pytest.raises(KschedError) as ei:
+                run(ev, c, f, ride=3)
+            assert ei.value.code == _lib.E_UNSUPPORTED
     finally:
         ev.set_kernel("auto")
 
@@ -61,11 +75,12 @@ def test_riding_pick_out_of_range_draws_and_no_feasible_node(evaluator):
     ev.set_nodes(**c.node_columns())
     ev.set_kernel("fused")
     try:
-        a, how, _ = run(ev, c, FIT | SEL | PICK_SAMPLED, ride=True)
         _, _, bind = oracle_eval(c, FIT | SEL | PICK_SAMPLED)
-        assert how == "fused"
-        assert np.array_equal(a.binding, bind)
-        assert (a.binding[:50] == -1).all() and (a.binding[100:150] == -1).all()
+        for form, name in ((3, "fused-tile"), (2, "fused")):
+            a, how, _ = run(ev, c, FIT | SEL | PICK_SAMPLED, ride=form)
+            assert how == name
+            assert np.array_equal(a.binding, bind), name
+            assert (a.binding[:50] == -1).all() and (a.binding[100:150] == -1).all()
     finally:
         ev.set_kernel("auto")
 
@@ -88,7 +103,33 @@ def test_the_pick_does_not_ride_where_it_cannot(evaluator):
     finally:
         ev.set_kernel("auto")
     r = ev.eval(pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], None, pc["samples"], FIT | SEL | PICK_SAMPLED)
-    assert ev.last_pick == "fused" and np.array_equal(r.binding, bind)
+    assert ev.last_pick == "fused-tile" and np.array_equal(r.binding, bind)  # (1500 nodes: two tiles)
+
+
+def test_tile_pick_more_than_eight_keys_and_partial_tiles(evaluator):
+    """More than eight label keys: the tile-test form does not apply (a pod's selector must fit the eight slots of its record) and the
+    library falls back to the waves of the fill.  Node counts around the 1024-node tile edge: draws on the padding bits of the
+    last, partial tile, and in tiles this block does not own."""
+    ev = evaluator
+    rng = np.random.default_rng(3)
+    ev.set_kernel("fused")
+    try:
+        for N in (1, 63, 1023, 1024, 1025, 2049, 3000):
+            c = synth.make_cluster(1200, N, n_keys=8, n_taints=0, seed=50 + N)
+            c.samples[:] = rng.integers(0, N + 40, size=c.samples.shape, dtype=np.uint32)  # some draws fall past the last node
+            ev.set_nodes(**c.node_columns())
+            _, _, bind = oracle_eval(c, FIT | SEL | PICK_SAMPLED)
+            a, how, _ = run(ev, c, FIT | SEL | PICK_SAMPLED, ride=3)
+            assert how == "fused-tile" and np.array_equal(a.binding, bind), N
+        c = synth.make_cluster(900, 2500, n_keys=8, n_taints=0, seed=8)
+        lab = np.concatenate([c.node_labels, rng.integers(0, 3, size=(3, c.N), dtype=np.uint32)])
+        sel = np.concatenate([c.pod_sel, np.where(rng.random((3, c.P)) < 0.3, rng.integers(1, 4, size=(3, c.P)), 0).astype(np.uint32)])
+        ev.set_nodes(c.avail_cpu, c.avail_mem, lab, None)
+        want = capi.eval_encoded(c.avail_cpu, c.avail_mem, lab, None, c.req_cpu, c.req_mem, sel, None, c.samples, FIT | SEL | PICK_SAMPLED)[2]
+        r = ev.eval(c.req_cpu, c.req_mem, sel, None, c.samples, FIT | SEL | PICK_SAMPLED)
+        assert ev.last_pick == "fused" and np.array_equal(r.binding, want)
+    finally:
+        ev.set_kernel("auto")
 
 
 def test_riding_pick_on_device_buffers_repeated_steps(evaluator):
@@ -107,9 +148,21 @@ def test_riding_pick_on_device_buffers_repeated_steps(evaluator):
         out.fill_(-7)
         ev.eval_device(d_cpu, d_mem, d_sel, None, d_smp, FIT | SEL | PICK_SAMPLED, out_feasible=mask, out_binding=out)
         torch.cuda.synchronize()
-        assert ev.last_pick == "fused"
+        assert ev.last_pick == "fused-tile"
         assert np.array_equal(out.cpu().numpy(), bind)
     assert np.array_equal(mask.cpu().numpy().view(np.uint64), feas)
+    # two streams in turn (what the pipe's alternate mode does): each stream has its own accumulators, launches may overlap
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    outs = [torch.full((c.P,), -7, dtype=torch.int32, device=dev) for _ in range(6)]
+    masks = [ev.alloc_mask(c.P, pitched=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    for j in range(6):
+        ev.eval_device(d_cpu, d_mem, d_sel, None, d_smp, FIT | SEL | PICK_SAMPLED, out_feasible=masks[j % 2], out_binding=outs[j], stream=(s1, s2)[j % 2])
+    torch.cuda.synchronize()
+    for j in range(6):
+        assert np.array_equal(outs[j].cpu().numpy(), bind), j
+    ev.forget_stream(s1)
+    ev.forget_stream(s2)
 
 
 # ---- nothing unwinds across the C ABI (include/ksched.h "Conventions") -------------------------------------

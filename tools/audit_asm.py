@@ -80,7 +80,7 @@ def audit_kernel(name: str, lines: list[str], meta: dict) -> list[str]:
             in_asm = False
             continue
         if in_asm:
-            if t.startswith("global_load_dword"):
+            if t.startswith("global_load_dword") or t.startswith("global_atomic_add_x2"):  # (the tile-test pick's returning atomic: in flight like a load)
                 dst = t.split(None, 1)[1].split(",")[0]
                 loads.append((i, regs_of(dst)))
             m = re.match(r"s_waitcnt vmcnt\((\d+)\)$", t)
@@ -106,7 +106,7 @@ def audit_kernel(name: str, lines: list[str], meta: dict) -> list[str]:
     hdr = max((i for i, ln in enumerate(lines[:first_load]) if "Loop Header: Depth=1" in ln), default=0)
     for i, ln in enumerate(lines):
         t = ln.split(";")[0].strip()
-        if not t or t.startswith(".") or t.endswith(":") or t.startswith("s_") or t.startswith("global_load_dword") and any(i == li for li, _ in loads):
+        if not t or t.startswith(".") or t.endswith(":") or t.startswith("s_") or (t.startswith("global_load_dword") or t.startswith("global_atomic_add_x2")) and any(i == li for li, _ in loads):
             continue
         ops = t.split(None, 1)
         if len(ops) < 2 or i < hdr:

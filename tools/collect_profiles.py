@@ -23,6 +23,11 @@ cp("prof_default_kernel_stats.csv", "rocprofv3_kernel_stats_bench_default.csv")
 cp("prof_default_bench.json", "bench_line_under_rocprofv3.json")
 cp("pmc_traffic.json", "pmc_traffic.json")
 cp("trace_C3.txt", "fused_phase_trace_C3.txt")
+cp("trace_C3_nopick.txt", "fused_phase_trace_C3_without_pick.txt")
+cp("bench_driver_form.json", "bench_driver_form_steps20_C3.json")
+cp("prof_driver_form_kernel_stats.csv", "rocprofv3_kernel_stats_bench_driver_form.csv")
+cp("prof_driver_form_bench.json", "bench_line_under_rocprofv3_driver_form.json")
+cp("prof_c5s_kernel_stats.csv", "rocprofv3_kernel_stats_bench_C5s.csv")
 cp("pytest_gpu.log", "pytest_gpu.log")
 cp("smoke.log", "smoke.log")
 cp("host_costs.txt", "host_costs_snapshot_calls.txt")

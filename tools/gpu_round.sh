@@ -24,21 +24,33 @@ if has smoke; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 fi
 if has bench; then
-  stamp "bench (default command)"
+  stamp "bench (default command, and the driver's form: --steps 20 --warmup 5)"
   timeout 600 python bench.py > $OUT/bench_default.log 2>&1; tail -1 $OUT/bench_default.log > $OUT/bench_default.json
-  python - <<PY
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_form.log 2>&1; tail -1 $OUT/bench_driver_form.log > $OUT/bench_driver_form.json
+  for f in bench_default bench_driver_form; do python - <<PY
 import json
-d=json.load(open("$OUT/bench_default.json")); r=d["roofline"]; c=d["cpu_baseline"]
-print("default: %.3e evals/s step %.1f us kernel %.1f us %.0f GB/s frac %.3f | cpu %.3e (%d cores) single %.3e encoded %.3e" % (d["value"], d["ms_per_step"]*1e3, r["avg_kernel_us"], r["achieved"], r["frac"], c["value"], c["cores"], c["single_core_value"], c["encoded_loop_value"]))
+d=json.load(open("$OUT/$f.json")); r=d["roofline"]; c=d["cpu_baseline"]; g=d["config"]
+print("$f: %.3e evals/s step %.2f us (step frac %.3f) kernel %.2f us %.0f GB/s frac %.3f pick=%s rot=%s | cpu %.3e (%d cores) single %.3e encoded %.3e" % (d["value"], d["ms_per_step"]*1e3, g["step_frac_of_hbm_peak"], r["avg_kernel_us"], r["achieved"], r["frac"], g["pick_launch"], g["mask_rotation"], c["value"], c["cores"], c["single_core_value"], c["encoded_loop_value"]))
+for k in ("in_place", "two_batches_in_flight"):
+    print("   ", k, {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in (g.get(k) or {}).items() if kk != "note"})
+for k, v in (g.get("other_workloads") or {}).items():
+    print("   ", k, {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk not in ("workload", "pick_alone_note")})
 PY
+  done
 fi
 if has prof; then
   stamp "rocprofv3 --kernel-trace --stats -- python bench.py"
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -o r -- python $REPO/bench.py > $OUT/prof_default.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_driver_form -o r -- python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/prof_driver_form.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5s -o r -- python $REPO/bench.py --workload C5s --no-cpu-baseline --no-others > $OUT/prof_c5s.log 2>&1
   cd $REPO
   grep "^{\"metric" $OUT/prof_default.log > $OUT/prof_default_bench.json
-  f=$(find $OUT/prof_default -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/prof_default_kernel_stats.csv && head -6 $f
+  grep "^{\"metric" $OUT/prof_driver_form.log > $OUT/prof_driver_form_bench.json
+  f=$(find $OUT/prof_default -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/prof_default_kernel_stats.csv && head -6 $f | cut -c1-260
+  f=$(find $OUT/prof_driver_form -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/prof_driver_form_kernel_stats.csv && head -4 $f | cut -c1-260
+  f=$(find $OUT/prof_c5s -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/prof_c5s_kernel_stats.csv && head -6 $f | cut -c1-200
+  find $OUT -name "*.db" -size +2M -delete
 fi
 if has pmc; then
   stamp "PMC passes (separate runs: FETCH_SIZE, WRITE_SIZE; calibration + bench)"
@@ -131,7 +143,8 @@ if has probe2; then
   PROBE_N=2 timeout 200 python tools/stream_probe.py --repeat 2>&1 | grep "context #\|consecutive" > $OUT/stream_probe.txt; cat $OUT/stream_probe.txt
 fi
 if has trace; then
-  stamp "fused kernel phase trace (C3)"
-  timeout 300 python tools/trace_fused.py --workload C3 > $OUT/trace_C3.txt 2>&1; head -20 $OUT/trace_C3.txt
+  stamp "fused kernel phase trace (C3), with the riding pick and without"
+  timeout 300 python tools/trace_fused.py --workload C3 --pick > $OUT/trace_C3.txt 2>&1; head -16 $OUT/trace_C3.txt
+  timeout 300 python tools/trace_fused.py --workload C3 > $OUT/trace_C3_nopick.txt 2>&1; head -15 $OUT/trace_C3_nopick.txt
 fi
 stamp "done"
