@@ -84,7 +84,7 @@ struct FusedArgs {
     uint32_t debug;
     uint32_t has_tol;  // tolerations were given (g_ptol is not null)
     uint32_t pick_ppb, pick_waves;  // PICK == 1: pods whose sampled pick one block carries, and how many of its waves carry them (the others stage)
-    uint64_t *pick_acc;             // PICK == 2: [p + 1] per-pod accumulators (count << 32 | feasible-draw bits), all zero between launches
+    uint64_t *pick_acc;             // PICK == 2: [ceil(p / 8)] accumulators, one per unit of eight pods (count << 40 | 8 x 5 feasible-draw bits), all zero between launches
     uint32_t off_park;              // PICK == 2: LDS byte offset of the per-wave park of the round's draws
     uint64_t *trace;  // diagnostics: per-block phase timestamps (100 MHz), or nullptr
 };
@@ -137,12 +137,12 @@ typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 // PICK == 2, the tile-test pick: a drawn candidate that lies in the block's tile is tested against the bitmap rows the block has in
 // LDS anyway -- the (pod, node) bit the block is about to write into the mask, read straight from the rows phase 1 has just named --
 // so no node record is fetched and no wave is taken off the staging.  Every (chunk, tile) block sees all five draws of its
-// chunk's pods and tests the ones that fall into its tile (lane = pod, phase 1); what it found goes into the pod's 64-bit
-// accumulator with ONE returning atomic add per pod and block: bits 0..4 = "draw i is feasible" (a draw lies in exactly one tile,
-// so the blocks' bit sets are disjoint and the add is an OR), bits 32.. = how many blocks have contributed.  The block whose add
-// returns tiles - 1 is the pod's last contributor: it holds every bit, takes the lowest set one (first feasible draw wins,
-// src/main.rs:61-65), writes the binding -- the drawn node, from the draws it parked in LDS -- and zeroes the accumulator for the next
-// launch.  The atomic is issued at the top of the NEXT trip and awaited by that trip's counted wait, like the operand loads: its
+// chunk's pods and tests the ones that fall into its tile (lane = pod, phase 1); what it found goes into a 64-bit accumulator per
+// unit of eight pods with ONE returning atomic add per unit and block: five bits per pod = "draw i is feasible" (a draw lies in
+// exactly one tile, so the blocks' bit sets are disjoint and the add is an OR), bits 40.. = how many blocks have contributed.  The
+// block whose add returns tiles - 1 is the unit's last contributor: it holds every bit, takes each pod's lowest set one (first
+// feasible draw wins, src/main.rs:61-65), writes the bindings -- the drawn nodes, from the draws it parked in LDS -- and zeroes the
+// accumulator for the next launch.  The atomic is issued at the top of the NEXT trip and awaited by that trip's counted wait, like the operand loads: its
 // return registers are in flight inside one trip only.
 template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST = false, int PICK = 0>
 __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
 #pragma unroll
             for (uint32_t i = 0; i < kPickAttempts; ++i) {
                 const uint32_t l = dv[i] - tile * (uint32_t)kTileNodes;  // in this tile <=> l < 1024 (unsigned; a draw >= n lies in no tile, or on padding bits, which are zero in every row)
-                if (l < (uint32_t)kTileNodes) {
+                if (l < (uint32_t)kTileNodes && !(a.debug & 0x8000000u)) {  // (debug bit 27: no tests -- what the tests cost; results invalid)
                     const uint32_t wofs = (l >> 5) << 2, sub = l >> 7;
                     auto word = [&](uint32_t off) -> uint32_t { return *(lds_u32 *)(lds + off + wofs); };
                     uint32_t v;
@@ -707,31 +707,53 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
     do {                 \
     } while (0)
 #endif
-    // PICK == 2: this block's word for the pods of the round prepared in the previous trip goes into their accumulators; the value
-    // that comes back says whether this block was a pod's last contributor (lanes past the end add nothing to a spare slot)
-    // (`nu` = units of that round: its pods are lanes [0, 8 nu); phase 1 prepares 64 lanes whatever the round holds, and the lanes past a
-    // short round's end are pods of the NEXT wave's range -- they contribute there, not here)
+    // PICK == 2: what this block found for the pods of the round prepared in the previous trip goes into their accumulators.  ONE
+    // 64-bit word per UNIT of eight pods -- bits [5j, 5j + 5) = pod j's feasible draws, bits 40.. = how many blocks have contributed --
+    // and one returning atomic add per unit, issued by the unit's first lane with the eight lanes' fields ORed together: the tile
+    // blocks of a chunk cut their pods into the same units, so a unit's pods always arrive together.  (One atomic per POD cost 1.5 us
+    // per launch at C3 and 5.6 us at the C4 shard, session r3h: the returning device-scope atomics were most of the pick's price.)
+    // `nu` = units of that round: its pods are lanes [0, 8 nu); phase 1 prepares 64 lanes whatever the round holds, and the lanes past
+    // a short round's end are pods of the NEXT wave's range -- they contribute there, not here.
     auto pick_contribute = [&](uint32_t pod0, uint32_t nu) {
-        const uint32_t pod = pod0 + lane;
-        const bool live = lane < nu * 8u && pod < a.p;
-        // (a lane that contributes nothing adds 0 to its own pod's slot -- or to the spare slot past the end --: all lanes to ONE spare
-        // slot serialised 20 000 atomics on one address, 278 us per launch at C3, session r3g2)
-        uint64_t *const slot = a.pick_acc + min(pod, a.p);
-        const uint64_t delta = live ? ((1ull << 32) | (uint64_t)pick_bits) : 0ull;
-        asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0 sc1" : "=v"(ar) : "v"(slot), "v"(delta) : "memory");
+        const uint32_t n_live = min(nu * 8u, a.p - pod0);  // wave-uniform: the round's pods that exist
+        const uint32_t j = lane & 7u;
+        uint32_t lo = 0, hi = 0;  // this pod's five bits at [5j, 5j + 5) of a 40-bit field
+        if (lane < n_live) {
+            const uint64_t f = (uint64_t)pick_bits << (5u * j);
+            lo = (uint32_t)f;
+            hi = (uint32_t)(f >> 32);
+        }
+#pragma unroll
+        for (uint32_t d = 1; d <= 4; d <<= 1) {  // OR over the unit's eight lanes
+            lo |= (uint32_t)__shfl_xor((int)lo, (int)d, 64);
+            hi |= (uint32_t)__shfl_xor((int)hi, (int)d, 64);
+        }
+        const uint64_t delta = (1ull << 40) | ((uint64_t)hi << 32) | (uint64_t)lo;
+        uint64_t *const slot = a.pick_acc + ((pod0 >> 3) + (lane >> 3));
+        // the units' first lanes only (EXEC is narrowed inside the statement: the compiler sees one unconditional definition of `ar`)
+        const uint64_t lead = 0x0101010101010101ull & (n_live >= 64u ? ~0ull : ((1ull << n_live) - 1ull));
+        uint64_t saved;
+        asm volatile("s_and_saveexec_b64 %1, %4\n\tglobal_atomic_add_x2 %0, %2, %3, off sc0 sc1\n\ts_mov_b64 exec, %1"
+                     : "=v"(ar), "=&s"(saved)
+                     : "v"(slot), "v"(delta), "s"(lead)
+                     : "memory", "scc");
     };
     auto pick_decide = [&](uint32_t pod0, uint32_t nu) {
-        const uint32_t pod = pod0 + lane;
-        if (lane < nu * 8u && pod < a.p && (uint32_t)(ar >> 32) == a.tiles - 1u) {  // every tile's block has contributed: this lane decides the pod
-            const uint32_t all = ((uint32_t)ar | pick_bits) & ((1u << kPickAttempts) - 1u);
+        const uint32_t n_live = min(nu * 8u, a.p - pod0);
+        const uint32_t j = lane & 7u, first = lane & ~7u;
+        // the unit's returned word, from its first lane
+        const uint32_t wlo = (uint32_t)__shfl((int)(uint32_t)ar, (int)first, 64), whi = (uint32_t)__shfl((int)(uint32_t)(ar >> 32), (int)first, 64);
+        const uint64_t word = ((uint64_t)whi << 32) | (uint64_t)wlo;
+        if (lane < n_live && (uint32_t)(word >> 40) == a.tiles - 1u) {  // every tile's block has contributed: this block decides the unit's pods
+            const uint32_t all = ((uint32_t)(word >> (5u * j)) | pick_bits) & ((1u << kPickAttempts) - 1u);
             int32_t bnd = -1;  // no drawn candidate is feasible: None -> NoNodeFound (src/main.rs:70,117)
             if (all) bnd = (int32_t)s_park[(uint32_t)__builtin_ctz(all) * 64u + lane];  // first feasible draw wins (src/main.rs:61-65)
-            sa.binding[pod] = bnd;
-            a.pick_acc[pod] = 0ull;  // ready for the next launch (nobody else touches the slot any more in this one)
+            sa.binding[pod0 + lane] = bnd;
+            if (j == 0u) a.pick_acc[(pod0 >> 3) + (lane >> 3)] = 0ull;  // ready for the next launch (nobody else touches the word any more in this one)
         }
     };
     while (true) {
-        if (PICK == 2 && have_prev) pick_contribute(prev_u * 8u, prev_nu);
+        if (PICK == 2 && have_prev && !(a.debug & 0x10000000u)) pick_contribute(prev_u * 8u, prev_nu);  // (debug bit 28: no atomics -- what they cost; results invalid)
         if (more) issue_ops(u * 8u + lane);
         if ((a.debug & 128u) && have_prev && !stamped4) stamp(1);  // experiment: after the 2nd round's operand loads were issued
         if (first) {

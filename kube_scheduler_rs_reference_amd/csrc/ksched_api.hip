@@ -727,9 +727,10 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
                 pa = &c->pick_acc.back();
                 pa->s = s;
             }
-            if (pa->buf.cap < (size_t)p + 1) {  // (re)allocated: zero once; from then on the kernel leaves every slot it used at zero
-                HIPCHK(c, pa->buf.reserve((size_t)p + 1));
-                HIPCHK(c, hipMemsetAsync(pa->buf.ptr, 0, ((size_t)p + 1) * 8, s));
+            const size_t units = ((size_t)p + 7) / 8 + 8;  // one word per unit of eight pods (+ slack: the lanes past a batch's last unit compute an address, never use it)
+            if (pa->buf.cap < units) {  // (re)allocated: zero once; from then on the kernel leaves every word it used at zero
+                HIPCHK(c, pa->buf.reserve(units));
+                HIPCHK(c, hipMemsetAsync(pa->buf.ptr, 0, units * 8, s));
             }
             ride_form = 2;
             ride_acc = pa->buf.ptr;

@@ -95,32 +95,44 @@ def audit_kernel(name: str, lines: list[str], meta: dict) -> list[str]:
     if len(counted) != 1:
         errs.append(f"expected exactly one counted wait, found {len(counted)}")
         return errs
-    # 2. between the wait and the loads in program order the loop body wraps around: check every
-    # instruction that is neither the loads themselves nor after-the-wait consumers.  Conservative
-    # form: outside the asm statements, no instruction may WRITE a destination register at all, and
-    # reads are only allowed in the basic blocks that follow the counted wait up to the next load.
+    # 2. the in-flight window of a destination register = from the asm statement that defines it (load / returning atomic) to the counted
+    # wait, in the loop body's order (the body may be laid out with the wait textually first: the window then wraps around the loop).
+    # Inside its window NO instruction outside the asm statements may read or write the register; outside it the register is an
+    # ordinary one (the waited value is consumed after the wait; once dead it may serve as a temporary until its next definition).
     first_load = min(i for i, _ in loads)
     wait_i = counted[0][0]
-    # everything before the header of the loop that holds the load site runs once, before any operand load exists:
-    # a register written there is simply reused later as a load destination
+    # everything before the header of the loop that holds the load site runs once, before any operand load exists
     hdr = max((i for i, ln in enumerate(lines[:first_load]) if "Loop Header: Depth=1" in ln), default=0)
+    # the loop's last line: the last backward branch to a label at or after the header (conservative: the last line of the function)
+    end = len(lines) - 1
+    def_line = {}
+    for li, regs in loads:
+        for r in regs:
+            def_line.setdefault(r, li)  # (one load site: every register is defined once)
+    asm_lines = set()
+    inside = False
     for i, ln in enumerate(lines):
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            inside = True
+        elif t.startswith(";;#ASMEND"):
+            inside = False
+        elif inside:
+            asm_lines.add(i)
+    for i, ln in enumerate(lines):
+        if i in asm_lines or i < hdr:
+            continue
         t = ln.split(";")[0].strip()
-        if not t or t.startswith(".") or t.endswith(":") or t.startswith("s_") or (t.startswith("global_load_dword") or t.startswith("global_atomic_add_x2")) and any(i == li for li, _ in loads):
+        if not t or t.startswith(".") or t.endswith(":") or t.startswith("s_"):
             continue
         ops = t.split(None, 1)
-        if len(ops) < 2 or i < hdr:
+        if len(ops) < 2:
             continue
-        used = regs_of(ops[1]) & dest
-        if not used:
-            continue
-        written = regs_of(ops[1].split(",")[0]) & dest if not ops[0].startswith(("global_store", "ds_write", "v_cmp", "buffer_store")) else set()
-        # instructions textually between the wait and the next load site are the consumers (phase 1)
-        in_consumer_region = (wait_i < i < first_load) if wait_i < first_load else (i > wait_i or i < first_load)
-        if written and not (i < min(wait_i, first_load) and ops[0].startswith("v_mov")):
-            errs.append(f"line {i}: writes operand register(s) {sorted(written)}: {t}")
-        elif not in_consumer_region and not (i < min(wait_i, first_load) and ops[0].startswith("v_mov")):
-            errs.append(f"line {i}: touches in-flight operand register(s) {sorted(used)} outside the consumer region: {t}")
+        for r in regs_of(ops[1]) & dest:
+            L = def_line[r]
+            in_window = (L < i < wait_i) if L < wait_i else (i > L or i < wait_i)
+            if in_window and i <= end:
+                errs.append(f"line {i}: touches v{r} inside its in-flight window (defined at line {L}, awaited at line {wait_i}): {t}")
     return errs
 
 
