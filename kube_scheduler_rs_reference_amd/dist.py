@@ -196,9 +196,14 @@ class PipelinedScheduler:
     group)."""
 
     def __init__(self, P: int, device: torch.device, depth: int = 2, group: Optional[dist.ProcessGroup] = None, pipe=None,
-                 gather_always: bool = False, gather_every: int = 1, comm: Optional[AbiComm] = None):
+                 gather_always: bool = False, gather_every: int = 1, comm: Optional[AbiComm] = None, alternate: bool = False):
+        """alternate = True (with a pipe in KSCHED_OPT_PIPE_MODE 1): the WHOLE step of a slot -- ONE launch when the pick rides in the
+        mask kernel -- goes onto stream (slot mod 2) and its all-gather behind it on the same stream, so the gather of batch i
+        overlaps the launch of batch i + 1 on the other stream (needs gather_every == 1 and an even depth)."""
         if depth < 1 or gather_every < 1:
             raise ValueError("depth >= 1, gather_every >= 1")
+        if alternate and (pipe is None or gather_every != 1 or depth % 2):
+            raise ValueError("alternate needs a pipe, gather_every == 1 and an even depth (a slot keeps its stream)")
         if pipe is not None and pipe.depth != depth * gather_every:
             raise ValueError("a pipe needs pipe.depth == depth * gather_every (one pipe slot per step in flight)")
         self.P, self.device, self.depth, self.group, self.pipe, self.gather_every = P, device, depth, group, pipe, gather_every
@@ -217,6 +222,8 @@ class PipelinedScheduler:
         self._fill = [0] * depth   # steps written into the slot since its last gather
         self._cur = 0              # slot being filled
         self._pick_stream = pipe.stream(1) if pipe is not None else None
+        self._alternate = alternate
+        self._streams2 = (pipe.stream(0), pipe.stream(1)) if alternate else None  # alternate: slot k lives on stream k % 2
         # single-stream form with the ABI communicator: the gather runs on a side stream behind an event, like torch's async_op
         self._side = torch.cuda.Stream(device=device) if (comm is not None and pipe is None) else None
         self._ready = [torch.cuda.Event() for _ in range(depth)] if self._side is not None else None  # reused: no event creation per step
@@ -236,8 +243,9 @@ class PipelinedScheduler:
         if self._gather and self._fill[k] > 0:
             if self.comm is not None:
                 if self._pick_stream is not None:  # stream-ordered behind the group's last pick: no event, nothing to wait for
-                    self.comm.all_gather(self._gathered[k], self._local[k], stream=self._pick_stream)
-                    self._work[k] = _StreamWork(self._pick_stream)
+                    st = self._streams2[k & 1] if self._alternate else self._pick_stream
+                    self.comm.all_gather(self._gathered[k], self._local[k], stream=st)
+                    self._work[k] = _StreamWork(st)
                 else:
                     self._ready[k].record(torch.cuda.current_stream(self.device))
                     self._side.wait_event(self._ready[k])
@@ -245,7 +253,7 @@ class PipelinedScheduler:
                     self._done[k].record(self._side)
                     self._work[k] = _EventWork(self._done[k])
             elif self._pick_stream is not None:
-                with torch.cuda.stream(self._pick_stream):
+                with torch.cuda.stream(self._streams2[k & 1] if self._alternate else self._pick_stream):
                     self._work[k] = dist.all_gather_into_tensor(self._gathered[k], self._local[k], group=self.group, async_op=True)
             else:
                 self._work[k] = dist.all_gather_into_tensor(self._gathered[k], self._local[k], group=self.group, async_op=True)
@@ -257,7 +265,7 @@ class PipelinedScheduler:
         if g == 0 and self._work[k] is not None:
             # first step into a reused slot: the all-gather that read its bindings must be done before they are overwritten
             if self._pick_stream is not None:
-                with torch.cuda.stream(self._pick_stream):
+                with torch.cuda.stream(self._streams2[k & 1] if self._alternate else self._pick_stream):
                     self._work[k].wait()
             else:
                 self._work[k].wait()

@@ -208,3 +208,61 @@ def test_an_exception_inside_the_library_comes_back_as_a_code(evaluator, kind, c
     with pytest.raises(KschedError):
         ev.eval(*args)
     ev.eval(*args)
+
+
+# ---- the pipe's alternate mode (KSCHED_OPT_PIPE_MODE = 1): whole steps on stream (slot mod 2) --------------------------------------
+
+@pytest.mark.parametrize("with_gather", [False, True])
+def test_pipe_alternate_mode_equals_oracle(evaluator, with_gather):
+    """Consecutive batches alternate between the pipe's two streams, each batch ONE launch (the pick rides) -- and, with the C ABI's
+    RCCL communicator, each batch's all-gather behind it on its own stream (the N > 1 default of bench.py, here in a one-rank group).
+    Slots reused over nine steps; every step's bindings and masks == oracle; wait_mask orders a consumer behind the slot's launch."""
+    import torch
+    from kube_scheduler_rs_reference_amd.dist import AbiComm, PipelinedScheduler
+    ev = evaluator
+    c = synth.make_cluster(6000, 2600, n_keys=8, n_taints=0, seed=314)
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", ev.device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    steps, depth = 9, 4
+    rolled = [np.roll(np.arange(c.P), 17 * j) for j in range(steps)]
+    batches = [dict(cpu=t(c.req_cpu[r], np.int64), mem=t(c.req_mem[r], np.int64), sel=t(c.pod_sel[:, r], np.int32), smp=t(c.samples[r], np.int32)) for r in rolled]
+    feas, _, base = oracle_eval(c, FIT | SEL | PICK_SAMPLED)
+    comm = AbiComm(ev) if with_gather else None
+    ev.set_option(_lib.OPT_PIPE_MODE, 1)
+    pipe = ev.pipe(depth)
+    try:
+        sched = PipelinedScheduler(c.P, dev, depth=depth, pipe=pipe, gather_always=with_gather, gather_every=1, comm=comm, alternate=True)
+        masks = [ev.alloc_mask(c.P) for _ in range(depth)]
+        state = {"j": 0}
+
+        def run(slot, out):
+            b = batches[state["j"]]
+            pipe.submit(slot, b["cpu"], b["mem"], b["sel"], None, b["smp"], FIT | SEL | PICK_SAMPLED, masks[slot], out)
+
+        got, pend = [], []
+        for j in range(steps):
+            state["j"] = j
+            pend.append((j, sched.step(run)))
+            assert ev.last_pick == "fused-tile"  # (2600 nodes: three tiles -- one launch per step)
+            if len(pend) >= depth:
+                jj, p = pend.pop(0)
+                got.append((jj, p.wait().clone()))
+        got += [(jj, p.wait().clone()) for jj, p in pend]
+        sched.drain()
+        # the last step's mask, read by a consumer stream ordered by wait_mask
+        consumer = torch.cuda.Stream(device=dev)
+        last_slot = (steps - 1) % depth
+        pipe.wait_mask(last_slot, stream=consumer)
+        with torch.cuda.stream(consumer):
+            m = masks[last_slot].clone()
+        consumer.synchronize()
+        torch.cuda.synchronize()
+        for jj, b in got:
+            assert np.array_equal(b.cpu().numpy(), base[rolled[jj]]), f"step {jj}"
+        assert np.array_equal(m.cpu().numpy().view(np.uint64), feas[rolled[steps - 1]])
+    finally:
+        pipe.close()
+        ev.set_option(_lib.OPT_PIPE_MODE, 0)
+        if comm is not None:
+            comm.close()

@@ -99,6 +99,15 @@ PY
 fi
 if has dist; then
   stamp "N > 1 bench path in a ONE-rank RCCL group (KSCHED_BENCH_FORCE_DIST=1): C ABI communicator vs torch, pipe vs one stream"
+  KSCHED_BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline 2>$OUT/dist_default.err | tail -1 > $OUT/dist_default.json
+  python - <<PY
+import json
+try:
+    d=json.load(open("$OUT/dist_default.json")); c=d["config"]
+    print("default N>1 path (one rank): %s | gather/step %.1f us/step | no gather %s | eff vs no gather %s | strong leg %s" % (c["workload"][:24], d["ms_per_step"]*1e3, (c.get("no_allgather") or {}).get("ms_per_step"), c.get("scaling_efficiency_vs_no_allgather"), {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (c.get("configs3_strong") or {}).items() if k not in ("workload", "no_allgather")}))
+except Exception as e:
+    print("default N>1 path FAILED", e); print(open("$OUT/dist_default.err").read()[-1500:])
+PY
   for wl in C3 C4s; do for mode in "" "--torch-gather" "--one-stream"; do
     KSCHED_BENCH_FORCE_DIST=1 timeout 300 python bench.py --workload $wl --no-cpu-baseline $mode 2>&1 | tail -1 > $OUT/dist_${wl}_${mode#--}.json
     python - <<PY
