@@ -20,6 +20,10 @@
  *     r02_a_toolchain_probe_gpu_box.txt), so there is no oracle/_ref.  Pinning is one command for anyone who has cargo:
  *     rust/pin_parity.sh runs the reference's OWN fits() / does_node_selector_match on tests/golden/*_objects.json and
  *     tests/test_reference_fixtures.py compares the result with the fixtures this oracle reproduces.
+ *     Outside D the unpinned half is BRACKETED: oracle_ref.py carries a second reading (kube_quantity 0.6.1 as the surveyor recalls
+ *     it: f32 scale factors kept to 7 digits) and tests/test_quantity_readings.py states, per spelling, where the two agree (D, Ki,
+ *     Mi, every decimal suffix) and where they do not (Gi and above, exponent forms); both fit masks are committed for the two
+ *     fixtures that hold such spellings.  This C file implements the exact reading only.
  *   - Taints/tolerations and best-fit are extensions (BASELINE.json config 5) with no
  *     reference code: semantics are defined in DESIGN.md and restated here independently.
  */
