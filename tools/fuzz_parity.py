@@ -14,6 +14,7 @@ rng = np.random.default_rng(seed)
 ev = Evaluator(0)
 t_end = time.time() + budget
 cases = fails = 0
+picks = {}
 I64 = np.iinfo(np.int64)
 while time.time() < t_end:
     cases += 1
@@ -50,6 +51,7 @@ while time.time() < t_end:
     flags = preds | pick | (L.WANT_FIT_MASK if r.random() < 0.5 else 0)
     try:
         ev.set_option(L.OPT_BESTFIT_STAGES, int(r.choice([0, 1, 2])))
+        ev.set_option(L.OPT_FUSED_PICK, int(r.choice([0, 1, 1, 2])))  # 3 (tile tests or E_UNSUPPORTED) below, where it applies
         ev.set_nodes(cpu, mem, lab, taints)
         for step in range(int(r.choice([1, 1, 3]))):
             if step:  # a snapshot update between evaluations
@@ -66,7 +68,22 @@ while time.time() < t_end:
                     (not pick or np.array_equal(got.binding, want[2]))
                 if not ok:
                     fails += 1
-                    print(f"FAIL case seed {cs}: N={N} P={P} K={K} cards={cards} nt={nt} flags={flags:#x} kernel={kernel}/{ev.last_kernel} step={step}", flush=True)
+                    print(f"FAIL case seed {cs}: N={N} P={P} K={K} cards={cards} nt={nt} flags={flags:#x} kernel={kernel}/{ev.last_kernel} pick={ev.last_pick} step={step}", flush=True)
+                picks[ev.last_pick] = picks.get(ev.last_pick, 0) + 1
+            if pick == L.PICK_SAMPLED and K <= 8 and not (preds & L.TAINT):  # the tile-test form of the riding pick, forced
+                ev.set_kernel("fused")
+                ev.set_option(L.OPT_FUSED_PICK, 3)
+                try:
+                    got = ev.eval(rc, rm, sel if K else None, None, smp, flags)
+                    if not (np.array_equal(got.feasible, want[0]) and np.array_equal(got.binding, want[2])):
+                        fails += 1
+                        print(f"FAIL tile pick case seed {cs}: N={N} P={P} K={K} cards={cards} flags={flags:#x} pick={ev.last_pick} step={step}", flush=True)
+                    picks[ev.last_pick] = picks.get(ev.last_pick, 0) + 1
+                except L.KschedError as e:
+                    if e.code != L.E_UNSUPPORTED:
+                        raise
+                    picks["tile-unsupported"] = picks.get("tile-unsupported", 0) + 1
+                ev.set_option(L.OPT_FUSED_PICK, 1)
         ev.set_kernel("auto")
         if r.random() < 0.3:  # ksched_explain on random pairs == the reason rebuilt from three single-predicate oracle masks
             from kube_scheduler_rs_reference_amd.evaluator import unpack_mask
@@ -84,5 +101,5 @@ while time.time() < t_end:
         fails += 1
         print(f"EXCEPTION case seed {cs}: N={N} P={P} K={K} cards={cards} nt={nt} flags={flags:#x}: {e}", flush=True)
         ev.set_kernel("auto")
-print(f"fuzz: {cases} cases, {fails} failures, seed {seed}")
+print(f"fuzz: {cases} cases, {fails} failures, seed {seed}, pick launches {picks}")
 sys.exit(1 if fails else 0)
