@@ -106,8 +106,9 @@ extern "C" {
  * HBM; 1 = the host code that specifies it (csrc/tile_index.hpp), uploaded.  Same tables bit for bit (ksched_index_checksum). */
 #define KSCHED_OPT_INDEX_BUILD 6
 /* KSCHED_OPT_BESTFIT_STAGES: the best-fit pick from the bitmaps in best-fit order runs in one stage (a wave per pod) or in two
- * (a lane per pod decides from the first 512 candidates, a wave per pod finishes the rest): 0 (default) = two stages from 65536
- * pods per call on, 1 = always one, 2 = always two.  Same bindings either way. */
+ * (a lane per pod decides from the first 512 - 1024 candidates, a wave per pod finishes the rest): 0 (default) = two stages from
+ * 24576 pods per call on (two dependent launches cost ~45 us whatever the batch; one stage ~20 us + 1 us per 1000 pods), 1 = always
+ * one, 2 = always two.  Same bindings either way. */
 #define KSCHED_OPT_BESTFIT_STAGES 7
 /* KSCHED_OPT_SNAPSHOT_STREAM: where ksched_set_nodes / ksched_update_nodes (and the lazy best-fit rebuild) enqueue their device
  * work.  0 (default) = when evaluations have been enqueued on exactly ONE caller stream so far, onto that stream: the change is

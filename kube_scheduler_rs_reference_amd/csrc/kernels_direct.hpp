@@ -405,8 +405,11 @@ __global__ __launch_bounds__(256) void k_pick_bestfit(const uint64_t *__restrict
 // do, so only candidates in the difference (at most q nodes of the whole snapshot) are tested individually.  The first
 // set bit of the lowest word wins.  No mask is read: like the sampled pick, this runs before and independently of
 // the mask kernel, and a bindings-only request launches no mask kernel.
+// The first stage appends the pods it hands over to kBfSublists lists, wave w to list w % kBfSublists: ONE list with one counter made
+// 2 000 waves queue for a returning atomic on one address (~8 ns each, up to 10 us of waiting per wave at the C5 shard).
+constexpr uint32_t kBfSublists = 128;
 struct BestfitRowsArgs {
-    const uint64_t *rows;          // [rows][Wbf] bitmaps over bf_order positions
+    const uint64_t *rows;          // [rows][Wbf] bitmaps over bf_order positions; Wbf = ceil(n / 64) rounded up to a multiple of 8 (rows are whole 64-byte lines)
     const uint32_t *lab_meta;      // lab_base[32], lab_max[32] (row numbers shared with the tile index)
     const int64_t *cpu_sorted;     // [n] ascending avail_cpu
     const int64_t *bf_mem, *bf_cpu;  // node columns in best-fit order
@@ -418,19 +421,25 @@ struct BestfitRowsArgs {
     int32_t *binding;
     uint32_t p, n, Wbf, nkeys, ngroups, row_valid, row_zero, row_taint, row_cpu0, q, do_fit, do_taint;
     uint32_t lab_base8[8], lab_max8[8];  // the first eight keys' row numbers as arguments (no dependent load)
-    // second stage of the two-stage pick (k_pick_bestfit_lanes): only the listed pods, count read from device memory
-    const uint32_t *pod_list, *pod_count;
+    // second stage of the two-stage pick (k_pick_bestfit_lanes): the handed-over pods' 64-byte records sit in kBfSublists sub-lists of
+    // `sub_cap` slots each, sub_count[32 * c] = entries of sub-list c; block b (one wave) takes entry b / kBfSublists of sub-list b % kBfSublists
+    const uint32_t *sub_count;
+    const uint32_t *pod_recs;
+    uint32_t sub_cap;
+    uint32_t rows_wide;   // groups of 64 words per round of the wave's scan after a pod's first round (1, 2 or 4)
     // 8-ary level arrays of bf_mem / cpu_sorted for the lane-per-pod searches: level k (1..nlev) holds the last element of every
     // block of 8^k entries; [mem level 1][mem level 2]...[cpu level 1]...; lvl_off[k - 1] = offset of level k inside one half
     const int64_t *lvl;
     uint32_t nlev, lvl_half, lvl_off[6];
-    uint32_t *fallback_list, *fallback_count;
-    uint32_t lane_words;  // candidate words (64 positions each) a lane looks at before handing the pod over
+    uint32_t *handover_recs;   // [kBfSublists][sub_cap][16]: first stage -> second stage
+    uint32_t *handover_count;  // [kBfSublists][32] (one counter per 128-byte line), this call's
+    uint32_t *zero_next;       // the counters of the NEXT two-stage call (three sets in rotation): zeroed here, so that no call pays a memset launch
+    uint32_t lane_blocks;  // 64-byte blocks of candidate words (8 x 64 positions each) a lane looks at before handing the pod over
     // snapshots with list keys (tile_index.hpp): pods that constrain one are collected for k_pick_bestfit_listed
     uint32_t nlist, list_col[2];
-    uint32_t *listed_list, *listed_count;
-    uint32_t lane_pair;   // k_pick_bestfit_lanes: 1 = two candidate words per trip
-    uint32_t *zero_next;  // the counters of the NEXT two-stage call (three slots in rotation): zeroed here, so that no call pays a memset launch
+    uint64_t *listed_mask;     // [ceil(p / 64)]
+    // KSCHED_OPT_DEBUG bit 20 (tools/bestfit_ab.py --trace): 100 MHz time stamps, 8 words per wave of the first stage, then 4 per wave of the second
+    uint64_t *trace, *trace2;
 };
 
 // first i in [0, n) with arr[i] >= key (n if none), by the whole wave: 64-ary search, three rounds for n <= 262144
@@ -494,42 +503,41 @@ __device__ __forceinline__ void wave_lower_bound_sampled2(const int64_t *__restr
     out1 = (cA1 >= n2) ? n : b1 * 64u + cC1;
 }
 
-// The scan of one pod by the whole wave, given start = first position whose memory can hold the pod, r = #nodes with cpu below the
-// request, and the first word to look at (w_first >= start >> 6; the caller vouches that no feasible position lies before it).
-// Returns the chosen node (every lane holds the same value).
-__device__ __forceinline__ int32_t bestfit_rows_scan(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane, uint32_t start, uint32_t r, uint32_t w_first,
-                                                     int64_t req_c, uint64_t tol, const uint32_t (&sel)[8]) {
-    uint32_t r_hi = q.row_valid, r_lo = q.row_valid;
-    if (q.do_fit) {
-        r_hi = q.row_cpu0 + (r + q.q - 1u) / q.q;  // only nodes that fit
-        r_lo = q.row_cpu0 + r / q.q;               // every node that fits
-    }
-    if (start >= q.n) return -1;
-    // the rows this pod ANDs (wave-uniform): selector keys, taint groups; row numbers of the first eight keys from the arguments
-    uint32_t lrow[8];
+// One round of the scan below: G groups of 64 words from word `wb` on (lane = word within the group), every row load of the round in
+// flight together.  Returns true when the pod is decided, `out` = the chosen node (every lane holds the same value).
+template <int G>
+__device__ __forceinline__ bool bestfit_rows_round(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane, uint32_t start, uint32_t wb, uint32_t r_hi,
+                                                   uint32_t r_lo, const uint32_t (&lrow)[8], const uint32_t (&sel)[8], uint64_t tol, int64_t req_c,
+                                                   int32_t &out) {
+    uint64_t base[G], hi[G], lo[G];
 #pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) lrow[k] = (sel[k] <= q.lab_max8[k]) ? q.lab_base8[k] + sel[k] - 1u : q.row_zero;
-    for (uint32_t wb = w_first; wb < q.Wbf; wb += 64u) {
-        const uint32_t w = wb + lane;
+    for (int g = 0; g < G; ++g) {
+        const uint32_t w = wb + (uint32_t)g * 64u + lane;
         const bool in = w < q.Wbf;
         const uint32_t wc = in ? w : 0u;
         // all row words of the round are loaded together, unconditionally (one round trip)
-        uint64_t base = q.rows[(size_t)q.row_valid * q.Wbf + wc];
-        const uint64_t hi = q.rows[(size_t)r_hi * q.Wbf + wc], lo = q.rows[(size_t)r_lo * q.Wbf + wc];
+        // (every row holds bits of live positions only, so with the cpu rows in the AND the all-valid row adds nothing: one load less)
+        base[g] = q.do_fit ? ~0ull : q.rows[(size_t)q.row_valid * q.Wbf + wc];
+        hi[g] = q.do_fit ? q.rows[(size_t)r_hi * q.Wbf + wc] : 0ull;
+        lo[g] = q.do_fit ? q.rows[(size_t)r_lo * q.Wbf + wc] : 0ull;
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k)
-            if (sel[k] != 0u) base &= q.rows[(size_t)lrow[k] * q.Wbf + wc];
+            if (sel[k] != 0u) base[g] &= q.rows[(size_t)lrow[k] * q.Wbf + wc];
         for (uint32_t k = 8; k < q.nkeys; ++k) {
             const uint32_t s = q.psel[(size_t)k * q.p + pod];
-            if (s != 0u) base &= q.rows[(size_t)((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero) * q.Wbf + wc];
+            if (s != 0u) base[g] &= q.rows[(size_t)((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero) * q.Wbf + wc];
         }
         if (q.do_taint)
-            for (uint32_t g = 0; g < q.ngroups; ++g)
-                base &= q.rows[(size_t)(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * q.Wbf + wc];
-        if (!in) base = 0;
-        if (w == (start >> 6)) base &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
-        const uint64_t sure = q.do_fit ? (base & hi) : base;
-        const uint64_t maybe = q.do_fit ? (base & lo & ~hi) : 0ull;
+            for (uint32_t t = 0; t < q.ngroups; ++t)
+                base[g] &= q.rows[(size_t)(q.row_taint + 16u * t + (uint32_t)((tol >> (4u * t)) & 15ull)) * q.Wbf + wc];
+        if (!in) base[g] = 0;
+        if (w == (start >> 6)) base[g] &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {  // groups hold ascending words: the first group with a hit decides
+        const uint32_t w = wb + (uint32_t)g * 64u + lane;
+        const uint64_t sure = q.do_fit ? (base[g] & hi[g]) : base[g];
+        const uint64_t maybe = q.do_fit ? (base[g] & lo[g] & ~hi[g]) : 0ull;
         // this lane's first feasible position (rarely more than one trip: `maybe` holds < 1/256 of the nodes)
         uint32_t found = 0xFFFFFFFFu;
         uint64_t cand = sure | maybe;
@@ -545,8 +553,43 @@ __device__ __forceinline__ int32_t bestfit_rows_scan(const BestfitRowsArgs &q, u
         const uint64_t hit = __ballot(found != 0xFFFFFFFFu);
         if (hit) {  // lanes hold ascending words: the lowest lane with a hit holds the best-fit node
             const uint32_t first = (uint32_t)__shfl((int)found, __builtin_ctzll(hit), 64);
-            return (int32_t)q.bf_order[first];
+            out = (int32_t)q.bf_order[first];
+            return true;
         }
+    }
+    return false;
+}
+
+// The scan of one pod by the whole wave, given start = first position whose memory can hold the pod, r = #nodes with cpu below the
+// request, and the first word to look at (w_first >= start >> 6; the caller vouches that no feasible position lies before it).
+// The first round looks at 64 words (four pods in five end there); a pod that goes on is a deep one -- every further round is one more
+// dependent round trip, twelve for a pod no node can hold at 50 k nodes -- so the later rounds look at q.rows_wide x 64 words each.
+// Returns the chosen node (every lane holds the same value).
+__device__ __forceinline__ int32_t bestfit_rows_scan(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane, uint32_t start, uint32_t r, uint32_t w_first,
+                                                     int64_t req_c, uint64_t tol, const uint32_t (&sel)[8]) {
+    uint32_t r_hi = q.row_valid, r_lo = q.row_valid;
+    if (q.do_fit) {
+        r_hi = q.row_cpu0 + (r + q.q - 1u) / q.q;  // only nodes that fit
+        r_lo = q.row_cpu0 + r / q.q;               // every node that fits
+    }
+    if (start >= q.n || w_first >= q.Wbf) return -1;
+    // the rows this pod ANDs (wave-uniform): selector keys, taint groups; row numbers of the first eight keys from the arguments
+    uint32_t lrow[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) lrow[k] = (sel[k] <= q.lab_max8[k]) ? q.lab_base8[k] + sel[k] - 1u : q.row_zero;
+    int32_t out = -1;
+    uint32_t wb = w_first;
+    if (bestfit_rows_round<1>(q, pod, lane, start, wb, r_hi, r_lo, lrow, sel, tol, req_c, out)) return out;
+    wb += 64u;
+    if (q.rows_wide >= 4u) {
+        for (; wb < q.Wbf; wb += 256u)
+            if (bestfit_rows_round<4>(q, pod, lane, start, wb, r_hi, r_lo, lrow, sel, tol, req_c, out)) return out;
+    } else if (q.rows_wide == 2u) {
+        for (; wb < q.Wbf; wb += 128u)
+            if (bestfit_rows_round<2>(q, pod, lane, start, wb, r_hi, r_lo, lrow, sel, tol, req_c, out)) return out;
+    } else {
+        for (; wb < q.Wbf; wb += 64u)
+            if (bestfit_rows_round<1>(q, pod, lane, start, wb, r_hi, r_lo, lrow, sel, tol, req_c, out)) return out;
     }
     return -1;
 }
@@ -575,6 +618,13 @@ __device__ __forceinline__ int32_t bestfit_rows_one_pod(const BestfitRowsArgs &q
     return bestfit_rows_scan(q, pod, lane, start, r, start >> 6, req_c, tol, sel);
 }
 
+// diagnostics (BestfitRowsArgs::trace): lane 0 of the wave stamps the 100 MHz clock once the value DEP has arrived
+#define KSCHED_BF_STAMP(BUF, SLOT, DEP)                                                                        \
+    if ((BUF) && (threadIdx.x & 63u) == 0u) {                                                                  \
+        uint64_t t_;                                                                                           \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"((uint32_t)(DEP)) : "memory"); \
+        (BUF)[SLOT] = t_;                                                                                      \
+    }
 // One wave per pod, one launch slot per pod.  (A persistent grid of 8192 waves walking the pods was measured slower,
 // 210 us against 147 us at the C5 shard: the kernel is bound by instruction issue -- ~280 scalar and ~240 vector
 // instructions per pod, mostly address arithmetic and wave-uniform control flow, rocprofv3 SQ counters -- not by wave
@@ -583,17 +633,30 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
     kernarg_warm<sizeof(BestfitRowsArgs)>();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (q.pod_list) {  // second stage of the two-stage pick: the pods the lane-per-pod kernel could not decide in its first words
-        // (one short-lived wave per listed pod, the grid sized for the worst case: waves beyond the count exit at once; a persistent
-        // grid walking the list was measured slower, like the persistent form of the one-stage kernel)
-        if (wave >= *q.pod_count) return;
+    if (q.sub_count) {  // second stage of the two-stage pick: the pods the lane-per-pod kernel could not decide in its first words.
+        // One short-lived wave per handed-over pod, ONE WAVE PER BLOCK: with four waves per block a CU's SIMD whose six slots hold deep
+        // pods (ten times the median scan) blocks the placement of whole blocks while eighteen other slots idle (traced: 3 900 of 6 141
+        // slots in use).  The grid covers a quarter of the lists' capacity, entries beyond that are walked (when > 1/4 of all pods are handed over).
+        const uint32_t c = blockIdx.x % kBfSublists, count = q.sub_count[32u * c], stride = gridDim.x / kBfSublists;
+        for (uint32_t i = blockIdx.x / kBfSublists; i < count; i += stride) {
+        const uint32_t slot = c * q.sub_cap + i;
+        uint64_t *const tr = q.trace2 ? q.trace2 + (size_t)slot * 4u : nullptr;
+        KSCHED_BF_STAMP(tr, 0, slot);
         // the first stage hands over everything it had in registers -- one 64-byte record {pod, start, cpu rank, next word,
         // tolerations, cpu request, selector ids 0..7}: no rank search and no operand round trip here, the row loads go out at once
-        const uint4 *rec = reinterpret_cast<const uint4 *>(q.pod_list) + (size_t)wave * 4u;
+        const uint4 *rec = reinterpret_cast<const uint4 *>(q.pod_recs) + (size_t)slot * 4u;
         const uint4 h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
         const uint32_t sel[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
         const int32_t b = bestfit_rows_scan(q, h.x, lane, h.y, h.z, h.w, (int64_t)(((uint64_t)o.w << 32) | o.z), ((uint64_t)o.y << 32) | o.x, sel);
         if (lane == 0) q.binding[h.x] = b;
+        KSCHED_BF_STAMP(tr, 1, (uint32_t)b);
+        if (tr && lane == 0) {
+            uint32_t xcc, hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc), "=s"(hw));
+            tr[2] = ((uint64_t)h.w << 32) | (uint32_t)b;  // (first word looked at, result)
+            tr[3] = ((uint64_t)xcc << 32) | hw;           // where the wave ran
+        }
+        }
         return;
     }
     if (wave >= q.p) return;
@@ -612,26 +675,31 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
 __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArgs q) {
     kernarg_warm<sizeof(BestfitRowsArgs)>();
     const uint32_t pod = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pod == 0u && q.zero_next) {  // (the slot after this call's: its last users finished two calls ago, its next ones start after this kernel)
-        q.zero_next[0] = 0u;
-        q.zero_next[1] = 0u;
-    }
-    if (pod >= q.p) return;
+    if (blockIdx.x == 0u && q.zero_next && threadIdx.x < kBfSublists) q.zero_next[32u * threadIdx.x] = 0u;  // (kBfSublists <= 256)
+    if ((pod & ~63u) >= q.p) return;  // a whole wave past the end
+    uint64_t *const tr = q.trace ? q.trace + (size_t)(pod >> 6) * 8u : nullptr;
+    KSCHED_BF_STAMP(tr, 0, pod);
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
-    if (q.nlist && q.psel) {  // a list key has no bitmap rows: a pod that constrains one is picked from the key's sorted lists instead
-        bool listed = false;
+    // No lane leaves before the wave has written its hand-over masks: a lane past the end, or one whose pod constrains a list key (no
+    // bitmap rows: such a pod is picked from the key's sorted lists, k_pick_bestfit_listed), just skips the work.
+    const bool live = pod < q.p;
+    bool listed = false;
+    if (live && q.nlist && q.psel)
         for (uint32_t j = 0; j < q.nlist; ++j) listed |= q.psel[(size_t)q.list_col[j] * q.p + pod] != 0u;
-        if (listed) {
-            q.listed_list[atomicAdd(q.listed_count, 1u)] = pod;
-            return;
-        }
-    }
-    const int64_t req_c = q.do_fit ? q.pcpu[pod] : 0, req_m = q.do_fit ? q.pmem[pod] : 0;
-    const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
-    uint32_t sel[8];
+    const bool work = live && !listed;
+    int32_t found = -1;
+    bool undecided = false;
+    uint32_t start = 0, r = 0;
+    int64_t req_c = 0;
+    uint64_t tol = 0ull;
+    uint32_t sel[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (work) {
+    req_c = q.do_fit ? q.pcpu[pod] : 0;
+    const int64_t req_m = q.do_fit ? q.pmem[pod] : 0;
+    tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
 #pragma unroll
     for (uint32_t k = 0; k < 8; ++k) sel[k] = (q.psel && k < q.nkeys) ? q.psel[(size_t)k * q.p + pod] : 0u;
-    uint32_t start = 0, r = 0;
+    KSCHED_BF_STAMP(tr, 1, (uint32_t)req_c ^ (uint32_t)req_m ^ (uint32_t)tol ^ sel[0] ^ sel[1] ^ sel[2] ^ sel[3] ^ sel[4] ^ sel[5] ^ sel[6] ^ sel[7]);
     if (q.do_fit) {
         // lower bounds of req_m in bf_mem and of req_c in cpu_sorted, level by level from the top (block = 8 entries = one line)
         auto count8 = [](const int64_t *a, uint32_t base, uint32_t limit, int64_t key) -> uint32_t {
@@ -657,8 +725,8 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
         start = min(start, q.n);
         r = min(r, q.n);
     }
-    int32_t found = -1;
-    bool undecided = start < q.n;
+    KSCHED_BF_STAMP(tr, 2, start ^ r);
+    undecided = start < q.n;
     // a required value no node carries (KSCHED_SEL_NEVER, or an id beyond the key's largest): the pod's AND of rows is empty --
     // no node, and no scan to the end of the snapshot to find that out (1 % of the constrained keys in the C5 workload)
 #pragma unroll
@@ -671,29 +739,8 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) lrow[k] = (sel[k] <= q.lab_max8[k]) ? q.lab_base8[k] + sel[k] - 1u : q.row_zero;
         const uint32_t w0 = start >> 6;
-        // the rows of word `w` (clamped: a word past the end reads as empty), all loads of one word in flight together
         struct Word {
             uint64_t base, hi, lo;
-        };
-        auto load_word = [&](uint32_t w) -> Word {
-            const bool in = w < q.Wbf;
-            const uint32_t wc = in ? w : q.Wbf - 1u;
-            Word x;
-            x.base = q.rows[(size_t)q.row_valid * q.Wbf + wc];
-            x.hi = q.rows[(size_t)r_hi * q.Wbf + wc];
-            x.lo = q.rows[(size_t)r_lo * q.Wbf + wc];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k)
-                if (sel[k] != 0u) x.base &= q.rows[(size_t)lrow[k] * q.Wbf + wc];
-            for (uint32_t k = 8; k < q.nkeys; ++k) {
-                const uint32_t s = q.psel[(size_t)k * q.p + pod];
-                if (s != 0u) x.base &= q.rows[(size_t)((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero) * q.Wbf + wc];
-            }
-            if (q.do_taint)
-                for (uint32_t g = 0; g < q.ngroups; ++g)
-                    x.base &= q.rows[(size_t)(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull)) * q.Wbf + wc];
-            if (!in) x.base = 0ull;
-            return x;
         };
         // first candidate of word `w` that fits (sure bits at once, the others by their exact cpu); returns whether one was found
         auto take_word = [&](uint32_t w, Word x) -> bool {
@@ -710,32 +757,77 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
             }
             return false;
         };
-        // TWO words per trip: both words' row loads are in flight together, so a lane that needs all its words makes half as many
-        // dependent round trips (a wave runs as long as its slowest lane, and one pod in five needs every word it may look at)
-        const uint32_t per_trip = q.lane_pair ? 2u : 1u;  // (KSCHED_OPT_DEBUG bit 11: one word per trip, the round-2 form -- A/B)
-        for (uint32_t t = 0; t < q.lane_words && undecided; t += per_trip) {
-            const uint32_t w = w0 + t;
-            if (w >= q.Wbf) {
-                undecided = false;  // ran off the end: no feasible node
-                break;
+        // ONE 64-BYTE BLOCK (8 words = 512 positions) of every row per trip, as four 16-byte requests to the same line in flight together:
+        // the L1 pulls a whole line per miss whatever part of it is asked for, and further requests to a line on its way cost little
+        // (tools/ubench_pending.hip: four units of one random line 0.76 us per dependent round, one unit 0.61, four lines 2.1).  One word per
+        // trip made eight dependent trips of this stage, an aligned pair four; the block containing `start` and the next one make two.
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const uint32_t b0 = w0 >> 3, b_end = min(b0 + q.lane_blocks, q.Wbf >> 3);  // blocks [b0, b_end) are this stage's (Wbf is a multiple of 8)
+        for (uint32_t bw = b0; bw < b_end && undecided; ++bw) {
+            uint64_t base[8], hi[8], lo[8];
+            auto and_row = [&](uint32_t row, uint64_t (&acc)[8], bool first) {
+                const u64x2 *v = reinterpret_cast<const u64x2 *>(q.rows + (size_t)row * q.Wbf + 8u * bw);
+                const u64x2 v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+                const uint64_t x[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) acc[j] = first ? x[j] : (acc[j] & x[j]);
+            };
+            // (every row holds bits of live positions only: with the cpu rows in the AND the all-valid row adds nothing -- one request less)
+            if (q.do_fit) {
+                and_row(r_hi, hi, true);
+                and_row(r_lo, lo, true);
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) base[j] = ~0ull;
+            } else {
+                and_row(q.row_valid, base, true);
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) hi[j] = lo[j] = 0ull;
             }
-            Word x0 = load_word(w);
-            const bool second = per_trip == 2u && t + 1u < q.lane_words;  // (an odd hand-over point: the last trip looks at one word)
-            Word x1 = second ? load_word(w + 1u) : Word{0ull, 0ull, 0ull};
-            if (t == 0) x0.base &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
-            if (take_word(w, x0) || (second && take_word(w + 1u, x1))) undecided = false;
-            if (undecided && w + (second ? 2u : 1u) >= q.Wbf) undecided = false;  // those were the last words: no feasible node
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k)
+                if (sel[k] != 0u) and_row(lrow[k], base, false);
+            for (uint32_t k = 8; k < q.nkeys; ++k) {
+                const uint32_t s = q.psel[(size_t)k * q.p + pod];
+                if (s != 0u) and_row((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero, base, false);
+            }
+            if (q.do_taint)
+                for (uint32_t g = 0; g < q.ngroups; ++g) and_row(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull), base, false);
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint32_t w = 8u * bw + j;
+                if (!undecided || w < w0) continue;  // (words of the block before `start`'s)
+                Word x{base[j], hi[j], lo[j]};
+                if (w == w0) x.base &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
+                if (take_word(w, x)) undecided = false;
+            }
+        }
+        if (undecided && b_end >= (q.Wbf >> 3)) undecided = false;  // those were the last words: no feasible node
+    }
+    }  // if (work)
+    KSCHED_BF_STAMP(tr, 3, (uint32_t)found ^ (uint32_t)undecided);
+    // the pods of this wave that go on to the second stage: ONE returning atomic per wave, on the counter of the wave's sub-list
+    const uint64_t um = __ballot(undecided), lm = __ballot(listed);
+    const uint32_t lane = threadIdx.x & 63u, sub = (pod >> 6) % kBfSublists;
+    if (lane == 0u) {
+        if (q.listed_mask) q.listed_mask[pod >> 6] = lm;  // (listed pods: wave = pod in k_pick_bestfit_listed, one mask word per wave, nothing to zero)
+        if (tr) tr[5] = (uint64_t)__popcll(um);
+    }
+    if (um) {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(um);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(q.handover_count + 32u * sub, (uint32_t)__popcll(um));
+        base = (uint32_t)__shfl((int)base, (int)leader, 64);
+        if (undecided) {  // the wave-per-pod kernel scans on behind the words looked at here
+            const uint32_t slot = sub * q.sub_cap + base + (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
+            uint4 *rec = reinterpret_cast<uint4 *>(q.handover_recs) + (size_t)slot * 4u;
+            rec[0] = make_uint4(pod, start, r, ((start >> 9) + q.lane_blocks) << 3);  // (the next word: a 64-byte boundary)
+            rec[1] = make_uint4((uint32_t)tol, (uint32_t)(tol >> 32), (uint32_t)(uint64_t)req_c, (uint32_t)((uint64_t)req_c >> 32));
+            rec[2] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
+            rec[3] = make_uint4(sel[4], sel[5], sel[6], sel[7]);
         }
     }
-    if (undecided) {  // the wave-per-pod kernel scans on behind the words looked at here
-        uint4 *rec = reinterpret_cast<uint4 *>(q.fallback_list) + (size_t)atomicAdd(q.fallback_count, 1u) * 4u;
-        rec[0] = make_uint4(pod, start, r, (start >> 6) + q.lane_words);
-        rec[1] = make_uint4((uint32_t)tol, (uint32_t)(tol >> 32), (uint32_t)(uint64_t)req_c, (uint32_t)((uint64_t)req_c >> 32));
-        rec[2] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
-        rec[3] = make_uint4(sel[4], sel[5], sel[6], sel[7]);
-    } else {
-        q.binding[pod] = found;
-    }
+    if (work && !undecided) q.binding[pod] = found;
+    KSCHED_BF_STAMP(tr, 4, pod);
 }
 
 // Best fit for pods that constrain a LIST key (a high-cardinality label key kept per tile as a sorted list, tile_index.hpp): only
@@ -750,7 +842,7 @@ struct BestfitListedArgs {
     const int64_t *pcpu, *pmem;
     const uint32_t *psel;
     const uint64_t *ptol;
-    const uint32_t *listed_list, *listed_count;
+    const uint64_t *listed_mask;   // [ceil(p / 64)], from k_pick_bestfit_lanes: wave = pod
     int32_t *binding;
     uint32_t p, n, nkeys, tiles, nlist, list_col[2], do_fit, do_taint;
 };
@@ -759,8 +851,9 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_listed(const BestfitListed
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wave >= *q.listed_count) return;
-    const uint32_t pod = q.listed_list[wave];
+    if (wave >= q.p) return;
+    if (!((q.listed_mask[wave >> 6] >> (wave & 63u)) & 1ull)) return;
+    const uint32_t pod = wave;
     const int64_t rc = q.do_fit ? q.pcpu[pod] : 0, rm = q.do_fit ? q.pmem[pod] : 0;
     const uint64_t tol = (q.do_taint && q.ptol) ? q.ptol[pod] : 0ull;
     // walk the lists of the first list key the pod constrains; the other constraints are checked per candidate

@@ -75,12 +75,13 @@ struct ksched_ctx {
     uint32_t bf_n1 = 0, bf_n2 = 0;
     DevBuf<int64_t> bf_levels;       // 8-ary level arrays of bf_mem / cpu_sorted (k_pick_bestfit_lanes)
     uint32_t bf_nlev = 0, bf_lvl_half = 0, bf_lvl_off[6] = {};
-    DevBuf<uint32_t> bf_fallback;    // 3 x 2 counters in rotation (64-byte header), then one 64-byte record per pod the lane-per-pod pick hands over, then the listed pods
-    uint32_t bf_slot = 0;            // which of the three counter pairs the next two-stage pick uses (the call before zeroed it)
+    DevBuf<uint32_t> bf_fallback;    // hand-over of the two-stage best-fit pick: 3 sets of sub-list counters in rotation, the listed mask, the sub-lists' 64-byte records
+    uint32_t bf_slot = 0;            // which of the three counter sets the next two-stage pick uses (the call before zeroed it)
     size_t bf_fallback_zeroed_cap = 0;
+    DevBuf<uint64_t> bf_trace;       // KSCHED_OPT_DEBUG bit 20: per-wave time stamps of the two best-fit stages (tools/bestfit_ab.py --trace)
     DevBuf<uint64_t> bf_rows;        // [rows][Wbf] bitmaps over best-fit positions (k_pick_bestfit_rows); built with the tile index
     bool bf_rows_built = false;
-    uint32_t bf_row_cpu0 = 0, bf_q = 1;
+    uint32_t bf_row_cpu0 = 0, bf_q = 1, bf_W = 0;
     // the best-fit structures are built lazily, by the first PICK_BESTFIT request after the snapshot changed
     bool bf_dirty = true;
     DevBuf<uint32_t> by_cpu, cpurank, iota;
@@ -493,7 +494,8 @@ int build_bestfit(ksched_ctx *c) {
     }
     if (c->idx.built) {  // (list keys have no rows: pods that constrain one are picked from the key's sorted lists, k_pick_bestfit_listed)
         const IndexedLayout &l = c->idx.lay;
-        const uint32_t Wbf = (n + 63u) / 64u, named = l.row_cpu, levels = 256u, q = (n + levels - 1u) / levels;
+        const uint32_t Wbf = ((n + 63u) / 64u + 7u) & ~7u, named = l.row_cpu;  // (rows padded to whole 64-byte lines: k_pick_bestfit_lanes reads aligned blocks of 8 words)
+        const uint32_t levels = 256u, q = (n + levels - 1u) / levels;
         const uint32_t rows = named + levels + 1u;
         HIPCHK(c, c->bf_rows.reserve((size_t)rows * Wbf));
         HIPCHK(c, hipMemsetAsync(c->bf_rows.ptr, 0, (size_t)rows * Wbf * 8, s));
@@ -516,6 +518,7 @@ int build_bestfit(ksched_ctx *c) {
         hipLaunchKernelGGL(k_bf_rows, dim3((Wbf + 3u) / 4u), dim3(256), 0, s, r);
         HIPCHK(c, hipGetLastError());
         c->bf_row_cpu0 = named;
+        c->bf_W = Wbf;
         c->bf_q = q;
         c->bf_rows_built = true;
     }
@@ -636,6 +639,61 @@ int launch_pick(ksched_ctx *c, uint32_t p, const uint64_t *feas, uint32_t pitch,
     }
     HIPCHK(c, hipGetLastError());
     return KSCHED_OK;
+}
+
+// KSCHED_OPT_DEBUG bit 20: where the waves of the two best-fit stages spend their time (synchronous; stderr; tools only)
+void bestfit_trace_report(ksched_ctx *c, uint32_t p, size_t slots2, hipStream_t s) {
+    const size_t waves1 = (p + 63) / 64, total = waves1 * 8 + slots2 * 4;
+    std::vector<uint64_t> h(total);
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(h.data(), c->bf_trace.ptr, total * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (const char *path = getenv("KSCHED_BF_TRACE_FILE"))  // the raw stamps: [waves of stage 1][8] then [hand-over slots][4] uint64
+        if (FILE *f = fopen(path, "wb")) {
+            fwrite(h.data(), 8, total, f);
+            fclose(f);
+        }
+    auto pct = [](std::vector<double> &v, double f) { return v.empty() ? 0.0 : v[(size_t)(f * (double)(v.size() - 1))]; };
+    const double ghz = 0.1;  // s_memrealtime: the constant 100 MHz reference clock
+    uint64_t t0 = ~0ull;
+    for (size_t w = 0; w < waves1; ++w)
+        if (h[w * 8]) t0 = std::min(t0, h[w * 8]);
+    const char *names[4] = {"operands", "searches", "word trips", "hand-over"};
+    std::vector<double> ph[4], entry, exit_, und;
+    for (size_t w = 0; w < waves1; ++w) {
+        const uint64_t *r = &h[w * 8];
+        if (!r[0] || !r[4]) continue;
+        for (int i = 0; i < 4; ++i) ph[i].push_back((double)(r[i + 1] - r[i]) / ghz * 1e-3);
+        entry.push_back((double)(r[0] - t0) / ghz * 1e-3);
+        exit_.push_back((double)(r[4] - t0) / ghz * 1e-3);
+        und.push_back((double)r[5]);
+    }
+    auto line = [&](const char *what, std::vector<double> &v) {
+        std::sort(v.begin(), v.end());
+        double sum = 0;
+        for (double x : v) sum += x;
+        fprintf(stderr, "  %-28s mean %7.2f   p10 %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f   (%zu waves)\n", what, v.empty() ? 0.0 : sum / (double)v.size(), pct(v, 0.1), pct(v, 0.5), pct(v, 0.9),
+                pct(v, 1.0), v.size());
+    };
+    fprintf(stderr, "best-fit stage 1 (k_pick_bestfit_lanes), us:\n");
+    line("entry after the first wave", entry);
+    for (int i = 0; i < 4; ++i) line(names[i], ph[i]);
+    line("exit after the first entry", exit_);
+    line("lanes handed over per wave", und);
+    const uint64_t *t2 = &h[waves1 * 8];
+    uint64_t t20 = ~0ull;
+    std::vector<double> e2, d2, x2, words;
+    for (size_t w = 0; w < slots2; ++w)
+        if (t2[w * 4]) t20 = std::min(t20, t2[w * 4]);
+    for (size_t w = 0; w < slots2; ++w) {
+        const uint64_t *r = &t2[w * 4];
+        if (!r[0] || !r[1]) continue;
+        e2.push_back((double)(r[0] - t20) / ghz * 1e-3);
+        d2.push_back((double)(r[1] - r[0]) / ghz * 1e-3);
+        x2.push_back((double)(r[1] - t20) / ghz * 1e-3);
+    }
+    fprintf(stderr, "best-fit stage 2 (k_pick_bestfit_rows), us:   first entry %.2f us after stage 1's first entry\n", t20 == ~0ull ? 0.0 : (double)(t20 - t0) / ghz * 1e-3);
+    line("entry after the first wave", e2);
+    line("scan of one pod", d2);
+    line("exit after the first entry", x2);
 }
 
 SelectArgs make_select_args(const ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
@@ -771,7 +829,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         q.binding = out_binding;
         q.p = p;
         q.n = c->n;
-        q.Wbf = c->W;
+        q.Wbf = c->bf_W;
         q.nkeys = sel ? c->nkeys : 0u;
         q.ngroups = l.ngroups;
         q.row_valid = l.row_valid;
@@ -788,9 +846,11 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         // one stage (a wave per pod) or two (a lane per pod first): the second launch and the hand-over list pay off from tens of
         // thousands of pods on (20k pods: 33 us against 44; 125k pods: 160 against 120) -- KSCHED_OPT_BESTFIT_STAGES overrides
         const bool lists = sel && l.nlist > 0;  // pods that constrain a list key are split off by the first stage: two stages it is
-        const bool two_stage = lists || c->opt_bestfit_stages == 2 || (c->opt_bestfit_stages == 0 && p >= 65536u);
+        const bool two_stage = lists || c->opt_bestfit_stages == 2 || (c->opt_bestfit_stages == 0 && p >= 24576u);  // (measured crossover at the C5 shard's snapshot: ~24 k pods)
         if (!lists && (!two_stage || (c->opt_debug & 0x400u) || c->n > (1u << 21))) {
-            hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q);
+            // one wave per pod, one wave per block (scans differ tenfold in length: with four waves per block the long ones hold up the
+            // placement of whole blocks; 158 against 172 us for 125 k pods at the C5 shard)
+            hipLaunchKernelGGL(k_pick_bestfit_rows, dim3(p), dim3(64), 0, s, q);
         } else {
             // two stages: one lane per pod decides from the first two candidate words; the rare rest goes to the wave-per-pod kernel
             if (c->n > (1u << 21)) {
@@ -798,33 +858,47 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
                 return KSCHED_E_UNSUPPORTED;
             }
             if (int rsc = scratch_enter(c, s)) return rsc;
-            HIPCHK(c, c->bf_fallback.reserve(16 * ((size_t)p + 1) + p));  // [3 x 2 counters, padding to 64 bytes][64-byte hand-over record x p][listed pods x p]
-            if (c->bf_fallback_zeroed_cap != c->bf_fallback.cap) {  // a fresh allocation: the header once; from then on every call zeroes the next call's pair
-                HIPCHK(c, hipMemsetAsync(c->bf_fallback.ptr, 0, 64, s));
+            // [3 sets of kBfSublists counters, one per 128-byte line, in rotation][listed mask: ceil(p / 64) words][64-byte hand-over records:
+            // kBfSublists lists of sub_cap slots]; each call zeroes the NEXT call's counters (no memset launch)
+            const size_t waves1 = ((size_t)p + 63) / 64, sub_cap = ((waves1 + kBfSublists - 1) / kBfSublists) * 64;
+            const size_t ctr_u32 = 3 * (size_t)kBfSublists * 32, mask_u32 = ((waves1 * 2 + 15) / 16) * 16;  // (records stay 64-byte aligned)
+            HIPCHK(c, c->bf_fallback.reserve(ctr_u32 + mask_u32 + 16 * (size_t)kBfSublists * sub_cap));
+            if (c->bf_fallback_zeroed_cap != c->bf_fallback.cap) {  // a fresh allocation: all counters once
+                HIPCHK(c, hipMemsetAsync(c->bf_fallback.ptr, 0, ctr_u32 * 4, s));
                 c->bf_fallback_zeroed_cap = c->bf_fallback.cap;
                 c->bf_slot = 0;
             }
-            uint32_t *const ctr = c->bf_fallback.ptr + 4u * c->bf_slot;
-            q.zero_next = c->bf_fallback.ptr + 4u * ((c->bf_slot + 1u) % 3u);
+            q.handover_count = c->bf_fallback.ptr + (size_t)c->bf_slot * kBfSublists * 32;
+            q.zero_next = c->bf_fallback.ptr + (size_t)((c->bf_slot + 1u) % 3u) * kBfSublists * 32;
+            q.sub_cap = (uint32_t)sub_cap;
             q.lvl = c->bf_levels.ptr;
             q.nlev = c->bf_nlev;
             q.lvl_half = c->bf_lvl_half;
             for (uint32_t k = 0; k < 6; ++k) q.lvl_off[k] = c->bf_lvl_off[k];
-            q.fallback_count = ctr;
-            q.fallback_list = c->bf_fallback.ptr + 16;
+            q.handover_recs = c->bf_fallback.ptr + ctr_u32 + mask_u32;
             q.nlist = lists ? l.nlist : 0u;
             for (uint32_t j = 0; j < q.nlist; ++j) q.list_col[j] = l.list_col[j];
-            q.listed_count = ctr + 1;
-            q.listed_list = c->bf_fallback.ptr + 16 * ((size_t)p + 1);
-            q.lane_words = ((c->opt_debug >> 12) & 15u) ? ((c->opt_debug >> 12) & 15u) : 8u;
-            q.lane_pair = (c->opt_debug & 0x800u) ? 0u : 1u;  // KSCHED_OPT_DEBUG bits 12-15: A/B of the hand-over point (8 words = 512 candidates measured best at the C5 shard)
+            q.listed_mask = lists ? reinterpret_cast<uint64_t *>(c->bf_fallback.ptr + ctr_u32) : nullptr;
+            q.lane_blocks = ((c->opt_debug >> 12) & 15u) ? ((c->opt_debug >> 12) & 15u) : 2u;  // KSCHED_OPT_DEBUG bits 12-15: A/B of the hand-over point (in 64-byte blocks of 8 words)
+            const bool tracing = (c->opt_debug & 0x100000u) != 0u;
+            if (tracing) {
+                HIPCHK(c, c->bf_trace.reserve(waves1 * 8 + (size_t)kBfSublists * sub_cap * 4));
+                HIPCHK(c, hipMemsetAsync(c->bf_trace.ptr, 0, (waves1 * 8 + (size_t)kBfSublists * sub_cap * 4) * 8, s));
+                q.trace = c->bf_trace.ptr;
+                q.trace2 = c->bf_trace.ptr + waves1 * 8;
+            }
             hipLaunchKernelGGL(k_pick_bestfit_lanes, dim3((p + 255) / 256), dim3(256), 0, s, q);
             HIPCHK(c, hipGetLastError());
-            c->bf_slot = (c->bf_slot + 1u) % 3u;  // (only once the kernel that zeroes the next pair is on its way)
+            c->bf_slot = (c->bf_slot + 1u) % 3u;  // (only once the kernel that zeroes the next set is on its way)
             BestfitRowsArgs q2 = q;
-            q2.pod_list = q.fallback_list;
-            q2.pod_count = q.fallback_count;
-            hipLaunchKernelGGL(k_pick_bestfit_rows, dim3((p + 3) / 4), dim3(256), 0, s, q2);
+            q2.sub_count = q.handover_count;
+            q2.pod_recs = q.handover_recs;
+            q2.rows_wide = 1u << ((c->opt_debug >> 23) & 3u);  // (KSCHED_OPT_DEBUG bits 23-24: A/B)
+            // one wave per block; the grid covers 1 / 2^k of the lists' capacity (KSCHED_OPT_DEBUG bits 21-22: k = 2 by default, A/B 0 / 1 / 3)
+            const uint32_t gshift = ((c->opt_debug >> 21) & 3u) == 0u ? 2u : ((c->opt_debug >> 21) & 3u) == 1u ? 0u : ((c->opt_debug >> 21) & 3u) == 2u ? 1u : 3u;
+            const uint32_t per_list = std::max<uint32_t>(1u, (uint32_t)sub_cap >> gshift);
+            hipLaunchKernelGGL(k_pick_bestfit_rows, dim3(kBfSublists * per_list), dim3(64), 0, s, q2);
+            if (tracing) bestfit_trace_report(c, p, (size_t)kBfSublists * sub_cap, s);
             if (lists) {
                 BestfitListedArgs la{};
                 la.lists = c->idx.d_list;
@@ -836,8 +910,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
                 la.pmem = pmem;
                 la.psel = psel;
                 la.ptol = ptol;
-                la.listed_list = q.listed_list;
-                la.listed_count = q.listed_count;
+                la.listed_mask = q.listed_mask;
                 la.binding = out_binding;
                 la.p = p;
                 la.n = c->n;
@@ -975,7 +1048,7 @@ void ksched_destroy(ksched_ctx *c) try {
         DeviceGuard g(c->device);
         (void)hipDeviceSynchronize();
         c->ncpu.release(); c->nmem.release(); c->nrec.release(); c->nlab.release(); c->ntaint.release();
-        c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release(); c->bf_cpu.release(); c->cpu_sorted.release(); c->bf_rows.release(); c->bf_samples.release(); c->bf_levels.release(); c->bf_fallback.release();
+        c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release(); c->bf_cpu.release(); c->cpu_sorted.release(); c->bf_rows.release(); c->bf_samples.release(); c->bf_levels.release(); c->bf_fallback.release(); c->bf_fallback_zeroed_cap = 0;
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
         c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release(); c->xpairs.release(); c->xreason.release();
         c->scratch_mask.release(); c->trace.release();

@@ -8,6 +8,7 @@ torch is used only as the owner of device memory and streams.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -58,6 +59,8 @@ class Evaluator:
         self.device = int(device)
         self.n = 0
         self.n_keys = 0
+        if os.environ.get("KSCHED_DEBUG"):  # A/B switches of tools/ (KSCHED_OPT_DEBUG), so that a whole test file can run under one
+            self.set_option(L.OPT_DEBUG, int(os.environ["KSCHED_DEBUG"], 0))
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):

@@ -664,7 +664,7 @@ def test_bestfit_direct_equals_bestfit_from_mask(evaluator, kernel, stages):
     and after ksched_update_nodes (the order changes)."""
     ev = evaluator
     ev.set_kernel(kernel)
-    ev.set_option(_lib.OPT_BESTFIT_STAGES, stages)  # 1: a wave per pod; 2: a lane per pod first (the default only from 65536 pods on)
+    ev.set_option(_lib.OPT_BESTFIT_STAGES, stages)  # 1: a wave per pod; 2: a lane per pod first (the default only from 24576 pods on)
     rng = np.random.default_rng(23)
     for (P, N, K) in [(1500, 6000, 8), (600, 2500, 12), (200, 100, 3), (64, 1, 8)]:
         c = synth.make_cluster(P, N, n_keys=min(K, 8), n_taints=16, seed=3 * P + K)
