@@ -426,7 +426,6 @@ struct BestfitRowsArgs {
     const uint32_t *sub_count;
     const uint32_t *pod_recs;
     uint32_t sub_cap;
-    uint32_t rows_wide;   // groups of 64 words per round of the wave's scan after a pod's first round (1, 2 or 4)
     // 8-ary level arrays of bf_mem / cpu_sorted for the lane-per-pod searches: level k (1..nlev) holds the last element of every
     // block of 8^k entries; [mem level 1][mem level 2]...[cpu level 1]...; lvl_off[k - 1] = offset of level k inside one half
     const int64_t *lvl;
@@ -509,26 +508,44 @@ template <int G>
 __device__ __forceinline__ bool bestfit_rows_round(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane, uint32_t start, uint32_t wb, uint32_t r_hi,
                                                    uint32_t r_lo, const uint32_t (&lrow)[8], const uint32_t (&sel)[8], uint64_t tol, int64_t req_c,
                                                    int32_t &out) {
-    uint64_t base[G], hi[G], lo[G];
+    // LOADS FIRST, ANDs AFTER: every row word of the round is requested before anything waits.  (Written as `if (constrained) base &=
+    // row[..]` the compiler waits for each row inside its own branch: the round became up to a dozen dependent round trips instead of one --
+    // found in the disassembly, `s_waitcnt vmcnt(0)` behind every single load.)
+    uint64_t base[G], hi[G], lo[G], xl[G][8], xt[G][4];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const uint32_t w = wb + (uint32_t)g * 64u + lane;
-        const bool in = w < q.Wbf;
-        const uint32_t wc = in ? w : 0u;
-        // all row words of the round are loaded together, unconditionally (one round trip)
+        const uint32_t wc = (w < q.Wbf) ? w : 0u;
         // (every row holds bits of live positions only, so with the cpu rows in the AND the all-valid row adds nothing: one load less)
         base[g] = q.do_fit ? ~0ull : q.rows[(size_t)q.row_valid * q.Wbf + wc];
         hi[g] = q.do_fit ? q.rows[(size_t)r_hi * q.Wbf + wc] : 0ull;
         lo[g] = q.do_fit ? q.rows[(size_t)r_lo * q.Wbf + wc] : 0ull;
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k)
-            if (sel[k] != 0u) base[g] &= q.rows[(size_t)lrow[k] * q.Wbf + wc];
-        for (uint32_t k = 8; k < q.nkeys; ++k) {
+        for (uint32_t k = 0; k < 8; ++k) {
+            xl[g][k] = ~0ull;
+            if (sel[k] != 0u) xl[g][k] = q.rows[(size_t)lrow[k] * q.Wbf + wc];
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) {
+            xt[g][t] = ~0ull;
+            if (q.do_taint && t < q.ngroups) xt[g][t] = q.rows[(size_t)(q.row_taint + 16u * t + (uint32_t)((tol >> (4u * t)) & 15ull)) * q.Wbf + wc];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const uint32_t w = wb + (uint32_t)g * 64u + lane;
+        const bool in = w < q.Wbf;
+        const uint32_t wc = in ? w : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) base[g] &= xl[g][k];
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) base[g] &= xt[g][t];
+        for (uint32_t k = 8; k < q.nkeys; ++k) {  // (rare: more than eight label keys, more than sixteen taints)
             const uint32_t s = q.psel[(size_t)k * q.p + pod];
             if (s != 0u) base[g] &= q.rows[(size_t)((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero) * q.Wbf + wc];
         }
         if (q.do_taint)
-            for (uint32_t t = 0; t < q.ngroups; ++t)
+            for (uint32_t t = 4; t < q.ngroups; ++t)
                 base[g] &= q.rows[(size_t)(q.row_taint + 16u * t + (uint32_t)((tol >> (4u * t)) & 15ull)) * q.Wbf + wc];
         if (!in) base[g] = 0;
         if (w == (start >> 6)) base[g] &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
@@ -562,8 +579,8 @@ __device__ __forceinline__ bool bestfit_rows_round(const BestfitRowsArgs &q, uin
 
 // The scan of one pod by the whole wave, given start = first position whose memory can hold the pod, r = #nodes with cpu below the
 // request, and the first word to look at (w_first >= start >> 6; the caller vouches that no feasible position lies before it).
-// The first round looks at 64 words (four pods in five end there); a pod that goes on is a deep one -- every further round is one more
-// dependent round trip, twelve for a pod no node can hold at 50 k nodes -- so the later rounds look at q.rows_wide x 64 words each.
+// 64 words per round, one dependent round trip each (twelve for a pod no node can hold at 50 k nodes).  Wider rounds (128 / 256 words)
+// were measured and lose: their registers (112 for 256 words) halve the waves a CU holds, and this stage is bound by wave slots.
 // Returns the chosen node (every lane holds the same value).
 __device__ __forceinline__ int32_t bestfit_rows_scan(const BestfitRowsArgs &q, uint32_t pod, uint32_t lane, uint32_t start, uint32_t r, uint32_t w_first,
                                                      int64_t req_c, uint64_t tol, const uint32_t (&sel)[8]) {
@@ -579,18 +596,8 @@ __device__ __forceinline__ int32_t bestfit_rows_scan(const BestfitRowsArgs &q, u
     for (uint32_t k = 0; k < 8; ++k) lrow[k] = (sel[k] <= q.lab_max8[k]) ? q.lab_base8[k] + sel[k] - 1u : q.row_zero;
     int32_t out = -1;
     uint32_t wb = w_first;
-    if (bestfit_rows_round<1>(q, pod, lane, start, wb, r_hi, r_lo, lrow, sel, tol, req_c, out)) return out;
-    wb += 64u;
-    if (q.rows_wide >= 4u) {
-        for (; wb < q.Wbf; wb += 256u)
-            if (bestfit_rows_round<4>(q, pod, lane, start, wb, r_hi, r_lo, lrow, sel, tol, req_c, out)) return out;
-    } else if (q.rows_wide == 2u) {
-        for (; wb < q.Wbf; wb += 128u)
-            if (bestfit_rows_round<2>(q, pod, lane, start, wb, r_hi, r_lo, lrow, sel, tol, req_c, out)) return out;
-    } else {
-        for (; wb < q.Wbf; wb += 64u)
-            if (bestfit_rows_round<1>(q, pod, lane, start, wb, r_hi, r_lo, lrow, sel, tol, req_c, out)) return out;
-    }
+    for (; wb < q.Wbf; wb += 64u)
+        if (bestfit_rows_round<1>(q, pod, lane, start, wb, r_hi, r_lo, lrow, sel, tol, req_c, out)) return out;
     return -1;
 }
 
@@ -701,27 +708,39 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
     for (uint32_t k = 0; k < 8; ++k) sel[k] = (q.psel && k < q.nkeys) ? q.psel[(size_t)k * q.p + pod] : 0u;
     KSCHED_BF_STAMP(tr, 1, (uint32_t)req_c ^ (uint32_t)req_m ^ (uint32_t)tol ^ sel[0] ^ sel[1] ^ sel[2] ^ sel[3] ^ sel[4] ^ sel[5] ^ sel[6] ^ sel[7]);
     if (q.do_fit) {
-        // lower bounds of req_m in bf_mem and of req_c in cpu_sorted, level by level from the top (block = 8 entries = one line)
-        auto count8 = [](const int64_t *a, uint32_t base, uint32_t limit, int64_t key) -> uint32_t {
-            if (base >= limit) return 0u;  // the search has run off the end (key above every entry)
-            const i64x2 *v = reinterpret_cast<const i64x2 *>(a + base);  // base is a multiple of 8: 64-byte aligned
-            const i64x2 v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];      // (reads past `limit` stay inside the padded arrays)
-            const int64_t e[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
-            uint32_t c = 0;
+        // lower bounds of req_m in bf_mem and of req_c in cpu_sorted, level by level from the top (block = 8 entries = one line); the two
+        // searches' loads of a level go out together (written as two calls of one helper they were issued and waited for one after the other)
+        auto count8x2 = [&](const int64_t *am, uint32_t basem, const int64_t *ac, uint32_t basec, uint32_t limit, uint32_t &cm, uint32_t &cc) {
+            const bool okm = basem < limit, okc = basec < limit;  // (a search that has run off the end -- key above every entry -- reads block 0 and counts 0)
+            const i64x2 *vm = reinterpret_cast<const i64x2 *>(am + (okm ? basem : 0u));  // bases are multiples of 8: 64-byte aligned
+            const i64x2 *vc = reinterpret_cast<const i64x2 *>(ac + (okc ? basec : 0u));  // (reads past `limit` stay inside the padded arrays)
+            const i64x2 m0 = vm[0], m1 = vm[1], m2 = vm[2], m3 = vm[3], c0 = vc[0], c1 = vc[1], c2 = vc[2], c3 = vc[3];
+            const int64_t em[8] = {m0.x, m0.y, m1.x, m1.y, m2.x, m2.y, m3.x, m3.y}, ec[8] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y, c3.x, c3.y};
+            uint32_t nm = 0, nc = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < 8; ++j) c += (base + j < limit && e[j] < key) ? 1u : 0u;
-            return c;
+            for (uint32_t j = 0; j < 8; ++j) {
+                nm += (okm && basem + j < limit && em[j] < req_m) ? 1u : 0u;
+                nc += (okc && basec + j < limit && ec[j] < req_c) ? 1u : 0u;
+            }
+            cm = nm;
+            cc = nc;
         };
         uint32_t bm = 0, bc = 0;  // block index at the level above
         for (uint32_t k = q.nlev; k >= 1u; --k) {
             uint32_t nk = q.n;  // entries of level k = ceil(n / 8^k)
             for (uint32_t t = 0; t < k; ++t) nk = (nk + 7u) / 8u;
             const int64_t *lm = q.lvl + q.lvl_off[k - 1u], *lc = lm + q.lvl_half;
-            bm = bm * 8u + count8(lm, bm * 8u, nk, req_m);
-            bc = bc * 8u + count8(lc, bc * 8u, nk, req_c);
+            uint32_t cm, cc;
+            count8x2(lm, bm * 8u, lc, bc * 8u, nk, cm, cc);
+            bm = bm * 8u + cm;
+            bc = bc * 8u + cc;
         }
-        start = bm * 8u + count8(q.bf_mem, bm * 8u, q.n, req_m);
-        r = bc * 8u + count8(q.cpu_sorted, bc * 8u, q.n, req_c);
+        {
+            uint32_t cm, cc;
+            count8x2(q.bf_mem, bm * 8u, q.cpu_sorted, bc * 8u, q.n, cm, cc);
+            start = bm * 8u + cm;
+            r = bc * 8u + cc;
+        }
         start = min(start, q.n);
         r = min(r, q.n);
     }
@@ -757,51 +776,78 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_lanes(const BestfitRowsArg
             }
             return false;
         };
-        // ONE 64-BYTE BLOCK (8 words = 512 positions) of every row per trip, as four 16-byte requests to the same line in flight together:
-        // the L1 pulls a whole line per miss whatever part of it is asked for, and further requests to a line on its way cost little
-        // (tools/ubench_pending.hip: four units of one random line 0.76 us per dependent round, one unit 0.61, four lines 2.1).  One word per
-        // trip made eight dependent trips of this stage, an aligned pair four; the block containing `start` and the next one make two.
+        // One trip = HALF A LINE (4 words = 256 positions) of every row, as two 16-byte requests per row, and ALL of a trip's requests in
+        // flight before anything waits: loads first, ANDs after.  (Written as `if (constrained) base &= row[..]` the compiler waits for each
+        // row inside its own branch -- `s_waitcnt vmcnt(0)` behind every load in the disassembly -- and a trip was up to fourteen dependent
+        // round trips instead of one.)  The stage looks at the 64-byte block of `start`'s word and the next `lane_blocks - 1` blocks:
+        // 9 .. 16 words by default, two to four trips; the hand-over point is a 64-byte boundary.
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-        const uint32_t b0 = w0 >> 3, b_end = min(b0 + q.lane_blocks, q.Wbf >> 3);  // blocks [b0, b_end) are this stage's (Wbf is a multiple of 8)
-        for (uint32_t bw = b0; bw < b_end && undecided; ++bw) {
-            uint64_t base[8], hi[8], lo[8];
-            auto and_row = [&](uint32_t row, uint64_t (&acc)[8], bool first) {
-                const u64x2 *v = reinterpret_cast<const u64x2 *>(q.rows + (size_t)row * q.Wbf + 8u * bw);
-                const u64x2 v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
-                const uint64_t x[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
-#pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) acc[j] = first ? x[j] : (acc[j] & x[j]);
+        const uint32_t h_end = min(((w0 >> 3) + q.lane_blocks) * 2u, q.Wbf >> 2);  // half-blocks [w0 >> 2, h_end) are this stage's (Wbf is a multiple of 8)
+        for (uint32_t hb = w0 >> 2; hb < h_end && undecided; ++hb) {
+            const uint64_t *const at = q.rows + 4u * hb;
+            auto ld = [&](uint32_t row, u64x2 &a, u64x2 &b) {
+                const u64x2 *v = reinterpret_cast<const u64x2 *>(at + (size_t)row * q.Wbf);
+                a = v[0];
+                b = v[1];
             };
+            const u64x2 ones = {~0ull, ~0ull}, zero = {0ull, 0ull};
+            u64x2 ha = zero, hb2 = zero, la = zero, lb = zero, ba = ones, bb = ones, xa[8], xb[8], ta[4], tb[4];
             // (every row holds bits of live positions only: with the cpu rows in the AND the all-valid row adds nothing -- one request less)
             if (q.do_fit) {
-                and_row(r_hi, hi, true);
-                and_row(r_lo, lo, true);
-#pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) base[j] = ~0ull;
+                ld(r_hi, ha, hb2);
+                ld(r_lo, la, lb);
             } else {
-                and_row(q.row_valid, base, true);
-#pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) hi[j] = lo[j] = 0ull;
+                ld(q.row_valid, ba, bb);
             }
 #pragma unroll
-            for (uint32_t k = 0; k < 8; ++k)
-                if (sel[k] != 0u) and_row(lrow[k], base, false);
-            for (uint32_t k = 8; k < q.nkeys; ++k) {
+            for (uint32_t k = 0; k < 8; ++k) {
+                xa[k] = ones;
+                xb[k] = ones;
+                if (sel[k] != 0u) ld(lrow[k], xa[k], xb[k]);
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < 4; ++g) {
+                ta[g] = ones;
+                tb[g] = ones;
+                if (q.do_taint && g < q.ngroups) ld(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull), ta[g], tb[g]);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                ba &= xa[k];
+                bb &= xb[k];
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < 4; ++g) {
+                ba &= ta[g];
+                bb &= tb[g];
+            }
+            for (uint32_t k = 8; k < q.nkeys; ++k) {  // (rare: more than eight label keys, more than sixteen taints)
                 const uint32_t s = q.psel[(size_t)k * q.p + pod];
-                if (s != 0u) and_row((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero, base, false);
+                if (s != 0u) {
+                    u64x2 a, b;
+                    ld((s <= q.lab_meta[32u + k]) ? q.lab_meta[k] + s - 1u : q.row_zero, a, b);
+                    ba &= a;
+                    bb &= b;
+                }
             }
             if (q.do_taint)
-                for (uint32_t g = 0; g < q.ngroups; ++g) and_row(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull), base, false);
+                for (uint32_t g = 4; g < q.ngroups; ++g) {
+                    u64x2 a, b;
+                    ld(q.row_taint + 16u * g + (uint32_t)((tol >> (4u * g)) & 15ull), a, b);
+                    ba &= a;
+                    bb &= b;
+                }
+            const uint64_t base[4] = {ba.x, ba.y, bb.x, bb.y}, hi[4] = {ha.x, ha.y, hb2.x, hb2.y}, lo[4] = {la.x, la.y, lb.x, lb.y};
 #pragma unroll
-            for (uint32_t j = 0; j < 8; ++j) {
-                const uint32_t w = 8u * bw + j;
-                if (!undecided || w < w0) continue;  // (words of the block before `start`'s)
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t w = 4u * hb + j;
+                if (!undecided || w < w0) continue;  // (words of the half-block before `start`'s)
                 Word x{base[j], hi[j], lo[j]};
                 if (w == w0) x.base &= ~0ull << (start & 63u);  // positions before `start` cannot hold the pod's memory
                 if (take_word(w, x)) undecided = false;
             }
         }
-        if (undecided && b_end >= (q.Wbf >> 3)) undecided = false;  // those were the last words: no feasible node
+        if (undecided && h_end >= (q.Wbf >> 2)) undecided = false;  // those were the last words: no feasible node
     }
     }  // if (work)
     KSCHED_BF_STAMP(tr, 3, (uint32_t)found ^ (uint32_t)undecided);

@@ -893,7 +893,6 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
             BestfitRowsArgs q2 = q;
             q2.sub_count = q.handover_count;
             q2.pod_recs = q.handover_recs;
-            q2.rows_wide = 1u << ((c->opt_debug >> 23) & 3u);  // (KSCHED_OPT_DEBUG bits 23-24: A/B)
             // one wave per block; the grid covers 1 / 2^k of the lists' capacity (KSCHED_OPT_DEBUG bits 21-22: k = 2 by default, A/B 0 / 1 / 3)
             const uint32_t gshift = ((c->opt_debug >> 21) & 3u) == 0u ? 2u : ((c->opt_debug >> 21) & 3u) == 1u ? 0u : ((c->opt_debug >> 21) & 3u) == 2u ? 1u : 3u;
             const uint32_t per_list = std::max<uint32_t>(1u, (uint32_t)sub_cap >> gshift);
