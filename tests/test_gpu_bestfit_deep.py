@@ -38,8 +38,8 @@ def test_sparse_and_infeasible_pods_one_and_two_stages(evaluator, N):
             want = want_of(c, sel, req_cpu, req_mem, flags)
             for stages in (2, 1):
                 ev.set_option(_lib.OPT_BESTFIT_STAGES, stages)
-                # bits 12-15: hand-over after this many words; bit 11: one candidate word per trip of the first stage instead of two
-                for dbg in ((0, 0x800, 1 << 12, 2 << 12, 3 << 12, (3 << 12) | 0x800, 15 << 12) if stages == 2 else (0,)):
+                # bits 12-15: the first stage hands over after this many 64-byte blocks of candidate words (default 2); bit 11: unused since round 3
+                for dbg in ((0, 1 << 12, 2 << 12, 3 << 12, 5 << 12, 15 << 12) if stages == 2 else (0,)):
                     ev.set_option(_lib.OPT_DEBUG, dbg)
                     r = ev.eval(req_cpu, req_mem, sel, c.pod_tol, None, flags | PICK_BESTFIT, want_mask=False)
                     assert np.array_equal(r.binding, want), (N, flags, stages, hex(dbg), int((r.binding != want).sum()))
@@ -49,9 +49,32 @@ def test_sparse_and_infeasible_pods_one_and_two_stages(evaluator, N):
         ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
 
 
+@pytest.mark.parametrize("what", ["nothing_fits", "only_the_largest_nodes"])
+def test_every_pod_handed_over(evaluator, what):
+    """Every pod of the batch is still undecided after the first stage (its cpu request excludes all, or all but the few largest, nodes): the
+    hand-over sub-lists fill to their capacity and the second stage's grid (a quarter of it) walks them; all against the oracle."""
+    ev = evaluator
+    P, N = 20_000, 20_000
+    c = synth.make_cluster(P, N, n_keys=8, n_taints=16, seed=4242)
+    req_cpu = np.full(P, c.avail_cpu.max() + (1 if what == "nothing_fits" else 0), dtype=np.int64)
+    req_mem = np.minimum(c.req_mem, np.sort(c.avail_mem)[N // 4])  # (so that `start` is early and the scan is long)
+    sel = np.zeros_like(c.pod_sel)
+    ev.set_nodes(**c.node_columns())
+    try:
+        ev.set_option(_lib.OPT_BESTFIT_STAGES, 2)
+        for flags in (FIT | TAINT, FIT):
+            want = want_of(c, sel, req_cpu, req_mem, flags)
+            for _ in range(4):  # (the counter sets rotate over three slots)
+                r = ev.eval(req_cpu, req_mem, sel, c.pod_tol, None, flags | PICK_BESTFIT, want_mask=False)
+                assert np.array_equal(r.binding, want), (what, flags, int((r.binding != want).sum()))
+            assert ((want == -1).all() if what == "nothing_fits" else (want >= 0).any())
+    finally:
+        ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
+
+
 def test_two_stage_pick_after_snapshot_updates_many_calls(evaluator):
-    """ksched_update_nodes marks the best-fit structures stale; the hand-over counters rotate over three slots (each call zeroes
-    the next call's pair instead of a memset launch): many consecutive two-stage calls stay == oracle."""
+    """ksched_update_nodes marks the best-fit structures stale; the hand-over counters (128 sub-lists) rotate over three sets (each call zeroes
+    the next call's set instead of a memset launch): many consecutive two-stage calls stay == oracle."""
     ev = evaluator
     c = synth.make_cluster(2000, 9000, n_keys=8, n_taints=16, seed=77)
     rng = np.random.default_rng(5)
