@@ -640,19 +640,37 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
     kernarg_warm<sizeof(BestfitRowsArgs)>();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (q.sub_count) {  // second stage of the two-stage pick: the pods the lane-per-pod kernel could not decide in its first words.
-        // One short-lived wave per handed-over pod, ONE WAVE PER BLOCK: with four waves per block a CU's SIMD whose six slots hold deep
-        // pods (ten times the median scan) blocks the placement of whole blocks while eighteen other slots idle (traced: 3 900 of 6 141
-        // slots in use).  The grid covers a quarter of the lists' capacity, entries beyond that are walked (when > 1/4 of all pods are handed over).
-        const uint32_t c = blockIdx.x % kBfSublists, count = q.sub_count[32u * c], stride = gridDim.x / kBfSublists;
-        for (uint32_t i = blockIdx.x / kBfSublists; i < count; i += stride) {
+    if (wave >= q.p) return;
+    const int32_t b = bestfit_rows_one_pod(q, wave, lane);
+    if (lane == 0) q.binding[wave] = b;
+}
+
+// Second stage of the two-stage pick: the pods the lane-per-pod kernel could not decide in its first words.  One short-lived wave per
+// handed-over pod, ONE WAVE PER BLOCK: with four waves per block a CU's SIMD whose six slots hold deep pods (ten times the median scan)
+// blocks the placement of whole blocks while eighteen other slots idle (traced: 3 900 of 6 141 slots in use).  The grid covers a quarter
+// of the lists' capacity, entries beyond that are walked (when > 1/4 of all pods are handed over).  Its own kernel (not a mode of
+// k_pick_bestfit_rows): the stage is bound by wave slots, and without the one-stage kernel's rank searches it needs fewer registers.
+__global__ __launch_bounds__(64) void k_pick_bestfit_handed(const BestfitRowsArgs q) {
+    kernarg_warm<sizeof(BestfitRowsArgs)>();
+    const uint32_t lane = threadIdx.x & 63u;
+    {
+        const uint32_t c = blockIdx.x % kBfSublists, stride = gridDim.x / kBfSublists;
+        uint32_t i = blockIdx.x / kBfSublists;
+        // the first stage hands over everything it had in registers -- one 64-byte record {pod, start, cpu rank, next word,
+        // tolerations, cpu request, selector ids 0..7}: no rank search and no operand round trip here, the row loads go out at once.
+        // The record is requested TOGETHER with the sub-list's count (the slot exists whether or not it was filled): one dependent
+        // round trip less in every wave's life, and wave slots are what this stage is bound by.
+        const uint4 *rec = reinterpret_cast<const uint4 *>(q.pod_recs) + (size_t)(c * q.sub_cap + i) * 4u;
+        uint4 h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
+        const uint32_t count = q.sub_count[32u * c];
+        for (; i < count; i += stride) {
         const uint32_t slot = c * q.sub_cap + i;
         uint64_t *const tr = q.trace2 ? q.trace2 + (size_t)slot * 4u : nullptr;
         KSCHED_BF_STAMP(tr, 0, slot);
-        // the first stage hands over everything it had in registers -- one 64-byte record {pod, start, cpu rank, next word,
-        // tolerations, cpu request, selector ids 0..7}: no rank search and no operand round trip here, the row loads go out at once
-        const uint4 *rec = reinterpret_cast<const uint4 *>(q.pod_recs) + (size_t)slot * 4u;
-        const uint4 h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
+        if (i >= stride) {  // (a walk: more than a quarter of the batch was handed over)
+            rec = reinterpret_cast<const uint4 *>(q.pod_recs) + (size_t)slot * 4u;
+            h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
+        }
         const uint32_t sel[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
         const int32_t b = bestfit_rows_scan(q, h.x, lane, h.y, h.z, h.w, (int64_t)(((uint64_t)o.w << 32) | o.z), ((uint64_t)o.y << 32) | o.x, sel);
         if (lane == 0) q.binding[h.x] = b;
@@ -664,11 +682,7 @@ __global__ __launch_bounds__(256) void k_pick_bestfit_rows(const BestfitRowsArgs
             tr[3] = ((uint64_t)xcc << 32) | hw;           // where the wave ran
         }
         }
-        return;
     }
-    if (wave >= q.p) return;
-    const int32_t b = bestfit_rows_one_pod(q, wave, lane);
-    if (lane == 0) q.binding[wave] = b;
 }
 
 // Best fit, first stage, ONE LANE PER POD.  The wave-per-pod kernel above spends a whole wave's chain of dependent round trips on

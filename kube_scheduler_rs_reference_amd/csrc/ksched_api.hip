@@ -896,7 +896,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
             // one wave per block; the grid covers 1 / 2^k of the lists' capacity (KSCHED_OPT_DEBUG bits 21-22: k = 2 by default, A/B 0 / 1 / 3)
             const uint32_t gshift = ((c->opt_debug >> 21) & 3u) == 0u ? 2u : ((c->opt_debug >> 21) & 3u) == 1u ? 0u : ((c->opt_debug >> 21) & 3u) == 2u ? 1u : 3u;
             const uint32_t per_list = std::max<uint32_t>(1u, (uint32_t)sub_cap >> gshift);
-            hipLaunchKernelGGL(k_pick_bestfit_rows, dim3(kBfSublists * per_list), dim3(64), 0, s, q2);
+            hipLaunchKernelGGL(k_pick_bestfit_handed, dim3(kBfSublists * per_list), dim3(64), 0, s, q2);
             if (tracing) bestfit_trace_report(c, p, (size_t)kBfSublists * sub_cap, s);
             if (lists) {
                 BestfitListedArgs la{};
