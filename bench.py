@@ -60,6 +60,8 @@ WORKLOADS = {
             "C4 shard: 125k pods x 10k nodes per GPU, fit + sel (BASELINE.json configs[3] = 8 shards)"),
     "C5s": ("C5", 125_000, 50_000, ("FIT", "SEL", "TAINT"), "bestfit",
             "C5 shard: 125k pods x 50k nodes per GPU, fit + sel + taints, best-fit pick (configs[4] = 8 shards)"),
+    "C3x4": ("C3", 400_000, 5_000, ("FIT", "SEL"), "sampled",
+             "four C3 batches a caller has queued, passed as ONE call (400k pods x 5k nodes): the tile index is staged once per block for all of them, but the pick no longer hides in the fill and runs as its own launch"),
 }
 
 
@@ -674,10 +676,12 @@ def main():
     others = None
     if not multi and default_workload and not args.no_others and not args.no_mask and args.refresh_every == 0 and not args.pods:
         others = {}
-        for name in ("C4s", "C5s"):
+        for name in ("C4s", "C5s", "C3x4"):
             try:
                 r = SingleRig(torch, L, synth, Evaluator, dev, name, kernel=args.kernel, fused_pick=args.fused_pick, packed=args.packed, debug=args.debug)
                 others[name] = r.measure(steps=100 if name == "C5s" else 200, samples=24)
+                if name == "C3x4":
+                    others[name]["us_per_100k_pods"] = others[name]["ms_per_step"] * 1e3 / 4.0
                 r.close()
                 del r
                 torch.cuda.empty_cache()

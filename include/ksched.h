@@ -118,12 +118,14 @@ extern "C" {
  * Same results either way: every evaluation sees the snapshot that was current when it was enqueued. */
 #define KSCHED_OPT_SNAPSHOT_STREAM 8
 /* KSCHED_OPT_FUSED_PICK: 1 (default) = when an evaluation asks for the feasibility mask AND the sampled pick and the fused mask
- * kernel runs, the pick rides in that launch (select_node_for_pod, src/main.rs:51-71): ONE kernel per step.  Two forms, chosen by
- * the request: tile tests -- every block tests the drawn candidates that lie in its own tile against the bitmap rows it holds in
- * LDS, the blocks of a pod combine through one atomic per pod (ATTEMPTS = 5 draws, no taint predicate, at most eight label
- * keys) -- or, otherwise, a few waves of every block test the pods' candidates from the node records while the block's tile is
+ * kernel runs, the pick rides in that launch (select_node_for_pod, src/main.rs:51-71): ONE kernel per step -- as long as the launch
+ * is short enough for the pick to hide in its fill (a wave of the kernel has at most five rounds of 64 pods: up to 261 000 pods
+ * against 5 000 nodes, 128 000 against 10 000); longer launches keep the pick as its own launch, which is cheaper there.  Two forms,
+ * chosen by the request: tile tests -- every block tests the drawn candidates that lie in its own tile against the bitmap rows it
+ * holds in LDS, the blocks of a pod combine through one atomic per eight pods (ATTEMPTS = 5 draws, no taint predicate, at most eight
+ * label keys) -- or, otherwise, a few waves of every block test the pods' candidates from the node records while the block's tile is
  * staged.  0 = the pick is its own launch ahead of the mask kernel (k_select_sampled); 2 = rides, always as waves of the fill;
- * 3 = rides as tile tests or the call fails with KSCHED_E_UNSUPPORTED.  Same bindings in every form. */
+ * 3 = rides as tile tests or the call fails with KSCHED_E_UNSUPPORTED (2 and 3: whatever the launch's length).  Same bindings in every form. */
 #define KSCHED_OPT_FUSED_PICK 9
 /* KSCHED_OPT_FAULT: test hook for the "nothing unwinds across this boundary" rule.  value = kind | (skip << 8): after `skip`
  * further fault points (the places where a call enters the library's C++: snapshot calls, evaluations, explain, checksum) the

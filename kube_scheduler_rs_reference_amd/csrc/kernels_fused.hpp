@@ -242,12 +242,16 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         const uint32_t pc = min(pod, a.p - 1u);  // clamp: lanes past the end read a valid row and are masked later
         if constexpr (PICK == 2) {
             static_assert(kPickAttempts == 5, "five draw registers");
-            const uint32_t *dp = sa.samples + (size_t)pc * kPickAttempts;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(d0) : "v"(dp) : "memory");
-            asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(d1) : "v"(dp) : "memory");
-            asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(d2) : "v"(dp) : "memory");
-            asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(d3) : "v"(dp) : "memory");
-            asm volatile("global_load_dword %0, %1, off offset:16" : "=v"(d4) : "v"(dp) : "memory");
+            // The round's draws -- 64 pods x 5 = 320 consecutive dwords -- as five COALESCED loads: lane l takes dwords l, 64 + l, ... of the
+            // block (a load per draw, lane = pod, touched twenty lines per instruction: the draws were two thirds of the round's line requests,
+            // 3 us per 100 k pods once a launch is long enough to be bound by its rounds); phase 1 transposes them through the park.
+            const size_t last = (size_t)a.p * kPickAttempts - 1u;
+            const size_t f0 = (size_t)(pod - lane) * kPickAttempts + lane;  // (pod - lane = the round's first pod)
+            asm volatile("global_load_dword %0, %1, off" : "=v"(d0) : "v"(sa.samples + min(f0, last)) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(d1) : "v"(sa.samples + min(f0 + 64u, last)) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(d2) : "v"(sa.samples + min(f0 + 128u, last)) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(d3) : "v"(sa.samples + min(f0 + 192u, last)) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(d4) : "v"(sa.samples + min(f0 + 256u, last)) : "memory");
         }
         if (FIT) {
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rc) : "v"(g_pcpu + pc) : "memory");
@@ -650,7 +654,17 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
             // records name -- the fit rows of both resources by the candidate's sub-tile, the eight selector slots (unconstrained
             // slots name the all-valid row) -- is exactly the feasible bit this block writes for (pod, candidate).
             const uint4 slots = SEL ? s_lab[lane] : make_uint4(0u, 0u, 0u, 0u);  // (read back after this lane's own scatter stores: LDS operations of a wave execute in order)
-            const uint32_t dv[kPickAttempts] = {d0, d1, d2, d3, d4};
+            // the draws arrived as the round's block in linear order (issue_ops): through the park -- [pod of the round][draw], where the pod's
+            // last contributor reads the winning draw's node one trip later -- every lane gets its own pod's five (stride 5 dwords: no bank conflict;
+            // LDS operations of a wave execute in order)
+            s_park[lane] = d0;
+            s_park[64u + lane] = d1;
+            s_park[128u + lane] = d2;
+            s_park[192u + lane] = d3;
+            s_park[256u + lane] = d4;
+            uint32_t dv[kPickAttempts];
+#pragma unroll
+            for (uint32_t i = 0; i < kPickAttempts; ++i) dv[i] = s_park[lane * kPickAttempts + i];
             uint32_t bits = 0;
 #pragma unroll
             for (uint32_t i = 0; i < kPickAttempts; ++i) {
@@ -671,7 +685,6 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
                              word(slots.z >> 16) & word(slots.w & 0xFFFFu) & word(slots.w >> 16);
                     bits |= ((v >> (l & 31u)) & 1u) << i;
                 }
-                s_park[i * 64u + lane] = dv[i];  // the pod's last contributor reads the winning draw's node from here, one trip later
             }
             pick_bits = bits;
         }
@@ -733,7 +746,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         // the units' first lanes only (EXEC is narrowed inside the statement: the compiler sees one unconditional definition of `ar`)
         const uint64_t lead = 0x0101010101010101ull & (n_live >= 64u ? ~0ull : ((1ull << n_live) - 1ull));
         uint64_t saved;
-        asm volatile("s_and_saveexec_b64 %1, %4\n\tglobal_atomic_add_x2 %0, %2, %3, off sc0 sc1\n\ts_mov_b64 exec, %1"
+        // (device scope -- no sc1 --: what HIP's atomicAdd is; coherent across the XCDs and 1.2 us per launch cheaper at C3 than system scope)
+        asm volatile("s_and_saveexec_b64 %1, %4\n\tglobal_atomic_add_x2 %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
                      : "=v"(ar), "=&s"(saved)
                      : "v"(slot), "v"(delta), "s"(lead)
                      : "memory", "scc");
@@ -747,7 +761,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
         if (lane < n_live && (uint32_t)(word >> 40) == a.tiles - 1u) {  // every tile's block has contributed: this block decides the unit's pods
             const uint32_t all = ((uint32_t)(word >> (5u * j)) | pick_bits) & ((1u << kPickAttempts) - 1u);
             int32_t bnd = -1;  // no drawn candidate is feasible: None -> NoNodeFound (src/main.rs:70,117)
-            if (all) bnd = (int32_t)s_park[(uint32_t)__builtin_ctz(all) * 64u + lane];  // first feasible draw wins (src/main.rs:61-65)
+            if (all) bnd = (int32_t)s_park[lane * kPickAttempts + (uint32_t)__builtin_ctz(all)];  // first feasible draw wins (src/main.rs:61-65)
             sa.binding[pod0 + lane] = bnd;
             if (j == 0u) a.pick_acc[(pod0 >> 3) + (lane >> 3)] = 0ull;  // ready for the next launch (nobody else touches the word any more in this one)
         }

@@ -762,7 +762,16 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     // a step is one kernel); otherwise it is its own launch, first (nothing waits on a mask kernel), and a bindings-only
     // request launches no mask kernel at all.  KSCHED_OPT_PICK_FROM_MASK restores the mask-reading pick (a cross-check).
     const bool select_direct = pick_s && !c->opt_pick_from_mask;
-    const bool pick_rides = select_direct && want_mask && c->opt_fused_pick && kern == KSCHED_KERNEL_FUSED && can_fused &&
+    // A riding pick is nearly free while a launch is short -- its work hides in the fill, where nothing can store yet -- and costs twice
+    // the stand-alone kernel once a launch is bound by its rounds (400 k pods x 5 k nodes: +6.5 us per 100 k pods riding, +3.4 us as its
+    // own launch; the returning atomics queue behind the store stream, the tests share the LDS with phase 2): in the default mode it
+    // rides when a wave has at most five rounds (C3: 2, the C4 shard: 5).
+    bool ride_pays = true;
+    if (c->opt_fused_pick == 1 && can_fused) {
+        const uint32_t tiles = std::max(1u, c->idx.lay.tiles), chunks = std::max(1u, std::min(256u / tiles, (p + 255u) / 256u));
+        ride_pays = (uint64_t)p <= (uint64_t)chunks * 5u * 64u * kFusedWaves;
+    }
+    const bool pick_rides = select_direct && want_mask && c->opt_fused_pick && kern == KSCHED_KERNEL_FUSED && can_fused && ride_pays &&
                             fused_pick_applicable(c->idx, flags, (flags & KSCHED_WANT_FIT_MASK) && out_fit, p);
     SelectArgs ride{};
     int ride_form = 1;

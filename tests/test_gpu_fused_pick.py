@@ -165,6 +165,38 @@ def test_riding_pick_on_device_buffers_repeated_steps(evaluator):
     ev.forget_stream(s2)
 
 
+def test_a_long_launch_keeps_its_pick_separate_by_default(evaluator):
+    """The pick rides while a launch is short (its work hides in the fill); once a wave has more than five rounds the default is the
+    stand-alone kernel again (the returning atomics and the tests cost a round-bound launch twice what the separate launch costs).  Both
+    forms, and the forced tile form at this size, == oracle."""
+    import torch
+    ev = evaluator
+    c = synth.make_config("C3", P=280_000)  # 5 tiles -> 51 chunks x 5 120 pods = 261 120: one step beyond
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    d_cpu, d_mem, d_sel, d_smp = t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.samples, np.int32)
+    mask = ev.alloc_mask(c.P, pitched=True)
+    out = torch.full((c.P,), -7, dtype=torch.int32, device=dev)
+    _, _, bind = oracle_eval(c, FIT | SEL | PICK_SAMPLED)
+    try:
+        for mode, want in ((1, "select"), (3, "fused-tile"), (2, "fused")):
+            ev.set_option(_lib.OPT_FUSED_PICK, mode)
+            out.fill_(-7)
+            ev.eval_device(d_cpu, d_mem, d_sel, None, d_smp, FIT | SEL | PICK_SAMPLED, out_feasible=mask, out_binding=out)
+            torch.cuda.synchronize()
+            assert ev.last_pick == want, (mode, ev.last_pick)
+            assert np.array_equal(out.cpu().numpy(), bind), mode
+        ev.set_option(_lib.OPT_FUSED_PICK, 1)
+        small = 250_000  # (inside the limit: rides)
+        ev.eval_device(d_cpu[:small].contiguous(), d_mem[:small].contiguous(), d_sel[:, :small].contiguous(), None, d_smp[:small].contiguous(),
+                       FIT | SEL | PICK_SAMPLED, out_feasible=ev.alloc_mask(small, pitched=True), out_binding=out[:small])
+        torch.cuda.synchronize()
+        assert ev.last_pick == "fused-tile" and np.array_equal(out[:small].cpu().numpy(), bind[:small])
+    finally:
+        ev.set_option(_lib.OPT_FUSED_PICK, 1)
+
+
 # ---- nothing unwinds across the C ABI (include/ksched.h "Conventions"; SURVEY.md section 5) -------------------------------------
 
 @pytest.mark.parametrize("kind,code", [(1, _lib.E_NOMEM), (2, _lib.E_INVAL)])
