@@ -525,10 +525,16 @@ __device__ __forceinline__ bool bestfit_rows_round(const BestfitRowsArgs &q, uin
             xl[g][k] = ~0ull;
             if (sel[k] != 0u) xl[g][k] = q.rows[(size_t)lrow[k] * q.Wbf + wc];
         }
+        // (the four taint rows UNCONDITIONALLY when the predicate is on -- a group the snapshot does not have reads the all-valid row --: behind a
+        // branch per group the compiler waited for each of these loads before issuing the next, `tools/audit_asm.py` counts the loads in flight)
 #pragma unroll
-        for (uint32_t t = 0; t < 4; ++t) {
-            xt[g][t] = ~0ull;
-            if (q.do_taint && t < q.ngroups) xt[g][t] = q.rows[(size_t)(q.row_taint + 16u * t + (uint32_t)((tol >> (4u * t)) & 15ull)) * q.Wbf + wc];
+        for (uint32_t t = 0; t < 4; ++t) xt[g][t] = ~0ull;
+        if (q.do_taint) {
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) {
+                const uint32_t row = (t < q.ngroups) ? q.row_taint + 16u * t + (uint32_t)((tol >> (4u * t)) & 15ull) : q.row_valid;
+                xt[g][t] = q.rows[(size_t)row * q.Wbf + wc];
+            }
         }
     }
 #pragma unroll
@@ -660,15 +666,33 @@ __global__ __launch_bounds__(64) void k_pick_bestfit_handed(const BestfitRowsArg
         // tolerations, cpu request, selector ids 0..7}: no rank search and no operand round trip here, the row loads go out at once.
         // The record is requested TOGETHER with the sub-list's count (the slot exists whether or not it was filled): one dependent
         // round trip less in every wave's life, and wave slots are what this stage is bound by.
-        const uint4 *rec = reinterpret_cast<const uint4 *>(q.pod_recs) + (size_t)(c * q.sub_cap + i) * 4u;
-        uint4 h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
+        // (inline-asm loads: written as plain loads the compiler sinks them below the count's wait -- they are only used inside the loop)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *rec = reinterpret_cast<const u32x4 *>(q.pod_recs) + (size_t)(c * q.sub_cap + i) * 4u;
+        u32x4 h, o, s0, s1;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(h) : "v"(rec) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(o) : "v"(rec) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(s0) : "v"(rec) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(s1) : "v"(rec) : "memory");
         const uint32_t count = q.sub_count[32u * c];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(h), "+v"(o), "+v"(s0), "+v"(s1) : "s"(count) : "memory");  // (after the count's load has been issued)
+        // (every lane read the same record: back to scalar registers -- the rows' addresses are wave-uniform, and VGPRs are wave slots here)
+        auto uni = [](u32x4 &v) {
+            v.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.x);
+            v.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.y);
+            v.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.z);
+            v.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.w);
+        };
+        uni(h);
+        uni(o);
+        uni(s0);
+        uni(s1);
         for (; i < count; i += stride) {
         const uint32_t slot = c * q.sub_cap + i;
         uint64_t *const tr = q.trace2 ? q.trace2 + (size_t)slot * 4u : nullptr;
         KSCHED_BF_STAMP(tr, 0, slot);
         if (i >= stride) {  // (a walk: more than a quarter of the batch was handed over)
-            rec = reinterpret_cast<const uint4 *>(q.pod_recs) + (size_t)slot * 4u;
+            rec = reinterpret_cast<const u32x4 *>(q.pod_recs) + (size_t)slot * 4u;
             h = rec[0], o = rec[1], s0 = rec[2], s1 = rec[3];
         }
         const uint32_t sel[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};

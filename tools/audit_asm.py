@@ -140,7 +140,8 @@ def audit_kernarg_warm(asm: str) -> list[str]:
     """csrc/kernarg.hpp: the hot kernels open with ONE group of scalar loads that touches every 64-byte line of the kernarg segment
     (s_load_dword at 0x0, 0x40, ... inside one asm statement, one wait) ahead of the first branch."""
     errs = []
-    want = {"12k_eval_fused": 6, "16k_select_sampled": 2, "20k_pick_bestfit_lanes": 6, "19k_pick_bestfit_rows": 6, "13k_eval_direct": 2}
+    want = {"12k_eval_fused": 6, "16k_select_sampled": 2, "20k_pick_bestfit_lanes": 6, "19k_pick_bestfit_rows": 6, "21k_pick_bestfit_handed": 6,
+            "13k_eval_direct": 2}
     seen = {k: 0 for k in want}
     for m in re.finditer(r"^(_ZN6ksched(\d+k_\w+?)I?[^:\n]*):.*?\n(.*?)\n\s+s_endpgm", asm, re.S | re.M):
         key = next((k for k in want if m.group(1).startswith("_ZN6ksched" + k)), None)
@@ -155,6 +156,43 @@ def audit_kernarg_warm(asm: str) -> list[str]:
     for k, n in seen.items():
         if n == 0:
             errs.append(f"no instantiation of {k} found in the assembly")
+    return errs
+
+
+def audit_bestfit_loads(asm: str) -> list[str]:
+    """The best-fit kernels request every row word of a round / trip before anything waits (kernels_direct.hpp, "loads first, ANDs
+    after"): written as `if (constrained) base &= row[..]` the compiler put `s_waitcnt vmcnt(0)` behind every single load and a round
+    was a dozen dependent round trips (round 3, found in the disassembly).  Checked here: the longest run of global loads with no
+    vmcnt wait in between, per kernel; and the second stage's register budget (it is bound by wave slots: <= 64 VGPRs, no scratch)."""
+    errs = []
+    want_run = {"21k_pick_bestfit_handed": 12, "20k_pick_bestfit_lanes": 24, "19k_pick_bestfit_rows": 12}
+    seen = set()
+    for m in re.finditer(r"^(_ZN6ksched(\d+k_pick_bestfit_\w+?)ENS_\S*):.*?\n(.*?)\n\s+s_endpgm", asm, re.S | re.M):
+        key = m.group(2)
+        if key not in want_run:
+            continue
+        seen.add(key)
+        run = best = 0
+        for line in m.group(3).split("\n"):
+            t = line.strip()
+            if t.startswith("global_load"):
+                run += 1
+                best = max(best, run)
+            elif t.startswith("s_waitcnt") and "vmcnt" in t:
+                run = 0
+        if best < want_run[key]:
+            errs.append(f"{key}: at most {best} global loads in flight together, expected >= {want_run[key]} (the compiler serialised the row loads again?)")
+    for key in want_run:
+        if key not in seen:
+            errs.append(f"no {key} found in the assembly")
+    m = re.search(r"\.amdhsa_kernel _ZN6ksched21k_pick_bestfit_handed.*?\n(.*?)\.end_amdhsa_kernel", asm, re.S)
+    if m:
+        v = re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(1))
+        sc = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(1))
+        if v and int(v.group(1)) > 64:
+            errs.append(f"k_pick_bestfit_handed uses {v.group(1)} VGPRs (> 64: fewer than seven waves per SIMD)")
+        if sc and int(sc.group(1)) > 0:
+            errs.append(f"k_pick_bestfit_handed uses {sc.group(1)} bytes of scratch")
     return errs
 
 
@@ -177,8 +215,12 @@ def main() -> int:
     kw = audit_kernarg_warm(asm)
     for e in kw:
         print("FAIL kernarg warm-up:", e)
-    print(f"audited {n} k_eval_fused instantiations, {bad} failing; kernarg warm-up groups: {'ok' if not kw else str(len(kw)) + ' failing'}")
-    return 1 if bad or n == 0 or kw else 0
+    bl = audit_bestfit_loads(asm)
+    for e in bl:
+        print("FAIL best-fit loads:", e)
+    print(f"audited {n} k_eval_fused instantiations, {bad} failing; kernarg warm-up groups: {'ok' if not kw else str(len(kw)) + ' failing'}; "
+          f"best-fit loads in flight: {'ok' if not bl else str(len(bl)) + ' failing'}")
+    return 1 if bad or n == 0 or kw or bl else 0
 
 
 if __name__ == "__main__":
