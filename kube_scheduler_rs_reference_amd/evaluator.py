@@ -60,6 +60,9 @@ class Evaluator:
         self.n = 0
         self.n_keys = 0
         if os.environ.get("KSCHED_DEBUG"):  # A/B switches of tools/ (KSCHED_OPT_DEBUG), so that a whole test file can run under one
+            import sys
+            print(f"kube_scheduler_rs_reference_amd: KSCHED_DEBUG={os.environ['KSCHED_DEBUG']} -> KSCHED_OPT_DEBUG (ablation switches: timings "
+                  "and possibly results are not the shipped path's)", file=sys.stderr)
             self.set_option(L.OPT_DEBUG, int(os.environ["KSCHED_DEBUG"], 0))
 
     # -- lifetime ---------------------------------------------------------------------------
