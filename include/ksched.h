@@ -35,6 +35,10 @@
  *   - a ksched_ctx is internally serialised by a mutex (host side); use one ctx per device.  Evaluations may be enqueued on
  *     any number of the caller's streams: the library orders them against snapshot changes and against each other's use
  *     of ctx-owned scratch memory with events.  Tell it before a stream is destroyed (ksched_forget_stream).
+ *   - the *_device entry points are not meant to be captured into a hipGraph and replayed: an evaluation may allocate scratch on its
+ *     first use, and some of its scratch is chosen per CALL on the host (the two-stage best-fit pick rotates over three sets of
+ *     hand-over counters, each call zeroing the next call's set instead of paying a memset launch).  What a graph would save -- the
+ *     launch gap between consecutive steps -- is what ksched_pipe's "alternate" mode addresses (KSCHED_OPT_PIPE_MODE).
  */
 #ifndef KSCHED_H
 #define KSCHED_H
