@@ -783,8 +783,9 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         const bool tile_ok = fused_tile_pick_applicable(c->idx, flags, attempts, psel != nullptr);
         // Which form when both apply: the tile tests cost every (pod, tile) pair five draw loads and a handful of LDS reads, the waves
         // of the fill cost every block a longer fill.  Measured (session r3g3, rotated outputs, step): 5 tiles (C3) 19.8 us against 21.6;
-        // 10 tiles (the C4 shard) 45.3 us against 42.1; 1 tile (C2) 7.1 us against 6.8.
-        const bool tile_pays = c->idx.lay.tiles >= 2u && c->idx.lay.tiles <= 6u;
+        // 10 tiles (the C4 shard) 45.3 us against 42.1; 1 tile (C2) 7.1 us against 6.8.  With one device-scope atomic per unit of eight pods and
+        // the draws loaded coalesced (later in round 3) the C4 shard reads 40.9 - 41.5 us against 42.1 - 42.3, C2 6.8 against 6.4: 2 .. 12 tiles.
+        const bool tile_pays = c->idx.lay.tiles >= 2u && c->idx.lay.tiles <= 12u;
         if (((c->opt_fused_pick == 1 && tile_pays) || c->opt_fused_pick == 3) && tile_ok) {
             ksched_ctx::PickAcc *pa = nullptr;
             for (auto &x : c->pick_acc)

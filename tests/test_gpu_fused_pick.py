@@ -45,7 +45,7 @@ def test_riding_pick_equals_standalone_pick_equals_oracle(evaluator, P, N, attem
         # the tile-test form: ATTEMPTS draws, the reference's two predicates (a taint predicate no node's taints make active is none)
         tile_ok = attempts == 5 and not ((flags & TAINT) and c.node_taints.any())
         a, how_a, kern_a = run(ev, c, f, ride=1)
-        assert kern_a == "fused" and how_a == ("fused-tile" if (tile_ok and 1024 < N <= 6 * 1024) else "fused")  # (the library picks the tile form from two to six tiles)
+        assert kern_a == "fused" and how_a == ("fused-tile" if (tile_ok and 1024 < N <= 12 * 1024) else "fused")  # (the library picks the tile form from two to twelve tiles)
         w, how_w, _ = run(ev, c, f, ride=2)
         b, how_b, _ = run(ev, c, f, ride=0)
         assert how_w == "fused" and how_b == "select"
