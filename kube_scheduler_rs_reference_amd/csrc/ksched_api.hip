@@ -690,7 +690,7 @@ void bestfit_trace_report(ksched_ctx *c, uint32_t p, size_t slots2, hipStream_t 
         d2.push_back((double)(r[1] - r[0]) / ghz * 1e-3);
         x2.push_back((double)(r[1] - t20) / ghz * 1e-3);
     }
-    fprintf(stderr, "best-fit stage 2 (k_pick_bestfit_rows), us:   first entry %.2f us after stage 1's first entry\n", t20 == ~0ull ? 0.0 : (double)(t20 - t0) / ghz * 1e-3);
+    fprintf(stderr, "best-fit stage 2 (k_pick_bestfit_handed), us:   first entry %.2f us after stage 1's first entry\n", t20 == ~0ull ? 0.0 : (double)(t20 - t0) / ghz * 1e-3);
     line("entry after the first wave", e2);
     line("scan of one pod", d2);
     line("exit after the first entry", x2);
