@@ -28,6 +28,8 @@ cp("bench_driver_form.json", "bench_driver_form_steps20_C3.json")
 cp("prof_driver_form_kernel_stats.csv", "rocprofv3_kernel_stats_bench_driver_form.csv")
 cp("prof_driver_form_bench.json", "bench_line_under_rocprofv3_driver_form.json")
 cp("prof_c5s_kernel_stats.csv", "rocprofv3_kernel_stats_bench_C5s.csv")
+cp("prof_default_by_phase.json", "rocprofv3_by_phase_default.json")
+cp("prof_driver_form_by_phase.json", "rocprofv3_by_phase_driver_form.json")
 cp("pytest_gpu.log", "pytest_gpu.log")
 cp("smoke.log", "smoke.log")
 cp("host_costs.txt", "host_costs_snapshot_calls.txt")

@@ -50,6 +50,12 @@ if has prof; then
   f=$(find $OUT/prof_default -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/prof_default_kernel_stats.csv && head -6 $f | cut -c1-260
   f=$(find $OUT/prof_driver_form -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/prof_driver_form_kernel_stats.csv && head -4 $f | cut -c1-260
   f=$(find $OUT/prof_c5s -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/prof_c5s_kernel_stats.csv && head -6 $f | cut -c1-200
+  # the dominant kernel's durations by phase of the command (ramp / timed region / repeats / legs): what corresponds to roofline.avg_kernel_us
+  for w in default driver_form; do
+    t=$(find $OUT/prof_$w -name "*kernel_trace.csv" | head -1)
+    [ -n "$t" ] && [ -s $OUT/prof_${w}_bench.json ] && python $REPO/tools/rocprof_timed_region.py $t $OUT/prof_${w}_bench.json "k_eval_fused" > $OUT/prof_${w}_by_phase.json 2>$OUT/prof_${w}_by_phase.err && python -c "
+import json; d=json.load(open('$OUT/prof_${w}_by_phase.json')); s=d['segments']; print('$w by phase:', d['kernel'], {k: (v['launches'], round(v['mean_us'], 2)) for k, v in s.items()}, 'all', round(d['all_launches_mean_us'], 2))"
+  done
   find $OUT -name "*.db" -size +2M -delete
 fi
 if has pmc; then
