@@ -237,9 +237,61 @@ void Snapshot::push_rows(const std::vector<uint32_t> &touched) {
 }
 
 size_t Snapshot::observe_pods(const std::vector<std::pair<PodEvent, const corev1::Pod *>> &events) {
+    std::vector<Observed> ev;
+    ev.reserve(events.size());
+    for (const auto &[kind, pod] : events)
+        if (pod) ev.push_back({pod, (kind == PodEvent::Applied && pod->spec && pod->spec->node_name) ? &*pod->spec->node_name : nullptr});
+    return observe_impl(ev);
+}
+
+size_t Snapshot::observe_bound(const std::vector<std::pair<const corev1::Pod *, const std::string *>> &bound) {
+    std::vector<Observed> ev;
+    ev.reserve(bound.size());
+    for (const auto &[pod, node] : bound)
+        if (pod) ev.push_back({pod, node});
+    return observe_impl(ev);
+}
+
+size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
     // Stage everything first (the new bookkeeping entries, the exact per-node change in nano-units), validate, then commit: an
     // EncodeError leaves the snapshot as it was.
+    // Per-event string work first -- the pod's key and the sum of its requests (quantity parsing) --, fanned out over threads for a
+    // large batch like encode_pods: it is what this call spends its time on, and the events are independent until they are merged.
+    struct Pre {
+        std::string key;
+        int idx = -1;
+        __int128 cpu = 0, mem = 0;
+        std::string error;
+    };
+    std::vector<Pre> pre(events.size());
+    auto prepare = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const Observed &e = events[i];
+            Pre &p = pre[i];
+            p.key = full_name(e.pod->metadata);
+            p.idx = e.node ? index_of(*e.node) : -1;
+            if (p.idx < 0) continue;
+            try {
+                const PodResources r = total_pod_resources(*e.pod);  // the sum the LIST loop subtracts (src/predicates.rs:37)
+                p.cpu = r.cpu.nanos();
+                p.mem = r.memory.nanos();
+            } catch (const QuantityError &x) {
+                p.error = "pod " + p.key + ": invalid pod spec: " + x.what();
+            }
+        }
+    };
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t nthreads = events.size() >= 4096 ? std::min<uint32_t>({hw, 32u, (uint32_t)(events.size() / 1024)}) : 1u;
+    if (nthreads <= 1) {
+        prepare(0, events.size());
+    } else {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < nthreads; ++t)
+            pool.emplace_back([&, t] { prepare(events.size() * t / nthreads, events.size() * (t + 1) / nthreads); });
+        for (auto &th : pool) th.join();
+    }
     std::unordered_map<std::string, std::optional<Counted>> staged;  // key -> its entry after these events (nullopt = not counted)
+    staged.reserve(events.size());
     std::map<uint32_t, std::pair<__int128, __int128>> delta;         // node -> change of available (cpu, mem) in nano-units
     auto current = [&](const std::string &key) -> std::optional<Counted> {
         auto st = staged.find(key);
@@ -249,28 +301,19 @@ size_t Snapshot::observe_pods(const std::vector<std::pair<PodEvent, const corev1
         return it->second;
     };
     size_t changed = 0;
-    for (const auto &[kind, pod] : events) {
-        if (!pod) continue;
-        const std::string key = full_name(pod->metadata);
-        int idx = -1;
-        if (kind == PodEvent::Applied && pod->spec && pod->spec->node_name) idx = index_of(*pod->spec->node_name);
-        const std::optional<Counted> was = current(key);
-        if (idx < 0) {  // deleted, not bound, or bound to a node this snapshot does not hold: counted nowhere from now on
+    for (size_t i = 0; i < events.size(); ++i) {
+        Pre &p = pre[i];
+        const std::optional<Counted> was = current(p.key);
+        if (p.idx < 0) {  // deleted, not bound, or bound to a node this snapshot does not hold: counted nowhere from now on
             if (!was) continue;
             delta[was->node].first += was->cpu_nanos;
             delta[was->node].second += was->mem_nanos;
-            staged[key] = std::nullopt;
+            staged[std::move(p.key)] = std::nullopt;
             ++changed;
             continue;
         }
-        Counted now{(uint32_t)idx, 0, 0};
-        try {
-            const PodResources r = total_pod_resources(*pod);  // the sum the LIST loop subtracts (src/predicates.rs:37)
-            now.cpu_nanos = r.cpu.nanos();
-            now.mem_nanos = r.memory.nanos();
-        } catch (const QuantityError &e) {
-            throw EncodeError("pod " + key + ": invalid pod spec: " + e.what());
-        }
+        if (!p.error.empty()) throw EncodeError(p.error);  // (in event order, like the sequential walk)
+        const Counted now{(uint32_t)p.idx, p.cpu, p.mem};
         if (was && was->node == now.node && was->cpu_nanos == now.cpu_nanos && was->mem_nanos == now.mem_nanos) continue;  // already counted
         if (was) {
             delta[was->node].first += was->cpu_nanos;
@@ -278,7 +321,7 @@ size_t Snapshot::observe_pods(const std::vector<std::pair<PodEvent, const corev1
         }
         delta[now.node].first -= now.cpu_nanos;
         delta[now.node].second -= now.mem_nanos;
-        staged[key] = now;
+        staged[std::move(p.key)] = now;
         ++changed;
     }
     std::vector<uint32_t> touched;

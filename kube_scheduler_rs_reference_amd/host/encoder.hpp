@@ -107,6 +107,9 @@ public:
     enum class PodEvent { Applied, Deleted };
     size_t observe_pods(const std::vector<std::pair<PodEvent, const corev1::Pod *>> &events);
     bool observe_pod(PodEvent kind, const corev1::Pod &pod) { return observe_pods({{kind, &pod}}) == 1; }
+    // The bindings a batch has just created: pod i now runs on node_names[i] (the pod objects themselves still carry no nodeName --
+    // no copies are made).  Same bookkeeping and guarantees as observe_pods with Applied events of those pods bound to those nodes.
+    size_t observe_bound(const std::vector<std::pair<const corev1::Pod *, const std::string *>> &bound);
     size_t counted_pods() const { return counted_.size(); }
 
     // Make sure every label key in `keys` (the selector keys of ONE batch) has a column; re-uploads the label columns when the
@@ -164,6 +167,12 @@ private:
     };
     std::unordered_map<std::string, Counted> counted_;  // namespace/name -> what `available` currently holds against that pod
     void push_rows(const std::vector<uint32_t> &touched);
+    // one event of observe_pods / observe_bound: the pod, and the node it runs on now (nullptr = none: deleted / unbound)
+    struct Observed {
+        const corev1::Pod *pod;
+        const std::string *node;
+    };
+    size_t observe_impl(const std::vector<Observed> &events);
 };
 
 // K8s ToleratesTaint (extension E2): does toleration `t` tolerate taint `x`?

@@ -171,29 +171,22 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
     for (size_t j = 0; j < pending.size(); ++j)
         if (sel.node_store_index[j] >= 0) chosen[j] = &ctx.node_store[(size_t)sel.node_store_index[j]];
     const std::vector<ReconcileOutcome> posted = post_bindings(pending, chosen, sink, post_concurrency);  // src/main.rs:94-108, overlapped
-    std::vector<corev1::Pod> landed;  // copies carrying spec.nodeName, for the snapshot update
+    std::vector<std::pair<const corev1::Pod *, const std::string *>> landed;  // (pod, the node it was bound to), for the snapshot update
     for (size_t j = 0; j < pending.size(); ++j) {
         out[where[j]] = posted[j];
-        if (out[where[j]].ok && out[where[j]].bound_to) {
-            corev1::Pod p = *pending[j];
-            if (!p.spec) p.spec = corev1::PodSpec{};
-            p.spec->node_name = *out[where[j]].bound_to;
-            landed.push_back(std::move(p));
-        }
+        if (out[where[j]].ok && out[where[j]].bound_to) landed.emplace_back(pending[j], &*out[where[j]].bound_to);  // (`out` is not resized any more)
     }
     // The whole batch was evaluated against ONE snapshot (the reference's racing reconciles all see the same API-server state).
     // The bindings it created then count against their nodes for the NEXT batch -- the reference gets that from re-LISTing on
     // every evaluation (src/predicates.rs:34-38); here the snapshot is patched in one device update.
     if (ctx.snapshot && !landed.empty()) {
-        // (observe_pods, the tracked form: when the watch later echoes these bindings as MODIFIED events they change nothing)
-        std::vector<std::pair<Snapshot::PodEvent, const corev1::Pod *>> events;
-        for (const auto &p : landed) events.emplace_back(Snapshot::PodEvent::Applied, &p);
+        // (observe_bound, the tracked form: when the watch later echoes these bindings as MODIFIED events they change nothing)
         // The bindings EXIST by now: whatever happens to the snapshot update, the caller gets `out` (an exception here would make
         // a batching caller lose the outcomes, or worse reconcile -- and POST -- the batch again).  A device failure leaves the
         // snapshot marked stale (it uploads everything before the next evaluation); a bookkeeping failure (int64 overflow of
         // `available`) drops the snapshot, so that the next batch starts from fresh LISTs.
         try {
-            ctx.snapshot->observe_pods(events);
+            ctx.snapshot->observe_bound(landed);
         } catch (const EncodeError &) {
             if (!ctx.snapshot->device_stale()) ctx.snapshot.reset();
         }
@@ -216,7 +209,7 @@ std::vector<ReconcileOutcome> reconcile_batch_sequential(const std::vector<const
         const BatchSelection sel = select_nodes_for_pods(batch, ctx, chooser);  // one device evaluation + pick
         std::vector<size_t> next;
         std::vector<bool> taken(ctx.node_store.size(), false);
-        std::vector<corev1::Pod> landed;  // copies carrying spec.nodeName, for the snapshot update
+        std::vector<std::pair<const corev1::Pod *, const std::string *>> landed;  // (pod, the node it was bound to), for the snapshot update
         for (size_t j = 0; j < pending.size(); ++j) {
             const size_t i = pending[j];
             const int32_t idx = sel.node_store_index[j];
@@ -232,14 +225,9 @@ std::vector<ReconcileOutcome> reconcile_batch_sequential(const std::vector<const
             out[i] = bind(*pods[i], &ctx.node_store[(size_t)idx], sink);
             if (!out[i].ok) continue;  // the POST failed: nothing landed on the node
             taken[(size_t)idx] = true;
-            corev1::Pod p = *pods[i];
-            if (!p.spec) p.spec = corev1::PodSpec{};
-            p.spec->node_name = *out[i].bound_to;
-            landed.push_back(std::move(p));
+            landed.emplace_back(pods[i], &*out[i].bound_to);  // (`out` keeps its size: the pointer stays valid)
         }
-        std::vector<std::pair<Snapshot::PodEvent, const corev1::Pod *>> events;
-        for (const auto &p : landed) events.emplace_back(Snapshot::PodEvent::Applied, &p);
-        ctx.snapshot->observe_pods(events);
+        ctx.snapshot->observe_bound(landed);
         pending.swap(next);
     }
     for (size_t i : pending) out[i] = bind(*pods[i], nullptr, sink);  // still colliding after max_rounds

@@ -165,7 +165,7 @@ static void print_outcomes(const std::vector<ReconcileOutcome> &out, const Recor
 
 int main(int argc, char **argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: objects_eval masks|columns|events|batch|sequential|stream <objects.json> [...]\n");
+        std::fprintf(stderr, "usage: objects_eval masks|columns|encodetime|events|batch|sequential|stream <objects.json> [...]\n");
         return 2;
     }
     try {
@@ -251,6 +251,25 @@ int main(int argc, char **argv) {
             std::printf(",\"list_calls\":%llu}\n", (unsigned long long)lister->list_calls);
             if (pp.empty()) break;
             }
+            return 0;
+        }
+        if (mode == "encodetime") {
+            // how long the wire-format step takes on this host (no device): objects -> columns, `reps` times; prints pods per second
+            const size_t reps = argc > 3 ? std::max<size_t>(1, std::strtoul(argv[3], nullptr, 0)) : 5;
+            Snapshot snap(Snapshot::kEncodeOnly);
+            const auto r0 = std::chrono::steady_clock::now();
+            snap.rebuild(ctx.node_store, lister.get());
+            const double rebuild_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
+            (void)snap.encode_pods(pp);  // (first call adds the batch's label columns)
+            const auto t0 = std::chrono::steady_clock::now();
+            uint64_t sink = 0;
+            for (size_t r = 0; r < reps; ++r) {
+                const PodColumns pc = snap.encode_pods(pp);
+                sink += (uint64_t)pc.req_cpu_milli[pc.p / 2];
+            }
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (double)reps;
+            std::printf("{\"pods\":%zu,\"nodes\":%u,\"rebuild_seconds\":%.6f,\"encode_seconds\":%.6f,\"pods_per_second\":%.0f,\"check\":%llu}\n", pp.size(), snap.n(),
+                        rebuild_s, sec, (double)pp.size() / sec, (unsigned long long)sink);
             return 0;
         }
         if (mode == "events") {
