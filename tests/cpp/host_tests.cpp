@@ -367,6 +367,42 @@ static void cpu_tests() {
         CHECK(snap.observe_pods({{E::Applied, &h1}, {E::Applied, &h2}}) == 2);
         CHECK(snap.columns().avail_cpu_milli[1] == 7999 && snap.counted_pods() == 3);
     });
+    run("snapshot builder: observe_bound == observe_pods on copies that carry the node name, also for a batch large enough for the thread fan-out", [] {
+        std::vector<corev1::Node> nodes;
+        for (int i = 0; i < 40; ++i) nodes.push_back(node_with("n" + std::to_string(100 + i), "64", "256Gi"));
+        Snapshot a(Snapshot::kEncodeOnly), b(Snapshot::kEncodeOnly);
+        a.rebuild(nodes, nullptr);
+        b.rebuild(nodes, nullptr);
+        const size_t P = 6000;  // (>= 4096: the per-event string work runs on several threads)
+        std::vector<corev1::Pod> pods, copies;
+        std::vector<std::string> names;
+        for (size_t i = 0; i < P; ++i) {
+            const std::string cpu = std::to_string(1 + i % 7) + "m", mem = std::to_string(1 + i % 5) + "Mi";
+            pods.push_back(pod_with("p" + std::to_string(i), {container(cpu.c_str(), mem.c_str())}, nullptr));
+            names.push_back(i % 97 == 0 ? std::string("not-in-the-snapshot") : "n" + std::to_string(100 + i % 40));
+            copies.push_back(pods.back());
+            copies.back().spec->node_name = names.back();
+        }
+        std::vector<std::pair<const corev1::Pod *, const std::string *>> bound;
+        std::vector<std::pair<Snapshot::PodEvent, const corev1::Pod *>> events;
+        for (size_t i = 0; i < P; ++i) {
+            bound.emplace_back(&pods[i], &names[i]);
+            events.emplace_back(Snapshot::PodEvent::Applied, &copies[i]);
+        }
+        const size_t ca = a.observe_bound(bound), cb = b.observe_pods(events);
+        CHECK(ca == cb && ca == P - (P + 96) / 97);
+        CHECK(a.columns().avail_cpu_milli == b.columns().avail_cpu_milli && a.columns().avail_mem_bytes == b.columns().avail_mem_bytes);
+        CHECK(a.counted_pods() == b.counted_pods());
+        CHECK(a.observe_bound(bound) == 0);  // the same bindings again (the watch's echo): nothing changes
+        // strong guarantee with the fan-out: one unparsable pod in the middle -> nothing is applied
+        pods[P / 2] = pod_with("late", {container("lots", nullptr)}, nullptr);
+        std::vector<std::pair<const corev1::Pod *, const std::string *>> again;
+        std::vector<std::string> other(P, "n101");
+        for (size_t i = 0; i < P; ++i) again.emplace_back(&pods[i], &other[i]);
+        const auto before = a.columns().avail_cpu_milli;
+        CHECK_THROWS(a.observe_bound(again));
+        CHECK(a.columns().avail_cpu_milli == before && a.counted_pods() == b.counted_pods());
+    });
     run("snapshot builder: a rebuild that throws leaves the snapshot as it was (commit at the end)", [] {
         // 5 nodes with taints enabled; then a rebuild of 2 nodes carrying 65 distinct taints: "more than 64" -- thrown BEFORE anything is
         // committed (it used to come after the columns had been replaced: host n = 2, device still 5 nodes)
