@@ -95,22 +95,22 @@ namespace {
 
 // One device call for pods [lo, hi) of the batch, written into rows [lo, hi) of `out`.
 void eval_range(Snapshot &snap, const std::vector<const corev1::Pod *> &pods, size_t lo, size_t hi, uint32_t pick,
-                const std::vector<uint32_t> *samples, uint32_t attempts, BatchValidity &out) {
+                const std::vector<uint32_t> *samples, uint32_t attempts, BatchValidity &out, bool want_masks) {
     const std::vector<const corev1::Pod *> part(pods.begin() + (std::ptrdiff_t)lo, pods.begin() + (std::ptrdiff_t)hi);
     PodColumns pc = snap.encode_pods(part);
     DeviceEvaluator &dev = snap.device();
     dev.check(ksched_eval(dev.handle(), pc.p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(),
                           pc.n_keys ? pc.sel_val_ids.data() : nullptr, (out.flags & KSCHED_TAINT) ? pc.tolerations.data() : nullptr,
                           (pick & KSCHED_PICK_SAMPLED) ? samples->data() + lo * attempts : nullptr, attempts,
-                          out.flags | KSCHED_WANT_FIT_MASK | pick, out.feasible.data() + lo * out.W, out.fit.data() + lo * out.W,
-                          pick ? out.binding.data() + lo : nullptr),
+                          out.flags | (want_masks ? KSCHED_WANT_FIT_MASK : 0u) | pick, want_masks ? out.feasible.data() + lo * out.W : nullptr,
+                          want_masks ? out.fit.data() + lo * out.W : nullptr, pick ? out.binding.data() + lo : nullptr),
               "ksched_eval");
 }
 
 }  // namespace
 
 BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, bool taints, uint32_t pick_flags,
-                                        const std::vector<uint32_t> *samples, uint32_t attempts) {
+                                        const std::vector<uint32_t> *samples, uint32_t attempts, bool want_masks) {
     if (!ctx.snapshot) ctx.refresh_snapshot();
     Snapshot &snap = *ctx.snapshot;
     if (taints && snap.has_taints()) snap.enable_taints();  // extension E2 is opt-in: interning happens (and can fail) only here
@@ -119,9 +119,12 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
     out.n = snap.n();
     out.W = snap.mask_words();
     out.flags = KSCHED_FIT | KSCHED_SEL | ((taints && snap.has_taints()) ? KSCHED_TAINT : 0u);
-    out.feasible.assign((size_t)out.p * out.W, 0ull);
-    out.fit.assign((size_t)out.p * out.W, 0ull);
     const uint32_t pick = pick_flags & (KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT);
+    if (!want_masks && !pick) throw EncodeError("check_node_validity_batch: nothing asked for (no masks, no pick)");
+    if (want_masks) {
+        out.feasible.assign((size_t)out.p * out.W, 0ull);
+        out.fit.assign((size_t)out.p * out.W, 0ull);
+    }
     if (pick) out.binding.assign(out.p, -1);
     if (out.p == 0 || out.n == 0) return out;  // no pods, or an empty store: nothing is feasible
     if ((pick & KSCHED_PICK_SAMPLED) && (!samples || samples->size() != (size_t)out.p * attempts))
@@ -136,17 +139,20 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
         Snapshot::selector_keys(*pods[i], mine);
         if (mine.size() > KSCHED_MAX_KEYS)
             throw EncodeError("pod " + full_name(pods[i]->metadata) + ": more than KSCHED_MAX_KEYS nodeSelector keys on one pod");
+        bool adds = false;
+        for (const auto &k : mine) adds |= keys.find(k) == keys.end();
+        if (!adds) continue;  // (the common case: no set is copied)
         std::set<std::string> merged = keys;
         merged.insert(mine.begin(), mine.end());
         if (merged.size() > KSCHED_MAX_KEYS) {
-            eval_range(snap, pods, lo, i, pick, samples, attempts, out);
+            eval_range(snap, pods, lo, i, pick, samples, attempts, out, want_masks);
             lo = i;
             keys = mine;
         } else {
             keys.swap(merged);
         }
     }
-    eval_range(snap, pods, lo, pods.size(), pick, samples, attempts, out);
+    eval_range(snap, pods, lo, pods.size(), pick, samples, attempts, out, want_masks);
     return out;
 }
 

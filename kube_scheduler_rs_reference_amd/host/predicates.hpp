@@ -58,9 +58,11 @@ struct BatchValidity {
 
 // check_node_validity for every (pod, node) pair.  `pick_flags` may add KSCHED_PICK_SAMPLED (with
 // `samples`, [p][attempts] canonical node indices) or KSCHED_PICK_BESTFIT; `taints` adds extension E2.
+// want_masks = false (with a pick): bindings only -- `feasible` / `fit` stay empty, no mask kernel runs and nothing but the bindings
+// comes back from the device (the reference's reconcile needs the chosen node, not the matrix: src/main.rs:53-66).
 BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, bool taints = false,
                                         uint32_t pick_flags = 0, const std::vector<uint32_t> *samples = nullptr,
-                                        uint32_t attempts = 0);
+                                        uint32_t attempts = 0, bool want_masks = true);
 
 // check_node_validity's result for listed (pod, node) pairs, decided pair by pair on the device (ksched_explain): what the
 // reference logs at WARN for every rejected candidate (src/main.rs:62).  Unlike BatchValidity::validity (two masks) this tells a

@@ -64,7 +64,8 @@ BatchSelection select_nodes_for_pods(const std::vector<const corev1::Pod *> &pod
             if (idx) samples[(size_t)i * ATTEMPTS + t] = snap.canonical_index((uint32_t)*idx);
         }
     if (n == 0 || p == 0) return out;
-    out.validity = predicates::check_node_validity_batch(pods, ctx, /*taints=*/false, KSCHED_PICK_SAMPLED, &samples, ATTEMPTS);
+    // (the masks only when the caller wants the rejected draws' reasons: a batch's bindings alone need no mask kernel and no mask copy)
+    out.validity = predicates::check_node_validity_batch(pods, ctx, /*taints=*/false, KSCHED_PICK_SAMPLED, &samples, ATTEMPTS, /*want_masks=*/want_rejected);
     for (uint32_t i = 0; i < p; ++i) {
         const int32_t b = out.validity.binding[i];
         if (b >= 0) out.node_store_index[i] = (int32_t)snap.store_index((uint32_t)b);

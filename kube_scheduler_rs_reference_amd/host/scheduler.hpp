@@ -65,7 +65,7 @@ std::optional<corev1::Node> select_node_for_pod(const corev1::Pod &pod, Context 
 struct BatchSelection {
     std::vector<int32_t> node_store_index;             // [p] index into ctx.node_store or -1
     std::vector<std::vector<RejectedCandidate>> rejected;  // [p] candidates tried and refused, in order (filled on request)
-    predicates::BatchValidity validity;                // both masks (canonical node order) for callers that want more
+    predicates::BatchValidity validity;                // the bindings; with want_rejected also both masks (canonical node order): without it no mask is computed or copied
 };
 BatchSelection select_nodes_for_pods(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
                                      bool want_rejected = false);
