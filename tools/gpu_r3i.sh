@@ -10,7 +10,7 @@ for wl in C3 C4s; do for mode in "" "--split-pipe" "--one-stream"; do
 import json
 try:
     d=json.load(open("$OUT/dist_${wl}_${mode#--}.json")); c=d["config"]
-    print("$wl %-14s %s | gather/step %.1f us/step %.3e evals/s | every 4: %s | no gather: %s | mask kernel %.1f us | pick=%s" % ("$mode", (c.get("pipe_mode") or "-")[:9], d["ms_per_step"]*1e3, d["value"], round((c["allgather_every_4"] or {}).get("ms_per_step", 0)*1e3, 1), round((c.get("no_allgather") or {}).get("ms_per_step", 0)*1e3, 1), d["roofline"]["avg_kernel_us"], c.get("pick_launch")))
+    print("$wl %-14s %s | gather/step %.1f us/step %.3e evals/s | other gather cadence: %s | no gather: %s | mask kernel %.1f us | pick=%s" % ("$mode", (c.get("pipe_mode") or "-")[:9], d["ms_per_step"]*1e3, d["value"], round((c.get("allgather_every_step") or c.get("allgather_every_4") or {}).get("ms_per_step", 0)*1e3, 1), round((c.get("no_allgather") or {}).get("ms_per_step", 0)*1e3, 1), d["roofline"]["avg_kernel_us"], c.get("pick_launch")))
 except Exception as e:
     print("$wl $mode FAILED", e); print(open("$OUT/err_${wl}_${mode#--}.log").read()[-1200:])
 PY

@@ -120,7 +120,7 @@ PY
 import json
 try:
     d=json.load(open("$OUT/dist_${wl}_${mode#--}.json")); c=d["config"]
-    print("$wl $mode: gather/step %.1f us/step %.3e evals/s | every 4: %s | no gather: %s | mask kernel %.1f us" % (d["ms_per_step"]*1e3, d["value"], (c["allgather_every_4"] or {}).get("ms_per_step"), (c.get("no_allgather") or {}).get("ms_per_step"), d["roofline"]["avg_kernel_us"]))
+    print("$wl $mode: gather/step %.1f us/step %.3e evals/s | other gather cadence: %s | no gather: %s | mask kernel %.1f us" % (d["ms_per_step"]*1e3, d["value"], (c.get("allgather_every_step") or c.get("allgather_every_4") or {}).get("ms_per_step"), (c.get("no_allgather") or {}).get("ms_per_step"), d["roofline"]["avg_kernel_us"]))
 except Exception as e:
     print("$wl $mode FAILED", e)
 PY
