@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600)
+def run_bench(*args, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line"
@@ -57,3 +58,20 @@ def test_other_workloads_and_bindings_only(built):
     assert d["config"]["nodes"] == 1000 and d["config"]["predicates"] == "FIT" and d["cpu_baseline"] is None
     d = run_bench("--steps", "50", "--warmup", "5", "--ramp-ms", "5", "--kernel-samples", "8", "--no-cpu-baseline", "--no-mask")
     assert d["config"]["mask_written"] is False and d["config"]["kernel"] == "none"
+
+
+def test_multi_gpu_path_in_a_one_rank_group(built):
+    """The N > 1 code path -- RCCL process group, pod-row shards, the all-gather of the bindings behind the C ABI, ksched_pipe -- in a
+    ONE-rank group (KSCHED_BENCH_FORCE_DIST=1; all a one-GPU box can run): the line carries the gather cadence and its two reference
+    points, and the strong-scaling leg of configs[3]."""
+    d = run_bench("--steps", "20", "--warmup", "5", "--ramp-ms", "5", "--kernel-samples", "8", "--no-cpu-baseline",
+                  env={"KSCHED_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    c = d["config"]
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and c["pods_per_gpu"] == 100_000 and c["nodes"] == 5_000  # the same workload at every N
+    assert c["steps_per_allgather"] == 4 and c["steps_in_flight"] >= 2 and c["allgather"].startswith("ksched_allgather_bindings")
+    for leg in ("allgather_every_step", "no_allgather"):
+        assert c[leg] and c[leg]["ms_per_step"] > 0, leg
+    assert 0.3 < c["scaling_efficiency_vs_no_allgather"] < 1.3
+    s = c["configs3_strong"]
+    assert s and "error" not in s and s["pods_total"] == 1_000_000 and s["nodes"] == 10_000 and s["value"] > 1e12
+    assert 0.05 < c["bound_fraction"] < 1.0
