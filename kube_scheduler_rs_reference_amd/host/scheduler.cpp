@@ -1,5 +1,9 @@
 #include "scheduler.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <atomic>
 #include <thread>
@@ -167,7 +171,10 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
         pending.push_back(pods[i]);
         where.push_back(i);
     }
+    const bool timing = std::getenv("KSCHED_HOST_TIMING") != nullptr;  // (tools/host_loop.py: where a batch's host time goes, to stderr)
+    const auto t0 = std::chrono::steady_clock::now();
     const BatchSelection sel = select_nodes_for_pods(pending, ctx, chooser);
+    const auto t1 = std::chrono::steady_clock::now();
     std::vector<const corev1::Node *> chosen(pending.size(), nullptr);
     for (size_t j = 0; j < pending.size(); ++j)
         if (sel.node_store_index[j] >= 0) chosen[j] = &ctx.node_store[(size_t)sel.node_store_index[j]];
@@ -177,6 +184,7 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
         out[where[j]] = posted[j];
         if (out[where[j]].ok && out[where[j]].bound_to) landed.emplace_back(pending[j], &*out[where[j]].bound_to);  // (`out` is not resized any more)
     }
+    const auto t2 = std::chrono::steady_clock::now();
     // The whole batch was evaluated against ONE snapshot (the reference's racing reconciles all see the same API-server state).
     // The bindings it created then count against their nodes for the NEXT batch -- the reference gets that from re-LISTing on
     // every evaluation (src/predicates.rs:34-38); here the snapshot is patched in one device update.
@@ -191,6 +199,12 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
         } catch (const EncodeError &) {
             if (!ctx.snapshot->device_stale()) ctx.snapshot.reset();
         }
+    }
+    if (timing) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "reconcile_batch %zu pods: draws + encode + device %.2f ms, bindings (POST) %.2f ms, snapshot update %.2f ms\n", pending.size(), ms(t0, t1),
+                     ms(t1, t2), ms(t2, t3));
     }
     return out;
 }

@@ -268,8 +268,19 @@ int main(int argc, char **argv) {
                 sink += (uint64_t)pc.req_cpu_milli[pc.p / 2];
             }
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (double)reps;
-            std::printf("{\"pods\":%zu,\"nodes\":%u,\"rebuild_seconds\":%.6f,\"encode_seconds\":%.6f,\"pods_per_second\":%.0f,\"check\":%llu}\n", pp.size(), snap.n(),
-                        rebuild_s, sec, (double)pp.size() / sec, (unsigned long long)sink);
+            // the snapshot update of a batch's bindings (observe_bound): every second pod bound to node (i mod n), then the same again (echo: nothing changes)
+            std::vector<std::pair<const corev1::Pod *, const std::string *>> bound;
+            const NodeColumns &nc = snap.columns();
+            for (size_t i = 0; i < pp.size(); i += 2) bound.emplace_back(pp[i], &nc.names[i % nc.n]);
+            const auto u0 = std::chrono::steady_clock::now();
+            const size_t changed = snap.observe_bound(bound);
+            const double upd = std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
+            const auto u1 = std::chrono::steady_clock::now();
+            const size_t echoed = snap.observe_bound(bound);
+            const double echo = std::chrono::duration<double>(std::chrono::steady_clock::now() - u1).count();
+            std::printf("{\"pods\":%zu,\"nodes\":%u,\"rebuild_seconds\":%.6f,\"encode_seconds\":%.6f,\"pods_per_second\":%.0f,\"observe_bound_seconds\":%.6f,\"observed\":%zu,"
+                        "\"echo_seconds\":%.6f,\"echo_changed\":%zu,\"check\":%llu}\n", pp.size(), snap.n(), rebuild_s, sec, (double)pp.size() / sec, upd, changed, echo, echoed,
+                        (unsigned long long)sink);
             return 0;
         }
         if (mode == "events") {
