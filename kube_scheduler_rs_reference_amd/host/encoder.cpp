@@ -1,12 +1,20 @@
 #include "encoder.hpp"
 
+#include <cstdlib>
 #include <optional>
+#include <string_view>
 
 #include <algorithm>
 #include <numeric>
 #include <thread>
 
 namespace ksched_host {
+
+// worker threads for the per-pod string work (KSCHED_HOST_THREADS overrides the hardware's count: 1 = everything on the caller's thread)
+static uint32_t host_threads() {
+    if (const char *e = std::getenv("KSCHED_HOST_THREADS")) return std::max(1u, (uint32_t)std::strtoul(e, nullptr, 0));
+    return std::max(1u, std::thread::hardware_concurrency());
+}
 
 DeviceEvaluator::DeviceEvaluator(int device) {
     int rc = ksched_create(&h_, device);
@@ -280,7 +288,7 @@ size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
             }
         }
     };
-    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t hw = host_threads();
     const uint32_t nthreads = events.size() >= 4096 ? std::min<uint32_t>({hw, 32u, (uint32_t)(events.size() / 1024)}) : 1u;
     if (nthreads <= 1) {
         prepare(0, events.size());
@@ -290,25 +298,27 @@ size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
             pool.emplace_back([&, t] { prepare(events.size() * t / nthreads, events.size() * (t + 1) / nthreads); });
         for (auto &th : pool) th.join();
     }
-    std::unordered_map<std::string, std::optional<Counted>> staged;  // key -> its entry after these events (nullopt = not counted)
+    // key -> its entry after these events (nullopt = not counted).  The keys are views into `pre` (not resized any more): no string
+    // is copied until the commit.
+    std::unordered_map<std::string_view, std::optional<Counted>> staged;
     staged.reserve(events.size());
     std::map<uint32_t, std::pair<__int128, __int128>> delta;         // node -> change of available (cpu, mem) in nano-units
-    auto current = [&](const std::string &key) -> std::optional<Counted> {
-        auto st = staged.find(key);
+    auto current = [&](const Pre &p) -> std::optional<Counted> {
+        auto st = staged.find(std::string_view(p.key));
         if (st != staged.end()) return st->second;
-        auto it = counted_.find(key);
+        auto it = counted_.find(p.key);
         if (it == counted_.end()) return std::nullopt;
         return it->second;
     };
     size_t changed = 0;
     for (size_t i = 0; i < events.size(); ++i) {
-        Pre &p = pre[i];
-        const std::optional<Counted> was = current(p.key);
+        const Pre &p = pre[i];
+        const std::optional<Counted> was = current(p);
         if (p.idx < 0) {  // deleted, not bound, or bound to a node this snapshot does not hold: counted nowhere from now on
             if (!was) continue;
             delta[was->node].first += was->cpu_nanos;
             delta[was->node].second += was->mem_nanos;
-            staged[std::move(p.key)] = std::nullopt;
+            staged[std::string_view(p.key)] = std::nullopt;
             ++changed;
             continue;
         }
@@ -321,7 +331,7 @@ size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
         }
         delta[now.node].first -= now.cpu_nanos;
         delta[now.node].second -= now.mem_nanos;
-        staged[std::move(p.key)] = now;
+        staged[std::string_view(p.key)] = now;
         ++changed;
     }
     std::vector<uint32_t> touched;
@@ -337,9 +347,10 @@ size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
         touched.push_back(node);
         fresh.emplace_back((int64_t)cpu, (int64_t)mem);
     }
+    counted_.reserve(counted_.size() + staged.size());
     for (auto &[key, entry] : staged) {  // commit
-        if (entry) counted_[key] = *entry;
-        else counted_.erase(key);
+        if (entry) counted_.insert_or_assign(std::string(key), *entry);
+        else counted_.erase(std::string(key));
     }
     for (size_t i = 0; i < touched.size(); ++i) {
         cols_.avail_cpu_milli[touched[i]] = fresh[i].first;
@@ -424,7 +435,7 @@ PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
     };
     // The wire-format step is per-pod string work (quantity parsing, dictionary lookups): for a large batch it is what the host
     // spends its time on, and the pods are independent -- fan it out over threads (each writes only its own rows).
-    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t hw = host_threads();
     const uint32_t nthreads = pc.p >= 4096u ? std::min<uint32_t>({hw, 32u, pc.p / 1024u}) : 1u;
     if (nthreads <= 1) {
         encode_range(0, pc.p);

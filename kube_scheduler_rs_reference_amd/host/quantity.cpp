@@ -7,10 +7,29 @@ namespace ksched_host {
 
 namespace {
 
-// 10^e as a 128-bit integer with overflow detection
+// v *= 10^e with overflow detection (one multiplication: the powers up to 10^38 fit 128 bits)
 bool scale10(__int128 &v, int e) {
-    for (; e > 0; --e)
-        if (__builtin_mul_overflow(v, (__int128)10, &v)) return false;
+    static const struct Pow10 {
+        __int128 p[39];
+        Pow10() {
+            p[0] = 1;
+            for (int i = 1; i < 39; ++i) p[i] = p[i - 1] * 10;
+        }
+    } t;
+    if (e <= 0) return true;
+    if (e > 38) return v == 0;
+    return !__builtin_mul_overflow(v, t.p[e], &v);
+}
+// v /= 10^e, exactly: false when a non-zero digit would be dropped
+bool unscale10(__int128 &v, int e) {
+    for (; e > 18; e -= 18) {
+        if (v % (__int128)1000000000000000000ll != 0) return false;
+        v /= (__int128)1000000000000000000ll;
+    }
+    static const int64_t p[19] = {1ll, 10ll, 100ll, 1000ll, 10000ll, 100000ll, 1000000ll, 10000000ll, 100000000ll, 1000000000ll, 10000000000ll, 100000000000ll,
+                                  1000000000000ll, 10000000000000ll, 100000000000000ll, 1000000000000000ll, 10000000000000000ll, 100000000000000000ll, 1000000000000000000ll};
+    if (v % (__int128)p[e] != 0) return false;
+    v /= (__int128)p[e];
     return true;
 }
 
@@ -53,11 +72,17 @@ ParsedQuantity ParsedQuantity::try_from(const std::string &text) {
     bool neg = false;
     if (i < text.size() && (text[i] == '+' || text[i] == '-')) neg = text[i++] == '-';
     __int128 mant = 0;
+    uint64_t m64 = 0;  // the mantissa while it has at most 18 digits (no overflow possible): nearly every quantity of a real spec
     int digits = 0, frac = 0;
     auto eat = [&](bool fractional) {
-        while (i < text.size() && std::isdigit((unsigned char)text[i])) {
-            if (__builtin_mul_overflow(mant, (__int128)10, &mant) || __builtin_add_overflow(mant, (__int128)(text[i] - '0'), &mant))
-                throw bad("mantissa too large");
+        while (i < text.size() && (unsigned)(text[i] - '0') < 10u) {
+            const unsigned d = (unsigned)(text[i] - '0');
+            if (digits < 18) {
+                m64 = m64 * 10u + d;
+            } else {
+                if (digits == 18) mant = (__int128)m64;
+                if (__builtin_mul_overflow(mant, (__int128)10, &mant) || __builtin_add_overflow(mant, (__int128)d, &mant)) throw bad("mantissa too large");
+            }
             ++digits;
             if (fractional) ++frac;
             ++i;
@@ -68,26 +93,29 @@ ParsedQuantity ParsedQuantity::try_from(const std::string &text) {
         ++i;
         eat(true);
     }
+    if (digits <= 18) mant = (__int128)m64;
     if (digits == 0) throw bad("no digits");
-    const std::string suf = text.substr(i);
+    const char *const suf = text.data() + i;  // (no copy of the suffix)
+    const size_t nsuf = text.size() - i;
+    auto isdig = [](char c) { return (unsigned)(c - '0') < 10u; };
     int exp10 = 0, shift = 0;
-    if (suf.empty()) {
-    } else if ((suf[0] == 'e' || suf[0] == 'E') && suf.size() > 1 && (std::isdigit((unsigned char)suf[1]) || suf[1] == '+' || suf[1] == '-')) {
+    if (nsuf == 0) {
+    } else if ((suf[0] == 'e' || suf[0] == 'E') && nsuf > 1 && (isdig(suf[1]) || suf[1] == '+' || suf[1] == '-')) {
         size_t j = 1;
         bool eneg = false;
         if (suf[j] == '+' || suf[j] == '-') eneg = suf[j++] == '-';
-        if (j >= suf.size()) throw bad("empty exponent");
+        if (j >= nsuf) throw bad("empty exponent");
         int ev = 0;
-        for (; j < suf.size(); ++j) {
-            if (!std::isdigit((unsigned char)suf[j])) throw bad("bad exponent");
+        for (; j < nsuf; ++j) {
+            if (!isdig(suf[j])) throw bad("bad exponent");
             ev = ev * 10 + (suf[j] - '0');
             if (ev > 100) throw bad("exponent too large");
         }
         exp10 = eneg ? -ev : ev;
-    } else if (suf.size() == 2 && suf[1] == 'i') {
+    } else if (nsuf == 2 && suf[1] == 'i') {
         shift = binary_suffix(suf[0]);
         if (!shift) throw bad("unknown binary suffix");
-    } else if (suf.size() == 1) {
+    } else if (nsuf == 1) {
         bool ok;
         exp10 = decimal_suffix(suf[0], ok);
         if (!ok) throw bad("unknown suffix");
@@ -96,12 +124,9 @@ ParsedQuantity ParsedQuantity::try_from(const std::string &text) {
     }
     __int128 v = mant;
     if (shift && __builtin_mul_overflow(v, ((__int128)1) << shift, &v)) throw bad("out of range");
-    int scale = 9 + exp10 - frac;
+    const int scale = 9 + exp10 - frac;
     if (scale > 0 && !scale10(v, scale)) throw bad("out of range");
-    for (; scale < 0; ++scale) {
-        if (v % 10 != 0) throw bad("finer than one nano-unit");
-        v /= 10;
-    }
+    if (scale < 0 && v != 0 && !unscale10(v, -scale)) throw bad("finer than one nano-unit");
     ParsedQuantity q;
     q.nanos_ = neg ? -v : v;
     return q;
