@@ -392,8 +392,24 @@ int Snapshot::index_of(const std::string &node_name) const {
 }
 
 PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
+    // the batch's selector keys: every worker collects its range's (a handful of distinct strings), merged afterwards -- one serial
+    // walk over 100 k pods inserting into one set was a third of this call's time
+    const uint32_t hw0 = host_threads();
+    const uint32_t kthreads = pods.size() >= 4096 ? std::min<uint32_t>({hw0, 32u, (uint32_t)(pods.size() / 1024)}) : 1u;
+    std::vector<std::set<std::string>> part(std::max(1u, kthreads));
+    auto collect = [&](uint32_t t) {
+        const size_t lo = pods.size() * t / part.size(), hi = pods.size() * (t + 1) / part.size();
+        for (size_t i = lo; i < hi; ++i) selector_keys(*pods[i], part[t]);
+    };
+    if (kthreads <= 1) {
+        collect(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < kthreads; ++t) pool.emplace_back(collect, t);
+        for (auto &th : pool) th.join();
+    }
     std::set<std::string> keys;
-    for (const auto *p : pods) selector_keys(*p, keys);
+    for (auto &s : part) keys.insert(s.begin(), s.end());
     ensure_keys(keys);
 
     PodColumns pc;

@@ -135,22 +135,20 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
     size_t lo = 0;
     std::set<std::string> keys;
     for (size_t i = 0; i < pods.size(); ++i) {
-        std::set<std::string> mine;
-        Snapshot::selector_keys(*pods[i], mine);
-        if (mine.size() > KSCHED_MAX_KEYS)
-            throw EncodeError("pod " + full_name(pods[i]->metadata) + ": more than KSCHED_MAX_KEYS nodeSelector keys on one pod");
-        bool adds = false;
-        for (const auto &k : mine) adds |= keys.find(k) == keys.end();
-        if (!adds) continue;  // (the common case: no set is copied)
-        std::set<std::string> merged = keys;
-        merged.insert(mine.begin(), mine.end());
-        if (merged.size() > KSCHED_MAX_KEYS) {
+        const corev1::Pod &pod = *pods[i];
+        if (!pod.spec || !pod.spec->node_selector || pod.spec->node_selector->empty()) continue;  // (most pods: nothing is built for them)
+        const auto &selector = *pod.spec->node_selector;  // (a map: its keys are distinct)
+        if (selector.size() > KSCHED_MAX_KEYS)
+            throw EncodeError("pod " + full_name(pod.metadata) + ": more than KSCHED_MAX_KEYS nodeSelector keys on one pod");
+        size_t adds = 0;
+        for (const auto &kv : selector) adds += keys.find(kv.first) == keys.end() ? 1u : 0u;
+        if (!adds) continue;
+        if (keys.size() + adds > KSCHED_MAX_KEYS) {
             eval_range(snap, pods, lo, i, pick, samples, attempts, out, want_masks);
             lo = i;
-            keys = mine;
-        } else {
-            keys.swap(merged);
+            keys.clear();
         }
+        for (const auto &kv : selector) keys.insert(kv.first);
     }
     eval_range(snap, pods, lo, pods.size(), pick, samples, attempts, out, want_masks);
     return out;
