@@ -300,12 +300,47 @@ size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
     }
     // key -> its entry after these events (nullopt = not counted).  The keys are views into `pre` (not resized any more): no string
     // is copied until the commit.
-    std::unordered_map<std::string_view, std::optional<Counted>> staged;
+    struct Staged {
+        std::optional<Counted> entry;
+        size_t last = 0;  // the latest event of this key: its string is MOVED into the bookkeeping at the commit
+    };
+    std::unordered_map<std::string_view, Staged> staged;
     staged.reserve(events.size());
-    std::map<uint32_t, std::pair<__int128, __int128>> delta;         // node -> change of available (cpu, mem) in nano-units
+    // node -> change of available (cpu, mem) in nano-units: a dense table for a batch's worth of events, a map for the watch's single ones
+    struct Delta {
+        bool dense;
+        std::vector<std::pair<__int128, __int128>> tab;
+        std::vector<uint8_t> seen;
+        std::vector<uint32_t> nodes;
+        std::map<uint32_t, std::pair<__int128, __int128>> sparse;
+        std::pair<__int128, __int128> &operator[](uint32_t node) {
+            if (!dense) return sparse[node];
+            if (!seen[node]) {
+                seen[node] = 1;
+                nodes.push_back(node);
+            }
+            return tab[node];
+        }
+        // (node, change) in ascending node order
+        std::vector<std::pair<uint32_t, std::pair<__int128, __int128>>> sorted() {
+            std::vector<std::pair<uint32_t, std::pair<__int128, __int128>>> out;
+            if (!dense) {
+                out.assign(sparse.begin(), sparse.end());
+            } else {
+                std::sort(nodes.begin(), nodes.end());
+                for (uint32_t node : nodes) out.emplace_back(node, tab[node]);
+            }
+            return out;
+        }
+    } delta;
+    delta.dense = events.size() >= 64 && cols_.n <= (1u << 22);
+    if (delta.dense) {
+        delta.tab.assign(cols_.n, {0, 0});
+        delta.seen.assign(cols_.n, 0);
+    }
     auto current = [&](const Pre &p) -> std::optional<Counted> {
         auto st = staged.find(std::string_view(p.key));
-        if (st != staged.end()) return st->second;
+        if (st != staged.end()) return st->second.entry;
         auto it = counted_.find(p.key);
         if (it == counted_.end()) return std::nullopt;
         return it->second;
@@ -318,7 +353,7 @@ size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
             if (!was) continue;
             delta[was->node].first += was->cpu_nanos;
             delta[was->node].second += was->mem_nanos;
-            staged[std::string_view(p.key)] = std::nullopt;
+            staged[std::string_view(p.key)] = Staged{std::nullopt, i};
             ++changed;
             continue;
         }
@@ -331,12 +366,12 @@ size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
         }
         delta[now.node].first -= now.cpu_nanos;
         delta[now.node].second -= now.mem_nanos;
-        staged[std::string_view(p.key)] = now;
+        staged[std::string_view(p.key)] = Staged{now, i};
         ++changed;
     }
     std::vector<uint32_t> touched;
     std::vector<std::pair<int64_t, int64_t>> fresh;
-    for (const auto &[node, d] : delta) {
+    for (const auto &[node, d] : delta.sorted()) {
         if (d.first == 0 && d.second == 0) continue;
         constexpr __int128 kMilli = 1000000, kUnit = 1000000000;
         if (d.first % kMilli != 0 || d.second % kUnit != 0)
@@ -348,9 +383,9 @@ size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
         fresh.emplace_back((int64_t)cpu, (int64_t)mem);
     }
     counted_.reserve(counted_.size() + staged.size());
-    for (auto &[key, entry] : staged) {  // commit
-        if (entry) counted_.insert_or_assign(std::string(key), *entry);
-        else counted_.erase(std::string(key));
+    for (auto &[key, st] : staged) {  // commit (no lookup in `staged` after this: its keys are views into the strings moved here)
+        if (st.entry) counted_.insert_or_assign(std::move(pre[st.last].key), *st.entry);
+        else counted_.erase(pre[st.last].key);
     }
     for (size_t i = 0; i < touched.size(); ++i) {
         cols_.avail_cpu_milli[touched[i]] = fresh[i].first;
