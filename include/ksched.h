@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define KSCHED_ABI_VERSION 3u
+#define KSCHED_ABI_VERSION 4u
 
 /* at most this many label-key columns per batch */
 #define KSCHED_MAX_KEYS 32u
@@ -153,6 +153,8 @@ int ksched_create(ksched_ctx **out, int device_id);
 void ksched_destroy(ksched_ctx *ctx);
 
 uint32_t ksched_abi_version(void);
+/* HIP devices the process sees (0 when there is none or the runtime cannot be initialised): what a host checks $KSCHED_DEVICES against */
+int ksched_device_count(void);
 const char *ksched_strerror(int code);
 /* text of the last HIP failure on this ctx (empty string if none); valid until the next call */
 const char *ksched_last_error(const ksched_ctx *ctx);
@@ -216,6 +218,44 @@ int ksched_eval(ksched_ctx *ctx, uint32_t p, const int64_t *req_cpu_milli, const
                 const uint32_t *sel_val_ids, const uint64_t *tolerations, const uint32_t *samples,
                 uint32_t attempts, uint32_t flags, uint64_t *out_feasible, uint64_t *out_fit,
                 int32_t *out_binding);
+
+/* ---- one host thread, several devices: ksched_eval in two halves ---------------------------------
+ * north_star: "the pod batch row-shards across the 8 GPUs of one node with an RCCL allgather of the resulting (pod -> node)
+ * bindings".  The reference is ONE process (src/main.rs:127-152); a drop-in host therefore drives n devices from one thread: one
+ * ksched_ctx per device, the node snapshot replicated to all of them (ksched_set_nodes / ksched_update_nodes on each), the batch's
+ * pod rows cut with ksched_shard_bounds, and per batch
+ *     for every device r : ksched_eval_begin(ctx[r], rows [lo_r, hi_r) ...)      copies in + evaluation enqueued, NO host wait
+ *     ksched_allgather_bindings_local(comms, n, local[], gathered[], count_per_rank, streams[])
+ *     ksched_eval_end(ctx[0], gathered[0], n * count_per_rank, host_table)       one copy of the whole table, one host wait
+ *     ksched_eval_end(ctx[r], NULL, 0, NULL) for the others                      (their masks, if asked for, have landed)
+ * host_table[r * count_per_rank + i] is the binding of pod row lo_r + i (rows past a shard's end are -1).
+ * (kube_scheduler_rs_reference_amd/host/sharded.cpp and rust/src/ksched.rs `ShardedEvaluator` are this loop.)
+ *
+ * ksched_shard_bounds   the one definition of the row split: rank r owns rows [lo, hi) = [r * c, min(p, (r + 1) * c)),
+ *                       c = count_per_rank = ceil(p / nranks); the last ranks may own fewer rows, or none.  Pure arithmetic.
+ * ksched_eval_begin     ksched_eval without its last two steps (the copy of the bindings to the host, the host wait):
+ *                       host pointers as in ksched_eval, for THIS ctx's rows only; `sel_val_ids` may point INTO the whole batch's
+ *                       [n_keys][sel_stride] array (sel_val_ids = all + lo, sel_stride = P: column k of the shard starts
+ *                       sel_stride entries after column k - 1's; sel_stride = p for a packed array).  Masks, when asked for, are
+ *                       copied to out_feasible / out_fit ([p][W], packed) behind the evaluation on the same stream: they are
+ *                       complete after ksched_eval_end.  With a pick the bindings stay ON THE DEVICE in a ctx-owned buffer of
+ *                       max(p, binding_capacity) int32 -- entries [p, binding_capacity) are -1, the padding the all-gather of
+ *                       unequal shards needs -- returned through *binding_dev; *hip_stream is the ctx's own stream, where all of
+ *                       this was enqueued (pass both to ksched_allgather_bindings*).  p = 0 is allowed (an empty shard still
+ *                       takes part in the exchange).  The input arrays may be reused when the call returns only if they are
+ *                       pageable memory (the runtime stages them); pinned arrays must stay untouched until ksched_eval_end.
+ *                       Buffers are valid until the next ksched_eval / ksched_eval_begin on the ctx.
+ * ksched_gather_buffer  a ctx-owned device buffer of `count` int32 for the gathered table (grown on demand, reused).
+ * ksched_eval_end       enqueue the copy of `count` int32 from `bindings_dev` (any device pointer: the gathered table, or
+ *                       *binding_dev itself) to `out_host` on the ctx's stream -- skipped when out_host is NULL -- and wait for
+ *                       the stream. */
+void ksched_shard_bounds(uint32_t p, uint32_t nranks, uint32_t rank, uint32_t *lo, uint32_t *hi, uint32_t *count_per_rank);
+int ksched_eval_begin(ksched_ctx *ctx, uint32_t p, const int64_t *req_cpu_milli, const int64_t *req_mem_bytes,
+                      const uint32_t *sel_val_ids, uint32_t sel_stride, const uint64_t *tolerations, const uint32_t *samples,
+                      uint32_t attempts, uint32_t flags, uint64_t *out_feasible, uint64_t *out_fit, uint32_t binding_capacity,
+                      int32_t **binding_dev, void **hip_stream);
+int ksched_gather_buffer(ksched_ctx *ctx, uint32_t count, int32_t **dev);
+int ksched_eval_end(ksched_ctx *ctx, const int32_t *bindings_dev, uint32_t count, int32_t *out_host);
 
 /* ---- evaluation, device buffers -----------------------------------------------------------
  * Same contract with every array already resident in HBM.  out_feasible may be NULL only when

@@ -14,7 +14,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KSCHED_LIB") or os.path.join(_PKG_DIR, "libksched_hip.so")
 
 # --- constants mirrored from include/ksched.h --------------------------------------------------
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_KEYS = 32
 MAX_ATTEMPTS = 64
 SEL_NEVER = 0xFFFFFFFF
@@ -65,6 +65,7 @@ SYMBOLS = {
     "ksched_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "ksched_destroy": (None, [_vp]),
     "ksched_abi_version": (_u32, []),
+    "ksched_device_count": (C.c_int, []),
     "ksched_strerror": (C.c_char_p, [C.c_int]),
     "ksched_last_error": (C.c_char_p, [_vp]),
     "ksched_mask_words": (_u32, [_u32]),
@@ -75,6 +76,10 @@ SYMBOLS = {
     "ksched_num_nodes": (_u32, [_vp]),
     "ksched_num_keys": (_u32, [_vp]),
     "ksched_eval": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "ksched_shard_bounds": (None, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "ksched_eval_begin": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp)]),
+    "ksched_gather_buffer": (C.c_int, [_vp, _u32, C.POINTER(_vp)]),
+    "ksched_eval_end": (C.c_int, [_vp, _vp, _u32, _vp]),
     "ksched_eval_device": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "ksched_eval_device_pitched": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     "ksched_mask_pitch": (_u32, [_u32]),

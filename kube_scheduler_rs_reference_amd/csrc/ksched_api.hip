@@ -126,6 +126,7 @@ struct ksched_ctx {
     DevBuf<uint32_t> psel, psamples;
     DevBuf<uint64_t> ptol, feas, fit;
     DevBuf<int32_t> binding;
+    DevBuf<int32_t> gathered;  // ksched_gather_buffer: the all-gathered binding table of a host that drives several devices
     DevBuf<uint32_t> xpairs;  // ksched_explain: [pair_pod][pair_node]
     DevBuf<int32_t> xreason;
     // scratch mask when a pick is requested without an output mask
@@ -1010,6 +1011,11 @@ extern "C" {
 
 uint32_t ksched_abi_version(void) { return KSCHED_ABI_VERSION; }
 
+int ksched_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 uint32_t ksched_mask_words(uint32_t n_nodes) { return (uint32_t)(((uint64_t)n_nodes + 63u) / 64u); }
 
 const char *ksched_strerror(int code) {
@@ -1059,7 +1065,7 @@ void ksched_destroy(ksched_ctx *c) try {
         c->ncpu.release(); c->nmem.release(); c->nrec.release(); c->nlab.release(); c->ntaint.release();
         c->bf_order.release(); c->bf_rank.release(); c->bf_mem.release(); c->bf_cpu.release(); c->cpu_sorted.release(); c->bf_rows.release(); c->bf_samples.release(); c->bf_levels.release(); c->bf_fallback.release(); c->bf_fallback_zeroed_cap = 0;
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
-        c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release(); c->xpairs.release(); c->xreason.release();
+        c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release(); c->gathered.release(); c->xpairs.release(); c->xreason.release();
         c->scratch_mask.release(); c->trace.release();
         c->by_cpu.release(); c->cpurank.release(); c->iota.release(); c->sort_keys.release(); c->sort_tmp.release(); c->d_stage.release();
         if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -1506,23 +1512,29 @@ int ksched_pick_device(ksched_ctx *c, uint32_t p, const uint64_t *feasible, uint
     return launch_pick(c, p, feasible, mask_pitch_words, req_mem_bytes, samples, attempts, flags, out_binding, s);
 } KSCHED_ABI_CATCH(c)
 
-int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
-                const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, uint64_t *out_feas,
-                uint64_t *out_fit, int32_t *out_binding) try {
-    if (!c) return KSCHED_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu);
-    if (!c->have_nodes) return KSCHED_E_STATE;
-    int rc = check_eval_args(c, p, pcpu, pmem, samples, attempts, flags, out_feas, out_fit, out_binding);
-    if (rc) return rc;
-    if (p == 0) return KSCHED_OK;
-    DeviceGuard g(c->device);
-    if (!g.ok) return KSCHED_E_HIP;
+// ---- the host-pointer evaluation in two halves (include/ksched.h "one host thread, several devices") -------------------------
+// eval_begin_locked: copy the batch in, enqueue the evaluation and the copies of the masks back -- all on the ctx's own stream, no
+// host wait.  The bindings stay in a ctx-owned device buffer of `capacity` >= p entries; entries [p, capacity) are -1 (the padding
+// an all-gather of unequal shards needs).  The caller holds the ctx's mutex and has checked the arguments.
+namespace {
+int eval_begin_locked(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel, uint32_t sel_stride,
+                      const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, uint64_t *out_feas,
+                      uint64_t *out_fit, uint32_t capacity, int32_t **binding_dev) {
     hipStream_t s = c->stream;
     const size_t W = c->W;
     const size_t pitch = ksched_mask_pitch(c->n);
     const bool pick = flags & (KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT);
     const bool use_sel = (flags & KSCHED_SEL) && psel && c->nkeys > 0;
     const bool use_tol = (flags & KSCHED_TAINT) && ptol;
+    int32_t *d_bind = nullptr;
+    if (pick) {
+        const size_t cap = std::max<size_t>(capacity, p);
+        HIPCHK(c, c->binding.reserve(cap));
+        d_bind = c->binding.ptr;
+        if (cap > p) HIPCHK(c, hipMemsetAsync(d_bind + p, 0xFF, (cap - p) * sizeof(int32_t), s));  // -1: "no node" rows past this shard's end
+    }
+    if (binding_dev) *binding_dev = d_bind;
+    if (p == 0) return KSCHED_OK;  // (a rank whose shard is empty still takes part in the exchange with `capacity` rows of -1)
 
     HIPCHK(c, c->pcpu.reserve(p));
     HIPCHK(c, c->pmem.reserve(p));
@@ -1530,7 +1542,10 @@ int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *p
     HIPCHK(c, hipMemcpyAsync(c->pmem.ptr, pmem, (size_t)p * 8, hipMemcpyHostToDevice, s));
     if (use_sel) {
         HIPCHK(c, c->psel.reserve((size_t)p * c->nkeys));
-        HIPCHK(c, hipMemcpyAsync(c->psel.ptr, psel, (size_t)p * c->nkeys * 4, hipMemcpyHostToDevice, s));
+        if (sel_stride == p)
+            HIPCHK(c, hipMemcpyAsync(c->psel.ptr, psel, (size_t)p * c->nkeys * 4, hipMemcpyHostToDevice, s));
+        else  // rows [lo, lo + p) of a [n_keys][sel_stride] array: column k of the shard starts sel_stride entries after column k - 1's
+            HIPCHK(c, hipMemcpy2DAsync(c->psel.ptr, (size_t)p * 4, psel, (size_t)sel_stride * 4, (size_t)p * 4, c->nkeys, hipMemcpyHostToDevice, s));
     }
     if (use_tol) {
         HIPCHK(c, c->ptol.reserve(p));
@@ -1541,7 +1556,6 @@ int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *p
         HIPCHK(c, hipMemcpyAsync(c->psamples.ptr, samples, (size_t)p * attempts * 4, hipMemcpyHostToDevice, s));
     }
     uint64_t *d_feas = nullptr, *d_fit = nullptr;
-    int32_t *d_bind = nullptr;
     // a mask is needed when the caller wants it, or when the pick reads it (best fit; sampled only with KSCHED_OPT_PICK_FROM_MASK)
     const bool pick_reads_mask = (flags & (KSCHED_PICK_BESTFIT | KSCHED_PICK_SAMPLED)) &&
                                  (c->opt_pick_from_mask || ((flags & KSCHED_PICK_BESTFIT) && !bf_rows_expected(c)));
@@ -1553,20 +1567,87 @@ int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *p
         HIPCHK(c, c->fit.reserve((size_t)p * pitch));
         d_fit = c->fit.ptr;
     }
-    if (pick) {
-        HIPCHK(c, c->binding.reserve(p));
-        d_bind = c->binding.ptr;
-    }
-    rc = eval_on_device(c, p, c->pcpu.ptr, c->pmem.ptr, use_sel ? c->psel.ptr : nullptr, use_tol ? c->ptol.ptr : nullptr,
-                        c->psamples.ptr, attempts, flags, d_feas, d_fit, d_bind, (uint32_t)pitch, s);
+    int rc = eval_on_device(c, p, c->pcpu.ptr, c->pmem.ptr, use_sel ? c->psel.ptr : nullptr, use_tol ? c->ptol.ptr : nullptr,
+                            c->psamples.ptr, attempts, flags, d_feas, d_fit, d_bind, (uint32_t)pitch, s);
     if (rc) return rc;
     // device rows are line-aligned (pitch words apart); the caller's rows are packed (W words)
     if (out_feas && W)
         HIPCHK(c, hipMemcpy2DAsync(out_feas, W * 8, d_feas, pitch * 8, W * 8, p, hipMemcpyDeviceToHost, s));
     if (out_fit && W)
         HIPCHK(c, hipMemcpy2DAsync(out_fit, W * 8, d_fit, pitch * 8, W * 8, p, hipMemcpyDeviceToHost, s));
-    if (pick && out_binding) HIPCHK(c, hipMemcpyAsync(out_binding, d_bind, (size_t)p * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    return KSCHED_OK;
+}
+}  // namespace
+
+int ksched_eval(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
+                const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, uint64_t *out_feas,
+                uint64_t *out_fit, int32_t *out_binding) try {
+    if (!c) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_nodes) return KSCHED_E_STATE;
+    int rc = check_eval_args(c, p, pcpu, pmem, samples, attempts, flags, out_feas, out_fit, out_binding);
+    if (rc) return rc;
+    if (p == 0) return KSCHED_OK;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    int32_t *d_bind = nullptr;
+    rc = eval_begin_locked(c, p, pcpu, pmem, psel, p, ptol, samples, attempts, flags, out_feas, out_fit, p, &d_bind);
+    if (rc) return rc;
+    if (d_bind && out_binding) HIPCHK(c, hipMemcpyAsync(out_binding, d_bind, (size_t)p * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSCHED_OK;
+} KSCHED_ABI_CATCH(c)
+
+void ksched_shard_bounds(uint32_t p, uint32_t nranks, uint32_t rank, uint32_t *lo, uint32_t *hi, uint32_t *count_per_rank) {
+    // rank r owns pod rows [r * shard, min(p, (r + 1) * shard)), shard = ceil(p / nranks): the last ranks may own fewer rows, or none
+    const uint64_t shard = nranks ? ((uint64_t)p + nranks - 1u) / nranks : p;
+    const uint64_t l = std::min<uint64_t>(p, shard * rank), h = std::min<uint64_t>(p, l + shard);
+    if (lo) *lo = (uint32_t)l;
+    if (hi) *hi = (uint32_t)h;
+    if (count_per_rank) *count_per_rank = (uint32_t)shard;
+}
+
+int ksched_eval_begin(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel, uint32_t sel_stride,
+                      const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, uint64_t *out_feas,
+                      uint64_t *out_fit, uint32_t binding_capacity, int32_t **binding_dev, void **hip_stream) try {
+    if (!c || !binding_dev || !hip_stream) return KSCHED_E_INVAL;
+    *binding_dev = nullptr;
+    *hip_stream = nullptr;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_nodes) return KSCHED_E_STATE;
+    if (psel && sel_stride < p) return KSCHED_E_INVAL;
+    int32_t sentinel = 0;  // (the bindings stay on the device: check_eval_args only wants to know that a pick has somewhere to go)
+    int rc = check_eval_args(c, p, pcpu, pmem, samples, attempts, flags, out_feas, out_fit,
+                             (flags & (KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT)) ? &sentinel : nullptr);
+    if (rc) return rc;
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    rc = eval_begin_locked(c, p, pcpu, pmem, psel, sel_stride, ptol, samples, attempts, flags, out_feas, out_fit, binding_capacity, binding_dev);
+    if (rc) return rc;
+    *hip_stream = (void *)c->stream;
+    return KSCHED_OK;
+} KSCHED_ABI_CATCH(c)
+
+int ksched_gather_buffer(ksched_ctx *c, uint32_t count, int32_t **dev) try {
+    if (!c || !dev) return KSCHED_E_INVAL;
+    *dev = nullptr;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    if (count > c->gathered.cap) HIPCHK(c, hipStreamSynchronize(c->stream));  // (growing frees the old table: nothing may still be reading it)
+    HIPCHK(c, c->gathered.reserve(count));
+    *dev = c->gathered.ptr;
+    return KSCHED_OK;
+} KSCHED_ABI_CATCH(c)
+
+int ksched_eval_end(ksched_ctx *c, const int32_t *bindings_dev, uint32_t count, int32_t *out_host) try {
+    if (!c) return KSCHED_E_INVAL;
+    if (count > 0 && out_host && !bindings_dev) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    if (count > 0 && out_host) HIPCHK(c, hipMemcpyAsync(out_host, bindings_dev, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return KSCHED_OK;
 } KSCHED_ABI_CATCH(c)
 

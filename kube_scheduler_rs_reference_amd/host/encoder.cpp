@@ -1,5 +1,7 @@
 #include "encoder.hpp"
 
+#include "sharded.hpp"
+
 #include <cstdlib>
 #include <optional>
 #include <string_view>
@@ -27,7 +29,25 @@ void DeviceEvaluator::check(int rc, const char *where) const {
 }
 
 Snapshot::Snapshot(int device) {
-    if (device != kEncodeOnly) dev_ = std::make_shared<DeviceEvaluator>(device);
+    if (device != kEncodeOnly) {
+        dev_ = std::make_shared<DeviceEvaluator>(device);
+        devs_.push_back(dev_);
+    }
+}
+
+Snapshot::Snapshot(const std::vector<int> &devices, bool force_sharded) {
+    if (devices.empty()) throw EncodeError("Snapshot: no device given");
+    for (int d : devices) devs_.push_back(std::make_shared<DeviceEvaluator>(d));
+    dev_ = devs_[0];
+    if (devs_.size() > 1 || force_sharded) sharded_ = std::make_unique<ShardedContext>(devs_);  // (throws when the RCCL communicator cannot be built)
+}
+
+Snapshot::~Snapshot() = default;  // (here, where ShardedContext is complete)
+
+ShardedContext *Snapshot::sharded() {
+    if (!sharded_) return nullptr;
+    if (device_stale_) upload();
+    return sharded_.get();
 }
 
 DeviceEvaluator &Snapshot::device() {
@@ -183,11 +203,12 @@ void Snapshot::encode_labels() {
 void Snapshot::upload() {
     ++generation_;
     if (!dev_) return;  // encode-only snapshot (host tests of the wire-format step)
-    device_stale_ = true;  // until the call below has succeeded: the host columns are ahead of the device
-    dev_->check(ksched_set_nodes(dev_->handle(), cols_.n, cols_.avail_cpu_milli.data(), cols_.avail_mem_bytes.data(),
-                                 cols_.n_keys ? cols_.label_val_ids.data() : nullptr, cols_.n_keys,
-                                 (taints_enabled_ && !taint_ids_.empty()) ? cols_.taints.data() : nullptr),
-                "ksched_set_nodes");
+    device_stale_ = true;  // until the calls below have succeeded: the host columns are ahead of the device(s)
+    for (const auto &d : devs_)  // replicated: every device holds the whole snapshot (<= 2.8 MB at configs[4]); the calls do not wait for the devices
+        d->check(ksched_set_nodes(d->handle(), cols_.n, cols_.avail_cpu_milli.data(), cols_.avail_mem_bytes.data(),
+                                  cols_.n_keys ? cols_.label_val_ids.data() : nullptr, cols_.n_keys,
+                                  (taints_enabled_ && !taint_ids_.empty()) ? cols_.taints.data() : nullptr),
+                 "ksched_set_nodes");
     device_stale_ = false;
 }
 
@@ -240,7 +261,7 @@ void Snapshot::push_rows(const std::vector<uint32_t> &touched) {
         cpu[i] = cols_.avail_cpu_milli[touched[i]];
         mem[i] = cols_.avail_mem_bytes[touched[i]];
     }
-    dev_->check(ksched_update_nodes(dev_->handle(), (uint32_t)touched.size(), touched.data(), cpu.data(), mem.data()), "ksched_update_nodes");
+    for (const auto &d : devs_) d->check(ksched_update_nodes(d->handle(), (uint32_t)touched.size(), touched.data(), cpu.data(), mem.data()), "ksched_update_nodes");
     device_stale_ = false;
 }
 

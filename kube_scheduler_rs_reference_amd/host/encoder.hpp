@@ -24,8 +24,9 @@ struct EncodeError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 // A POD of a batch cannot be encoded (unparsable requests, a value outside the exact integer domain -- where the reference's
-// .expect("invalid pod spec") panics, src/util.rs:65,68).  Thrown by Snapshot::encode_pods only, i.e. BEFORE anything of the
-// batch has been evaluated or POSTed: the one failure a batching caller may answer by retrying the batch's pods one at a time.
+// .expect("invalid pod spec") panics, src/util.rs:65,68), or a single pod names more than KSCHED_MAX_KEYS nodeSelector keys.  Thrown by
+// Snapshot::encode_pods and by check_node_validity_batch's key-budget walk only, i.e. BEFORE anything of the batch has been evaluated
+// or POSTed: the one failure a batching caller may answer by retrying the batch's pods one at a time.
 struct PodEncodeError : EncodeError {
     using EncodeError::EncodeError;
 };
@@ -64,12 +65,20 @@ struct NodeColumns {
 
 using TaintId = std::tuple<std::string, std::string, std::string>;  // key, value, effect
 
+class ShardedContext;  // sharded.hpp: the batch over several devices
+
 class Snapshot {
 public:
     // device = HIP device index; kEncodeOnly builds the columns on the host and uploads nothing
     // (used to test the wire-format step where there is no GPU; such a snapshot cannot evaluate).
     static constexpr int kEncodeOnly = -1;
     explicit Snapshot(int device);
+    // Several devices (one process, n MI355X: sharded.hpp): the snapshot is REPLICATED -- every ksched_set_nodes /
+    // ksched_update_nodes goes to every device -- and batches are row-sharded over them by sharded().  `devices` must not be
+    // empty; one device and force_sharded = false is exactly Snapshot(int).  force_sharded = true builds the ShardedContext (and
+    // its one-rank RCCL communicator) for a single device too: the same code path on the one GPU a test box has.
+    explicit Snapshot(const std::vector<int> &devices, bool force_sharded = false);
+    ~Snapshot();
 
     // Encode `nodes` (any order) against the pods `client` LISTs per node and upload.
     // available[n] = allocatable[n] - sum(total_pod_resources(p) for p in LIST(n))
@@ -138,7 +147,10 @@ public:
     uint32_t n() const { return cols_.n; }
     uint32_t mask_words() const { return ksched_mask_words(cols_.n); }
     bool has_taints() const { return any_counted_taint_; }  // some node carries a NoSchedule / NoExecute taint
-    DeviceEvaluator &device();
+    DeviceEvaluator &device();  // the first device (per-pair calls, ksched_explain)
+    size_t device_count() const { return devs_.size(); }
+    // the batch path over every device of this snapshot, or nullptr (one device, not forced): callers then use device()
+    ShardedContext *sharded();
     const std::map<TaintId, uint32_t> &taint_ids() const { return taint_ids_; }
     uint64_t generation() const { return generation_; }
     // A device call failed after the host columns had been committed (ksched_set_nodes / ksched_update_nodes returned an error):
@@ -149,7 +161,9 @@ private:
     void encode_labels();
     void upload();
 
-    std::shared_ptr<DeviceEvaluator> dev_;
+    std::shared_ptr<DeviceEvaluator> dev_;                 // == devs_[0] (nullptr: encode-only)
+    std::vector<std::shared_ptr<DeviceEvaluator>> devs_;  // every device the snapshot is replicated to
+    std::unique_ptr<ShardedContext> sharded_;
     NodeColumns cols_;
     std::vector<uint32_t> store_of_canonical_, canonical_of_store_;
     std::vector<corev1::StringMap> node_labels_;            // canonical order; empty map when labels is None

@@ -1,5 +1,7 @@
 #include "predicates.hpp"
 
+#include "sharded.hpp"
+
 #include <cstdlib>
 #include <mutex>
 #include <set>
@@ -98,11 +100,20 @@ void eval_range(Snapshot &snap, const std::vector<const corev1::Pod *> &pods, si
                 const std::vector<uint32_t> *samples, uint32_t attempts, BatchValidity &out, bool want_masks) {
     const std::vector<const corev1::Pod *> part(pods.begin() + (std::ptrdiff_t)lo, pods.begin() + (std::ptrdiff_t)hi);
     PodColumns pc = snap.encode_pods(part);
+    const uint32_t flags = out.flags | (want_masks ? KSCHED_WANT_FIT_MASK : 0u) | pick;
+    if (ShardedContext *sh = snap.sharded()) {
+        // several devices (or KSCHED_SHARDED): the range's rows are cut over them, each device evaluates its rows against its
+        // replica of the snapshot, the bindings meet in one RCCL all-gather (sharded.hpp); masks land in this range's rows directly
+        sh->eval(pc, (pick & KSCHED_PICK_SAMPLED) ? samples->data() + lo * attempts : nullptr, attempts, flags, out.W,
+                 want_masks ? out.feasible.data() + lo * out.W : nullptr, want_masks ? out.fit.data() + lo * out.W : nullptr,
+                 pick ? out.binding.data() + lo : nullptr);
+        return;
+    }
     DeviceEvaluator &dev = snap.device();
     dev.check(ksched_eval(dev.handle(), pc.p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(),
                           pc.n_keys ? pc.sel_val_ids.data() : nullptr, (out.flags & KSCHED_TAINT) ? pc.tolerations.data() : nullptr,
                           (pick & KSCHED_PICK_SAMPLED) ? samples->data() + lo * attempts : nullptr, attempts,
-                          out.flags | (want_masks ? KSCHED_WANT_FIT_MASK : 0u) | pick, want_masks ? out.feasible.data() + lo * out.W : nullptr,
+                          flags, want_masks ? out.feasible.data() + lo * out.W : nullptr,
                           want_masks ? out.fit.data() + lo * out.W : nullptr, pick ? out.binding.data() + lo : nullptr),
               "ksched_eval");
 }
@@ -138,8 +149,9 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
         const corev1::Pod &pod = *pods[i];
         if (!pod.spec || !pod.spec->node_selector || pod.spec->node_selector->empty()) continue;  // (most pods: nothing is built for them)
         const auto &selector = *pod.spec->node_selector;  // (a map: its keys are distinct)
-        if (selector.size() > KSCHED_MAX_KEYS)
-            throw EncodeError("pod " + full_name(pod.metadata) + ": more than KSCHED_MAX_KEYS nodeSelector keys on one pod");
+        if (selector.size() > KSCHED_MAX_KEYS)  // a per-pod failure raised before anything of the batch was evaluated or POSTed: PodEncodeError, so that
+                                                // run_batches isolates the offender instead of the exception taking the scheduling loop down
+            throw PodEncodeError("pod " + full_name(pod.metadata) + ": more than KSCHED_MAX_KEYS nodeSelector keys on one pod");
         size_t adds = 0;
         for (const auto &kv : selector) adds += keys.find(kv.first) == keys.end() ? 1u : 0u;
         if (!adds) continue;

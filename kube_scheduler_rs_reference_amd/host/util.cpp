@@ -1,6 +1,9 @@
 #include "util.hpp"
 
+#include <cstdlib>
+
 #include "encoder.hpp"
+#include "sharded.hpp"
 
 namespace ksched_host {
 
@@ -36,7 +39,12 @@ PodResources total_pod_resources(const corev1::Pod &pod) {
 }
 
 void Context::refresh_snapshot() {
-    if (!snapshot) snapshot = std::make_shared<Snapshot>(device);
+    if (!snapshot) {
+        const std::vector<int> devs = devices.empty() ? devices_from_env(std::getenv("KSCHED_DEVICES"), device) : devices;
+        const char *force = std::getenv("KSCHED_SHARDED");
+        const bool sharded = force && *force && *force != '0';
+        snapshot = (devs.size() > 1 || sharded) ? std::make_shared<Snapshot>(devs, sharded) : std::make_shared<Snapshot>(devs[0]);
+    }
     snapshot->rebuild(node_store, client.get());
 }
 

@@ -47,7 +47,10 @@ struct PodResources {
 struct Context {
     std::shared_ptr<PodLister> client;     // pub client: Client
     std::vector<corev1::Node> node_store;  // pub node_store: reflector::Store<Node> (state() = this vector, any order)
-    int device = 0;                        // HIP device the evaluator lives on
+    int device = 0;                        // HIP device the evaluator lives on ...
+    // ... or several: the batch row-shards over them and the bindings are all-gathered (sharded.hpp).  Empty = $KSCHED_DEVICES
+    // ("0,1,2,3" / "all"), and without that variable {device}.  $KSCHED_SHARDED=1 takes the sharded path with one device too.
+    std::vector<int> devices;
     // Device-resident snapshot of node_store + LISTs (added field; SURVEY.md section 8b allows it).
     std::shared_ptr<Snapshot> snapshot;
     // one-node scratch snapshot used by the per-pair predicates::* entry points

@@ -81,6 +81,215 @@ impl Drop for Evaluator {
     }
 }
 
+// ---- the devices of one host process --------------------------------------------------------------------------------
+
+/// $KSCHED_DEVICES -> HIP device ids: "0,1,2,3" = those devices, "all" = every visible one, unset / empty = [0].  Err on anything
+/// else: not a number, a device listed twice, a device the process does not see (`visible` = ksched_device_count()).  Twin of
+/// devices_from_env in the C++ host mirror (host/sharded.cpp).
+pub fn parse_device_ids(text: Option<&str>, visible: i32) -> Result<Vec<i32>, String> {
+    let text = match text {
+        Some(t) if !t.is_empty() => t,
+        _ => return Ok(vec![0]),
+    };
+    if text == "all" {
+        if visible <= 0 {
+            return Err("KSCHED_DEVICES=all: the process sees no HIP device".into());
+        }
+        return Ok((0..visible).collect());
+    }
+    let mut ids: Vec<i32> = Vec::new();
+    for part in text.split(',') {
+        let d: i32 = part.trim().parse().map_err(|_| format!("KSCHED_DEVICES: cannot read '{}' (expected e.g. 0,1,2,3 or all)", text))?;
+        if d < 0 || d >= visible {
+            return Err(format!("KSCHED_DEVICES names device {}, the process sees {}", d, visible));
+        }
+        if ids.contains(&d) {
+            return Err(format!("KSCHED_DEVICES lists device {} twice", d));
+        }
+        ids.push(d);
+    }
+    return Ok(ids);
+}
+
+/// rank r's pod rows [lo, hi) and the padded shard size (ksched_shard_bounds: the one definition of the split)
+pub fn shard_bounds(p: u32, nranks: u32, rank: u32) -> (u32, u32, u32) {
+    let (mut lo, mut hi, mut count_per_rank) = (0u32, 0u32, 0u32);
+    unsafe { sys::ksched_shard_bounds(p, nranks, rank, &mut lo, &mut hi, &mut count_per_rank) };
+    return (lo, hi, count_per_rank);
+}
+
+/// One host process, n MI355X (north_star: "the pod batch row-shards across the 8 GPUs of one node with an RCCL allgather of the
+/// resulting (pod -> node) bindings over xGMI").  The reference is one process (src/main.rs:127-152) and stays one: this owns
+/// one `Evaluator` per device of $KSCHED_DEVICES and, with more than one, the RCCL communicator over them
+/// (ksched_comm_create_local).  The node snapshot is REPLICATED (every ksched_set_nodes / ksched_update_nodes goes to every
+/// device); a batch's pod rows are cut with ksched_shard_bounds, every device evaluates its rows (ksched_eval_begin: no host
+/// wait), ONE ksched_allgather_bindings_local exchanges the int32 bindings, and the whole table comes back from device 0 in
+/// one copy (ksched_eval_end).  Twin of the C++ host mirror's ShardedContext (host/sharded.cpp).
+pub struct Devices {
+    evaluators: Vec<Evaluator>,
+    comms: Vec<*mut sys::ksched_comm>, // one per device; empty with a single device (plain ksched_eval, no exchange)
+    table: Vec<i32>,                   // [n][count_per_rank]: the gathered bindings, host copy
+}
+unsafe impl Send for Devices {}
+
+impl Devices {
+    /// the devices $KSCHED_DEVICES names (default: device 0)
+    pub fn from_env() -> Result<Devices, KschedError> {
+        let text = std::env::var("KSCHED_DEVICES").ok();
+        let visible = unsafe { sys::ksched_device_count() };
+        let ids = parse_device_ids(text.as_deref(), visible).map_err(|message| KschedError { code: sys::KSCHED_E_INVAL, message })?;
+        return Devices::new(&ids);
+    }
+
+    pub fn new(ids: &[i32]) -> Result<Devices, KschedError> {
+        if ids.is_empty() {
+            return Err(KschedError { code: sys::KSCHED_E_INVAL, message: "no device given".into() });
+        }
+        let mut evaluators = Vec::with_capacity(ids.len());
+        for &d in ids {
+            evaluators.push(Evaluator::new(d)?);
+        }
+        let mut comms: Vec<*mut sys::ksched_comm> = Vec::new();
+        if evaluators.len() > 1 {
+            let ctxs: Vec<*mut sys::ksched_ctx> = evaluators.iter().map(|e| e.raw()).collect();
+            comms = vec![std::ptr::null_mut(); ctxs.len()];
+            let rc = unsafe { sys::ksched_comm_create_local(ctxs.as_ptr(), ctxs.len() as i32, comms.as_mut_ptr()) }; // ncclCommInitAll
+            if rc != sys::KSCHED_OK {
+                let detail = unsafe { CStr::from_ptr(sys::ksched_comm_last_error()) }.to_string_lossy().into_owned();
+                return Err(KschedError { code: rc, message: format!("ksched_comm_create_local: {} ({})", strerror(rc), detail) });
+            }
+        }
+        return Ok(Devices { evaluators, comms, table: Vec::new() });
+    }
+
+    pub fn len(&self) -> usize {
+        return self.evaluators.len();
+    }
+
+    pub fn first(&self) -> &Evaluator {
+        return &self.evaluators[0];
+    }
+
+    /// ksched_set_nodes on every device (the snapshot is replicated: <= 2.8 MB at BASELINE configs[4]; the calls do not wait for the devices)
+    fn set_nodes(&self, n: u32, cpu: &[i64], mem: &[i64], label_val_ids: &[u32], n_keys: u32) -> Result<(), KschedError> {
+        for ev in &self.evaluators {
+            let rc = unsafe {
+                sys::ksched_set_nodes(ev.raw(), n, cpu.as_ptr(), mem.as_ptr(), if n_keys > 0 { label_val_ids.as_ptr() } else { std::ptr::null() }, n_keys, std::ptr::null())
+            };
+            ev.check(rc, "ksched_set_nodes")?;
+        }
+        return Ok(());
+    }
+
+    /// ksched_update_nodes on every device
+    fn update_nodes(&self, idx: &[u32], cpu: &[i64], mem: &[i64]) -> Result<(), KschedError> {
+        for ev in &self.evaluators {
+            let rc = unsafe { sys::ksched_update_nodes(ev.raw(), idx.len() as u32, idx.as_ptr(), cpu.as_ptr(), mem.as_ptr()) };
+            ev.check(rc, "ksched_update_nodes")?;
+        }
+        return Ok(());
+    }
+
+    /// The sampled pick of one encoded batch (KSCHED_FIT | KSCHED_SEL | KSCHED_PICK_SAMPLED, bindings only: no mask kernel runs):
+    /// `samples` = [cols.p][attempts] canonical node indices.  One device: ksched_eval.  Several: rows sharded, bindings all-gathered.
+    pub fn pick_sampled(&mut self, cols: &PodColumns, samples: &[u32], attempts: u32) -> Result<Vec<i32>, KschedError> {
+        let p = cols.p;
+        let flags = sys::KSCHED_FIT | sys::KSCHED_SEL | sys::KSCHED_PICK_SAMPLED;
+        let mut binding = vec![-1i32; p as usize];
+        if p == 0 {
+            return Ok(binding);
+        }
+        let sel = |lo: u32| if cols.n_keys > 0 { cols.sel_val_ids[lo as usize..].as_ptr() } else { std::ptr::null() };
+        if self.comms.is_empty() {
+            let ev = &self.evaluators[0];
+            let rc = unsafe {
+                sys::ksched_eval(
+                    ev.raw(), p, cols.req_cpu_milli.as_ptr(), cols.req_mem_bytes.as_ptr(), sel(0), std::ptr::null(), samples.as_ptr(), attempts, flags,
+                    std::ptr::null_mut(), std::ptr::null_mut(), binding.as_mut_ptr(),
+                )
+            };
+            ev.check(rc, "ksched_eval")?;
+            return Ok(binding);
+        }
+        let n = self.evaluators.len() as u32;
+        let count_per_rank = shard_bounds(p, n, 0).2;
+        let mut local: Vec<*const i32> = vec![std::ptr::null(); n as usize];
+        let mut gathered: Vec<*mut i32> = vec![std::ptr::null_mut(); n as usize];
+        let mut streams: Vec<*mut std::os::raw::c_void> = vec![std::ptr::null_mut(); n as usize];
+        let mut failure: Option<KschedError> = None;
+        let mut begun = 0usize;
+        // 1. every device gets its rows: copies in and kernels enqueued on the device's own stream, no host wait
+        for r in 0..n {
+            let (lo, hi, _) = shard_bounds(p, n, r);
+            let ev = &self.evaluators[r as usize];
+            let mut dev_binding: *mut i32 = std::ptr::null_mut();
+            let rc = unsafe {
+                sys::ksched_eval_begin(
+                    ev.raw(), hi - lo, cols.req_cpu_milli[lo as usize..].as_ptr(), cols.req_mem_bytes[lo as usize..].as_ptr(), sel(lo), p, std::ptr::null(),
+                    samples[(lo * attempts) as usize..].as_ptr(), attempts, flags, std::ptr::null_mut(), std::ptr::null_mut(), count_per_rank, &mut dev_binding,
+                    &mut streams[r as usize],
+                )
+            };
+            if let Err(e) = ev.check(rc, "ksched_eval_begin") {
+                failure = Some(e);
+                break;
+            }
+            local[r as usize] = dev_binding as *const i32;
+            begun += 1;
+        }
+        // 2. ONE all-gather of ceil(p / n) int32 per device over xGMI, enqueued behind each device's pick on its own stream
+        if failure.is_none() {
+            for r in 0..n as usize {
+                let ev = &self.evaluators[r];
+                let rc = unsafe { sys::ksched_gather_buffer(ev.raw(), n * count_per_rank, &mut gathered[r]) };
+                if let Err(e) = ev.check(rc, "ksched_gather_buffer") {
+                    failure = Some(e);
+                    break;
+                }
+            }
+        }
+        if failure.is_none() {
+            let rc = unsafe {
+                sys::ksched_allgather_bindings_local(self.comms.as_ptr(), n as i32, local.as_ptr(), gathered.as_ptr() as *const *mut i32, count_per_rank, streams.as_ptr() as *const *mut std::os::raw::c_void)
+            };
+            if rc != sys::KSCHED_OK {
+                let detail = unsafe { CStr::from_ptr(sys::ksched_comm_last_error()) }.to_string_lossy().into_owned();
+                failure = Some(KschedError { code: rc, message: format!("ksched_allgather_bindings_local: {} ({})", strerror(rc), detail) });
+            }
+        }
+        // 3. the table comes back in one copy from device 0; whatever happened above, every device that was given work is waited for
+        self.table.resize((n * count_per_rank) as usize, -1);
+        for r in 0..begun {
+            let ev = &self.evaluators[r];
+            let rc = if r == 0 && failure.is_none() {
+                unsafe { sys::ksched_eval_end(ev.raw(), gathered[0] as *const i32, n * count_per_rank, self.table.as_mut_ptr()) }
+            } else {
+                unsafe { sys::ksched_eval_end(ev.raw(), std::ptr::null(), 0, std::ptr::null_mut()) }
+            };
+            if let Err(e) = ev.check(rc, "ksched_eval_end") {
+                failure.get_or_insert(e);
+            }
+        }
+        if let Some(e) = failure {
+            return Err(e);
+        }
+        for r in 0..n {
+            let (lo, hi, _) = shard_bounds(p, n, r);
+            let from = (r * count_per_rank) as usize;
+            binding[lo as usize..hi as usize].copy_from_slice(&self.table[from..from + (hi - lo) as usize]);
+        }
+        return Ok(binding);
+    }
+}
+
+impl Drop for Devices {
+    fn drop(&mut self) {
+        for &c in &self.comms {
+            unsafe { sys::ksched_comm_destroy(c) } // (before the evaluators go: fields drop after this body)
+        }
+    }
+}
+
 // ---- quantities -------------------------------------------------------------------------------------------------
 
 /// Kubernetes resource.Quantity text -> exact nano-units.  Grammar: sign? digits ('.' digits)? suffix with suffix one of
@@ -256,6 +465,15 @@ pub enum PodEvent<'a> {
     Deleted(&'a corev1::Pod),
 }
 
+/// The same events, owned: what the pod watch and the reconciles SEND to the batch task (src/main.rs `Work::Event`).  The batch task
+/// owns the ClusterState and the Devices outright -- no lock is shared with the async workers: a device call of tens of
+/// milliseconds never blocks a reconcile's POST or the watch.
+pub enum ClusterEvent {
+    Applied(corev1::Pod),
+    Deleted(corev1::Pod),
+    Restarted(Vec<corev1::Pod>),
+}
+
 fn pod_key(pod: &corev1::Pod) -> String {
     return match &pod.metadata.namespace {
         Some(ns) => format!("{}/{}", ns, pod.metadata.name.clone().unwrap_or_default()),
@@ -387,7 +605,7 @@ impl Snapshot {
     /// Encode `pods` against this snapshot and bring the device's copy up to date: a full ksched_set_nodes when the batch's
     /// selector keys differ from the ones the device holds (or nothing is there yet), otherwise only the rows pod events have
     /// changed since the last call (ksched_update_nodes), otherwise nothing.
-    pub fn encode_and_upload(&mut self, ev: &Evaluator, pods: &[&corev1::Pod]) -> Result<PodColumns, String> {
+    pub fn encode_and_upload(&mut self, devices: &Devices, pods: &[&corev1::Pod]) -> Result<PodColumns, String> {
         let mut keys = BTreeSet::new();
         for p in pods {
             if let Some(corev1::PodSpec { node_selector: Some(sel), .. }) = &p.spec {
@@ -399,26 +617,22 @@ impl Snapshot {
         let wanted: Vec<String> = keys.iter().cloned().collect();
         let n = self.n();
         if self.on_device.as_ref() != Some(&wanted) {
+            // (nothing is on the devices that this bookkeeping could vouch for until the upload below has succeeded: encode_labels
+            // replaces self.keys, and a failed ksched_set_nodes leaves the library without a snapshot)
+            self.on_device = None;
             self.encode_labels(&keys)?;
             let n_keys = self.keys.len() as u32;
-            let rc = unsafe {
-                sys::ksched_set_nodes(
-                    ev.raw(), n, self.avail_cpu_milli.as_ptr(), self.avail_mem_bytes.as_ptr(),
-                    if n_keys > 0 { self.label_val_ids.as_ptr() } else { std::ptr::null() }, n_keys, std::ptr::null(),
-                )
-            };
-            ev.check(rc, "ksched_set_nodes").map_err(|e| e.to_string())?;
+            devices.set_nodes(n, &self.avail_cpu_milli, &self.avail_mem_bytes, &self.label_val_ids, n_keys).map_err(|e| e.to_string())?;
             self.on_device = Some(wanted);
             self.touched.clear();
         } else if !self.touched.is_empty() {
             let idx: Vec<u32> = self.touched.iter().cloned().collect();
             let cpu: Vec<i64> = idx.iter().map(|&i| self.avail_cpu_milli[i as usize]).collect();
             let mem: Vec<i64> = idx.iter().map(|&i| self.avail_mem_bytes[i as usize]).collect();
-            let rc = unsafe { sys::ksched_update_nodes(ev.raw(), idx.len() as u32, idx.as_ptr(), cpu.as_ptr(), mem.as_ptr()) };
-            if rc != sys::KSCHED_OK {
+            if let Err(e) = devices.update_nodes(&idx, &cpu, &mem) {
                 self.on_device = None; // the library refuses evaluations until the next ksched_set_nodes: upload everything next time
+                return Err(e.to_string());
             }
-            ev.check(rc, "ksched_update_nodes").map_err(|e| e.to_string())?;
             self.touched.clear();
         }
         let n_keys = self.keys.len() as u32;
@@ -469,8 +683,9 @@ impl BatchValidity {
 /// check_node_validity (src/predicates.rs:63-77) for every (pod, node) pair in ONE device call, optionally with the
 /// sampled pick of select_node_for_pod (src/main.rs:51-71): `samples` = [p][attempts] canonical node indices.
 #[cfg(test)]
-pub fn eval_batch(ev: &Evaluator, snap: &mut Snapshot, pods: &[&corev1::Pod], samples: Option<(&[u32], u32)>) -> Result<BatchValidity, String> {
-    let cols = snap.encode_and_upload(ev, pods)?;
+pub fn eval_batch(devices: &Devices, snap: &mut Snapshot, pods: &[&corev1::Pod], samples: Option<(&[u32], u32)>) -> Result<BatchValidity, String> {
+    let ev = devices.first(); // (both masks of the whole batch from one device: the test builds' view)
+    let cols = snap.encode_and_upload(devices, pods)?;
     let n = snap.n();
     let words = unsafe { sys::ksched_mask_words(n) };
     let mut out = BatchValidity { p: cols.p, n, words, feasible: vec![0u64; (cols.p * words) as usize], fit: vec![0u64; (cols.p * words) as usize], binding: Vec::new() };
@@ -591,6 +806,18 @@ impl ClusterState {
         return Ok(true);
     }
 
+    /// One event from the channel.  Err = the event could not be applied (its text is logged by the caller); the state is unchanged.
+    pub fn apply(&mut self, event: ClusterEvent) -> Result<(), String> {
+        return match event {
+            ClusterEvent::Applied(pod) => self.observe(PodEvent::Applied(&pod)).map(|_| ()),
+            ClusterEvent::Deleted(pod) => self.observe(PodEvent::Deleted(&pod)).map(|_| ()),
+            ClusterEvent::Restarted(pods) => {
+                self.resync(&pods);
+                Ok(())
+            },
+        };
+    }
+
     fn snapshot_for(&mut self, nodes: &[Arc<corev1::Node>]) -> Result<&mut Snapshot, String> {
         let fingerprint: Vec<(String, String)> = nodes
             .iter()
@@ -603,12 +830,14 @@ impl ClusterState {
         return Ok(self.snapshot.as_mut().expect("snapshot was just built"));
     }
 
-    /// select_node_for_pod (src/main.rs:51-71) for a batch of pending pods in ONE device call: `draws` holds `attempts` indices
-    /// into `nodes` (the store's own order; u32::MAX = no draw: empty store) per pod, made up front by the caller; the first
-    /// feasible draw wins.  Returns the chosen index into `nodes` per pod, -1 = none (NoNodeFound in reconcile).  A pod whose
-    /// requests cannot be encoded (the reference's .expect("invalid pod spec") panics on it) gets -1 and a warning; the other
-    /// pods of the batch are evaluated as usual.
-    pub fn pick_batch(&mut self, ev: &Evaluator, nodes: &[Arc<corev1::Node>], pods: &[Arc<corev1::Pod>], draws: &[u32], attempts: u32) -> Result<Vec<i32>, String> {
+    /// select_node_for_pod (src/main.rs:51-71) for a batch of pending pods in ONE evaluation over the process's devices: `draws` holds
+    /// `attempts` indices into `nodes` (the store's own order; u32::MAX = no draw: empty store) per pod, made up front by the caller;
+    /// the first feasible draw wins.  Returns the chosen index into `nodes` per pod, -1 = none (NoNodeFound in reconcile).  A pod whose
+    /// requests cannot be encoded (the reference's .expect("invalid pod spec") panics on it) or that alone names more than
+    /// KSCHED_MAX_KEYS selector keys gets -1 and a warning; the other pods of the batch are evaluated as usual.  The reference has no
+    /// limit on selector keys: a batch that uses more than KSCHED_MAX_KEYS distinct ones is evaluated in consecutive pod ranges, each
+    /// within the budget (twin of check_node_validity_batch's walk in the C++ host mirror, host/predicates.cpp).
+    pub fn pick_batch(&mut self, devices: &mut Devices, nodes: &[Arc<corev1::Node>], pods: &[Arc<corev1::Pod>], draws: &[u32], attempts: u32) -> Result<Vec<i32>, String> {
         if draws.len() != pods.len() * attempts as usize {
             return Err("draws must hold attempts indices per pod".into());
         }
@@ -621,38 +850,59 @@ impl ClusterState {
         for (canonical, &store) in snap.store_index.iter().enumerate() {
             canonical_of_store[store] = canonical as u32;
         }
-        // the pods that can be encoded, and their draws in canonical column indices
+        // the pods that can be encoded
         let mut which: Vec<usize> = Vec::with_capacity(pods.len());
         for (i, p) in pods.iter().enumerate() {
+            let keys_of_pod = match &p.spec {
+                Some(corev1::PodSpec { node_selector: Some(sel), .. }) => sel.len(),
+                _ => 0,
+            };
+            if keys_of_pod > sys::KSCHED_MAX_KEYS as usize {
+                tracing::warn!("pod {} cannot be scheduled: {} nodeSelector keys on one pod (limit {})", pod_key(p), keys_of_pod, sys::KSCHED_MAX_KEYS);
+                continue;
+            }
             match total_pod_resources_nanos(p).and_then(|(c, m)| nanos_to_i64(c, 1_000_000, "milli-cores").and(nanos_to_i64(m, 1_000_000_000, "bytes"))) {
                 Ok(_) => which.push(i),
                 Err(e) => tracing::warn!("pod {} cannot be scheduled: {}", pod_key(p), e),
             }
         }
-        if which.is_empty() {
-            return Ok(chosen);
-        }
-        let refs: Vec<&corev1::Pod> = which.iter().map(|&i| pods[i].as_ref()).collect();
-        let mut samples: Vec<u32> = Vec::with_capacity(which.len() * attempts as usize);
-        for &i in &which {
-            for a in 0..attempts as usize {
-                let d = draws[i * attempts as usize + a];
-                samples.push(if (d as usize) < nodes.len() { canonical_of_store[d as usize] } else { u32::MAX });
+        // consecutive ranges of `which`, each with at most KSCHED_MAX_KEYS distinct selector keys
+        let mut ranges: Vec<(usize, usize)> = Vec::new();
+        let mut lo = 0usize;
+        let mut keys: BTreeSet<&str> = BTreeSet::new();
+        for (j, &i) in which.iter().enumerate() {
+            if let Some(corev1::PodSpec { node_selector: Some(sel), .. }) = &pods[i].spec {
+                let adds = sel.keys().filter(|k| !keys.contains(k.as_str())).count();
+                if adds > 0 && keys.len() + adds > sys::KSCHED_MAX_KEYS as usize {
+                    ranges.push((lo, j));
+                    lo = j;
+                    keys.clear();
+                }
+                for k in sel.keys() {
+                    keys.insert(k.as_str());
+                }
             }
         }
-        let cols = snap.encode_and_upload(ev, &refs)?;
-        let mut binding = vec![-1i32; which.len()];
-        let rc = unsafe {
-            sys::ksched_eval(
-                ev.raw(), cols.p, cols.req_cpu_milli.as_ptr(), cols.req_mem_bytes.as_ptr(),
-                if cols.n_keys > 0 { cols.sel_val_ids.as_ptr() } else { std::ptr::null() }, std::ptr::null(), samples.as_ptr(), attempts,
-                sys::KSCHED_FIT | sys::KSCHED_SEL | sys::KSCHED_PICK_SAMPLED, std::ptr::null_mut(), std::ptr::null_mut(), binding.as_mut_ptr(),
-            )
-        };
-        ev.check(rc, "ksched_eval").map_err(|e| e.to_string())?;
-        for (j, &i) in which.iter().enumerate() {
-            if binding[j] >= 0 {
-                chosen[i] = snap.store_index[binding[j] as usize] as i32;
+        if lo < which.len() {
+            ranges.push((lo, which.len()));
+        }
+        for (from, to) in ranges {
+            let part = &which[from..to];
+            let refs: Vec<&corev1::Pod> = part.iter().map(|&i| pods[i].as_ref()).collect();
+            // the range's draws in canonical column indices
+            let mut samples: Vec<u32> = Vec::with_capacity(part.len() * attempts as usize);
+            for &i in part {
+                for a in 0..attempts as usize {
+                    let d = draws[i * attempts as usize + a];
+                    samples.push(if (d as usize) < nodes.len() { canonical_of_store[d as usize] } else { u32::MAX });
+                }
+            }
+            let cols = snap.encode_and_upload(devices, &refs)?; // (a new range re-uploads the label columns it needs)
+            let binding = devices.pick_sampled(&cols, &samples, attempts).map_err(|e| e.to_string())?;
+            for (j, &i) in part.iter().enumerate() {
+                if binding[j] >= 0 {
+                    chosen[i] = snap.store_index[binding[j] as usize] as i32;
+                }
             }
         }
         return Ok(chosen);

@@ -1,4 +1,4 @@
-// src/ksched_sys.rs -- mechanical binding of include/ksched.h (ABI version 3): one `extern "C"` item per symbol the
+// src/ksched_sys.rs -- mechanical binding of include/ksched.h (ABI version 4): one `extern "C"` item per symbol the
 // header declares, same order.  Nothing here allocates or panics.  tests/test_abi_symbols.py (in the ksched repository)
 // checks this list against the header and the shared library's exports.
 #![allow(non_camel_case_types)]
@@ -17,7 +17,7 @@ pub struct ksched_comm {
     _private: [u8; 0],
 }
 
-pub const KSCHED_ABI_VERSION: u32 = 3;
+pub const KSCHED_ABI_VERSION: u32 = 4;
 pub const KSCHED_MAX_KEYS: u32 = 32;
 pub const KSCHED_MAX_ATTEMPTS: u32 = 64;
 pub const KSCHED_SEL_NEVER: u32 = 0xFFFF_FFFF;
@@ -61,6 +61,7 @@ extern "C" {
     pub fn ksched_create(out: *mut *mut ksched_ctx, device_id: c_int) -> c_int;
     pub fn ksched_destroy(ctx: *mut ksched_ctx);
     pub fn ksched_abi_version() -> u32;
+    pub fn ksched_device_count() -> c_int;
     pub fn ksched_strerror(code: c_int) -> *const c_char;
     pub fn ksched_last_error(ctx: *const ksched_ctx) -> *const c_char;
     pub fn ksched_mask_words(n_nodes: u32) -> u32;
@@ -82,6 +83,15 @@ extern "C" {
         tolerations: *const u64, samples: *const u32, attempts: u32, flags: u32, out_feasible: *mut u64, out_fit: *mut u64,
         out_binding: *mut i32,
     ) -> c_int;
+    // ---- one host thread, several devices: ksched_eval in two halves
+    pub fn ksched_shard_bounds(p: u32, nranks: u32, rank: u32, lo: *mut u32, hi: *mut u32, count_per_rank: *mut u32);
+    pub fn ksched_eval_begin(
+        ctx: *mut ksched_ctx, p: u32, req_cpu_milli: *const i64, req_mem_bytes: *const i64, sel_val_ids: *const u32, sel_stride: u32,
+        tolerations: *const u64, samples: *const u32, attempts: u32, flags: u32, out_feasible: *mut u64, out_fit: *mut u64,
+        binding_capacity: u32, binding_dev: *mut *mut i32, hip_stream: *mut *mut c_void,
+    ) -> c_int;
+    pub fn ksched_gather_buffer(ctx: *mut ksched_ctx, count: u32, dev: *mut *mut i32) -> c_int;
+    pub fn ksched_eval_end(ctx: *mut ksched_ctx, bindings_dev: *const i32, count: u32, out_host: *mut i32) -> c_int;
     pub fn ksched_eval_device(
         ctx: *mut ksched_ctx, p: u32, req_cpu_milli: *const i64, req_mem_bytes: *const i64, sel_val_ids: *const u32,
         tolerations: *const u64, samples: *const u32, attempts: u32, flags: u32, out_feasible: *mut u64, out_fit: *mut u64,
@@ -145,6 +155,7 @@ pub fn symbol_table() -> Vec<(&'static str, usize)> {
         ("ksched_create", ksched_create as usize),
         ("ksched_destroy", ksched_destroy as usize),
         ("ksched_abi_version", ksched_abi_version as usize),
+        ("ksched_device_count", ksched_device_count as usize),
         ("ksched_strerror", ksched_strerror as usize),
         ("ksched_last_error", ksched_last_error as usize),
         ("ksched_mask_words", ksched_mask_words as usize),
@@ -155,6 +166,10 @@ pub fn symbol_table() -> Vec<(&'static str, usize)> {
         ("ksched_num_nodes", ksched_num_nodes as usize),
         ("ksched_num_keys", ksched_num_keys as usize),
         ("ksched_eval", ksched_eval as usize),
+        ("ksched_shard_bounds", ksched_shard_bounds as usize),
+        ("ksched_eval_begin", ksched_eval_begin as usize),
+        ("ksched_gather_buffer", ksched_gather_buffer as usize),
+        ("ksched_eval_end", ksched_eval_end as usize),
         ("ksched_eval_device", ksched_eval_device as usize),
         ("ksched_eval_device_pitched", ksched_eval_device_pitched as usize),
         ("ksched_mask_pitch", ksched_mask_pitch as usize),

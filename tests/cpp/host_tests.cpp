@@ -21,6 +21,7 @@
 #include "../../kube_scheduler_rs_reference_amd/host/batcher.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/encoder.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/predicates.hpp"
+#include "../../kube_scheduler_rs_reference_amd/host/sharded.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/scheduler.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/util.hpp"
 
@@ -640,6 +641,47 @@ static void cpu_tests() {
         CHECK_THROWS(run_batches(c, [](const std::vector<const corev1::Pod *> &) { return std::vector<ReconcileOutcome>{}; },
                                  [](const PodBatcher::PodPtr &, const ReconcileOutcome &) {}));
     });
+    run("row sharding: ksched_shard_bounds / merge_gathered (SURVEY.md 8e: contiguous rows, ceil(p / n) per device, padded all-gather)", [] {
+        for (uint32_t n = 1; n <= 9; ++n)
+            for (uint32_t p = 0; p <= 200; ++p) {
+                uint32_t next = 0, cpr0 = shard_bounds(p, n, 0).count_per_rank;
+                CHECK(cpr0 == (p + n - 1) / n);
+                std::vector<int32_t> table((size_t)n * cpr0, -7), want(p), got(p, -9);
+                for (uint32_t r = 0; r < n; ++r) {
+                    const ShardBounds b = shard_bounds(p, n, r);
+                    CHECK(b.lo == next && b.hi >= b.lo && b.hi - b.lo <= cpr0 && b.count_per_rank == cpr0);  // contiguous, in rank order, within the slot
+                    CHECK(b.lo == std::min(p, r * cpr0));
+                    next = b.hi;
+                    for (uint32_t i = b.lo; i < b.hi; ++i) {
+                        want[i] = (int32_t)(i * 31u % 1000u) - 1;                      // what rank r's device wrote for its row i - lo
+                        table[(size_t)r * cpr0 + (i - b.lo)] = want[i];
+                    }
+                }
+                CHECK(next == p);  // every row owned exactly once
+                merge_gathered(table.data(), p, n, got.data());
+                CHECK(got == want);
+            }
+        // the C ABI's own entry point with null outputs, and ranks past the end
+        ksched_shard_bounds(10, 4, 3, nullptr, nullptr, nullptr);
+        const ShardBounds last = shard_bounds(10, 4, 3), beyond = shard_bounds(2, 4, 3);
+        CHECK(last.lo == 9 && last.hi == 10 && last.count_per_rank == 3);
+        CHECK(beyond.lo == 2 && beyond.hi == 2);  // an empty shard
+        // $KSCHED_DEVICES
+        CHECK(devices_from_env(nullptr, 5) == std::vector<int>{5});
+        CHECK(devices_from_env("", 2) == std::vector<int>{2});
+        CHECK_THROWS(devices_from_env("zero", 0));
+        CHECK_THROWS(devices_from_env("0;1", 0));
+        CHECK_THROWS(devices_from_env("-1", 0));
+        if (ksched_device_count() >= 1) {
+            CHECK(devices_from_env("0", 3) == std::vector<int>{0});
+            CHECK(devices_from_env("all", 3).size() == (size_t)ksched_device_count());
+            CHECK_THROWS(devices_from_env("0,0", 0));  // a device listed twice
+            CHECK_THROWS(devices_from_env(std::to_string(ksched_device_count()).c_str(), 0));  // a device the process does not see
+        } else {
+            CHECK_THROWS(devices_from_env("0", 0));
+            CHECK_THROWS(devices_from_env("all", 0));
+        }
+    });
     run("choosers: scripted and SplitMix draws", [] {
         ScriptedChooser s;
         s.script = {3, 3, 7, 1, 0};
@@ -850,6 +892,36 @@ static void gpu_tests() {
             }
     });
 
+    run("run_batches isolates a pod with more than KSCHED_MAX_KEYS selector keys (ADVICE r3): the other pods of its batch are scheduled", [] {
+        std::vector<corev1::Node> nodes = {node_with("node-a", "64", "68719476736"), node_with("node-b", "64", "68719476736")};
+        Context ctx = make_ctx(nodes);
+        PodBatcher b(16);
+        std::vector<corev1::Pod> pods;
+        for (int i = 0; i < 7; ++i) pods.push_back(pod_with("p" + std::to_string(i), {container("100m", "1048576")}));
+        corev1::StringMap many;
+        for (uint32_t k = 0; k <= KSCHED_MAX_KEYS; ++k) many["key-" + std::to_string(k)] = "v";  // 33 keys on ONE pod
+        pods[3].spec->node_selector = many;
+        for (auto &p : pods) CHECK(b.push(std::make_shared<corev1::Pod>(p)));
+        b.close();
+        RecordingSink sink;
+        SplitMixChooser chooser(3);
+        int done_n = 0, failed_n = 0;
+        std::string failed_name, failed_why;
+        const BatchLoopStats st = run_batches(
+            b, [&](const std::vector<const corev1::Pod *> &batch) { return reconcile_batch(batch, ctx, chooser, sink); },
+            [&](const PodBatcher::PodPtr &, const ReconcileOutcome &o) {
+                ++done_n;
+                CHECK(o.ok && o.bound_to);
+            },
+            [&](const PodBatcher::PodPtr &p, const std::string &why) {
+                ++failed_n;
+                failed_name = *p->metadata.name;
+                failed_why = why;
+            });
+        CHECK(done_n == 6 && failed_n == 1 && failed_name == "p3" && failed_why.find("KSCHED_MAX_KEYS") != std::string::npos);
+        CHECK(st.isolated_batches == 1 && st.failed_pods == 1 && st.pods == 7);
+        CHECK(sink.posts.size() == 6);  // every other pod of the batch got its binding, exactly once
+    });
     run("reconcile / reconcile_batch (src/main.rs:73-125)", [] {
         std::vector<corev1::Node> nodes = {node_with("node-a", "4", "8589934592"), node_with("node-b", "100m", "1")};
         Context ctx = make_ctx(nodes);
@@ -1088,13 +1160,132 @@ static void comm_tests() {
     });
 }
 
+// One host process, several devices (host/sharded.hpp; include/ksched.h "one host thread, several devices").  A test box has ONE GPU:
+//   * the product path -- RCCL communicator from ksched_comm_create_local, ksched_eval_begin / ksched_allgather_bindings_local /
+//     ksched_eval_end -- runs with one device (n = 1) through the mirror's own entry points and must give what the single-device
+//     path gives, draw for draw and bit for bit;
+//   * the shard arithmetic on the device -- unequal and empty shards, selector columns addressed with the whole batch's stride,
+//     masks landing in the right rows -- runs with 2 .. 5 evaluators on the one GPU and the HostCopies exchange (RCCL refuses a
+//     communicator that names one device twice), against one plain ksched_eval of the whole batch.
+static void sharded_tests() {
+    run("sharded host path, one device, RCCL exchange == single-device path (select_nodes_for_pods, masks, reasons)", [] {
+        std::vector<corev1::Node> nodes;
+        std::vector<corev1::Pod> bound;
+        for (int i = 0; i < 37; ++i) {
+            corev1::Node n = node_with("node-" + std::to_string(100 + (i * 7) % 37), (i % 3) ? "4" : "2", "8589934592");
+            n.metadata.labels = corev1::StringMap{{"zone", (i % 2) ? "a" : "b"}, {"tier", std::to_string(i % 4)}};
+            if (i % 5 == 0) n.metadata.labels.reset();
+            nodes.push_back(n);
+            bound.push_back(pod_with("load-" + std::to_string(i), {container((i % 4) ? "1500m" : "3900m", "1073741824")}, corev1::name_any(n.metadata).c_str()));
+        }
+        std::vector<corev1::Pod> pods;
+        for (int i = 0; i < 301; ++i) {
+            corev1::Pod p = pod_with("pod-" + std::to_string(i), {container((i % 3) ? "500m" : "2500m", "2147483648")});
+            if (i % 4 == 1) p.spec->node_selector = corev1::StringMap{{"zone", "a"}};
+            if (i % 4 == 2) p.spec->node_selector = corev1::StringMap{{"zone", "b"}, {"tier", "2"}};
+            if (i % 10 == 3) p.spec->node_selector = corev1::StringMap{{"gpu", "yes"}};
+            pods.push_back(p);
+        }
+        std::vector<const corev1::Pod *> ptrs;
+        for (auto &p : pods) ptrs.push_back(&p);
+        Context plain = make_ctx(nodes, bound), sharded = make_ctx(nodes, bound);
+        plain.snapshot = std::make_shared<Snapshot>(0);
+        plain.snapshot->rebuild(plain.node_store, plain.client.get());
+        sharded.snapshot = std::make_shared<Snapshot>(std::vector<int>{0}, /*force_sharded=*/true);
+        sharded.snapshot->rebuild(sharded.node_store, sharded.client.get());
+        CHECK(plain.snapshot->sharded() == nullptr);
+        CHECK(sharded.snapshot->sharded() != nullptr && sharded.snapshot->sharded()->size() == 1 &&
+              sharded.snapshot->sharded()->exchange() == ShardedContext::Exchange::Rccl);
+        for (bool want_rejected : {false, true}) {
+            SplitMixChooser c1(7), c2(7);
+            const BatchSelection a = select_nodes_for_pods(ptrs, plain, c1, want_rejected), b = select_nodes_for_pods(ptrs, sharded, c2, want_rejected);
+            CHECK(a.node_store_index == b.node_store_index);
+            CHECK(a.validity.binding == b.validity.binding && a.validity.feasible == b.validity.feasible && a.validity.fit == b.validity.fit);
+            int bound_n = 0;
+            for (int32_t x : b.node_store_index) bound_n += x >= 0;
+            CHECK(bound_n > 30 && bound_n < 301);
+            if (want_rejected) {
+                CHECK(a.rejected.size() == b.rejected.size());
+                for (size_t i = 0; i < a.rejected.size(); ++i) {
+                    CHECK(a.rejected[i].size() == b.rejected[i].size());
+                    for (size_t k = 0; k < a.rejected[i].size() && k < b.rejected[i].size(); ++k)
+                        CHECK(a.rejected[i][k].node_name == b.rejected[i][k].node_name && a.rejected[i][k].reason == b.rejected[i][k].reason);
+                }
+            }
+        }
+        CHECK(sharded.snapshot->sharded()->batches() == 2);
+        // the callers: a batch reconciled through the sharded context leaves the same POSTs and the same snapshot behind
+        RecordingSink s1, s2;
+        SplitMixChooser c1(99), c2(99);
+        const auto o1 = reconcile_batch(ptrs, plain, c1, s1), o2 = reconcile_batch(ptrs, sharded, c2, s2);
+        CHECK(s1.posts == s2.posts && !s1.posts.empty());
+        for (size_t i = 0; i < o1.size(); ++i) CHECK(o1[i].ok == o2[i].ok && o1[i].bound_to == o2[i].bound_to);
+        CHECK(plain.snapshot->columns().avail_cpu_milli == sharded.snapshot->columns().avail_cpu_milli);
+        // ... and the NEXT batch sees the bindings of this one on every replica (ksched_update_nodes went to every device)
+        SplitMixChooser d1(5), d2(5);
+        CHECK(select_nodes_for_pods(ptrs, plain, d1).node_store_index == select_nodes_for_pods(ptrs, sharded, d2).node_store_index);
+    });
+    run("sharded host path: 2 .. 5 shards (evaluators on one GPU, HostCopies exchange) == one ksched_eval of the whole batch", [] {
+        const uint32_t n = 1500, keys = 3, attempts = ATTEMPTS;
+        SplitMixChooser rng(2024);
+        NodeColumns nc;
+        std::vector<int64_t> ncpu(n), nmem(n);
+        std::vector<uint32_t> nlab((size_t)keys * n);
+        for (uint32_t i = 0; i < n; ++i) {
+            ncpu[i] = 500 + (int64_t)*rng.choose(8000);
+            nmem[i] = (int64_t)1 << (20 + *rng.choose(14));
+            for (uint32_t k = 0; k < keys; ++k) nlab[(size_t)k * n + i] = (uint32_t)*rng.choose(4 + k);  // 0 = key absent
+        }
+        const uint32_t W = ksched_mask_words(n);
+        for (uint32_t shards : {2u, 3u, 5u})
+            for (uint32_t p : {1u, 4u, 1001u}) {  // fewer pods than shards (empty shards), ragged last shard
+                PodColumns pc;
+                pc.p = p;
+                pc.n_keys = keys;
+                pc.req_cpu_milli.resize(p);
+                pc.req_mem_bytes.resize(p);
+                pc.sel_val_ids.assign((size_t)keys * p, 0u);
+                std::vector<uint32_t> samples((size_t)p * attempts);
+                for (uint32_t i = 0; i < p; ++i) {
+                    pc.req_cpu_milli[i] = 100 + (int64_t)*rng.choose(6000);
+                    pc.req_mem_bytes[i] = (int64_t)1 << (18 + *rng.choose(14));
+                    for (uint32_t k = 0; k < keys; ++k)
+                        if (*rng.choose(5) == 0) pc.sel_val_ids[(size_t)k * p + i] = (*rng.choose(20) == 0) ? KSCHED_SEL_NEVER : 1u + (uint32_t)*rng.choose(3 + k);
+                    for (uint32_t t = 0; t < attempts; ++t) samples[(size_t)i * attempts + t] = (uint32_t)*rng.choose(n + 2);  // (some draws out of range)
+                }
+                std::vector<std::shared_ptr<DeviceEvaluator>> devs;
+                for (uint32_t r = 0; r < shards; ++r) {
+                    devs.push_back(std::make_shared<DeviceEvaluator>(0));
+                    CHECK(ksched_set_nodes(devs.back()->handle(), n, ncpu.data(), nmem.data(), nlab.data(), keys, nullptr) == KSCHED_OK);  // replicated
+                }
+                ShardedContext sh(devs, ShardedContext::Exchange::HostCopies);
+                const uint32_t flags = KSCHED_FIT | KSCHED_SEL | KSCHED_PICK_SAMPLED | KSCHED_WANT_FIT_MASK;
+                std::vector<uint64_t> feas((size_t)p * W, 0xABull), fit((size_t)p * W, 0xCDull), feas1((size_t)p * W), fit1((size_t)p * W);
+                std::vector<int32_t> bind(p, 12345), bind1(p);
+                sh.eval(pc, samples.data(), attempts, flags, W, feas.data(), fit.data(), bind.data());
+                CHECK(ksched_eval(devs[0]->handle(), p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), pc.sel_val_ids.data(), nullptr, samples.data(), attempts, flags,
+                                  feas1.data(), fit1.data(), bind1.data()) == KSCHED_OK);
+                CHECK(feas == feas1 && fit == fit1 && bind == bind1);
+                // bindings only (what reconcile_batch asks for): no mask buffers at all
+                std::vector<int32_t> bind2(p, 777);
+                sh.eval(pc, samples.data(), attempts, KSCHED_FIT | KSCHED_SEL | KSCHED_PICK_SAMPLED, W, nullptr, nullptr, bind2.data());
+                CHECK(bind2 == bind1);
+            }
+    });
+    run("sharded host path: a communicator over one device named twice is refused loudly (no silent stand-in)", [] {
+        std::vector<std::shared_ptr<DeviceEvaluator>> devs = {std::make_shared<DeviceEvaluator>(0), std::make_shared<DeviceEvaluator>(0)};
+        CHECK_THROWS(ShardedContext(devs));
+    });
+}
+
 int main(int argc, char **argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (mode == "cpu") cpu_tests();
     else if (mode == "gpu") gpu_tests();
     else if (mode == "comm") comm_tests();
+    else if (mode == "sharded") sharded_tests();
     else {
-        std::printf("usage: host_tests cpu|gpu|comm\n");
+        std::printf("usage: host_tests cpu|gpu|comm|sharded\n");
         return 2;
     }
     std::printf("%d test(s), %d failed check(s)\n", g_run, g_fail);

@@ -16,9 +16,9 @@ def _build():
     assert os.path.exists(BIN), "tests/cpp/host_tests has not been built (make host)"
 
 
-def _run(mode):
+def _run(mode, env=None):
     _build()
-    r = subprocess.run([BIN, mode], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([BIN, mode], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 failed check(s)" in r.stdout
@@ -44,3 +44,20 @@ def test_rccl_allgather_through_the_c_abi():
     enqueued behind ksched_eval_device's pick on the same HIP stream."""
     out = _run("comm")
     assert "ok  " in out and "RCCL all-gather" in out
+
+
+@pytest.mark.gpu
+def test_sharded_host_path():
+    """One host process, several devices (host/sharded.cpp): the RCCL path with one device == the single-device path; 2 .. 5
+    shards on one GPU (HostCopies exchange) == one ksched_eval of the whole batch; a bad communicator is refused."""
+    out = _run("sharded")
+    assert out.count("ok  ") >= 3
+
+
+@pytest.mark.gpu
+def test_host_mirror_gpu_through_the_sharded_path():
+    """Every device test of the mirror once more with KSCHED_SHARDED=1: Context builds its snapshot over [device] WITH the
+    ShardedContext (ksched_comm_create_local, ksched_eval_begin / allgather / end), so the KATs, the derived vectors, the batching
+    reconciler and the sequential accounting all run through the multi-device code path."""
+    out = _run("gpu", env={"KSCHED_SHARDED": "1"})
+    assert "test_does_node_selector_match_true (KAT-S3)" in out

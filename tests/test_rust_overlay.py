@@ -190,12 +190,17 @@ def test_the_batched_pick_is_wired_into_the_running_binary(tmp_path):
     assert '#[cfg(feature = "ksched")]\nasync fn select_node_for_pod(pod: &Arc<corev1::Pod>, ctx: &Context) -> Option<corev1::Node>' in main_rs
     assert strip_rust(main_rs).count("select_node_for_pod(&pod, &ctx).await") == 1 and "select_node_for_pod(&pod, &ctx).await" in ref_main
     # the batch task: ready_chunks -> one device call per batch -> replies; spawned from main(); the pod watch too
-    for needle in ("requests.ready_chunks(MAX_BATCH)", "state.pick_batch(&evaluator_b, &nodes_b, &pods, &draws, ATTEMPTS)", "tokio::task::spawn_blocking",
-                   "tokio::spawn(run_pick_batches(pick_requests, node_store.clone(), cluster.clone(), evaluator));",
-                   "tokio::spawn(watch_bound_pods(client.clone(), cluster.clone()));", "watcher::Event::Applied(pod)", "watcher::Event::Deleted(pod)",
-                   "watcher::Event::Restarted(pods)", "ctx.picker.unbounded_send((pod.clone(), reply))"):
+    for needle in ("work.ready_chunks(MAX_BATCH)", "state.pick_batch(&mut devices, &nodes_b, &pods, &draws, ATTEMPTS)", "tokio::task::spawn_blocking",
+                   "tokio::spawn(run_pick_batches(work, node_store.clone(), devices));",
+                   "tokio::spawn(watch_bound_pods(client.clone(), picker.clone()));", "watcher::Event::Applied(pod)", "watcher::Event::Deleted(pod)",
+                   "watcher::Event::Restarted(pods)", "ctx.picker.unbounded_send(Work::Pick(pod.clone(), reply))",
+                   # the binding a reconcile has just POSTed is registered through the same channel (no lock shared with the async workers: ADVICE r3)
+                   "ctx.picker.unbounded_send(Work::Event(ksched::ClusterEvent::Applied(landed)))",
+                   # every device of $KSCHED_DEVICES, not a hard-coded device 0
+                   "ksched::Devices::from_env()"):
         assert needle in main_rs, needle
-    assert "picker: futures::channel::mpsc::UnboundedSender<crate::PickRequest>" in util_rs and "cluster: std::sync::Arc<std::sync::Mutex<crate::ksched::ClusterState>>" in util_rs
+    assert "Evaluator::new(0)" not in main_rs and "std::sync::Mutex" not in main_rs
+    assert "picker: futures::channel::mpsc::UnboundedSender<crate::Work>" in util_rs and "Mutex" not in util_rs
     # no LIST per batch any more
     assert "Api::<corev1::Pod>::all" not in main_rs and ".list(" not in main_rs
     # the binding POST of reconcile (src/main.rs:83-103) is the reference's text, line for line
@@ -203,7 +208,31 @@ def test_the_batched_pick_is_wired_into_the_running_binary(tmp_path):
     assert post in main_rs
     # what the overlay's ksched.rs offers is what main.rs calls
     ksched_rs = (out / "src" / "ksched.rs").read_text()
-    for item in ("pub fn pick_batch(", "pub fn observe(", "pub fn resync(", "pub fn is_synced(", "pub fn counted_pods(", "pub enum PodEvent", "pub struct ClusterState"):
+    for item in ("pub fn pick_batch(", "pub fn observe(", "pub fn resync(", "pub fn is_synced(", "pub fn counted_pods(", "pub enum PodEvent", "pub struct ClusterState",
+                 "pub enum ClusterEvent", "pub fn apply(", "pub struct Devices", "pub fn from_env(", "pub fn pick_sampled("):
         assert item in ksched_rs, item
     for call in re.findall(r"\bksched::(\w+)", main_rs):
         assert re.search(r"pub (?:struct|enum|fn|type) %s\b" % call, ksched_rs), call
+
+
+def test_the_row_shard_over_several_devices_is_behind_the_rust_host():
+    """the 8-GPU pod-row shard + RCCL all-gather reachable from the drop-in HOST.  `Devices` owns one Evaluator per
+    device of $KSCHED_DEVICES and the communicator over them; a batch goes through ksched_eval_begin on every device, ONE
+    ksched_allgather_bindings_local, ksched_eval_end -- the calls of include/ksched.h "one host thread, several devices", in that order --
+    and the snapshot uploads are replicated."""
+    text = strip_rust(rust_sources()["src/ksched.rs"])
+    body = text[text.index("impl Devices {"):text.index("impl Drop for Devices")]
+    order = [body.index(n) for n in ("sys::ksched_comm_create_local(", "sys::ksched_set_nodes(", "sys::ksched_update_nodes(", "sys::ksched_eval_begin(",
+                                     "sys::ksched_gather_buffer(", "sys::ksched_allgather_bindings_local(", "sys::ksched_eval_end(")]
+    assert order == sorted(order), order
+    assert "sys::ksched_shard_bounds(" in text and "sys::ksched_device_count()" in text and "sys::ksched_comm_destroy(" in text
+    assert 'std::env::var("KSCHED_DEVICES")' in rust_sources()["src/ksched.rs"]  # (strip_rust blanks string literals)
+    # uploads go to every device: the snapshot code calls the replicated forms, never a single evaluator's entry point
+    snap = text[text.index("impl Snapshot {"):text.index("pub struct ClusterState")]
+    assert "devices.set_nodes(" in snap and "devices.update_nodes(" in snap and "sys::ksched_set_nodes(" not in snap and "sys::ksched_update_nodes(" not in snap
+    # a failed upload never leaves bookkeeping that vouches for the devices (ADVICE r3: on_device after a failed ksched_set_nodes)
+    up = snap[snap.index("pub fn encode_and_upload"):]
+    assert up.index("self.on_device = None;") < up.index("self.encode_labels(&keys)?;") < up.index("devices.set_nodes(") < up.index("self.on_device = Some(wanted);")
+    # the key budget: pick_batch walks consecutive ranges instead of failing the whole batch (ADVICE r3)
+    pick = text[text.index("pub fn pick_batch("):]
+    assert "ranges.push((lo, j));" in pick and "sys::KSCHED_MAX_KEYS" in pick and "for (from, to) in ranges" in pick

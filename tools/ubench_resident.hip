@@ -91,7 +91,7 @@ __global__ __launch_bounds__(1024) void k_resident(Ctl *c, uint32_t nblocks, uin
                 uint32_t q = 0;
                 if (wave == 0) {
                     if (lane == 0) {
-                        tail = ld_rlx(&c->bell[blockIdx.x][0]);
+                        tail = (variant & 64u) ? ld_sys(&c->bell[blockIdx.x][0]) : ld_rlx(&c->bell[blockIdx.x][0]);
                         if ((++polls & 1023u) == 0u) {  // the shared words and the chip-wide clock only once in a while
                             q = (uint32_t)ld_rlx(&c->quit[0]);
                             if (wall_clock64() - t_start > life_limit) q = 1;
@@ -412,7 +412,13 @@ int main(int argc, char **argv) {
         fflush(stdout);
         return !bad;
     };
-    g_ring = 6;
-    run(248, 0, 7, 32);
+    for (uint32_t variant : {32u | 64u, 32u}) {
+        printf("---- the block's poller reads its doorbell at %s scope\n", (variant & 64u) ? "SYSTEM (sc0 sc1)" : "agent (sc1)");
+        g_ring = 6;
+        bool ok = true;
+        for (uint32_t work : {0u, 1200u})
+            for (int mode : {7, 8})
+                if (ok) ok = run(248, work, mode, variant);
+    }
     return 0;
 }
