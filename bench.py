@@ -227,6 +227,10 @@ def main():
     ap.add_argument("--pods", type=int, default=None, help="override pods per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mask", action="store_true", help="bindings only (not the graded form)")
+    ap.add_argument("--no-parity-check", action="store_true",
+                    help="skip the self-check after the timed region (the last timed step's bindings -- all of this rank's pods -- and >= 4096 of its "
+                         "mask rows against the oracle's integer loop; the run exits non-zero on a mismatch)")
+    ap.add_argument("--parity-rows", type=int, default=4096, help="mask rows the self-check compares word for word (spread evenly over the rank's pods)")
     ap.add_argument("--packed", action="store_true",
                     help="mask rows packed at W words (default: rows pitched to ksched_mask_pitch(n) = W rounded up to 128 B)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (timing experiments; results invalid)")
@@ -252,7 +256,9 @@ def main():
                          "(roofline.avg_kernel_us = their mean; min / median reported).  Events cost launch gap, not kernel time, so "
                          "they are kept out of the timed steps")
     ap.add_argument("--gather-every", type=int, default=None,
-                    help="N > 1: one all-gather per this many steps (their bindings share a buffer).  Default 1 (one per batch)")
+                    help="N > 1: one all-gather per this many steps (their bindings share a buffer).  Default 1: one per batch -- north_star's step is "
+                         "\"evaluate + RCCL allgather of the resulting bindings\" -- and the same run also times one gather per FOUR batches and "
+                         "reports it as config.allgather_every_4 (fewer, larger collectives: replicas then see bindings up to four batches late)")
     ap.add_argument("--torch-gather", action="store_true",
                     help="N > 1: all-gather with torch.distributed.all_gather_into_tensor instead of the C ABI's communicator "
                          "(ksched_allgather_bindings); A/B only, the default is the ABI")
@@ -375,14 +381,12 @@ def main():
     P_total, lo, hi = rig.P_total, rig.lo, rig.hi
     depth = args.depth if args.depth else (2 if multi else 1)
     pipelined = depth > 1 and not args.no_mask
-    # N > 1: the ranks exchange their bindings with one RCCL all-gather per FOUR batches by default (--gather-every G; G = 1: one per
-    # batch).  xGMI is point to point and an 8-rank all-gather of one batch's 400 KB per rank is latency-bound (tens of microseconds:
-    # longer than a C3 launch, so a per-batch gather would set the step time); the bindings of four consecutive batches in one
-    # collective hide behind the four launches.  Every binding is still gathered to every rank; what changes is that the replicas'
-    # snapshot generation advances every 4 batches instead of every batch (a batch is evaluated against ONE snapshot either way).
-    # The default run also times G = 1 (whole steps alternating between two streams, each with its gather) and reports it next to
-    # the primary number (config.allgather_every_step).
-    gather_every = max(1, args.gather_every or 4) if (multi and pipelined) else 1
+    # N > 1: ONE RCCL all-gather of the bindings per batch (north_star: "evaluate + RCCL allgather of the resulting bindings"; VERDICT r3:
+    # the amortised form left the exchange out of 3 of 4 timed steps).  The pipe runs in its alternate mode: batch i = one launch (mask +
+    # riding pick) on stream (i mod 2) and its all-gather right behind it on the same stream, so the gather of batch i overlaps the launch
+    # of batch i + 1 on the other stream.  --gather-every G > 1 = the bindings of G consecutive batches in one collective; the default run
+    # also times G = 4 and reports it next to the primary number (config.allgather_every_4).
+    gather_every = max(1, args.gather_every or 1) if (multi and pipelined) else 1
     if multi and pipelined and not args.one_stream:
         # N > 1 default: ksched_pipe -- mask kernels on one stream; pick -> all-gather -> pick -> ... on the other.  The gather is
         # ordered behind its pick by the stream itself (no event per step) and overlaps the next batches' mask kernels.
@@ -436,16 +440,20 @@ def main():
                 submit = self.pipe.bind(rig.d_cpu, rig.d_mem, rig.d_sel, rig.d_tol, rig.d_smp, rig.flags, self.masks, [slot_outs[k] for k in keys])  # pipe slot = k * G + g
             n_rot = max(1, self.R) if self.pipe is None and not args.no_mask else 1
             k_rot = [0]
+            self.last_mask = 0  # index into self.masks of the buffer the latest step wrote (the self-check reads it back)
 
             def local_eval(binding_out):
-                bound(index_of[binding_out.data_ptr()], k_rot[0] % n_rot)
+                self.last_mask = k_rot[0] % n_rot
+                bound(index_of[binding_out.data_ptr()], self.last_mask)
                 k_rot[0] += 1
 
             def run(slot, binding_out):  # pipelined form: bindings and masks are per slot
                 if submit is not None:
+                    self.last_mask = slot
                     submit(slot)
                 else:
-                    bound(index_of[binding_out.data_ptr()], k_rot[0] % n_rot)
+                    self.last_mask = k_rot[0] % n_rot
+                    bound(index_of[binding_out.data_ptr()], self.last_mask)
                     k_rot[0] += 1
             self.step = (lambda: sched.step(run)) if pipelined else (lambda: sched.step(local_eval))
 
@@ -538,6 +546,46 @@ def main():
     sync()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     bindings = (last.wait() if pipelined else last).clone()
+    # ---- self-check ("the driver-run bench asserts nothing"): what the LAST TIMED STEP wrote -- this rank's bindings, all of
+    # them, and --parity-rows of its mask rows word for word -- against the oracle's scalar loop on the encoded columns (test
+    # infrastructure, used here as the checker only; it never runs inside a timed region).  A mismatch is in the JSON line AND the exit code.
+    parity = None
+    if not args.no_parity_check:
+        try:
+            from oracle import capi
+            torch.cuda.synchronize()
+            n_loc = hi - lo
+            sel_all = c.pod_sel[:, lo:hi] if (c.n_keys and "SEL" in flag_names) else None
+            o_flags = sum(getattr(capi, f) for f in flag_names) | (capi.PICK_SAMPLED if pick == "sampled" else capi.PICK_BESTFIT)
+            oracle_args = dict(avail_cpu=c.avail_cpu, avail_mem=c.avail_mem, label_ids=c.node_labels if sel_all is not None else None,
+                               taints=c.node_taints if taint else None)
+            # bindings: every pod of the shard when the host has the cores for it, else the first pods of the shard
+            threads = capi.num_threads()
+            n_b = n_loc if threads >= 8 else min(n_loc, max(1, int(2e9 / max(N, 1))))
+            _, _, want_b = capi.eval_encoded(**oracle_args, req_cpu=c.req_cpu[lo:lo + n_b], req_mem=c.req_mem[lo:lo + n_b],
+                                             sel_ids=None if sel_all is None else sel_all[:, :n_b], tolerations=c.pod_tol[lo:lo + n_b] if taint else None,
+                                             samples=c.samples[lo:lo + n_b] if pick == "sampled" else None, flags=o_flags, want_mask=False)
+            got_b = bindings[lo:lo + n_b].cpu().numpy() if bindings.numel() >= hi else bindings[:n_b].cpu().numpy()
+            bad_b = int((got_b != want_b).sum())
+            bad_w = rows_checked = words = 0
+            if not args.no_mask and n_loc > 0:
+                rows = np.unique(np.linspace(0, n_loc - 1, num=min(n_loc, max(1, args.parity_rows))).astype(np.int64))
+                want_m, _, _ = capi.eval_encoded(**oracle_args, req_cpu=c.req_cpu[lo:hi][rows], req_mem=c.req_mem[lo:hi][rows],
+                                                 sel_ids=None if sel_all is None else np.ascontiguousarray(sel_all[:, rows]),
+                                                 tolerations=c.pod_tol[lo:hi][rows] if taint else None, samples=None,
+                                                 flags=o_flags & ~(capi.PICK_SAMPLED | capi.PICK_BESTFIT), want_mask=True)
+                got_m = loop.masks[loop.last_mask][torch.from_numpy(rows).to(dev)].cpu().numpy().view(np.uint64)
+                bad_w = int((got_m != want_m).sum())
+                rows_checked, words = int(rows.size), int(want_m.size)
+            parity = {"checked": "the last timed step's outputs against oracle.c ora_eval_encoded (scalar loop on the encoded columns)",
+                      "bindings": int(n_b), "binding_mismatches": bad_b, "rows": rows_checked, "words": words, "word_mismatches": bad_w,
+                      "mismatches": bad_b + bad_w}
+        except Exception as e:  # noqa: BLE001
+            parity = {"error": f"{type(e).__name__}: {e}", "mismatches": -1}
+        if multi:  # every rank checks its own shard; the line carries the sum
+            pm = torch.tensor([parity.get("mismatches", -1) if parity.get("mismatches", -1) >= 0 else 1 << 30], dtype=torch.int64, device=dev)
+            dist.all_reduce(pm, op=dist.ReduceOp.SUM)
+            parity["mismatches_all_ranks"] = int(pm.item())
     # further regions of the same K steps: how much one region of K steps moves from run to run (the graded one is the first)
     repeats = []
     for _ in range(max(0, args.repeats)):
@@ -590,18 +638,20 @@ def main():
         except Exception as e:  # noqa: BLE001 -- a secondary figure must never take the graded line down with it
             in_place = {"error": f"{type(e).__name__}: {e}"}
 
-    # ---- N > 1, second number: the same K steps with ONE all-gather per step (whole steps alternate between the pipe's two streams,
-    # each step's gather behind it) ------------
+    # ---- N > 1, second number: the same K steps with the bindings of FOUR consecutive batches in ONE all-gather (the pipe in its split
+    # mode: mask kernels on one stream; pick -> ... -> all-gather on the other, ordered by the stream itself) ------------
     alt = None
     if multi and pipelined and args.gather_every is None:
         loop.drain()
-        loop_alt = Loop(rig, 1, alternate=not args.split_pipe and not args.one_stream and depth % 2 == 0)
+        loop_alt = Loop(rig, 4, alternate=False)
         for _ in range(32):
             loop_alt.step()
         loop_alt.drain()
         e_alt, _ = loop_alt.timed(args.steps)
-        alt = {"value": float(P_total) * N * args.steps / e_alt, "ms_per_step": e_alt / args.steps * 1e3, "steps": args.steps}
+        alt = {"value": float(P_total) * N * args.steps / e_alt, "ms_per_step": e_alt / args.steps * 1e3, "steps": args.steps, "steps_per_allgather": 4,
+               "note": "fewer, larger collectives: every binding still reaches every rank, the replicas' snapshot generation advances every four batches"}
         loop_alt.close()
+        loop.use()
 
     # ---- N = 1, second number: the same K steps with consecutive batches alternating between TWO streams (ksched_pipe in its
     # "alternate" mode: each step is still ONE launch; the next launch's blocks fill while the previous one's last blocks store).
@@ -740,16 +790,16 @@ def main():
                        "pipe_mode": (("alternate: whole steps + their all-gather on stream (slot mod 2)" if loop.alternate else
                                       "split: mask kernels on one stream, pick -> all-gather on the other") if pipe is not None else None),
                        "steps_per_allgather": gather_every if (pipelined and multi) else (1 if multi else None),
-                       "steps_per_allgather_note": ("the bindings of 4 consecutive batches travel in ONE RCCL all-gather (xGMI is point to point: a per-batch "
-                                                    "gather of 400 KB per rank is latency-bound and longer than a C3 launch); every binding still reaches every rank; "
-                                                    "config.allgather_every_step is the same loop with one gather per batch") if (multi and pipelined and gather_every > 1) else None,
+                       "steps_per_allgather_note": ((f"the bindings of {gather_every} consecutive batches travel in ONE RCCL all-gather" if gather_every > 1 else
+                                                     "one RCCL all-gather of the bindings per batch (north_star's step); config.allgather_every_4 is the same loop with "
+                                                     "four batches' bindings per collective") if (multi and pipelined) else None),
                        "allgather": (("torch.distributed.all_gather_into_tensor" if args.torch_gather else "ksched_allgather_bindings (C ABI, ncclAllGather on the pick's stream)") if multi else None),
-                       "two_batches_in_flight": overlapped, "allgather_every_step": alt, "no_allgather": solo, "allgather_fallback": rig.comm_note,
+                       "two_batches_in_flight": overlapped, "allgather_every_4": alt, "no_allgather": solo, "allgather_fallback": rig.comm_note,
                        "scaling_efficiency_vs_no_allgather": (value / (world * per_gpu_solo) if per_gpu_solo else None),
                        "configs3_strong": strong,
                        "parallelism": f"pod-row shards x{world}, node snapshot replicated, "
                        "allgather(int32 bindings)" if world > 1 else "single GPU",
-                       "bound_fraction": bound_frac,
+                       "bound_fraction": bound_frac, "parity_check": parity,
                        "snapshot_refresh": ({"every_steps": args.refresh_every, "nodes_per_update": args.refresh_nodes,
                                              "updates_issued": refresh["calls"]} if args.refresh_every > 0 else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -767,6 +817,7 @@ def main():
                                    f"(clock ramp {ramp_steps} untimed steps >= {args.ramp_ms:.0f} ms before it); outputs rotate over {loop.R} mask buffer(s)",
                          "mask_kernel_evals_per_s": (hi - lo) * N / avg_kernel_s if avg_kernel_s > 0 else 0.0},
         }
+        out["parity_check"] = parity
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, flag_names)
         else:
@@ -784,6 +835,9 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)  # the ONE line, last
+    if parity is not None and parity.get("mismatches_all_ranks", parity.get("mismatches", 0)) != 0:
+        sys.stderr.write(f"bench.py: the self-check FAILED on rank {rank}: {parity}\n")
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -51,6 +51,19 @@ def test_default_line_contract(built):
     assert r["traffic"] is None or r["traffic_source"].startswith("profiles/pmc_traffic.json")
     b = d["cpu_baseline"]
     assert b["kind"] == "port" and b["unit"] == "evals/s" and b["cores"] >= 1 and b["value"] > 0 and "sample" in b
+    # the run checks what it timed: the last timed step's bindings -- every pod -- and >= 4096 mask rows against the oracle
+    pc = d["parity_check"]
+    assert pc == c["parity_check"] and pc["mismatches"] == 0 and pc["bindings"] == 100_000 and pc["rows"] >= 4096 and pc["words"] == pc["rows"] * 79, pc
+
+
+def test_a_wrong_result_fails_the_bench(built):
+    """The self-check is live: with a kernel ablation bit set (KSCHED_OPT_DEBUG: results invalid by definition -- bit 1 skips the rank
+    searches) the line reports mismatches and the process exits non-zero."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--ramp-ms", "2", "--kernel-samples", "4",
+                        "--no-cpu-baseline", "--no-others", "--repeats", "0", "--debug", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0, "a bench whose kernel skips the rank searches must not pass its self-check"
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["parity_check"]["mismatches"] > 0 and "self-check FAILED" in r.stderr
 
 
 def test_other_workloads_and_bindings_only(built):
@@ -68,9 +81,13 @@ def test_multi_gpu_path_in_a_one_rank_group(built):
                   env={"KSCHED_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     c = d["config"]
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and c["pods_per_gpu"] == 100_000 and c["nodes"] == 5_000  # the same workload at every N
-    assert c["steps_per_allgather"] == 4 and c["steps_in_flight"] >= 2 and c["allgather"].startswith("ksched_allgather_bindings")
-    for leg in ("allgather_every_step", "no_allgather"):
+    # north_star's step: one all-gather per batch is the graded form; four batches per gather is the secondary figure
+    assert c["steps_per_allgather"] == 1 and c["steps_in_flight"] >= 2 and c["allgather"].startswith("ksched_allgather_bindings")
+    assert c["pipe_mode"].startswith("alternate")
+    for leg in ("allgather_every_4", "no_allgather"):
         assert c[leg] and c[leg]["ms_per_step"] > 0, leg
+    assert c["allgather_every_4"]["steps_per_allgather"] == 4
+    assert d["parity_check"]["mismatches"] == 0 and d["parity_check"]["mismatches_all_ranks"] == 0 and d["parity_check"]["bindings"] == 100_000
     assert 0.3 < c["scaling_efficiency_vs_no_allgather"] < 1.3
     s = c["configs3_strong"]
     assert s and "error" not in s and s["pods_total"] == 1_000_000 and s["nodes"] == 10_000 and s["value"] > 1e12

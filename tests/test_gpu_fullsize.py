@@ -121,6 +121,41 @@ def test_full_size_properties(evaluator, name):
     ev.set_kernel("auto")
 
 
+@pytest.mark.parametrize("name", ["C3", "C4s"])
+def test_full_size_the_variant_the_bench_times(evaluator, name):
+    """`test_full_size_properties` always asks for the fit mask too, so at full size it exercises the stand-alone pick + the
+    two-mask kernel -- not the launch bench.py times.  This is that launch: ONE mask, pitched rows, the sampled pick riding in the fused
+    kernel as tile tests (`ksched_last_pick` == "fused-tile": C3 has 5 tiles, the C4 shard 10), at 100k x 5k and 125k x 10k.  Every
+    feasible word and every binding == the oracle, twice in a row into two different buffers (the accumulators of the tile-test pick must
+    be back at zero after a launch)."""
+    import torch
+    cfg, P, N, preds, pick = CASES[name]
+    c = synth.make_config(cfg, P=P, N=N)
+    ev = evaluator
+    dev = torch.device("cuda", ev.device)
+    ev.set_nodes(**c.node_columns())
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    d_cpu, d_mem, d_sel, d_smp = t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.samples, np.int32)
+    flags = preds | pick  # no WANT_FIT_MASK
+    ev.set_kernel("auto")
+    runs = []
+    for _ in range(2):
+        feas = ev.alloc_mask(P, pitched=True)
+        bind = torch.full((P,), -7, dtype=torch.int32, device=dev)
+        ev.eval_device(d_cpu, d_mem, d_sel, None, d_smp, flags, out_feasible=feas, out_binding=bind)
+        torch.cuda.synchronize()
+        assert ev.last_kernel == "fused" and ev.last_pick == "fused-tile", (ev.last_kernel, ev.last_pick)
+        runs.append((feas, bind))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    feas, bind = runs[1]
+    for lo in range(0, P, CHUNK_ROWS):
+        hi = min(P, lo + CHUNK_ROWS)
+        o_feas, _, o_bind = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, None, c.req_cpu[lo:hi], c.req_mem[lo:hi],
+                                              np.ascontiguousarray(c.pod_sel[:, lo:hi]), None, np.ascontiguousarray(c.samples[lo:hi]), flags)
+        assert np.array_equal(feas[lo:hi].contiguous().cpu().numpy().view(np.uint64), o_feas), f"feasible != oracle in rows [{lo}, {hi})"
+        assert np.array_equal(bind[lo:hi].cpu().numpy(), o_bind), f"bindings != oracle in rows [{lo}, {hi})"
+
+
 def test_mask_larger_than_4_gib(evaluator):
     """One evaluation whose mask does not fit 32-bit byte offsets: 700k pods x 50k nodes (C5's predicates, pitched rows of 784 words)
     = 4.39 GB of feasible mask, more than half of BASELINE.json's configs[4] on ONE GPU.  Every word and every binding == the oracle
