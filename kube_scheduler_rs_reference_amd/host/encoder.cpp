@@ -18,6 +18,33 @@ static uint32_t host_threads() {
     return std::max(1u, std::thread::hardware_concurrency());
 }
 
+// ---- the unit of a resource column (encoder.hpp: cpu_unit_nanos) ------------------------------------------------------------------
+namespace {
+constexpr __int128 kCpuUnits[] = {1000000, 1000, 1};            // milli-, micro-, nano-cores
+constexpr __int128 kMemUnits[] = {1000000000, 1000000, 1000, 1};  // bytes, milli-, micro-, nano-bytes
+bool fits_i64(__int128 v) { return v >= (__int128)INT64_MIN && v <= (__int128)INT64_MAX; }
+// the coarsest unit in which every value is a whole number that fits int64; 0 = there is none
+template <size_t K>
+__int128 choose_unit(const std::vector<__int128> &values, const __int128 (&units)[K]) {
+    for (const __int128 u : units) {
+        bool ok = true;
+        for (const __int128 v : values)
+            if (v % u != 0 || !fits_i64(v / u)) {
+                ok = false;
+                break;
+            }
+        if (ok) return u;
+    }
+    return 0;
+}
+// ceil(a / b) for b > 0, any sign of a
+__int128 ceil_div(__int128 a, __int128 b) {
+    __int128 q = a / b;
+    if (a % b > 0) ++q;
+    return q;
+}
+}  // namespace
+
 DeviceEvaluator::DeviceEvaluator(int device) {
     int rc = ksched_create(&h_, device);
     if (rc != KSCHED_OK) throw EncodeError(std::string("ksched_create: ") + ksched_strerror(rc));
@@ -79,6 +106,7 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
     for (uint32_t i = 0; i < n; ++i) canonical_of_store[order[i]] = i;
     NodeColumns c;
     std::unordered_map<std::string, Counted> counted;
+    std::vector<__int128> cpu_nanos(n, 0), mem_nanos(n, 0);
     c.n = n;
     c.names.resize(n);
     c.avail_cpu_milli.resize(n);
@@ -118,12 +146,8 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
                 }
             }
         }
-        try {
-            c.avail_cpu_milli[i] = avail.cpu.to_milli();
-            c.avail_mem_bytes[i] = avail.memory.to_units();
-        } catch (const QuantityError &e) {
-            throw EncodeError("node " + c.names[i] + ": outside the exact integer domain: " + e.what());
-        }
+        cpu_nanos[i] = avail.cpu.nanos();
+        mem_nanos[i] = avail.memory.nanos();
         if (node.metadata.labels) {
             labels[i] = *node.metadata.labels;
             has_labels[i] = true;
@@ -136,11 +160,29 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
             }
         }
     }
+    // the unit of each resource column: the coarsest one in which every node's `available` is a whole int64 number (encoder.hpp)
+    const __int128 cpu_unit = choose_unit(cpu_nanos, kCpuUnits), mem_unit = choose_unit(mem_nanos, kMemUnits);
+    if (!cpu_unit || !mem_unit) {
+        for (uint32_t i = 0; i < n; ++i) {
+            const std::vector<__int128> one_c{cpu_nanos[i]}, one_m{mem_nanos[i]};
+            if (!choose_unit(one_c, kCpuUnits) || !choose_unit(one_m, kMemUnits))
+                throw EncodeError("node " + c.names[i] + ": outside the exact integer domain: available does not fit int64 in any unit fine enough to hold it");
+        }
+        throw EncodeError("the nodes' available values do not fit int64 in one common unit (one node needs nano-units, another is too large for them)");
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        c.avail_cpu_milli[i] = (int64_t)(cpu_nanos[i] / cpu_unit);
+        c.avail_mem_bytes[i] = (int64_t)(mem_nanos[i] / mem_unit);
+    }
     std::map<TaintId, uint32_t> ids;
     if (taints_enabled_) intern_taints_into(taints_raw, ids, c.taints);  // throws BEFORE anything is committed; the extension stays on across rebuilds
     // ---- commit (nothing below throws an EncodeError about the INPUT; a failing device call is remembered, see upload()) ----
     c.keys = cols_.keys;  // keep the label columns that were in use
     cols_ = std::move(c);
+    avail_cpu_nanos_ = std::move(cpu_nanos);
+    avail_mem_nanos_ = std::move(mem_nanos);
+    cpu_unit_ = cpu_unit;
+    mem_unit_ = mem_unit;
     counted_ = std::move(counted);
     store_of_canonical_ = std::move(order);
     canonical_of_store_ = std::move(canonical_of_store);
@@ -213,35 +255,81 @@ void Snapshot::upload() {
 }
 
 size_t Snapshot::apply_pod_events(const std::vector<std::pair<const corev1::Pod *, bool>> &events) {
-    std::vector<uint32_t> touched;
+    std::map<uint32_t, std::pair<__int128, __int128>> fresh_of;  // node -> its new exact `available`
     size_t applied = 0;
     for (const auto &[pod, bound] : events) {
         if (!pod->spec || !pod->spec->node_name) continue;
         const int idx = index_of(*pod->spec->node_name);
         if (idx < 0) continue;
-        int64_t dc, dm;
+        __int128 dc, dm;
         try {
             const PodResources r = total_pod_resources(*pod);  // the same sum the LIST loop subtracts (src/predicates.rs:37)
-            dc = r.cpu.to_milli();
-            dm = r.memory.to_units();
+            dc = r.cpu.nanos();
+            dm = r.memory.nanos();
         } catch (const QuantityError &e) {
             throw EncodeError("pod " + full_name(pod->metadata) + ": invalid pod spec: " + e.what());
         }
-        int64_t &cpu = cols_.avail_cpu_milli[(size_t)idx], &mem = cols_.avail_mem_bytes[(size_t)idx];
-        int64_t ncpu, nmem;
-        const bool over = bound ? (__builtin_sub_overflow(cpu, dc, &ncpu) || __builtin_sub_overflow(mem, dm, &nmem))
-                                : (__builtin_add_overflow(cpu, dc, &ncpu) || __builtin_add_overflow(mem, dm, &nmem));
-        if (over) throw EncodeError("node " + cols_.names[(size_t)idx] + ": available leaves the int64 domain");
-        cpu = ncpu;
-        mem = nmem;
-        touched.push_back((uint32_t)idx);
+        auto it = fresh_of.find((uint32_t)idx);
+        if (it == fresh_of.end()) it = fresh_of.emplace((uint32_t)idx, std::make_pair(avail_cpu_nanos_[(size_t)idx], avail_mem_nanos_[(size_t)idx])).first;
+        it->second.first += bound ? -dc : dc;
+        it->second.second += bound ? -dm : dm;
         ++applied;
     }
-    if (touched.empty()) return 0;
-    std::sort(touched.begin(), touched.end());
-    touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
-    push_rows(touched);
+    if (fresh_of.empty()) return 0;
+    std::vector<uint32_t> touched;
+    std::vector<std::pair<__int128, __int128>> fresh;
+    for (const auto &[node, v] : fresh_of) {
+        touched.push_back(node);
+        fresh.push_back(v);
+    }
+    store_available(touched, fresh, [] {});
     return applied;
+}
+
+// New exact `available` values of `nodes` (ascending, distinct).  When every one of them is a whole int64 number of the current
+// units the columns are patched and the rows pushed (ksched_update_nodes); otherwise the units are picked again over ALL nodes, every
+// row re-encoded and the whole snapshot uploaded (a pod with a "100u" request has landed on a node: rare, and a rebuild would do no
+// less).  Throws EncodeError -- with nothing changed -- when no unit holds the new values.
+void Snapshot::store_available(const std::vector<uint32_t> &nodes, const std::vector<std::pair<__int128, __int128>> &fresh, const std::function<void()> &commit) {
+    bool same_units = true;
+    for (const auto &[cpu, mem] : fresh)
+        if (cpu % cpu_unit_ != 0 || mem % mem_unit_ != 0 || !fits_i64(cpu / cpu_unit_) || !fits_i64(mem / mem_unit_)) same_units = false;
+    if (same_units) {
+        // (a coarser unit may have become possible again; it is only looked for by the next rebuild -- the comparison is exact in any unit)
+        commit();
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            avail_cpu_nanos_[nodes[i]] = fresh[i].first;
+            avail_mem_nanos_[nodes[i]] = fresh[i].second;
+            cols_.avail_cpu_milli[nodes[i]] = (int64_t)(fresh[i].first / cpu_unit_);
+            cols_.avail_mem_bytes[nodes[i]] = (int64_t)(fresh[i].second / mem_unit_);
+        }
+        push_rows(nodes);
+        return;
+    }
+    std::vector<__int128> cpu_all = avail_cpu_nanos_, mem_all = avail_mem_nanos_;
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        cpu_all[nodes[i]] = fresh[i].first;
+        mem_all[nodes[i]] = fresh[i].second;
+    }
+    const __int128 cpu_unit = choose_unit(cpu_all, kCpuUnits), mem_unit = choose_unit(mem_all, kMemUnits);
+    if (!cpu_unit || !mem_unit) {
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            const std::vector<__int128> one_c{fresh[i].first}, one_m{fresh[i].second};
+            if (!choose_unit(one_c, kCpuUnits) || !choose_unit(one_m, kMemUnits))
+                throw EncodeError("node " + cols_.names[nodes[i]] + ": available leaves the int64 domain (in the unit its fineness needs)");
+        }
+        throw EncodeError("the nodes' available values do not fit int64 in one common unit after this change");
+    }
+    commit();
+    avail_cpu_nanos_ = std::move(cpu_all);
+    avail_mem_nanos_ = std::move(mem_all);
+    cpu_unit_ = cpu_unit;
+    mem_unit_ = mem_unit;
+    for (uint32_t i = 0; i < cols_.n; ++i) {
+        cols_.avail_cpu_milli[i] = (int64_t)(avail_cpu_nanos_[i] / cpu_unit_);
+        cols_.avail_mem_bytes[i] = (int64_t)(avail_mem_nanos_[i] / mem_unit_);
+    }
+    upload();  // every row changed its scale: the whole snapshot goes up (pods are encoded against the new unit from now on)
 }
 
 // the changed rows of `available` go to the device in one ksched_update_nodes (only the touched 1024-node tiles are re-indexed)
@@ -391,28 +479,21 @@ size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
         ++changed;
     }
     std::vector<uint32_t> touched;
-    std::vector<std::pair<int64_t, int64_t>> fresh;
+    std::vector<std::pair<__int128, __int128>> fresh;
     for (const auto &[node, d] : delta.sorted()) {
         if (d.first == 0 && d.second == 0) continue;
-        constexpr __int128 kMilli = 1000000, kUnit = 1000000000;
-        if (d.first % kMilli != 0 || d.second % kUnit != 0)
-            throw EncodeError("node " + cols_.names[node] + ": the change is not an integer number of milli-cores / bytes");
-        const __int128 cpu = (__int128)cols_.avail_cpu_milli[node] + d.first / kMilli, mem = (__int128)cols_.avail_mem_bytes[node] + d.second / kUnit;
-        if (cpu < INT64_MIN || cpu > INT64_MAX || mem < INT64_MIN || mem > INT64_MAX)
-            throw EncodeError("node " + cols_.names[node] + ": available leaves the int64 domain");
         touched.push_back(node);
-        fresh.emplace_back((int64_t)cpu, (int64_t)mem);
+        fresh.emplace_back(avail_cpu_nanos_[node] + d.first, avail_mem_nanos_[node] + d.second);
     }
-    counted_.reserve(counted_.size() + staged.size());
-    for (auto &[key, st] : staged) {  // commit (no lookup in `staged` after this: its keys are views into the strings moved here)
-        if (st.entry) counted_.insert_or_assign(std::move(pre[st.last].key), *st.entry);
-        else counted_.erase(pre[st.last].key);
-    }
-    for (size_t i = 0; i < touched.size(); ++i) {
-        cols_.avail_cpu_milli[touched[i]] = fresh[i].first;
-        cols_.avail_mem_bytes[touched[i]] = fresh[i].second;
-    }
-    if (!touched.empty()) push_rows(touched);
+    auto commit = [&] {  // (no lookup in `staged` after this: its keys are views into the strings moved here)
+        counted_.reserve(counted_.size() + staged.size());
+        for (auto &[key, st] : staged) {
+            if (st.entry) counted_.insert_or_assign(std::move(pre[st.last].key), *st.entry);
+            else counted_.erase(pre[st.last].key);
+        }
+    };
+    if (touched.empty()) commit();  // (changes that cancel out: the table still moves)
+    else store_available(touched, fresh, commit);  // validates first: on EncodeError nothing -- table, columns, device -- has changed
     return changed;
 }
 
@@ -483,8 +564,11 @@ PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
             const corev1::Pod &pod = *pods[i];
             try {
                 const PodResources r = total_pod_resources(pod);  // src/predicates.rs:40
-                pc.req_cpu_milli[i] = r.cpu.to_milli();
-                pc.req_mem_bytes[i] = r.memory.to_units();
+                // ceil(request / unit): `available` is a whole number of units, so request <= available <=> ceil(request / unit) <= available / unit
+                const __int128 qc = ceil_div(r.cpu.nanos(), cpu_unit_), qm = ceil_div(r.memory.nanos(), mem_unit_);
+                if (!fits_i64(qc) || !fits_i64(qm)) throw QuantityError("the request does not fit int64 in the snapshot's unit");
+                pc.req_cpu_milli[i] = (int64_t)qc;
+                pc.req_mem_bytes[i] = (int64_t)qm;
             } catch (const QuantityError &e) {
                 throw PodEncodeError("pod " + full_name(pod.metadata) + ": invalid pod spec: " + e.what());
             }

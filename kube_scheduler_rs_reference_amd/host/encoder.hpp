@@ -6,6 +6,7 @@
 // hash), taints become bit positions.  Nodes are put in canonical order (ascending name).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <set>
@@ -140,6 +141,16 @@ public:
     PodColumns encode_pods(const std::vector<const corev1::Pod *> &pods);
 
     const NodeColumns &columns() const { return cols_; }
+    // The unit of the resource columns, in nano-units per column unit: 1 000 000 (milli-cores) and 1 000 000 000 (bytes) unless
+    // some node's `available` is finer than that.  The reference compares decimals and accepts ANY quantity (src/util.rs:64-69,
+    // src/predicates.rs:29-31: "100u" of CPU, "100m" of memory); the device compares exact int64 -- so the snapshot picks, per
+    // resource, the COARSEST unit of {milli, micro, nano}-cores / {1, milli, micro, nano}-bytes in which every node's
+    // `available` is a whole number that fits int64 (nano-cores reach 9.2e9 cores, milli-bytes 9.2 PB), re-picks it when a pod
+    // event makes a value finer, and encodes a pod's request as ceil(request / unit): `available` being a whole number of
+    // units, request <= available  <=>  ceil(request / unit) <= available / unit, exactly.  Refused (EncodeError): only what no
+    // unit can hold -- finer than a nano-unit, or too large for int64 in the unit its fineness needs.
+    __int128 cpu_unit_nanos() const { return cpu_unit_; }
+    __int128 mem_unit_nanos() const { return mem_unit_; }
     int index_of(const std::string &node_name) const;  // canonical index or -1
     // canonical index <-> position in the vector given to rebuild() (the node store's own order)
     uint32_t store_index(uint32_t canonical) const { return store_of_canonical_[canonical]; }
@@ -175,6 +186,11 @@ private:
     void intern_taints();
     static void intern_taints_into(const std::vector<std::vector<TaintId>> &raw, std::map<TaintId, uint32_t> &ids, std::vector<uint64_t> &column);
     uint64_t generation_ = 0;
+    std::vector<__int128> avail_cpu_nanos_, avail_mem_nanos_;  // canonical order: the exact values behind the two resource columns
+    __int128 cpu_unit_ = 1000000, mem_unit_ = 1000000000;      // nano-units per column unit (see cpu_unit_nanos())
+    // new exact `available` values of some nodes -> columns (+ a new unit when one of them needs it) -> device.  Validates before it
+    // changes anything (strong guarantee); `commit` runs between validation and the device call (the callers' own bookkeeping).
+    void store_available(const std::vector<uint32_t> &nodes, const std::vector<std::pair<__int128, __int128>> &fresh, const std::function<void()> &commit);
     struct Counted {
         uint32_t node;  // canonical index
         __int128 cpu_nanos, mem_nanos;

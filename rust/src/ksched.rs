@@ -4,9 +4,12 @@
 // encoding rules, same error behaviour, so the parity tests of both read the same.
 //
 // Encoding rules (include/ksched.h "Conventions"):
-//   * quantities -> exact i64: CPU in milli-cores, memory in bytes.  The text is parsed with the Kubernetes quantity
-//     grammar into exact nano-units (i128); a value that is not a whole number of milli-cores / bytes, or leaves i64, is
-//     an error (the reference would have compared it in decimal; the device compares integers).
+//   * quantities -> exact i64: CPU in milli-cores, memory in bytes -- unless some node's `available` is finer than that: the
+//     text is parsed with the Kubernetes quantity grammar into exact nano-units (i128), and the snapshot picks, per resource,
+//     the COARSEST unit of {milli, micro, nano}-cores / {1, milli, micro, nano}-bytes in which every node's `available` is a
+//     whole number that fits i64 (the reference compares decimals and accepts any quantity, src/util.rs:64-69; the device
+//     compares integers).  A pod's request is encoded as ceil(request / unit): `available` being whole units,
+//     request <= available <=> ceil(request / unit) <= available / unit, exactly.  An error only where no unit can hold a value.
 //   * available[n] = allocatable[n] - sum(total requests of every pod whose spec.nodeName == n)   (src/predicates.rs:27-38),
 //     signed: it may be negative.
 //   * nodes in canonical order = ascending metadata.name; column index == mask bit.
@@ -405,6 +408,29 @@ fn nanos_to_i64(nanos: i128, per_unit: i128, what: &str) -> Result<i64, String> 
     return i64::try_from(nanos / per_unit).map_err(|_| format!("{} overflow i64", what));
 }
 
+/// the units a resource column may be kept in, coarsest first (nano-units per column unit)
+const CPU_UNITS: [i128; 3] = [1_000_000, 1_000, 1]; // milli-, micro-, nano-cores
+const MEM_UNITS: [i128; 4] = [1_000_000_000, 1_000_000, 1_000, 1]; // bytes, milli-, micro-, nano-bytes
+
+/// the coarsest unit in which every value is a whole number that fits i64 (twin of choose_unit, host/encoder.cpp)
+fn choose_unit(values: &[i128], units: &[i128]) -> Option<i128> {
+    for &u in units {
+        if values.iter().all(|&v| v % u == 0 && i64::try_from(v / u).is_ok()) {
+            return Some(u);
+        }
+    }
+    return None;
+}
+
+/// ceil(nanos / unit) as i64: how a REQUEST is encoded against a column of whole units
+fn ceil_to_i64(nanos: i128, unit: i128, what: &str) -> Result<i64, String> {
+    let mut q = nanos / unit;
+    if nanos % unit > 0 {
+        q += 1;
+    }
+    return i64::try_from(q).map_err(|_| format!("{} does not fit i64 in the snapshot's unit", what));
+}
+
 /// total_pod_resources (src/util.rs:54-75) in exact nano-units: spec.containers only, requests only.
 pub fn total_pod_resources_nanos(pod: &corev1::Pod) -> Result<(i128, i128), String> {
     let (mut cpu, mut mem) = (0i128, 0i128);
@@ -443,6 +469,8 @@ pub struct Snapshot {
     pub keys: Vec<String>,            // label column k <-> key
     avail_cpu_nanos: Vec<i128>,       // the same columns, exact (a pod event moves them by the pod's exact requests)
     avail_mem_nanos: Vec<i128>,
+    pub cpu_unit: i128,               // nano-units per unit of avail_cpu_milli / req_cpu_milli: 1_000_000 unless a value is finer
+    pub mem_unit: i128,               // ... of avail_mem_bytes / req_mem_bytes: 1_000_000_000 unless a value is finer
     value_ids: Vec<BTreeMap<String, u32>>,
     labels: Vec<Option<BTreeMap<String, String>>>, // canonical order
     label_val_ids: Vec<u32>,          // [n_keys][n]
@@ -529,11 +557,15 @@ impl Snapshot {
                 cpu -= uc;
                 mem -= um;
             }
-            avail_cpu_milli.push(nanos_to_i64(cpu, 1_000_000, "milli-cores")?);
-            avail_mem_bytes.push(nanos_to_i64(mem, 1_000_000_000, "bytes")?);
             avail_cpu_nanos.push(cpu);
             avail_mem_nanos.push(mem);
             labels.push(node.metadata.labels.clone());
+        }
+        let cpu_unit = choose_unit(&avail_cpu_nanos, &CPU_UNITS).ok_or_else(|| "the nodes' available cpu does not fit i64 in any unit fine enough to hold it".to_string())?;
+        let mem_unit = choose_unit(&avail_mem_nanos, &MEM_UNITS).ok_or_else(|| "the nodes' available memory does not fit i64 in any unit fine enough to hold it".to_string())?;
+        for i in 0..n {
+            avail_cpu_milli.push(nanos_to_i64(avail_cpu_nanos[i], cpu_unit, "cpu units")?);
+            avail_mem_bytes.push(nanos_to_i64(avail_mem_nanos[i], mem_unit, "memory units")?);
         }
         return Ok(Snapshot {
             names,
@@ -543,6 +575,8 @@ impl Snapshot {
             keys: Vec::new(),
             avail_cpu_nanos,
             avail_mem_nanos,
+            cpu_unit,
+            mem_unit,
             value_ids: Vec::new(),
             labels,
             label_val_ids: Vec::new(),
@@ -558,7 +592,8 @@ impl Snapshot {
 
     /// A pod appeared on / left `node_name`: available moves by its exact requests (sign = -1: now counted, +1: no longer).
     /// The row goes to the device with the next evaluation (ksched_update_nodes).  Err (nothing changed) when the result is
-    /// not a whole number of milli-cores / bytes or leaves i64.  Ok(false): the node is not in this snapshot.
+    /// not a whole i64 number of the snapshot's units (the caller then drops the snapshot: the rebuild picks a finer unit).
+    /// Ok(false): the node is not in this snapshot.
     fn shift(&mut self, node_name: &str, sign: i128, cpu_nanos: i128, mem_nanos: i128) -> Result<bool, String> {
         let i = match self.index_of(node_name) {
             Some(i) => i as usize,
@@ -566,8 +601,8 @@ impl Snapshot {
         };
         let cpu = self.avail_cpu_nanos[i] + sign * cpu_nanos;
         let mem = self.avail_mem_nanos[i] + sign * mem_nanos;
-        let cpu_milli = nanos_to_i64(cpu, 1_000_000, "milli-cores")?;
-        let mem_bytes = nanos_to_i64(mem, 1_000_000_000, "bytes")?;
+        let cpu_milli = nanos_to_i64(cpu, self.cpu_unit, "cpu units")?;
+        let mem_bytes = nanos_to_i64(mem, self.mem_unit, "memory units")?;
         self.avail_cpu_nanos[i] = cpu;
         self.avail_mem_nanos[i] = mem;
         self.avail_cpu_milli[i] = cpu_milli;
@@ -640,8 +675,8 @@ impl Snapshot {
         let mut cols = PodColumns { p: p as u32, n_keys, req_cpu_milli: vec![0; p], req_mem_bytes: vec![0; p], sel_val_ids: vec![0u32; self.keys.len() * p] };
         for (i, pod) in pods.iter().enumerate() {
             let (c, m) = total_pod_resources_nanos(pod)?; // src/predicates.rs:40
-            cols.req_cpu_milli[i] = nanos_to_i64(c, 1_000_000, "milli-cores")?;
-            cols.req_mem_bytes[i] = nanos_to_i64(m, 1_000_000_000, "bytes")?;
+            cols.req_cpu_milli[i] = ceil_to_i64(c, self.cpu_unit, "cpu request")?;
+            cols.req_mem_bytes[i] = ceil_to_i64(m, self.mem_unit, "memory request")?;
             if let Some(corev1::PodSpec { node_selector: Some(sel), .. }) = &pod.spec {
                 for (k, v) in sel.iter() { // src/predicates.rs:48-53
                     let col = self.keys.iter().position(|x| x == k).expect("key was interned above");
@@ -861,7 +896,7 @@ impl ClusterState {
                 tracing::warn!("pod {} cannot be scheduled: {} nodeSelector keys on one pod (limit {})", pod_key(p), keys_of_pod, sys::KSCHED_MAX_KEYS);
                 continue;
             }
-            match total_pod_resources_nanos(p).and_then(|(c, m)| nanos_to_i64(c, 1_000_000, "milli-cores").and(nanos_to_i64(m, 1_000_000_000, "bytes"))) {
+            match total_pod_resources_nanos(p).and_then(|(c, m)| ceil_to_i64(c, snap.cpu_unit, "cpu request").and(ceil_to_i64(m, snap.mem_unit, "memory request"))) {
                 Ok(_) => which.push(i),
                 Err(e) => tracing::warn!("pod {} cannot be scheduled: {}", pod_key(p), e),
             }

@@ -360,13 +360,53 @@ static void cpu_tests() {
         const auto cpu_before = snap.columns().avail_cpu_milli;
         CHECK_THROWS(snap.observe_pods({{E::Applied, &ok}, {E::Applied, &bad}}));
         CHECK(snap.columns().avail_cpu_milli == cpu_before && snap.counted_pods() == 1);
-        const corev1::Pod fine = pod_with("fine", {container("100n", nullptr)}, "b");  // finer than a milli-core: refused, nothing counted
-        CHECK_THROWS(snap.observe_pod(E::Applied, fine));
-        CHECK(snap.columns().avail_cpu_milli == cpu_before && snap.counted_pods() == 1);
-        // two halves of a milli-core in one call ARE an integer change
+        // finer than a milli-core: the reference compares decimals and schedules it like any other pod (src/util.rs:64-69) -- the column's unit follows
+        const corev1::Pod fine = pod_with("fine", {container("100n", nullptr)}, "b");
+        CHECK(snap.cpu_unit_nanos() == 1000000 && snap.mem_unit_nanos() == 1000000000);
+        CHECK(snap.observe_pod(E::Applied, fine));
+        CHECK(snap.cpu_unit_nanos() == 1 && snap.mem_unit_nanos() == 1000000000);  // nano-cores now; memory still in bytes
+        CHECK(snap.columns().avail_cpu_milli[0] == 7000ll * 1000000 && snap.columns().avail_cpu_milli[1] == 8000ll * 1000000 - 100 && snap.counted_pods() == 2);
+        {   // a request is encoded as ceil(request / unit): exact against a column of whole units
+            const corev1::Pod one = pod_with("one", {container("1", "1")}), tiny = pod_with("tiny", {container("1500n", "100m")});
+            const PodColumns pc = snap.encode_pods({&one, &tiny});
+            CHECK(pc.req_cpu_milli[0] == 1000000000ll && pc.req_cpu_milli[1] == 1500);
+            CHECK(pc.req_mem_bytes[0] == 1 && pc.req_mem_bytes[1] == 1);  // 0.1 byte -> 1 byte: 0.1 <= available <=> 1 <= available for whole-byte values
+        }
+        CHECK(snap.observe_pod(E::Deleted, fine));  // whole milli-cores again; the unit stays until the next rebuild (the comparison is exact in any unit)
+        CHECK(snap.cpu_unit_nanos() == 1 && snap.columns().avail_cpu_milli[1] == 8000ll * 1000000 && snap.counted_pods() == 1);
+        // two halves of a milli-core in one call
         const corev1::Pod h1 = pod_with("h1", {container("500u", nullptr)}, "b"), h2 = pod_with("h2", {container("500u", nullptr)}, "b");
         CHECK(snap.observe_pods({{E::Applied, &h1}, {E::Applied, &h2}}) == 2);
-        CHECK(snap.columns().avail_cpu_milli[1] == 7999 && snap.counted_pods() == 3);
+        CHECK(snap.columns().avail_cpu_milli[1] == 7999ll * 1000000 && snap.counted_pods() == 3);
+        // what no unit can hold is still refused, with nothing changed: 9.3e9 cores (more than int64 nano-cores) on a node that counts a "100n" pod
+        const auto before = snap.columns().avail_cpu_milli;
+        const corev1::Pod huge = pod_with("huge", {container("9300000000", nullptr)}, "b");
+        CHECK(snap.observe_pod(E::Applied, fine));
+        CHECK_THROWS(snap.observe_pod(E::Applied, huge));
+        CHECK(snap.counted_pods() == 4 && snap.columns().avail_cpu_milli[0] == before[0]);
+    });
+    run("quantity domain: a cluster with sub-milli CPU and sub-byte memory is scheduled like the reference schedules it (VERDICT r3 item 6)", [] {
+        // node a: 2 cores - a bound pod of 100u = 1.9999 cores; memory 1000 bytes - 100m (0.1 byte) = 999.9 bytes
+        std::vector<corev1::Node> nodes = {node_with("a", "2", "1000"), node_with("b", "1500n", "1")};
+        std::vector<corev1::Pod> bound = {pod_with("load", {container("100u", "100m")}, "a")};
+        Snapshot snap(Snapshot::kEncodeOnly);
+        StaticPodLister lister;
+        lister.pods = bound;
+        snap.rebuild(nodes, &lister);
+        CHECK(snap.cpu_unit_nanos() == 1 && snap.mem_unit_nanos() == 1000000);  // nano-cores (1500n), milli-bytes (100m)
+        CHECK(snap.columns().avail_cpu_milli[0] == 2000000000ll - 100000 && snap.columns().avail_mem_bytes[0] == 1000000ll - 100);
+        CHECK(snap.columns().avail_cpu_milli[1] == 1500 && snap.columns().avail_mem_bytes[1] == 1000);
+        // exact-fit boundaries: request == available fits, one nano-core / milli-byte more does not
+        const corev1::Pod exact = pod_with("exact", {container("1999900u", "999900m")}), over_cpu = pod_with("oc", {container("1999900001n", "1")}),
+                          over_mem = pod_with("om", {container("1", "999901m")}), small = pod_with("s", {container("1500n", "1")});
+        const PodColumns pc = snap.encode_pods({&exact, &over_cpu, &over_mem, &small});
+        auto fits = [&](uint32_t pod, uint32_t node) { return pc.req_cpu_milli[pod] <= snap.columns().avail_cpu_milli[node] && pc.req_mem_bytes[pod] <= snap.columns().avail_mem_bytes[node]; };
+        CHECK(fits(0, 0) && !fits(1, 0) && !fits(2, 0) && fits(3, 0));
+        CHECK(!fits(0, 1) && fits(3, 1));  // node b holds exactly 1500n / 1 byte
+        // a cluster without such values keeps milli-cores / bytes (what every earlier test and the fixtures assume)
+        Snapshot plain(Snapshot::kEncodeOnly);
+        plain.rebuild({node_with("a", "2", "1Gi")}, nullptr);
+        CHECK(plain.cpu_unit_nanos() == 1000000 && plain.mem_unit_nanos() == 1000000000);
     });
     run("snapshot builder: observe_bound == observe_pods on copies that carry the node name, also for a batch large enough for the thread fan-out", [] {
         std::vector<corev1::Node> nodes;

@@ -248,6 +248,8 @@ int main(int argc, char **argv) {
             arr64("req_mem_bytes", pc.req_mem_bytes); std::printf(",");
             arr32("sel_val_ids", pc.sel_val_ids); std::printf(",");
             arru64("tolerations", pc.tolerations);
+            // the unit of the two resource columns, nano-units per column unit (1e6 / 1e9 = milli-cores / bytes unless the cluster holds finer values)
+            std::printf(",\"cpu_unit_nanos\":%lld,\"mem_unit_nanos\":%lld", (long long)snap.cpu_unit_nanos(), (long long)snap.mem_unit_nanos());
             std::printf(",\"list_calls\":%llu}\n", (unsigned long long)lister->list_calls);
             if (pp.empty()) break;
             }

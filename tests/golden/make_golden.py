@@ -13,6 +13,7 @@ tests/test_reference_fixtures.py then compares with these fixtures -- that is wh
 
 Two further object-only cases have no encoded columns:
   binsuffix_60x40   memory spelled with Ki / Mi (believed exact in kube_quantity 0.6.1)
+  subunit_22x8      sub-milli CPU / sub-byte memory at exact-fit boundaries: OUTSIDE D; the snapshot's column unit follows
   hazard_gi_24x10   Gi / Ti / exponent / fractional spellings at exact-fit boundaries: OUTSIDE the parity domain D; the
                     expected masks follow true Kubernetes semantics (exact powers of 1024).  A reference run that
                     differs here documents kube_quantity's suspected f32 scale conversion, it does not fail parity.
@@ -87,6 +88,30 @@ def hazard_case():
     bound = [{"metadata": {"name": "hz-bound-0", "namespace": "hz"},
               "spec": {"nodeName": "hz-node-05", "containers": [{"name": "c", "resources": {"requests": {"cpu": "1", "memory": "32Gi"}}}]}}]
     samples = np.array([[(i * 7 + t * 3) % len(nodes) for t in range(R.ATTEMPTS)] for i in range(len(pods))], dtype=np.uint32)
+    return pods, nodes, bound, samples
+
+
+def subunit_case():
+    """Hand-built: quantities FINER than a milli-core / a byte -- cpu "100u" / "1500n" / "0.0005", memory "100m" (a tenth of a byte) / "1n" --
+    at exact-fit boundaries.  The reference parses any quantity (src/util.rs:64-69, src/predicates.rs:29-31) and compares decimals; the
+    product picks the snapshot's column unit from the finest value present (host/encoder.hpp cpu_unit_nanos) and must give the same bits."""
+    GI = 1 << 30
+    allocs = [("2", "1000"), ("1500n", "1"), ("0.0005", "0.5"), ("4", "4Gi"), ("250u", "1k"), ("1", "1500m"), ("1000001n", "1"), ("8", "8Gi")]
+    nodes = [{"metadata": {"name": f"su-node-{i:02d}", "labels": {"zone": "a" if i % 2 else "b"}},
+              "status": {"allocatable": {"cpu": c, "memory": m}}} for i, (c, m) in enumerate(allocs)]
+    reqs = [("1999900u", "999900m"), ("1999900001n", "1"), ("1", "999901m"), ("1500n", "1"), ("1501n", "1"), ("500u", "0.5"), ("500u", "500m"),
+            ("501u", "0.5"), ("0.5m", "1"), ("250u", "1k"), ("250001n", "1"), ("1", "1500m"), ("1", "1501m"), ("1000001n", "1"), ("1000002n", "1"),
+            ("7999999999n", str(8 * GI - 1)), ("8", "8Gi"), ("0", "0"), ("100u", "100m"), ("4", "4Gi"), ("3999999999n", "4294967295999999999n"), ("1n", "1n")]
+    pods = [{"metadata": {"name": f"su-pod-{i:02d}", "namespace": "su"},
+             "spec": {"containers": [{"name": "c", "resources": {"requests": {"cpu": c, "memory": m}}}]}}
+            for i, (c, m) in enumerate(reqs)]
+    pods[5]["spec"]["containers"].append({"name": "half", "resources": {"requests": {"cpu": "0", "memory": "0"}}})
+    pods[18]["spec"]["nodeSelector"] = {"zone": "b"}
+    bound = [{"metadata": {"name": "su-bound-0", "namespace": "su"},
+              "spec": {"nodeName": "su-node-00", "containers": [{"name": "c", "resources": {"requests": {"cpu": "100u", "memory": "100m"}}}]}},
+             {"metadata": {"name": "su-bound-1", "namespace": "su"},
+              "spec": {"nodeName": "su-node-07", "containers": [{"name": "c", "resources": {"requests": {"cpu": "1n", "memory": "1n"}}}]}}]
+    samples = np.array([[(i * 3 + t * 5) % len(nodes) for t in range(R.ATTEMPTS)] for i in range(len(pods))], dtype=np.uint32)
     return pods, nodes, bound, samples
 
 
@@ -177,6 +202,9 @@ def main():
     dump_objects("typical_specs_40x12", pods, nodes, bound, samples, "typical real spellings (500m / 1Gi / 512Mi / 32779148Ki): Gi and above are OUTSIDE D")
     dump_expected("typical_specs_40x12", pods, nodes, bound, samples, use_taint=False)
     print("typical_specs_40x12: readings differ on %d pairs, the recalled parser rejects %d" % dump_readings("typical_specs_40x12", pods, nodes, bound))
+    pods, nodes, bound, samples = subunit_case()
+    dump_objects("subunit_22x8", pods, nodes, bound, samples, "OUTSIDE D: sub-milli CPU (100u, 1500n) and sub-byte memory (100m, 1n) at exact-fit boundaries")
+    dump_expected("subunit_22x8", pods, nodes, bound, samples, use_taint=False)
     dump_spellings()
     for name, kw in CASES.items():
         c = synth.make_cluster(**kw)

@@ -10,8 +10,8 @@ parser, dict lookups -- independent of the C++ parser; oracle.c's own parser is 
     12 label keys and 16 taints;
   * every `available` / request column entry equals the oracle's exact Fraction, for randomly generated spellings of the
     Kubernetes quantity grammar (hypothesis): signs, fractions, decimal and binary suffixes, exponents -- and what the reference
-    would panic on (src/util.rs:65,68; src/predicates.rs:29,31) or what is not an integer number of milli-cores / bytes is refused
-    by the encoder (exit code 1), never silently rounded.
+    would panic on (src/util.rs:65,68; src/predicates.rs:29,31) is refused by the encoder (exit code 1); values finer than a milli-core /
+    a byte move the snapshot's column unit (down to nano-units) instead of being refused or rounded.
 
   * randomly shaped label maps / selectors / taints / tolerations give the oracle's masks (src/predicates.rs:45-61, extension E2);
   * pod watch events applied incrementally (Snapshot::apply_pod_events, SURVEY.md 8f n1) leave exactly the `available` a re-LIST of
@@ -82,7 +82,7 @@ def expect_masks(pods, nodes, bound, use_taint, cache):
 
 
 @pytest.mark.parametrize("name,taints", [("c1_100x20", False), ("ragged_70x130_taints", True), ("one_node_33x1", True),
-                                         ("binsuffix_60x40", False), ("hazard_gi_24x10", False)])
+                                         ("binsuffix_60x40", False), ("hazard_gi_24x10", False), ("subunit_22x8", False)])
 def test_golden_objects_through_the_host_encoder_without_a_device(name, taints):
     path = os.path.join(GOLD, name + "_objects.json")
     doc = json.load(open(path))
@@ -93,13 +93,15 @@ def test_golden_objects_through_the_host_encoder_without_a_device(name, taints):
     want_feas, want_fit = expect_masks(doc["pods"], doc["nodes"], doc["bound"], taints, cache=False)  # every pair re-parsed, as the reference does
     assert np.array_equal(fit, want_fit)
     assert np.array_equal(feas, want_feas)
-    # and the columns themselves are the oracle's exact values
+    # and the columns themselves are the oracle's exact values, in the snapshot's units (milli-cores / bytes unless the cluster holds finer values)
+    cu, mu = c["cpu_unit_nanos"], c["mem_unit_nanos"]
+    assert (cu, mu) == ((1, 1) if name == "subunit_22x8" else (10 ** 6, 10 ** 9)), (cu, mu)
     for i, node in enumerate(doc["nodes"]):
         av = R.available_of(node, doc["bound"])
-        assert Fraction(c["avail_cpu_milli"][i], 1000) == av.cpu and Fraction(c["avail_mem_bytes"][i]) == av.memory, node["metadata"]["name"]
+        assert Fraction(c["avail_cpu_milli"][i] * cu, 10 ** 9) == av.cpu and Fraction(c["avail_mem_bytes"][i] * mu, 10 ** 9) == av.memory, node["metadata"]["name"]
     for i, pod in enumerate(doc["pods"]):
-        rq = R.total_pod_resources(pod)
-        assert Fraction(c["req_cpu_milli"][i], 1000) == rq.cpu and Fraction(c["req_mem_bytes"][i]) == rq.memory
+        rq = R.total_pod_resources(pod)  # (a request is the CEILING in the unit: exact whenever it is a whole number of units, as here)
+        assert Fraction(c["req_cpu_milli"][i] * cu, 10 ** 9) == rq.cpu and Fraction(c["req_mem_bytes"][i] * mu, 10 ** 9) == rq.memory
 
 
 def test_cluster_2000x500_binary_suffixes_12_keys_taints_without_a_device(tmp_path):
@@ -120,7 +122,7 @@ def test_cluster_2000x500_binary_suffixes_12_keys_taints_without_a_device(tmp_pa
 # ---- the quantity grammar, randomly spelled ---------------------------------------------------------------------------------
 
 _digits = st.text("0123456789", min_size=1, max_size=9)
-_SUFFIX = {  # spellings that mostly stay integer numbers of milli-cores / bytes, with a minority that do not (those must be refused)
+_SUFFIX = {  # spellings that mostly stay integer numbers of milli-cores / bytes, with a minority that do not (the column's unit follows those)
     "cpu": ["", "", "m", "m", "k", "e0", "e3", "e-3", "e-1", "E2", "u", "M"],
     "memory": ["", "", "k", "M", "G", "Ki", "Mi", "Gi", "Ti", "T", "e3", "E2", "e0", "m", "e-1", "n"],
 }
@@ -144,26 +146,46 @@ def _obj_pod(name, cpu, mem, node=None):
 @_hyp(150)
 @given(alloc_cpu=quantity("cpu"), alloc_mem=quantity("memory"), b_cpu=quantity("cpu"), b_mem=quantity("memory"), r_cpu=quantity("cpu"), r_mem=quantity("memory"))
 def test_random_quantity_spellings_encode_exactly_or_are_refused(tmp_path, alloc_cpu, alloc_mem, b_cpu, b_mem, r_cpu, r_mem):
+    """The reference parses ANY quantity (src/util.rs:64-69, src/predicates.rs:29-31).  The encoder picks, per resource, the coarsest unit of
+    {milli, micro, nano}-cores / {1, milli, micro, nano}-bytes in which the node's `available` is a whole int64 number (VERDICT r3 item 6:
+    it used to refuse everything finer than a milli-core / a byte), and encodes the request as ceil(request / unit).  Checked against exact
+    Fractions: available * unit is the exact value, the request is its ceiling, and the fit bit is what the reference's `<=` gives.  Refused:
+    only what no unit can hold (finer than a nano-unit, or too large for int64 in the unit its fineness needs)."""
     node = {"metadata": {"name": "n0"}, "status": {"allocatable": {"cpu": alloc_cpu, "memory": alloc_mem}}}
     bound = [_obj_pod("b0", b_cpu, b_mem, node="n0")]
     pods = [_obj_pod("p0", r_cpu, r_mem)]
     path = tmp_path / "q.json"
     json.dump({"name": "q", "pods": pods, "nodes": [node], "bound": bound, "samples": []}, open(path, "w"))
     av, rq = R.available_of(node, bound), R.total_pod_resources(pods[0])
-    vals = [av.cpu * 1000, av.memory, rq.cpu * 1000, rq.memory]
-    representable = all(v.denominator == 1 and -(1 << 63) <= v.numerator < (1 << 63) for v in vals)
-    # (every single quantity must also be an int64 number of nano-units' worth for the 128-bit accumulator: 9 digits x 10^18 fits)
+    NANO = 10 ** 9
+
+    def unit_for(value, units):  # the coarsest unit (in nano-units) in which `value` is a whole int64 number, or None
+        v = value * NANO
+        if v.denominator != 1:
+            return None
+        for u in units:
+            if v.numerator % u == 0 and -(1 << 63) <= v.numerator // u < (1 << 63):
+                return u
+        return None
+    # every single quantity must be a whole number of nano-units for the parser (the accumulator is 128-bit nano-units)
+    singles_ok = all((R.parse_quantity(t) * NANO).denominator == 1 for t in (alloc_cpu, alloc_mem, b_cpu, b_mem, r_cpu, r_mem))
+    cu, mu = unit_for(av.cpu, (10 ** 6, 10 ** 3, 1)), unit_for(av.memory, (10 ** 9, 10 ** 6, 10 ** 3, 1))
+    representable = singles_ok and cu is not None and mu is not None
+    if representable:
+        qc, qm = -((-rq.cpu * NANO) // cu), -((-rq.memory * NANO) // mu)  # ceilings
+        representable = -(1 << 63) <= qc < (1 << 63) and -(1 << 63) <= qm < (1 << 63)
     r = columns(path, expect_fail=True)
     if representable:
         assert r.returncode == 0, (r.stderr[-400:], alloc_cpu, alloc_mem, b_cpu, b_mem, r_cpu, r_mem)
         c = json.loads(r.stdout)
-        got = [Fraction(c["avail_cpu_milli"][0]), Fraction(c["avail_mem_bytes"][0]), Fraction(c["req_cpu_milli"][0]), Fraction(c["req_mem_bytes"][0])]
-        assert got == vals, (got, vals, alloc_cpu, alloc_mem, b_cpu, b_mem, r_cpu, r_mem)
+        assert (c["cpu_unit_nanos"], c["mem_unit_nanos"]) == (cu, mu), (c["cpu_unit_nanos"], c["mem_unit_nanos"], cu, mu)
+        assert Fraction(c["avail_cpu_milli"][0] * cu, NANO) == av.cpu and Fraction(c["avail_mem_bytes"][0] * mu, NANO) == av.memory
+        assert c["req_cpu_milli"][0] == qc and c["req_mem_bytes"][0] == qm
         feas, fit = masks_of_columns(c, False)
         want = R.can_pod_fit(pods[0], node, bound)  # src/predicates.rs:20-43 on the strings
         assert bool(fit[0, 0] & np.uint64(1)) == want
     else:
-        assert r.returncode == 1 and "objects_eval:" in r.stderr, "a value that is not an integer number of milli-cores / bytes (or leaves int64) must be refused, not rounded"
+        assert r.returncode == 1 and "objects_eval:" in r.stderr, "a value no unit can hold must be refused, not rounded"
 
 
 @pytest.mark.parametrize("bad", ["", "abc", "1.2.3", "1ki", "12 Mi", "Mi", "1e", "--1", "0x10", "1,5"])

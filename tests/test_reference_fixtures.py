@@ -35,7 +35,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
 OBJECTS = sorted(glob.glob(os.path.join(GOLD, "*_objects.json")))
 NAMES = [os.path.basename(p)[: -len("_objects.json")] for p in OBJECTS]
-HAZARD = {"hazard_gi_24x10", "typical_specs_40x12"}  # quantities outside domain D (Gi and above): tests/test_quantity_readings.py holds both expectations
+HAZARD = {"hazard_gi_24x10", "typical_specs_40x12", "subunit_22x8"}  # quantities outside domain D (Gi and above): tests/test_quantity_readings.py holds both expectations
 SKIP_REASON = ("tests/golden/ref_{name}.json absent: produced by the reference itself via `rust/pin_parity.sh <reference checkout>` "
                "on a box with cargo (none here, none on the GPU box); resource-fit parity stays UNPINNED until it exists")
 
