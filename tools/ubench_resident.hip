@@ -194,6 +194,7 @@ __global__ void k_post_blocks(Ctl *c, uint64_t seq, uint32_t nblocks, uint64_t r
     if (seq > ring) {
         uint64_t polls = 0;
         while (ld_rlx(&c->fin[b][0]) + ring < seq) {
+            if ((polls & 1023u) == 1023u && ld_rlx(&c->err[0])) return;  // (somebody has already run into a limit: end at once)
             if (++polls > limit) {
                 st_rel(&c->err[0], seq | (1ull << 62) | ((uint64_t)b << 40));  // bit 62: a POST's flow control ran into its limit (block b)
                 return;
@@ -208,6 +209,7 @@ __global__ void k_wait_blocks(Ctl *c, uint64_t seq, uint32_t nblocks, uint64_t l
     if (b >= nblocks) return;
     uint64_t polls = 0;
     while (ld_rlx(&c->fin[b][0]) < seq) {
+        if ((polls & 1023u) == 1023u && ld_rlx(&c->err[0])) return;
         if (++polls > limit) {
             if (!ld_rlx(&c->err[0])) st_rel(&c->err[0], seq | ((uint64_t)b << 40) | (ld_rlx(&c->fin[b][0]) << 20));  // block b's fin in bits 20..39
             return;
@@ -303,7 +305,8 @@ int main(int argc, char **argv) {
                                   "C + every wave stores 16 KiB sc1, no timed work", "D host writes the doorbell, host polls the completion word (pinned host memory), per batch",
                                   "E like D, posts 6 ahead", "F per-block doorbells: post + wait per batch on the caller's stream",
                                   "G per-block doorbells: posts on an internal stream (ring of 6, flow control on the device), one wait per batch on the caller's stream",
-                                  "H like G, one wait per 4 batches"};
+                                  "H like G, one wait per 4 batches", "I per-block doorbells, ONE stream: posts 6 ahead of the waits",
+                                  "J per-block doorbells: every post first (own stream, no flow control), one wait at the end"};
     // returns false when batches do not get through
     auto run = [&](uint32_t nblocks, uint32_t work, int mode, uint32_t variant) -> bool {
         if (mode == 1 && !can_wait) return true;
@@ -335,7 +338,7 @@ int main(int argc, char **argv) {
         bool host_timeout = false;
         auto post = [&]() {
             ++seq;
-            if (mode == 6) k_post_blocks<<<1, 256, 0, s_call>>>(ctl, seq, nblocks, 6, 200000);
+            if (mode == 6 || mode == 9) k_post_blocks<<<1, 256, 0, s_call>>>(ctl, seq, nblocks, 1000000, 200000);
             else if (mode >= 7) k_post_blocks<<<1, 256, 0, s_post>>>(ctl, seq, nblocks, g_ring, 200000);
             else if (mode >= 4) __atomic_store_n(host_tail, seq, __ATOMIC_RELEASE);
             else if (mode == 1) CK(hipStreamWriteValue64(s_call, &ctl->tail[0], seq, 0));
@@ -343,6 +346,7 @@ int main(int argc, char **argv) {
         };
         auto wait = [&](uint64_t sq) {
             if (mode >= 6) {
+                if (mode == 10) return;  // (J: no wait before the end)
                 if (mode != 8 || sq % 4 == 0) k_wait_blocks<<<1, 256, 0, s_call>>>(ctl, sq, nblocks, 200000);
             } else if (mode >= 4) {  // (in-order completion is what the flag of this mode says: the last block of batch sq publishes sq; batches finish in order within a block)
                 const double tw = now_us();
@@ -354,7 +358,7 @@ int main(int argc, char **argv) {
             } else if (mode == 1) CK(hipStreamWaitValue64(s_call, sig_host[sq % kSlots], sq, hipStreamWaitValueGte, ~0ull));
             else k_wait<<<1, 1, 0, s_call>>>(ctl, sq, 1000 * tick_ms);
         };
-        const uint32_t depth = (mode == 2 || mode == 3 || mode == 5) ? kSlots - 2 : 1;
+        const uint32_t depth = (mode == 2 || mode == 3 || mode == 5 || mode == 9) ? kSlots - 2 : 1;
         // (modes G / H: the posts run ahead on their own stream; the device-side flow control bounds them)
         for (int i = 0; i < K + warm && !host_timeout; ++i) {
             if (i == warm) {
@@ -412,13 +416,17 @@ int main(int argc, char **argv) {
         fflush(stdout);
         return !bad;
     };
-    for (uint32_t variant : {32u | 64u, 32u}) {
-        printf("---- the block's poller reads its doorbell at %s scope\n", (variant & 64u) ? "SYSTEM (sc0 sc1)" : "agent (sc1)");
-        g_ring = 6;
-        bool ok = true;
-        for (uint32_t work : {0u, 1200u})
-            for (int mode : {7, 8})
-                if (ok) ok = run(248, work, mode, variant);
+    g_ring = 1000000;
+    printf("---- which part of the pipelined form stops the grid?\n");
+    run(248, 1200, 9, 32);   // I: posts ahead, but one stream
+    run(248, 1200, 10, 32);  // J: posts on their own stream, nothing else running
+    for (uint32_t threads : {64u, 256u}) {  // G with fewer waves per resident block
+        g_threads = threads;
+        printf("resident blocks of %u threads: ", threads);
+        run(248, 1200, 7, 32);
     }
+    g_threads = 1024;
+    for (uint32_t nblocks : {32u, 64u, 128u, 192u, 240u})  // G: how many resident blocks does it take?
+        run(nblocks, 1200, 7, 32);
     return 0;
 }
