@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_build_nrec(const int64_t *__restrict__ 
     for (uint32_t k = 0; k < 4; ++k) r[4 + k] = (int64_t)(((uint64_t)l[2 * k + 1] << 32) | l[2 * k]);
 }
 
-// ---- best-fit structures (DESIGN.md 2.2), after the two device sorts ------------------------------------------------------
+// ---- best-fit structures (DESIGN.md section 2), after the two device sorts ------------------------------------------------------
 // by_cpu[r]   : node with cpu rank r (ascending (cpu, node))           -- sort 1
 // bf_order[i] : node at best-fit position i (ascending (mem, cpu, node)) -- sort 2 (stable, by mem, of by_cpu)
 struct BfGatherArgs {

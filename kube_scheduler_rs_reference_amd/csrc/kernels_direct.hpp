@@ -15,7 +15,7 @@
 // consecutive words of "its" pod row.  The four waves of a block sit on adjacent columns, so a
 // block emits 16 consecutive words (128 B) per pod row.
 //
-// Cost model (measured numbers live in DESIGN.md): per (pod, 64 nodes) the VALU issues are
+// Cost model (measured numbers live in profiles/HISTORY.md): per (pod, 64 nodes) the VALU issues are
 // 2 x v_cmp_i64 (fit) + one v_cmp_u32 per *constrained* key (unconstrained keys are skipped by a
 // scalar branch) + 3 for taints + 2 x v_writelane.  That makes this kernel VALU-bound well below
 // the HBM write roofline; it is the general, always-applicable path.  The fused kernel

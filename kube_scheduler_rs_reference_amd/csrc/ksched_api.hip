@@ -420,7 +420,7 @@ int launch_build_named(ksched_ctx *c) {
     return KSCHED_OK;
 }
 
-// Best-fit candidate order of the snapshot, ascending (avail_mem, avail_cpu, node) (DESIGN.md 2.2), its inverse, the node
+// Best-fit candidate order of the snapshot, ascending (avail_mem, avail_cpu, node) (DESIGN.md section 2), its inverse, the node
 // columns in that order, the sorted cpu column with the sample arrays of the two rank searches, and -- when the snapshot has a
 // bitmap index -- the named rows once more over best-fit positions plus the 257 cpu threshold rows (k_pick_bestfit_rows).
 // Two stable device radix sorts (rocPRIM) and two kernels, on the ctx's stream; called lazily by the first PICK_BESTFIT request

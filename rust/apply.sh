@@ -3,7 +3,7 @@
 # Copies the reference (acrlabs/kube-scheduler-rs-reference) to <output dir> and overlays the ksched binding on it:
 #   patches/0001  src/predicates.rs : pure `fits()` seam under can_pod_fit (arithmetic untouched), check_node_validity_batch
 #   patches/0002  src/main.rs       : feature ksched: select_node_for_pod -> the batch task (ready_chunks -> one device call), the pod watch
-#   patches/0004  src/util.rs       : Context gains `picker` and `cluster` (feature ksched)
+#   patches/0004  src/util.rs       : Context gains `picker`, the channel to the batch task (feature ksched)
 #   patches/0003  Cargo.toml        : feature `ksched`, dev-dependencies serde / serde_json
 #   build.rs, src/ksched_sys.rs, src/ksched.rs, src/predicates/{parity_dump,device_parity}.rs   (new files)
 set -euo pipefail

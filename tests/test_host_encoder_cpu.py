@@ -243,7 +243,7 @@ def small_cluster(draw):
 @given(cluster=small_cluster(), use_taint=st.booleans())
 def test_random_labels_selectors_taints_tolerations_encode_to_the_oracles_masks(tmp_path, cluster, use_taint):
     """src/predicates.rs:45-61 on label maps that are absent / empty / carry empty keys and values, selectors naming keys or values no
-    node has; extension E2 on every operator / key / value / effect combination of a toleration.  The encoder's
+    node has; extension E2 on every operator / key / value / effect combination of a toleration ("Extension semantics").  The encoder's
     dictionary ids and taint bits, evaluated by the integer loop, must give the masks the oracle computes from the objects."""
     pods, nodes = cluster
     path = tmp_path / "lab.json"

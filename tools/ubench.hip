@@ -1,6 +1,6 @@
 // ubench.hip -- store-pattern and VALU micro-benchmarks that size the mask kernels' design.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench tools/ubench.hip ; run on the GPU box.
-// Not part of the product; numbers are quoted in DESIGN.md.
+// Not part of the product; numbers are quoted in profiles/HISTORY.md.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

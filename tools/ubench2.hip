@@ -1,6 +1,6 @@
 // ubench2.hip -- store-pattern experiments for the fused mask kernel (tile = 16 words = 128 B per pod row).
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench2 tools/ubench2.hip ; run on the GPU box.
-// Not part of the product; the numbers it prints are quoted in DESIGN.md.
+// Not part of the product; the numbers it prints are quoted in profiles/HISTORY.md.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

@@ -1,7 +1,7 @@
 // ubench3.hip -- how fast can the mask's store pattern go?  Pure store kernels in the fused kernel's block -> (chunk, tile)
 // mapping (XCD-contiguous runs), rows pitched to 128 B, for tile widths of 16 / 32 / 64 words per pod row and the store
 // policies plain / sc1 (write-through) / nt, timed with events attached to the dispatch.  Also a flat stream (each wave
-// instruction writes 1 KiB contiguous) as the ceiling.  Not part of the product; numbers are quoted in DESIGN.md.
+// instruction writes 1 KiB contiguous) as the ceiling.  Not part of the product; numbers are quoted in profiles/HISTORY.md.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench3 tools/ubench3.hip
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
