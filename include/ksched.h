@@ -242,9 +242,9 @@ int ksched_eval(ksched_ctx *ctx, uint32_t p, const int64_t *req_cpu_milli, const
  *                       max(p, binding_capacity) int32 -- entries [p, binding_capacity) are -1, the padding the all-gather of
  *                       unequal shards needs -- returned through *binding_dev; *hip_stream is the ctx's own stream, where all of
  *                       this was enqueued (pass both to ksched_allgather_bindings*).  p = 0 is allowed (an empty shard still
- *                       takes part in the exchange).  The input arrays may be reused when the call returns only if they are
- *                       pageable memory (the runtime stages them); pinned arrays must stay untouched until ksched_eval_end.
- *                       Buffers are valid until the next ksched_eval / ksched_eval_begin on the ctx.
+ *                       takes part in the exchange).  The input arrays and the two host mask arrays must stay alive and untouched
+ *                       until ksched_eval_end has returned (the copies are asynchronous).  The device buffers are valid until the
+ *                       next ksched_eval / ksched_eval_begin on the ctx.
  * ksched_gather_buffer  a ctx-owned device buffer of `count` int32 for the gathered table (grown on demand, reused).
  * ksched_eval_end       enqueue the copy of `count` int32 from `bindings_dev` (any device pointer: the gathered table, or
  *                       *binding_dev itself) to `out_host` on the ctx's stream -- skipped when out_host is NULL -- and wait for

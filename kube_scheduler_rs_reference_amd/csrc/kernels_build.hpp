@@ -397,13 +397,77 @@ __global__ __launch_bounds__(256) void k_bf_levels(const BfLevelsArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_iota(uint32_t *out, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = i;
+// ---- the two orders of the best-fit structures: a merge sort written for them ----------------------------------------------------
+// Records (k0, k1, idx) are ordered lexicographically; idx is unique, so the order is total and there is nothing to keep stable:
+//   ascending (cpu, node)       -> k0 = cpu,  k1 absent (reads as 0)
+//   ascending (mem, cpu, node)  -> k0 = mem,  k1 = cpu
+// k_sort_runs sorts every run of 1024 consecutive records with a bitonic network over LDS (slots past n hold +infinity and are not
+// written back); k_merge_pass merges neighbouring runs of `run` records into runs of 2 * run BY RANKING: a record's place in the merged
+// run is its index in its own run plus the number of records of the sibling run that come before it (one binary search per record;
+// the order being total, both sides count strictly smaller records).  ceil(log2(n / 1024)) passes, each a launch of n independent
+// threads; the structures are rebuilt lazily, by the first PICK_BESTFIT request after the snapshot changed (n = 50 000: 6 passes).
+// (Rounds 1 - 3 called rocPRIM's radix sort here: the one place a library did device work.)
+struct SortArgs {
+    const int64_t *k0_in, *k1_in;  // k1_in == nullptr: the records have no second key
+    const uint32_t *idx_in;        // nullptr: idx = position (the first pass sorts the columns as they are)
+    int64_t *k0_out, *k1_out;      // k1_out == nullptr with k1_in == nullptr
+    uint32_t *idx_out;
+    uint32_t n, run;
+};
+__device__ __forceinline__ bool rec_less(int64_t a0, int64_t a1, uint32_t ai, int64_t b0, int64_t b1, uint32_t bi) {
+    if (a0 != b0) return a0 < b0;
+    if (a1 != b1) return a1 < b1;
+    return ai < bi;
 }
-__global__ __launch_bounds__(256) void k_gather_i64(const int64_t *__restrict__ src, const uint32_t *__restrict__ idx, int64_t *__restrict__ out, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = src[idx[i]];
+__global__ __launch_bounds__(1024) void k_sort_runs(const SortArgs a) {
+    __shared__ int64_t s_k0[1024], s_k1[1024];
+    __shared__ uint32_t s_i[1024];
+    const uint32_t t = threadIdx.x, g = blockIdx.x * 1024u + t;
+    const bool live = g < a.n;
+    int64_t k0 = live ? a.k0_in[g] : INT64_MAX, k1 = live ? (a.k1_in ? a.k1_in[g] : 0) : INT64_MAX;
+    uint32_t ki = live ? (a.idx_in ? a.idx_in[g] : g) : 0xFFFFFFFFu;
+    for (uint32_t k = 2; k <= 1024u; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            s_k0[t] = k0;
+            s_k1[t] = k1;
+            s_i[t] = ki;
+            __syncthreads();
+            const int64_t p0 = s_k0[t ^ j], p1 = s_k1[t ^ j];
+            const uint32_t pi = s_i[t ^ j];
+            __syncthreads();  // everybody has read before anybody writes its slot again
+            const bool ascending = (t & k) == 0u, lower = (t & j) == 0u;
+            const bool p_less = rec_less(p0, p1, pi, k0, k1, ki);
+            const bool take = (lower == ascending) ? p_less : !p_less;  // the lower slot of an ascending pair keeps the smaller record
+            k0 = take ? p0 : k0;
+            k1 = take ? p1 : k1;
+            ki = take ? pi : ki;
+        }
+    }
+    if (live) {  // (the +infinity records end up behind the n live ones of the last run: positions >= n)
+        a.k0_out[g] = k0;
+        if (a.k1_out) a.k1_out[g] = k1;
+        a.idx_out[g] = ki;
+    }
+}
+__global__ __launch_bounds__(256) void k_merge_pass(const SortArgs a) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n) return;
+    const uint32_t span = 2u * a.run, base = (g / span) * span, off = g - base;
+    const bool in_a = off < a.run;
+    const uint32_t b_lo = min(a.n, base + a.run), b_hi = (uint32_t)min((uint64_t)a.n, (uint64_t)base + span);
+    const uint32_t s_lo = in_a ? b_lo : base, s_hi = in_a ? b_hi : b_lo;  // the sibling run
+    const int64_t m0 = a.k0_in[g], m1 = a.k1_in ? a.k1_in[g] : 0;
+    const uint32_t mi = a.idx_in[g];
+    uint32_t lo = s_lo, hi = s_hi;
+    while (lo < hi) {  // records of the sibling run that come before this one
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (rec_less(a.k0_in[mid], a.k1_in ? a.k1_in[mid] : 0, a.idx_in[mid], m0, m1, mi)) lo = mid + 1u;
+        else hi = mid;
+    }
+    const uint32_t out = base + (in_a ? off : off - a.run) + (lo - s_lo);
+    a.k0_out[out] = m0;
+    if (a.k1_out) a.k1_out[out] = m1;
+    a.idx_out[out] = mi;
 }
 
 }  // namespace ksched

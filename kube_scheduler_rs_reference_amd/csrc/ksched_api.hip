@@ -18,7 +18,6 @@
 #include <string>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
 
 #include "comm_rccl.hpp"
 #include "kernels_build.hpp"
@@ -84,9 +83,9 @@ struct ksched_ctx {
     uint32_t bf_row_cpu0 = 0, bf_q = 1, bf_W = 0;
     // the best-fit structures are built lazily, by the first PICK_BESTFIT request after the snapshot changed
     bool bf_dirty = true;
-    DevBuf<uint32_t> by_cpu, cpurank, iota;
-    DevBuf<int64_t> sort_keys;
-    DevBuf<uint8_t> sort_tmp;
+    DevBuf<uint32_t> by_cpu, cpurank;
+    DevBuf<int64_t> srt_k0[2], srt_k1[2];  // ping-pong sets of the best-fit orders' merge sort (kernels_build.hpp)
+    DevBuf<uint32_t> srt_idx[2];
     IndexedSnapshot idx;  // per-tile bitmap index (tile_index.hpp), built on the device (kernels_build.hpp)
     std::string index_reason;  // why the snapshot has no bitmap index (the fused kernel is then not applicable)
     // host -> device staging for the snapshot calls: pinned, so the copies are asynchronous on the ctx's stream
@@ -423,7 +422,7 @@ int launch_build_named(ksched_ctx *c) {
 // Best-fit candidate order of the snapshot, ascending (avail_mem, avail_cpu, node), its inverse, the node
 // columns in that order, the sorted cpu column with the sample arrays of the two rank searches, and -- when the snapshot has a
 // bitmap index -- the named rows once more over best-fit positions plus the 257 cpu threshold rows (k_pick_bestfit_rows).
-// Two stable device radix sorts (rocPRIM) and two kernels, on the ctx's stream; called lazily by the first PICK_BESTFIT request
+// Two device merge sorts (kernels_build.hpp: k_sort_runs + k_merge_pass) and two kernels, on the ctx's stream; called lazily by the first PICK_BESTFIT request
 // after the snapshot changed (ksched_set_nodes / ksched_update_nodes only mark it dirty).
 int build_bestfit(ksched_ctx *c) {
     const uint32_t n = c->n;
@@ -436,22 +435,58 @@ int build_bestfit(ksched_ctx *c) {
     const uint32_t n1 = (n + 63u) / 64u, n2 = (n + 4095u) / 4096u;
     HIPCHK(c, c->by_cpu.reserve(n));
     HIPCHK(c, c->cpurank.reserve(n));
-    HIPCHK(c, c->iota.reserve(n));
-    HIPCHK(c, c->sort_keys.reserve(n));
     HIPCHK(c, c->bf_samples.reserve(2 * (size_t)(n1 + n2)));
     const dim3 grid((n + 255u) / 256u), block(256);
-    size_t tmp1 = 0, tmp2 = 0;
-    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp1, (const int64_t *)c->ncpu.ptr, c->cpu_sorted.ptr, (const uint32_t *)c->iota.ptr, c->by_cpu.ptr, n, 0, 64, s));
-    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp2, (const int64_t *)c->sort_keys.ptr, c->bf_mem.ptr, (const uint32_t *)c->by_cpu.ptr, c->bf_order.ptr, n, 0, 64, s));
-    HIPCHK(c, c->sort_tmp.reserve(std::max(tmp1, tmp2)));
-    size_t tmp = c->sort_tmp.cap;
-    hipLaunchKernelGGL(k_iota, grid, block, 0, s, c->iota.ptr, n);
-    // sort 1: ascending (cpu, node): stable radix sort of cpu with the node index as payload
-    HIPCHK(c, rocprim::radix_sort_pairs((void *)c->sort_tmp.ptr, tmp, (const int64_t *)c->ncpu.ptr, c->cpu_sorted.ptr, (const uint32_t *)c->iota.ptr, c->by_cpu.ptr, n, 0, 64, s));
-    // sort 2: stable by memory of that order = ascending (mem, cpu, node)
-    hipLaunchKernelGGL(k_gather_i64, grid, block, 0, s, (const int64_t *)c->nmem.ptr, (const uint32_t *)c->by_cpu.ptr, c->sort_keys.ptr, n);
-    tmp = c->sort_tmp.cap;
-    HIPCHK(c, rocprim::radix_sort_pairs((void *)c->sort_tmp.ptr, tmp, (const int64_t *)c->sort_keys.ptr, c->bf_mem.ptr, (const uint32_t *)c->by_cpu.ptr, c->bf_order.ptr, n, 0, 64, s));
+    // The two orders, by the merge sort of kernels_build.hpp: runs of 1024 sorted in LDS, then merged by ranking, ping-pong between two
+    // sets of (k0, k1, idx) arrays; the last pass of each sort lands in the arrays the pick kernels read.
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(c, c->srt_k0[b].reserve(n));
+        HIPCHK(c, c->srt_k1[b].reserve(n));
+        HIPCHK(c, c->srt_idx[b].reserve(n));
+    }
+    auto device_sort = [&](const int64_t *k0, const int64_t *k1, int64_t *dst_k0, uint32_t *dst_idx) -> int {
+        uint32_t passes = 0;
+        for (uint64_t run = 1024; run < n; run <<= 1) ++passes;
+        // buffer of pass i's output: the destination arrays for the last one, the ping-pong sets before it
+        auto out_of = [&](uint32_t i, SortArgs &q) {  // i = 0: k_sort_runs, i = 1 .. passes: merge passes
+            if (i == passes) {
+                q.k0_out = dst_k0;
+                q.k1_out = k1 ? c->srt_k1[i & 1].ptr : nullptr;  // (nobody reads the second key of the final order)
+                q.idx_out = dst_idx;
+            } else {
+                q.k0_out = c->srt_k0[i & 1].ptr;
+                q.k1_out = k1 ? c->srt_k1[i & 1].ptr : nullptr;
+                q.idx_out = c->srt_idx[i & 1].ptr;
+            }
+        };
+        SortArgs q{};
+        q.n = n;
+        q.k0_in = k0;
+        q.k1_in = k1;
+        q.idx_in = nullptr;
+        q.run = 0;
+        out_of(0, q);
+        hipLaunchKernelGGL(k_sort_runs, dim3((n + 1023u) / 1024u), dim3(1024), 0, s, q);
+        HIPCHK(c, hipGetLastError());
+        uint32_t i = 0;
+        for (uint64_t run = 1024; run < n; run <<= 1) {
+            SortArgs m{};
+            m.n = n;
+            m.run = (uint32_t)run;
+            m.k0_in = q.k0_out;
+            m.k1_in = q.k1_out;
+            m.idx_in = q.idx_out;
+            out_of(++i, m);
+            hipLaunchKernelGGL(k_merge_pass, grid, block, 0, s, m);
+            HIPCHK(c, hipGetLastError());
+            q = m;
+        }
+        return KSCHED_OK;
+    };
+    // order 1: ascending (cpu, node) -> cpu_sorted (the sorted cpu column), by_cpu (node with cpu rank r)
+    if (int rc = device_sort(c->ncpu.ptr, nullptr, c->cpu_sorted.ptr, c->by_cpu.ptr)) return rc;
+    // order 2: ascending (mem, cpu, node) -> bf_mem, bf_order
+    if (int rc = device_sort(c->nmem.ptr, c->ncpu.ptr, c->bf_mem.ptr, c->bf_order.ptr)) return rc;
     BfGatherArgs g{};
     g.ncpu = c->ncpu.ptr;
     g.nmem = c->nmem.ptr;
@@ -1067,7 +1102,8 @@ void ksched_destroy(ksched_ctx *c) try {
         c->pcpu.release(); c->pmem.release(); c->psel.release(); c->psamples.release();
         c->ptol.release(); c->feas.release(); c->fit.release(); c->binding.release(); c->gathered.release(); c->xpairs.release(); c->xreason.release();
         c->scratch_mask.release(); c->trace.release();
-        c->by_cpu.release(); c->cpurank.release(); c->iota.release(); c->sort_keys.release(); c->sort_tmp.release(); c->d_stage.release();
+        c->by_cpu.release(); c->cpurank.release(); c->d_stage.release();
+        for (int b = 0; b < 2; ++b) { c->srt_k0[b].release(); c->srt_k1[b].release(); c->srt_idx[b].release(); }
         if (c->h_stage) (void)hipHostFree(c->h_stage);
         for (auto &x : c->pick_acc) x.buf.release();
         for (auto &u : c->user_streams) (void)hipEventDestroy(u.ev);

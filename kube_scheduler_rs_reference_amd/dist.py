@@ -103,6 +103,25 @@ class AbiComm:
         self._check(self._lib.ksched_allgather_bindings(self._h, C.c_void_p(local.data_ptr()), C.c_void_p(gathered.data_ptr()),
                                                         local.numel(), C.c_void_p(stream.cuda_stream)), "ksched_allgather_bindings")
 
+    def bind_all_gather(self, gathered: torch.Tensor, local: torch.Tensor, stream):
+        """The same call pre-marshalled (the checks of all_gather done once): returns a zero-argument callable that enqueues
+        ksched_allgather_bindings for exactly these buffers on exactly this stream.  A step of the pipelined scheduler is tens of
+        microseconds of device time; per-call argument checks and ctypes conversions are a measurable part of a host loop at that rate."""
+        import ctypes as C
+        if local.dtype != torch.int32 or gathered.dtype != torch.int32 or not local.is_contiguous() or not gathered.is_contiguous():
+            raise ValueError("bindings must be contiguous int32 CUDA tensors")
+        if gathered.numel() != local.numel() * self.world:
+            raise ValueError("gathered must hold world * len(local) entries")
+        fn, h = self._lib.ksched_allgather_bindings, self._h
+        a_local, a_gathered, a_count, a_stream = C.c_void_p(local.data_ptr()), C.c_void_p(gathered.data_ptr()), C.c_uint32(local.numel()), C.c_void_p(stream.cuda_stream)
+        check = self._check
+
+        def call():
+            rc = fn(h, a_local, a_gathered, a_count, a_stream)
+            if rc != 0:
+                check(rc, "ksched_allgather_bindings")
+        return call
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.ksched_comm_destroy(self._h)
@@ -228,6 +247,13 @@ class PipelinedScheduler:
         self._side = torch.cuda.Stream(device=device) if (comm is not None and pipe is None) else None
         self._ready = [torch.cuda.Event() for _ in range(depth)] if self._side is not None else None  # reused: no event creation per step
         self._done = [torch.cuda.Event() for _ in range(depth)] if self._side is not None else None
+        # the host loop runs at the rate of the device steps (tens of microseconds): views and calls that do not change are made once
+        self._views = [[self._local[k][g * self.shard: g * self.shard + self.n_local] for g in range(G)] for k in range(depth)]
+        self._gather_calls = None
+        if self._gather and comm is not None and self._pick_stream is not None:
+            self._gather_calls = [comm.bind_all_gather(self._gathered[k], self._local[k], self._streams2[k & 1] if alternate else self._pick_stream)
+                                  for k in range(depth)]
+            self._stream_work = [_StreamWork(self._streams2[k & 1] if alternate else self._pick_stream) for k in range(depth)]
 
     @property
     def n_local(self) -> int:
@@ -236,16 +262,15 @@ class PipelinedScheduler:
     def binding_buffer(self, k: int, g: int = 0) -> torch.Tensor:
         """The int32 [n_local] buffer that step `g` of buffer slot `k`'s gather group writes (for callers that pre-marshal their
         launches: the same tensor `run` receives)."""
-        return self._local[k][g * self.shard: g * self.shard + self.n_local]
+        return self._views[k][g]
 
     def _flush(self, k: int) -> None:
         """Issue the (asynchronous) all-gather of slot k's group and move on to the next slot."""
         if self._gather and self._fill[k] > 0:
             if self.comm is not None:
                 if self._pick_stream is not None:  # stream-ordered behind the group's last pick: no event, nothing to wait for
-                    st = self._streams2[k & 1] if self._alternate else self._pick_stream
-                    self.comm.all_gather(self._gathered[k], self._local[k], stream=st)
-                    self._work[k] = _StreamWork(st)
+                    self._gather_calls[k]()
+                    self._work[k] = self._stream_work[k]
                 else:
                     self._ready[k].record(torch.cuda.current_stream(self.device))
                     self._side.wait_event(self._ready[k])
@@ -264,7 +289,9 @@ class PipelinedScheduler:
         k, g = self._cur, self._fill[self._cur]
         if g == 0 and self._work[k] is not None:
             # first step into a reused slot: the all-gather that read its bindings must be done before they are overwritten
-            if self._pick_stream is not None:
+            if self._gather_calls is not None:
+                pass  # the slot's next pick goes onto the very stream its gather was enqueued on: the stream's own order is the wait
+            elif self._pick_stream is not None:
                 with torch.cuda.stream(self._streams2[k & 1] if self._alternate else self._pick_stream):
                     self._work[k].wait()
             else:

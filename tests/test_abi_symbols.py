@@ -66,6 +66,28 @@ def test_null_arguments_are_errors_not_crashes(built):
     assert b"no CPU fallback" in lib.ksched_strerror(_lib.E_NODEVICE)
 
 
+def test_shard_bounds_is_the_one_definition_of_the_row_split(built):
+    """ksched_shard_bounds (C ABI) == dist.shard_bounds (Python) for every (P, world, rank): the C++ host mirror, the Rust overlay and the
+    one-process-per-GPU scheduler all cut a batch's pod rows the same way (contiguous rows, ceil(P / n) per device)."""
+    from kube_scheduler_rs_reference_amd import _lib
+    from kube_scheduler_rs_reference_amd.dist import shard_bounds
+    lib = _lib.load()
+    lo, hi, cpr = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    for world in range(1, 10):
+        for P in list(range(0, 70)) + [999, 1000, 1001, 100_000, 1_000_000, (1 << 32) - 1]:
+            covered = 0
+            for rank in range(world):
+                lib.ksched_shard_bounds(P, world, rank, C.byref(lo), C.byref(hi), C.byref(cpr))
+                assert (lo.value, hi.value, cpr.value) == shard_bounds(P, world, rank), (P, world, rank)
+                assert lo.value == covered and hi.value - lo.value <= cpr.value
+                covered = hi.value
+            assert covered == P
+    lib.ksched_shard_bounds(10, 4, 1, None, None, None)  # null outputs are allowed
+    assert lib.ksched_device_count() >= 0
+    assert lib.ksched_eval_begin(None, 0, None, None, None, 0, None, None, 0, 0, None, None, 0, None, None) == _lib.E_INVAL
+    assert lib.ksched_gather_buffer(None, 0, None) == _lib.E_INVAL and lib.ksched_eval_end(None, None, 0, None) == _lib.E_INVAL
+
+
 def test_reason_helper(built):
     import numpy as np
     from kube_scheduler_rs_reference_amd import _lib

@@ -768,3 +768,47 @@ def test_evaluations_on_two_streams_share_the_ctx_scratch(evaluator):
     torch.cuda.synchronize()
     assert np.array_equal(outs[0].cpu().numpy(), want[rolled[0]]) and np.array_equal(outs[1].cpu().numpy(), want[rolled[1]])
     ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
+
+
+def test_eval_in_two_halves_equals_ksched_eval(evaluator):
+    """ABI 4: ksched_eval_begin (copies in + evaluation enqueued, bindings left on the device, padded with -1) + ksched_eval_end (one copy,
+    one wait) == ksched_eval, for a shard addressed INSIDE a larger batch (selector columns with the whole batch's stride), with and without
+    masks, and for an empty shard (p = 0: `capacity` rows of -1)."""
+    import ctypes as C
+    from kube_scheduler_rs_reference_amd import _lib as L
+    c = synth.make_config("C3", P=3000, N=700)
+    ev = evaluator
+    ev.set_nodes(**c.node_columns())
+    lib, h = ev._lib, ev._h
+    flags = FIT | SEL | PICK_SAMPLED
+    W = ev.W
+    want_feas, want_fit, want_b = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, None, c.req_cpu, c.req_mem, c.pod_sel, None, c.samples, flags | WANT_FIT_MASK)
+    P, K = c.P, c.n_keys
+    sel = np.ascontiguousarray(c.pod_sel, dtype=np.uint32)
+    smp = np.ascontiguousarray(c.samples, dtype=np.uint32)
+    cpu, mem = np.ascontiguousarray(c.req_cpu, dtype=np.int64), np.ascontiguousarray(c.req_mem, dtype=np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for lo, hi, masks in ((0, P, True), (700, 1811, True), (1811, P, False), (5, 5, False)):
+        p = hi - lo
+        cap = p + 37
+        feas = np.full((max(p, 1), W), 0xAB, dtype=np.uint64)
+        fit = np.full((max(p, 1), W), 0xCD, dtype=np.uint64)
+        dev_b, stream = C.c_void_p(), C.c_void_p()
+        rc = lib.ksched_eval_begin(h, p, C.c_void_p(cpu.ctypes.data + 8 * lo), C.c_void_p(mem.ctypes.data + 8 * lo), C.c_void_p(sel.ctypes.data + 4 * lo), P, None,
+                                   C.c_void_p(smp.ctypes.data + 4 * 5 * lo), 5, flags | (WANT_FIT_MASK if masks else 0), vp(feas) if masks else None,
+                                   vp(fit) if masks else None, cap, C.byref(dev_b), C.byref(stream))
+        assert rc == 0, lib.ksched_last_error(h)
+        assert dev_b.value and stream.value
+        got = np.full((cap,), 12345, dtype=np.int32)
+        assert lib.ksched_eval_end(h, dev_b, cap, vp(got)) == 0
+        assert np.array_equal(got[:p], want_b[lo:hi]) and (got[p:] == -1).all(), (lo, hi)
+        if masks:
+            assert np.array_equal(feas[:p], want_feas[lo:hi]) and np.array_equal(fit[:p], want_fit[lo:hi])
+    # a selector stride shorter than the shard is refused; so is a pick with nowhere to go
+    dev_b, stream = C.c_void_p(), C.c_void_p()
+    assert lib.ksched_eval_begin(h, 10, vp(cpu), vp(mem), vp(sel), 9, None, vp(smp), 5, flags, None, None, 10, C.byref(dev_b), C.byref(stream)) == L.E_INVAL
+    assert lib.ksched_eval_begin(h, 10, vp(cpu), vp(mem), vp(sel), P, None, vp(smp), 5, flags, None, None, 10, None, C.byref(stream)) == L.E_INVAL
+    g = C.c_void_p()
+    assert lib.ksched_gather_buffer(h, 4096, C.byref(g)) == 0 and g.value
+    g2 = C.c_void_p()
+    assert lib.ksched_gather_buffer(h, 100, C.byref(g2)) == 0 and g2.value == g.value  # grown on demand, reused
