@@ -168,7 +168,7 @@ namespace {
 
 // ---- nothing unwinds across the C ABI (include/ksched.h "Conventions") -----------------------------------------------------
 // Every extern "C" body below is a function-try-block ending in KSCHED_ABI_CATCH: the library's own C++ (std::vector,
-// std::string, std::mutex, rocPRIM) may throw -- std::bad_alloc above all -- and an exception leaving an extern "C" function
+// std::string, std::mutex) may throw -- std::bad_alloc above all -- and an exception leaving an extern "C" function
 // called from Rust or C is an abort.  bad_alloc -> KSCHED_E_NOMEM, anything else -> KSCHED_E_INVAL, text in ksched_last_error.
 int abi_caught(ksched_ctx *c, int code, const char *what) noexcept {
     if (c) {

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Randomised differential test of the HIP path against the oracle (GPU box): random shapes, key counts and cardinalities (incl.
-list keys and > 8 keys), taints, predicate subsets, both picks, snapshot updates between evaluations, both kernels, per-pair reasons (ksched_explain).
+list keys and > 8 keys), taints, predicate subsets, both picks, snapshot updates between evaluations, both kernels, per-pair reasons (ksched_explain),
+the two halves of ksched_eval over 1 .. 5 row shards (ksched_shard_bounds / ksched_eval_begin / ksched_eval_end).
 usage: python tools/fuzz_parity.py [seconds] [seed]       prints one line per failure and a summary; exit code 1 on any failure"""
 import os, sys, time
 import numpy as np
@@ -85,6 +86,46 @@ while time.time() < t_end:
                     picks["tile-unsupported"] = picks.get("tile-unsupported", 0) + 1
                 ev.set_option(L.OPT_FUSED_PICK, 1)
         ev.set_kernel("auto")
+        if pick and r.random() < 0.35:
+            # the host-side row shard (include/ksched.h "one host thread, several devices"): the batch cut into 1 .. 5 shards with
+            # ksched_shard_bounds, every shard through ksched_eval_begin (selector columns addressed inside the whole batch's array with its
+            # stride, bindings padded to ceil(P / n) with -1) + ksched_eval_end, merged like an all-gathered table -- on this one evaluator,
+            # shard after shard
+            import ctypes as C
+            n_sh = int(r.choice([1, 2, 3, 5]))
+            W = ev.W
+            lo_, hi_, cpr_ = C.c_uint32(), C.c_uint32(), C.c_uint32()
+            rc_c, rm_c = np.ascontiguousarray(rc), np.ascontiguousarray(rm)
+            sel_c = np.ascontiguousarray(sel) if K else None
+            tol_c = np.ascontiguousarray(tol) if (preds & L.TAINT) else None
+            smp_c = np.ascontiguousarray(smp)
+            feas_s = np.zeros((P, W), dtype=np.uint64)
+            fit_s = np.zeros((P, W), dtype=np.uint64)
+            bind_s = np.full((P,), 777, dtype=np.int32)
+            for rank in range(n_sh):
+                ev._lib.ksched_shard_bounds(P, n_sh, rank, C.byref(lo_), C.byref(hi_), C.byref(cpr_))
+                lo, hi, cpr = lo_.value, hi_.value, cpr_.value
+                dev_b, stream = C.c_void_p(), C.c_void_p()
+                rcode = ev._lib.ksched_eval_begin(
+                    ev._h, hi - lo, C.c_void_p(rc_c.ctypes.data + 8 * lo), C.c_void_p(rm_c.ctypes.data + 8 * lo),
+                    C.c_void_p(sel_c.ctypes.data + 4 * lo) if K else None, P, C.c_void_p(tol_c.ctypes.data + 8 * lo) if tol_c is not None else None,
+                    C.c_void_p(smp_c.ctypes.data + 20 * lo) if pick == L.PICK_SAMPLED else None, 5 if pick == L.PICK_SAMPLED else 0, flags,
+                    C.c_void_p(feas_s.ctypes.data + 8 * W * lo), C.c_void_p(fit_s.ctypes.data + 8 * W * lo) if flags & L.WANT_FIT_MASK else None, cpr,
+                    C.byref(dev_b), C.byref(stream))
+                if rcode != 0:
+                    raise L.KschedError(rcode, "ksched_eval_begin", ev._lib.ksched_last_error(ev._h).decode())
+                part = np.full((cpr,), 555, dtype=np.int32)
+                rcode = ev._lib.ksched_eval_end(ev._h, dev_b, cpr, part.ctypes.data_as(C.c_void_p))
+                if rcode != 0:
+                    raise L.KschedError(rcode, "ksched_eval_end", ev._lib.ksched_last_error(ev._h).decode())
+                bind_s[lo:hi] = part[:hi - lo]
+                if not (part[hi - lo:] == -1).all():
+                    fails += 1
+                    print(f"FAIL shard padding case seed {cs}: P={P} shards={n_sh} rank={rank}", flush=True)
+            if not (np.array_equal(feas_s, want[0]) and (not (flags & L.WANT_FIT_MASK) or np.array_equal(fit_s, want[1])) and np.array_equal(bind_s, want[2])):
+                fails += 1
+                print(f"FAIL sharded halves case seed {cs}: N={N} P={P} K={K} nt={nt} flags={flags:#x} shards={n_sh}", flush=True)
+            picks["sharded-halves"] = picks.get("sharded-halves", 0) + 1
         if r.random() < 0.3:  # ksched_explain on random pairs == the reason rebuilt from three single-predicate oracle masks
             from kube_scheduler_rs_reference_amd.evaluator import unpack_mask
             one = lambda f: unpack_mask(capi.eval_encoded(cpu, mem, lab, taints, rc, rm, sel, tol, None, f)[0], N)  # noqa: E731
