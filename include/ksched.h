@@ -295,7 +295,7 @@ int ksched_pick_device(ksched_ctx *ctx, uint32_t p, const uint64_t *feasible, ui
  * Consecutive batches do not depend on each other, and within a batch the pick only needs the finished mask.  A
  * ksched_pipe runs them software-pipelined on two internal HIP streams: the mask kernel of batch i + 1 on the
  * "mask" stream while the pick of batch i (and whatever the caller enqueues behind it, e.g. the RCCL all-gather of
- * the bindings) is still running on the "pick" stream.  `depth` slots; the caller owns the per-slot output buffers
+ * the bindings) is still running on the "pick" stream.  `depth` slots (1 .. 64); the caller owns the per-slot output buffers
  * (device memory) and passes them to every submit, so the library retains nothing but streams and events.
  *
  *   ksched_pipe_submit(slot, ...)  enqueue one batch into `slot` (round-robin 0 .. depth-1):

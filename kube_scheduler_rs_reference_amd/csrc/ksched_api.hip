@@ -1408,7 +1408,7 @@ struct ksched_pipe {
 };
 
 int ksched_pipe_create(ksched_ctx *c, uint32_t depth, ksched_pipe **out) try {
-    if (!c || !out || depth == 0 || depth > 16) return KSCHED_E_INVAL;
+    if (!c || !out || depth == 0 || depth > 64) return KSCHED_E_INVAL;  // (a slot is two events and the caller's buffers: 64 is plenty for "enough masks in flight to exceed the Infinity Cache")
     *out = nullptr;
     DeviceGuard g(c->device);
     if (!g.ok) return KSCHED_E_HIP;

@@ -84,6 +84,7 @@ def test_multi_gpu_path_in_a_one_rank_group(built):
     # north_star's step: one all-gather per batch is the graded form; four batches per gather is the secondary figure
     assert c["steps_per_allgather"] == 1 and c["steps_in_flight"] >= 2 and c["allgather"].startswith("ksched_allgather_bindings")
     assert c["pipe_mode"].startswith("alternate")
+    assert c["mask_rotation_bytes"] > 256 * 2**20 and c["steps_in_flight"] % 2 == 0, "the N > 1 loop's slots must exceed the Infinity Cache too"
     for leg in ("allgather_every_4", "no_allgather"):
         assert c[leg] and c[leg]["ms_per_step"] > 0, leg
     assert c["allgather_every_4"]["steps_per_allgather"] == 4
