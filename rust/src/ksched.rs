@@ -308,12 +308,18 @@ pub fn parse_quantity_nanos(text: &str) -> Result<i128, String> {
         i += 1;
     }
     let mut mant: i128 = 0;
+    let mut small: u64 = 0; // the first 18 digits: no 128-bit multiply per digit (twin of the fast path of host/quantity.cpp)
     let mut digits = 0u32;
     let mut frac = 0i32;
     let mut in_frac = false;
     loop {
         if i < b.len() && b[i].is_ascii_digit() {
-            mant = mant.checked_mul(10).and_then(|m| m.checked_add((b[i] - b'0') as i128)).ok_or_else(|| bad("mantissa too large"))?;
+            if digits < 18 {
+                small = small * 10 + (b[i] - b'0') as u64;
+                mant = small as i128;
+            } else {
+                mant = mant.checked_mul(10).and_then(|m| m.checked_add((b[i] - b'0') as i128)).ok_or_else(|| bad("mantissa too large"))?;
+            }
             digits += 1;
             if in_frac {
                 frac += 1;
@@ -673,18 +679,46 @@ impl Snapshot {
         let n_keys = self.keys.len() as u32;
         let p = pods.len();
         let mut cols = PodColumns { p: p as u32, n_keys, req_cpu_milli: vec![0; p], req_mem_bytes: vec![0; p], sel_val_ids: vec![0u32; self.keys.len() * p] };
-        for (i, pod) in pods.iter().enumerate() {
+        // one pod: its two requests (ceilings in the snapshot's units) and its selector's (column, id) pairs
+        let encode_one = |pod: &corev1::Pod| -> Result<(i64, i64, Vec<(usize, u32)>), String> {
             let (c, m) = total_pod_resources_nanos(pod)?; // src/predicates.rs:40
-            cols.req_cpu_milli[i] = ceil_to_i64(c, self.cpu_unit, "cpu request")?;
-            cols.req_mem_bytes[i] = ceil_to_i64(m, self.mem_unit, "memory request")?;
+            let mut ids: Vec<(usize, u32)> = Vec::new();
             if let Some(corev1::PodSpec { node_selector: Some(sel), .. }) = &pod.spec {
                 for (k, v) in sel.iter() { // src/predicates.rs:48-53
                     let col = self.keys.iter().position(|x| x == k).expect("key was interned above");
-                    cols.sel_val_ids[col * p + i] = match self.value_ids[col].get(v) {
+                    ids.push((col, match self.value_ids[col].get(v) {
                         Some(id) => *id,
                         None => sys::KSCHED_SEL_NEVER,
-                    };
+                    }));
                 }
+            }
+            return Ok((ceil_to_i64(c, self.cpu_unit, "cpu request")?, ceil_to_i64(m, self.mem_unit, "memory request")?, ids));
+        };
+        // The wire-format step is per-pod string work (quantity parsing, dictionary lookups): for a large batch it is what the host
+        // spends its time on, and the pods are independent -- fanned out over scoped threads (twin of Snapshot::encode_pods,
+        // host/encoder.cpp: from 4096 pods on, at most 32 threads, at least 1024 pods each)
+        let threads = if p >= 4096 { std::thread::available_parallelism().map(|n| n.get()).unwrap_or(1).min(32).min(p / 1024).max(1) } else { 1 };
+        let mut encoded: Vec<Result<(i64, i64, Vec<(usize, u32)>), String>> = Vec::with_capacity(p);
+        if threads <= 1 {
+            for pod in pods.iter() {
+                encoded.push(encode_one(pod));
+            }
+        } else {
+            let per = (p + threads - 1) / threads;
+            let parts: Vec<Vec<Result<(i64, i64, Vec<(usize, u32)>), String>>> = std::thread::scope(|scope| {
+                let handles: Vec<_> = pods.chunks(per).map(|chunk| scope.spawn(move || chunk.iter().map(|pod| encode_one(pod)).collect::<Vec<_>>())).collect();
+                return handles.into_iter().map(|h| h.join().expect("encoding thread panicked")).collect();
+            });
+            for part in parts {
+                encoded.extend(part);
+            }
+        }
+        for (i, e) in encoded.into_iter().enumerate() {
+            let (c, m, ids) = e?; // (the first pod that cannot be encoded, in batch order)
+            cols.req_cpu_milli[i] = c;
+            cols.req_mem_bytes[i] = m;
+            for (col, id) in ids {
+                cols.sel_val_ids[col * p + i] = id;
             }
         }
         return Ok(cols);
