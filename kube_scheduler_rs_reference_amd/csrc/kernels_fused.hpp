@@ -62,6 +62,15 @@
 #ifndef KSCHED_PROFILE
 #define KSCHED_PROFILE 0
 #endif
+//   KSCHED_FUSED_WPE     experiment (tools/build_variants.sh): waves per SIMD the compiler must leave room for (5 = at most 96 VGPRs instead of 128:
+//                        a 16-wave block then leaves a CU's SIMDs 128 registers each for the waves of ANOTHER kernel)
+#if defined(KSCHED_FUSED_NUM_VGPR)
+#define KSCHED_FUSED_WPE_ATTR __attribute__((amdgpu_num_vgpr(KSCHED_FUSED_NUM_VGPR)))
+#elif defined(KSCHED_FUSED_WPE)
+#define KSCHED_FUSED_WPE_ATTR __attribute__((amdgpu_waves_per_eu(KSCHED_FUSED_WPE, KSCHED_FUSED_WPE)))
+#else
+#define KSCHED_FUSED_WPE_ATTR
+#endif
 
 namespace ksched {
 
@@ -145,7 +154,7 @@ typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 // accumulator for the next launch.  The atomic is issued at the top of the NEXT trip and awaited by that trip's counted wait, like the operand loads: its
 // return registers are in flight inside one trip only.
 template <bool FIT, bool SEL, bool TAINT, bool WANT_FIT, bool LIST = false, int PICK = 0>
-__global__ __launch_bounds__(kFusedThreads) void k_eval_fused(
+__global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fused(
     const uint64_t *__restrict__ g_tables, const uint64_t *__restrict__ g_aux, const int64_t *__restrict__ g_pcpu,
     const int64_t *__restrict__ g_pmem, const uint32_t *__restrict__ g_psel, const uint64_t *__restrict__ g_ptol,
     uint64_t *__restrict__ out_feas, uint64_t *__restrict__ out_fit, const uint8_t *__restrict__ g_list, const FusedArgs a,
