@@ -1312,6 +1312,44 @@ static void sharded_tests() {
                 CHECK(bind2 == bind1);
             }
     });
+    run("sharded host path: a shard whose evaluation fails inside the library (KSCHED_OPT_FAULT) -> EncodeError, every device drained, the next batch is whole", [] {
+        const uint32_t n = 900, p = 2000, attempts = ATTEMPTS;
+        SplitMixChooser rng(404);
+        std::vector<int64_t> ncpu(n), nmem(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            ncpu[i] = 500 + (int64_t)*rng.choose(8000);
+            nmem[i] = (int64_t)1 << (20 + *rng.choose(14));
+        }
+        PodColumns pc;
+        pc.p = p;
+        pc.req_cpu_milli.resize(p);
+        pc.req_mem_bytes.resize(p);
+        std::vector<uint32_t> samples((size_t)p * attempts);
+        for (uint32_t i = 0; i < p; ++i) {
+            pc.req_cpu_milli[i] = 100 + (int64_t)*rng.choose(6000);
+            pc.req_mem_bytes[i] = (int64_t)1 << (18 + *rng.choose(14));
+            for (uint32_t t = 0; t < attempts; ++t) samples[(size_t)i * attempts + t] = (uint32_t)*rng.choose(n);
+        }
+        std::vector<std::shared_ptr<DeviceEvaluator>> devs;
+        for (int r = 0; r < 3; ++r) {
+            devs.push_back(std::make_shared<DeviceEvaluator>(0));
+            CHECK(ksched_set_nodes(devs.back()->handle(), n, ncpu.data(), nmem.data(), nullptr, 0, nullptr) == KSCHED_OK);
+        }
+        ShardedContext sh(devs, ShardedContext::Exchange::HostCopies);
+        const uint32_t flags = KSCHED_FIT | KSCHED_PICK_SAMPLED;
+        std::vector<int32_t> want(p), got(p, 31337);
+        CHECK(ksched_eval(devs[0]->handle(), p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), nullptr, nullptr, samples.data(), attempts, flags, nullptr, nullptr,
+                          want.data()) == KSCHED_OK);
+        for (int victim : {0, 1, 2}) {  // the first, a middle and the last shard
+            CHECK(ksched_set_option(devs[(size_t)victim]->handle(), KSCHED_OPT_FAULT, 2) == KSCHED_OK);  // the next entry into that ctx throws std::runtime_error
+            std::fill(got.begin(), got.end(), 31337);
+            CHECK_THROWS(sh.eval(pc, samples.data(), attempts, flags, ksched_mask_words(n), nullptr, nullptr, got.data()));
+            for (int32_t b : got) CHECK(b == 31337);  // nothing half-written comes back
+            sh.eval(pc, samples.data(), attempts, flags, ksched_mask_words(n), nullptr, nullptr, got.data());  // the contexts work on
+            CHECK(got == want);
+        }
+        CHECK(sh.batches() == 3);
+    });
     run("sharded host path: a communicator over one device named twice is refused loudly (no silent stand-in)", [] {
         std::vector<std::shared_ptr<DeviceEvaluator>> devs = {std::make_shared<DeviceEvaluator>(0), std::make_shared<DeviceEvaluator>(0)};
         CHECK_THROWS(ShardedContext(devs));
