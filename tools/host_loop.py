@@ -21,7 +21,15 @@ for P, N in ((5_000, 500), (20_000, 2_000)):
         if r.returncode:
             print(mode, P, N, "FAILED", r.stderr[-300:])
             continue
-        d = json.loads(r.stdout)
+        # (RCCL prints a five-line version banner to stdout when a communicator is created -- KSCHED_SHARDED=1 --, in the middle of the tool's JSON)
+        banner = ("RCCL version", "HIP version", "ROCm version", "Hostname", "Librccl path")
+        kept = []
+        for ln in r.stdout.splitlines(keepends=True):
+            if ln.startswith("{") and ln[1:].startswith(banner):
+                kept.append("{")
+            elif not ln.startswith(banner):
+                kept.append(ln)
+        d = json.loads("".join(kept))
         print(f"{mode:10s} {P} pods x {N} nodes: {d['posted_count']} bound in {d['seconds'] * 1e3:.1f} ms = {d['posted_count'] / d['seconds']:.0f} pods/s"
               + (f" ({d['rounds']} rounds, {d['conflicts']} deferrals)" if mode == "sequential" else "") + f"   [process wall {wall:.1f} s incl. JSON load + snapshot]")
     os.unlink(path)
