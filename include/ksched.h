@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define KSCHED_ABI_VERSION 4u
+#define KSCHED_ABI_VERSION 5u
 
 /* at most this many label-key columns per batch */
 #define KSCHED_MAX_KEYS 32u
@@ -136,12 +136,21 @@ extern "C" {
  * next one throws inside the call -- kind 1: std::bad_alloc, kind 2: std::runtime_error -- once.  That call must come back with
  * KSCHED_E_NOMEM / KSCHED_E_INVAL and ksched_last_error set; the process must not terminate.  0 = off (default). */
 #define KSCHED_OPT_FAULT 10
-/* KSCHED_OPT_PIPE_MODE: how ksched_pipe_submit spreads a batch over the pipe's two streams.  0 (default) = split: the mask kernel
+/* KSCHED_OPT_PIPE_MODE: how ksched_pipe_submit spreads a batch over the pipe's streams.  0 (default) = split: the mask kernel
  * on the mask stream, the pick (and whatever the caller enqueues behind it, e.g. the all-gather of the bindings) on the pick
- * stream.  1 = alternate: the WHOLE evaluation of a slot -- one launch when the pick rides in the mask kernel -- goes onto stream
- * (slot mod 2): consecutive batches overlap at their edges (the next launch's blocks fill while the previous one's last blocks
- * still store).  Same results either way; ksched_pipe_wait / ksched_pipe_wait_mask order a consumer behind the slot's work. */
+ * stream.  m >= 1 = alternate: the WHOLE evaluation of a slot -- one launch when the pick rides in the mask kernel -- goes onto
+ * stream (slot mod k), k = max(2, m) <= KSCHED_PIPE_MAX_STREAMS: consecutive batches overlap (the next launch's blocks fill while
+ * the previous one's blocks still store -- as far as the chip has room for them: KSCHED_OPT_GRID_CUS).  Same results either way;
+ * ksched_pipe_wait / ksched_pipe_wait_mask order a consumer behind the slot's work, ksched_pipe_slot_stream names its stream. */
 #define KSCHED_OPT_PIPE_MODE 11
+#define KSCHED_PIPE_MAX_STREAMS 8u
+/* KSCHED_OPT_GRID_CUS: how many of the chip's 256 compute units ONE fused mask launch may occupy (0, the default, = all of them;
+ * else 8 .. 256).  A block of the fused kernel owns a compute unit (its tile index fills the LDS), and every block of a launch
+ * spends the first microseconds filling it while nothing can be stored; a launch that takes the whole chip leaves no room for
+ * the next batch's launch to do that in the meantime.  With the launches of k batches in flight on k streams (the pipe's
+ * alternate mode) and 256 / k compute units each, one batch's fill hides under the others' stores.  A throughput setting:
+ * a single batch's own latency grows.  Results do not depend on it. */
+#define KSCHED_OPT_GRID_CUS 12
 
 typedef struct ksched_ctx ksched_ctx;
 
@@ -312,7 +321,11 @@ int ksched_pick_device(ksched_ctx *ctx, uint32_t p, const uint64_t *feasible, ui
  *   ksched_pipe_wait_mask(slot, stream)  the same for the slot's MASK (the two streams are not ordered against each other, so
  *        a finished pick says nothing about the mask kernel).  Waits for everything submitted to the mask stream so far; the
  *        event is recorded by this call, so consumers that only read bindings pay nothing for it.
- *   ksched_pipe_stream(which)       the internal hipStream_t: 0 = mask stream, 1 = pick stream.
+ *   ksched_pipe_stream(which)       the internal hipStream_t: 0 = mask stream, 1 = pick stream, 2 .. = the further streams of the
+ *        alternate mode over more than two (NULL until a submit has used them).
+ *   ksched_pipe_slot_stream(slot)   the stream that carried the slot's latest pick (alternate mode: its whole evaluation): work
+ *        enqueued THERE after the submit -- the all-gather of the slot's bindings -- is ordered behind it by the stream itself,
+ *        whatever mode the submit ran in (NULL before the slot's first submit).
  * Results are identical to ksched_eval_device_pitched with the same arguments (tests/test_gpu_parity.py).
  */
 typedef struct ksched_pipe ksched_pipe;
@@ -324,6 +337,7 @@ int ksched_pipe_submit(ksched_pipe *pipe, uint32_t slot, uint32_t p, const int64
 int ksched_pipe_wait(ksched_pipe *pipe, uint32_t slot, void *hip_stream);
 int ksched_pipe_wait_mask(ksched_pipe *pipe, uint32_t slot, void *hip_stream);
 void *ksched_pipe_stream(ksched_pipe *pipe, int which);
+void *ksched_pipe_slot_stream(ksched_pipe *pipe, uint32_t slot);
 
 /* ---- reasons ------------------------------------------------------------------------------
  * Host helper: rebuild check_node_validity's result for one pair from the two masks, in the

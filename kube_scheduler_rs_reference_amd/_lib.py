@@ -14,7 +14,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KSCHED_LIB") or os.path.join(_PKG_DIR, "libksched_hip.so")
 
 # --- constants mirrored from include/ksched.h --------------------------------------------------
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_KEYS = 32
 MAX_ATTEMPTS = 64
 SEL_NEVER = 0xFFFFFFFF
@@ -53,6 +53,8 @@ OPT_SNAPSHOT_STREAM = 8
 OPT_FUSED_PICK = 9
 OPT_FAULT = 10
 OPT_PIPE_MODE = 11
+PIPE_MAX_STREAMS = 8
+OPT_GRID_CUS = 12
 TRACE_WORDS = 8
 KERNEL_AUTO = 0
 KERNEL_DIRECT = 1
@@ -90,6 +92,7 @@ SYMBOLS = {
     "ksched_pipe_wait": (C.c_int, [_vp, _u32, _vp]),
     "ksched_pipe_wait_mask": (C.c_int, [_vp, _u32, _vp]),
     "ksched_pipe_stream": (_vp, [_vp, C.c_int]),
+    "ksched_pipe_slot_stream": (_vp, [_vp, _u32]),
     "ksched_reason": (C.c_int, [_vp, _vp, _u32, _u32]),
     "ksched_comm_unique_id": (C.c_int, [_vp]),
     "ksched_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),

@@ -1055,7 +1055,8 @@ inline bool fused_applicable(const IndexedSnapshot &s, uint32_t flags) {
 inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                             const uint64_t *ptol, uint32_t flags, uint64_t *out_feas, uint64_t *out_fit, uint32_t pitch, hipStream_t stream,
                             uint32_t debug = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint64_t *trace = nullptr,
-                            uint32_t trace_blocks = 0, const SelectArgs *pick = nullptr, int pick_form = 1, uint64_t *pick_acc = nullptr) {
+                            uint32_t trace_blocks = 0, const SelectArgs *pick = nullptr, int pick_form = 1, uint64_t *pick_acc = nullptr,
+                            uint32_t grid_cus = 0) {
     const IndexedLayout &l = s.lay;
     FusedArgs a{};
     a.W = l.W;
@@ -1099,7 +1100,10 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     if (((debug >> 18) & 3u) == 2u) per_block = 4u;
     if (((debug >> 18) & 3u) == 3u) per_block = 1u;
     const uint32_t want = (rounds + per_block - 1u) / per_block;
-    a.chunks = std::max(1u, std::min((256u * blocks_per_cu) / l.tiles, want));
+    // grid_cus (KSCHED_OPT_GRID_CUS): the launch keeps to that many compute units, so that the launches of the FOLLOWING batches
+    // (other streams) find free ones and fill while this one stores; 0 = the whole chip
+    const uint32_t cus = grid_cus ? std::min(256u, grid_cus) : 256u;
+    a.chunks = std::max(1u, std::min((cus * blocks_per_cu) / l.tiles, want));
     a.unit_q = a.units / a.chunks;
     a.unit_rem = a.units % a.chunks;
     a.tiles_rcp = (uint32_t)std::min<uint64_t>((1ull << 32) / l.tiles, 0xFFFFFFFFull);

@@ -147,7 +147,8 @@ struct ksched_ctx {
         DevBuf<uint64_t> buf;
     };
     std::vector<PickAcc> pick_acc;
-    int opt_pipe_mode = 0;        // KSCHED_OPT_PIPE_MODE: 0 split (mask stream / pick stream), 1 alternate (whole steps, stream = slot % 2)
+    int opt_pipe_mode = 0;        // KSCHED_OPT_PIPE_MODE: 0 split (mask stream / pick stream), m >= 1 alternate (whole steps, stream = slot % max(2, m))
+    uint32_t opt_grid_cus = 0;    // KSCHED_OPT_GRID_CUS: compute units ONE fused mask launch may occupy (0 = the whole chip)
     uint32_t fault_kind = 0, fault_skip = 0;  // KSCHED_OPT_FAULT (test hook of the no-unwind rule)
     int opt_bestfit_stages = 0;  // KSCHED_OPT_BESTFIT_STAGES: 0 auto, 1 one stage, 2 two stages
     int opt_index_build = 0;  // KSCHED_OPT_INDEX_BUILD: 0 = device kernels (default), 1 = host spec (tile_index.hpp)
@@ -804,7 +805,8 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     // rides when a wave has at most five rounds (C3: 2, the C4 shard: 5).
     bool ride_pays = true;
     if (c->opt_fused_pick == 1 && can_fused) {
-        const uint32_t tiles = std::max(1u, c->idx.lay.tiles), chunks = std::max(1u, std::min(256u / tiles, (p + 255u) / 256u));
+        const uint32_t tiles = std::max(1u, c->idx.lay.tiles), cus = c->opt_grid_cus ? c->opt_grid_cus : 256u;
+        const uint32_t chunks = std::max(1u, std::min(cus / tiles, (p + 255u) / 256u));
         ride_pays = (uint64_t)p <= (uint64_t)chunks * 5u * 64u * kFusedWaves;
     }
     const bool pick_rides = select_direct && want_mask && c->opt_fused_pick && kern == KSCHED_KERNEL_FUSED && can_fused && ride_pays &&
@@ -1004,7 +1006,8 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         }
         hipError_t e = run_fused(c->idx, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, pitch, s, c->opt_debug,
                                  timed ? c->ev_pool[slot].a : nullptr, timed ? c->ev_pool[slot].b : nullptr,
-                                 c->opt_trace ? c->trace.ptr : nullptr, kTraceBlocks, pick_rides ? &ride : nullptr, ride_form, ride_acc);
+                                 c->opt_trace ? c->trace.ptr : nullptr, kTraceBlocks, pick_rides ? &ride : nullptr, ride_form, ride_acc,
+                                 c->opt_grid_cus);
         if (e != hipSuccess) return fail_hip(c, e, "run_fused");
         c->last_kernel = "fused";
         if (pick_rides) c->last_pick = ride_form == 2 ? "fused-tile" : "fused";
@@ -1166,8 +1169,12 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) try {
             c->opt_fused_pick = (int)value;
             return KSCHED_OK;
         case KSCHED_OPT_PIPE_MODE:
-            if (value != 0 && value != 1) return KSCHED_E_INVAL;
+            if (value < 0 || value > (int64_t)KSCHED_PIPE_MAX_STREAMS) return KSCHED_E_INVAL;
             c->opt_pipe_mode = (int)value;
+            return KSCHED_OK;
+        case KSCHED_OPT_GRID_CUS:
+            if (value != 0 && (value < 8 || value > 256)) return KSCHED_E_INVAL;
+            c->opt_grid_cus = (uint32_t)value;
             return KSCHED_OK;
         case KSCHED_OPT_FAULT:  // low byte: 0 off, 1 std::bad_alloc, 2 std::runtime_error; bits 8..: fault points to pass first
             if (value < 0 || (value & 0xFF) > 2 || value > 0xFFFFFF) return KSCHED_E_INVAL;
@@ -1403,8 +1410,10 @@ struct ksched_pipe {
     ksched_ctx *ctx = nullptr;
     uint32_t depth = 0;
     hipStream_t s_mask = nullptr, s_pick = nullptr;
+    std::vector<hipStream_t> extra;  // streams 2 .. of the alternate mode over more than two streams (created on first use)
     std::vector<hipEvent_t> mask_done, pick_done;
     std::vector<hipStream_t> slot_stream;  // the stream that carries the slot's mask kernel (alternate mode: also its pick)
+    std::vector<hipStream_t> pick_stream;  // the stream that carried the slot's latest pick (ksched_pipe_slot_stream)
 };
 
 int ksched_pipe_create(ksched_ctx *c, uint32_t depth, ksched_pipe **out) try {
@@ -1419,6 +1428,7 @@ int ksched_pipe_create(ksched_ctx *c, uint32_t depth, ksched_pipe **out) try {
     bool ok = hipStreamCreateWithFlags(&q->s_mask, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&q->s_pick, hipStreamNonBlocking) == hipSuccess;
     q->slot_stream.assign(depth, nullptr);
+    q->pick_stream.assign(depth, nullptr);
     for (uint32_t i = 0; ok && i < 2 * depth; ++i) {
         hipEvent_t e;
         ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -1438,21 +1448,38 @@ void ksched_pipe_destroy(ksched_pipe *q) try {
         DeviceGuard g(q->ctx->device);
         if (q->s_mask) (void)hipStreamSynchronize(q->s_mask);
         if (q->s_pick) (void)hipStreamSynchronize(q->s_pick);
+        for (auto st : q->extra) (void)hipStreamSynchronize(st);
         {
             std::lock_guard<std::mutex> lk(q->ctx->mu);  // the ctx must not record events on streams that are about to go away
             stream_forget(q->ctx, q->s_mask);
             stream_forget(q->ctx, q->s_pick);
+            for (auto st : q->extra) stream_forget(q->ctx, st);
         }
         for (auto e : q->mask_done) (void)hipEventDestroy(e);
         for (auto e : q->pick_done) (void)hipEventDestroy(e);
         if (q->s_mask) (void)hipStreamDestroy(q->s_mask);
         if (q->s_pick) (void)hipStreamDestroy(q->s_pick);
+        for (auto st : q->extra) (void)hipStreamDestroy(st);
     }
     delete q;
 } catch (...) {  // nothing unwinds across the C ABI
 }
 
-void *ksched_pipe_stream(ksched_pipe *q, int which) { return q ? (void *)(which == 0 ? q->s_mask : q->s_pick) : nullptr; }
+void *ksched_pipe_stream(ksched_pipe *q, int which) {
+    if (!q || which < 0) return nullptr;
+    if (which < 2) return (void *)(which == 0 ? q->s_mask : q->s_pick);
+    return (size_t)(which - 2) < q->extra.size() ? (void *)q->extra[(size_t)(which - 2)] : nullptr;
+}
+
+// the stream that carried the slot's latest evaluation in the alternate mode / its pick in the split mode: what a consumer of the
+// slot's bindings (the all-gather) has to be enqueued behind
+void *ksched_pipe_slot_stream(ksched_pipe *q, uint32_t slot) try {
+    if (!q || slot >= q->depth) return nullptr;
+    std::lock_guard<std::mutex> lk(q->ctx->mu);
+    return (void *)q->pick_stream[slot];
+} catch (...) {
+    return nullptr;
+}
 
 int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t *pcpu, const int64_t *pmem, const uint32_t *psel,
                        const uint64_t *ptol, const uint32_t *samples, uint32_t attempts, uint32_t flags, uint64_t *mask,
@@ -1472,18 +1499,32 @@ int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t 
     // best fit: bitmaps kept in best-fit order), so the two streams need no ordering at all: each is in order by itself
     // (mask kernels of successive batches on one, picks on the other), which also covers the reuse of a slot's buffers.
     const bool pick_reads_mask = c->opt_pick_from_mask || ((pick & KSCHED_PICK_BESTFIT) && !bf_rows_expected(c));
-    if (c->opt_pipe_mode == 1 && !pick_reads_mask) {
-        // alternate: the whole evaluation of the slot on one of the two streams (ONE launch when the pick rides in the mask
-        // kernel); a slot always comes back to the same stream, so the reuse of its buffers is ordered by the stream itself
-        hipStream_t st = (slot & 1u) ? q->s_pick : q->s_mask;
+    if (c->opt_pipe_mode >= 1 && !pick_reads_mask) {
+        // alternate: the whole evaluation of the slot on ONE of the pipe's streams (one launch when the pick rides in the mask
+        // kernel), stream = slot mod k.  While depth is a multiple of k a slot always comes back to the same stream, so the reuse
+        // of its buffers is ordered by the stream itself; otherwise the slot's new stream first waits for its previous use.
+        const uint32_t k = std::max(2u, (uint32_t)c->opt_pipe_mode), which = slot % k;
+        while (which >= 2u && q->extra.size() < (size_t)which - 1u) {
+            hipStream_t ns = nullptr;
+            HIPCHK(c, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+            q->extra.push_back(ns);
+        }
+        hipStream_t st = which == 0u ? q->s_mask : which == 1u ? q->s_pick : q->extra[which - 2u];
+        if (q->pick_stream[slot] && q->pick_stream[slot] != st) HIPCHK(c, hipStreamWaitEvent(st, q->pick_done[slot], 0));
         q->slot_stream[slot] = st;
+        q->pick_stream[slot] = st;
         rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, mask, nullptr, binding, mask_pitch_words, st);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(q->pick_done[slot], st));
         return KSCHED_OK;
     }
     hipStream_t sm = q->s_mask;
+    if (q->pick_stream[slot] && q->pick_stream[slot] != q->s_pick) {  // the slot last ran in the alternate mode on another stream
+        HIPCHK(c, hipStreamWaitEvent(q->s_pick, q->pick_done[slot], 0));
+        HIPCHK(c, hipStreamWaitEvent(sm, q->pick_done[slot], 0));
+    }
     q->slot_stream[slot] = sm;
+    q->pick_stream[slot] = q->s_pick;
     if (pick_reads_mask) HIPCHK(c, hipStreamWaitEvent(sm, q->pick_done[slot], 0));  // the slot's mask may be overwritten once its pick has run
     rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, nullptr, 0, flags & ~pick, mask, nullptr, nullptr, mask_pitch_words, sm);
     if (rc) return rc;

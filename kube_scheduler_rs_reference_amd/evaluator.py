@@ -376,9 +376,16 @@ class Pipe:
             pass
 
     def stream(self, which: int):
-        """torch view of an internal stream: 0 = mask stream, 1 = pick stream."""
+        """torch view of an internal stream: 0 = mask stream, 1 = pick stream, 2 .. = further streams of the alternate mode."""
         import torch
         return torch.cuda.ExternalStream(int(self._lib.ksched_pipe_stream(self._h, which)), device=self.ev.device)
+
+    def slot_stream(self, slot: int):
+        """The stream that carried the slot's latest pick (alternate mode: its whole evaluation), or None before its first submit:
+        work enqueued there is ordered behind the slot's bindings by the stream itself (ksched_pipe_slot_stream)."""
+        import torch
+        h = self._lib.ksched_pipe_slot_stream(self._h, slot)
+        return torch.cuda.ExternalStream(int(h), device=self.ev.device) if h else None
 
     def submit(self, slot: int, req_cpu_milli, req_mem_bytes, sel_val_ids, tolerations, samples, flags: int, mask, binding):
         """torch CUDA tensors (see Evaluator.eval_device); `mask` is a [p, W] (possibly pitched) view, `binding` int32 [p]."""

@@ -17,7 +17,7 @@ pub struct ksched_comm {
     _private: [u8; 0],
 }
 
-pub const KSCHED_ABI_VERSION: u32 = 4;
+pub const KSCHED_ABI_VERSION: u32 = 5;
 pub const KSCHED_MAX_KEYS: u32 = 32;
 pub const KSCHED_MAX_ATTEMPTS: u32 = 64;
 pub const KSCHED_SEL_NEVER: u32 = 0xFFFF_FFFF;
@@ -55,6 +55,8 @@ pub const KSCHED_OPT_SNAPSHOT_STREAM: c_int = 8;
 pub const KSCHED_OPT_FUSED_PICK: c_int = 9;
 pub const KSCHED_OPT_FAULT: c_int = 10;
 pub const KSCHED_OPT_PIPE_MODE: c_int = 11;
+pub const KSCHED_PIPE_MAX_STREAMS: u32 = 8;
+pub const KSCHED_OPT_GRID_CUS: c_int = 12;
 
 extern "C" {
     // ---- lifetime
@@ -118,6 +120,7 @@ extern "C" {
     pub fn ksched_pipe_wait(pipe: *mut ksched_pipe, slot: u32, hip_stream: *mut c_void) -> c_int;
     pub fn ksched_pipe_wait_mask(pipe: *mut ksched_pipe, slot: u32, hip_stream: *mut c_void) -> c_int;
     pub fn ksched_pipe_stream(pipe: *mut ksched_pipe, which: c_int) -> *mut c_void;
+    pub fn ksched_pipe_slot_stream(pipe: *mut ksched_pipe, slot: u32) -> *mut c_void;
     // ---- reasons
     pub fn ksched_reason(feasible_row: *const u64, fit_row: *const u64, node: u32, flags: u32) -> c_int;
     pub fn ksched_explain(
@@ -180,6 +183,7 @@ pub fn symbol_table() -> Vec<(&'static str, usize)> {
         ("ksched_pipe_wait", ksched_pipe_wait as usize),
         ("ksched_pipe_wait_mask", ksched_pipe_wait_mask as usize),
         ("ksched_pipe_stream", ksched_pipe_stream as usize),
+        ("ksched_pipe_slot_stream", ksched_pipe_slot_stream as usize),
         ("ksched_reason", ksched_reason as usize),
         ("ksched_explain", ksched_explain as usize),
         ("ksched_comm_unique_id", ksched_comm_unique_id as usize),
@@ -237,5 +241,7 @@ pub fn constant_table() -> Vec<(&'static str, i64)> {
         ("KSCHED_OPT_FUSED_PICK", KSCHED_OPT_FUSED_PICK as i64),
         ("KSCHED_OPT_FAULT", KSCHED_OPT_FAULT as i64),
         ("KSCHED_OPT_PIPE_MODE", KSCHED_OPT_PIPE_MODE as i64),
+        ("KSCHED_PIPE_MAX_STREAMS", KSCHED_PIPE_MAX_STREAMS as i64),
+        ("KSCHED_OPT_GRID_CUS", KSCHED_OPT_GRID_CUS as i64),
     ];
 }

@@ -298,3 +298,72 @@ def test_pipe_alternate_mode_equals_oracle(evaluator, with_gather):
         ev.set_option(_lib.OPT_PIPE_MODE, 0)
         if comm is not None:
             comm.close()
+
+
+# ---- several batches in flight on shares of the chip (KSCHED_OPT_PIPE_MODE = k streams, KSCHED_OPT_GRID_CUS) ------------------------------
+
+@pytest.mark.parametrize("k,cus,depth", [(2, 128, 4), (3, 88, 6), (4, 64, 8), (3, 96, 4), (8, 32, 8), (2, 0, 3)])
+def test_pipe_k_streams_on_a_share_of_the_chip_equals_oracle(evaluator, k, cus, depth):
+    """The pipe's alternate mode over k streams with every mask launch kept to `cus` compute units (the next batches' launches fill on the
+    others while this one stores): every step's bindings and masks == oracle, also when depth is not a multiple of k (a slot then moves
+    between streams and is ordered by its event) and when the mode changes back to split on the same pipe."""
+    import torch
+    ev = evaluator
+    c = synth.make_cluster(9000, 5000, n_keys=8, n_taints=0, seed=2718)
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", ev.device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    steps = 3 * depth + 1
+    rolled = [np.roll(np.arange(c.P), 29 * j) for j in range(steps)]
+    batches = [dict(cpu=t(c.req_cpu[r], np.int64), mem=t(c.req_mem[r], np.int64), sel=t(c.pod_sel[:, r], np.int32), smp=t(c.samples[r], np.int32)) for r in rolled]
+    feas, _, base = oracle_eval(c, FIT | SEL | PICK_SAMPLED)
+    ev.set_option(_lib.OPT_PIPE_MODE, k)
+    ev.set_option(_lib.OPT_GRID_CUS, cus)
+    pipe = ev.pipe(depth)
+    try:
+        masks = [ev.alloc_mask(c.P) for _ in range(depth)]
+        outs = [torch.full((c.P,), -7, dtype=torch.int32, device=dev) for _ in range(depth)]
+        assert pipe.slot_stream(0) is None
+        for j in range(steps):
+            slot = j % depth
+            if j >= depth:  # the slot's previous batch, before it is overwritten
+                pipe.wait(slot, host=True)
+                jj = j - depth
+                assert np.array_equal(outs[slot].cpu().numpy(), base[rolled[jj]]), f"step {jj}"
+                pipe.wait_mask(slot, host=True)
+                if jj % 4 == 0:
+                    assert np.array_equal(masks[slot].cpu().numpy().view(np.uint64), feas[rolled[jj]]), f"mask of step {jj}"
+            b = batches[j]
+            if j == steps - 2:
+                ev.set_option(_lib.OPT_PIPE_MODE, 0)  # one split-mode batch in between: ordered against the slot's alternate-mode past
+            pipe.submit(slot, b["cpu"], b["mem"], b["sel"], None, b["smp"], FIT | SEL | PICK_SAMPLED, masks[slot], outs[slot])
+            if j == steps - 2:
+                ev.set_option(_lib.OPT_PIPE_MODE, k)
+            assert pipe.slot_stream(slot) is not None
+        torch.cuda.synchronize()
+        for j in range(steps - depth, steps):
+            assert np.array_equal(outs[j % depth].cpu().numpy(), base[rolled[j]]), f"step {j}"
+            assert np.array_equal(masks[j % depth].cpu().numpy().view(np.uint64), feas[rolled[j]]), f"mask of step {j}"
+    finally:
+        pipe.close()
+        ev.set_option(_lib.OPT_PIPE_MODE, 0)
+        ev.set_option(_lib.OPT_GRID_CUS, 0)
+
+
+def test_grid_cus_option_is_validated_and_changes_nothing_in_the_results(evaluator):
+    ev = evaluator
+    for bad in (1, 7, 257, -1):
+        with pytest.raises(KschedError):
+            ev.set_option(_lib.OPT_GRID_CUS, bad)
+    with pytest.raises(KschedError):
+        ev.set_option(_lib.OPT_PIPE_MODE, _lib.PIPE_MAX_STREAMS + 1)
+    c = synth.make_cluster(3000, 2100, n_keys=8, n_taints=0, seed=99)
+    ev.set_nodes(**c.node_columns())
+    feas, _, base = oracle_eval(c, FIT | SEL | PICK_SAMPLED)
+    try:
+        for cus in (0, 8, 24, 100, 256):
+            ev.set_option(_lib.OPT_GRID_CUS, cus)
+            r = ev.eval(c.req_cpu, c.req_mem, c.pod_sel, None, c.samples, FIT | SEL | PICK_SAMPLED)
+            assert np.array_equal(r.feasible, feas) and np.array_equal(r.binding, base), cus
+    finally:
+        ev.set_option(_lib.OPT_GRID_CUS, 0)

@@ -2,6 +2,8 @@
 // mapping (XCD-contiguous runs), rows pitched to 128 B, for tile widths of 16 / 32 / 64 words per pod row and the store
 // policies plain / sc1 (write-through) / nt, timed with events attached to the dispatch.  Also a flat stream (each wave
 // instruction writes 1 KiB contiguous) as the ceiling.  Not part of the product; numbers are quoted in profiles/HISTORY.md.
+// Round 5: an 8-word tile (64-byte segments: what a 512-node tile of the mask kernel would write) next to the 16-word one, and
+// every pattern once more with the output ROTATED over enough buffers to exceed the 256 MiB Infinity Cache (ROT, the bench's form).
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench3 tools/ubench3.hip
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
@@ -66,8 +68,12 @@ __global__ __launch_bounds__(1024) void st_flat(uint64_t *__restrict__ out, size
     for (size_t w = ((size_t)blockIdx.x * 1024u + threadIdx.x) * 2u; w + 1 < words; w += stride) st16<POL>(out + w, u32x4{(uint32_t)w, 1u, 2u, 3u});
 }
 
+static uint64_t *g_rot[16];
+static int g_nrot = 1, g_k = 0;
+static uint64_t *next_out() { return g_rot[(g_k++) % g_nrot]; }
+
 template <class L>
-float time_us(L launch, int reps = 20) {
+float time_us(L launch, int reps = 24) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
@@ -101,8 +107,9 @@ void run_tiles(const char *name, uint64_t *out, uint32_t P, uint32_t W) {
     const uint32_t lds = 100 * 1024;
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const float us = time_us([&](hipEvent_t s, hipEvent_t e) {
-        if (s) hipExtLaunchKernelGGL(kern, dim3(a.run * 8u), dim3(1024), lds, 0, s, e, 0, out, a);
-        else hipLaunchKernelGGL(kern, dim3(a.run * 8u), dim3(1024), lds, 0, out, a);
+        uint64_t *o = next_out();
+        if (s) hipExtLaunchKernelGGL(kern, dim3(a.run * 8u), dim3(1024), lds, 0, s, e, 0, o, a);
+        else hipLaunchKernelGGL(kern, dim3(a.run * 8u), dim3(1024), lds, 0, o, a);
     });
     const double bytes = (double)P * W * 8;
     printf("  %-34s %7.2f us  %7.1f GB/s  (blocks %u = %u chunks x %u tiles)\n", name, us, bytes / us * 1e-3, total, a.chunks, a.tiles);
@@ -113,19 +120,28 @@ void run_flat(const char *name, uint64_t *out, uint32_t P, uint32_t W) {
     const size_t words = (size_t)P * ((W + 15u) & ~15u);
     auto kern = st_flat<POL>;
     const float us = time_us([&](hipEvent_t s, hipEvent_t e) {
-        if (s) hipExtLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, s, e, 0, out, words);
-        else hipLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, out, words);
+        uint64_t *o = next_out();
+        if (s) hipExtLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, s, e, 0, o, words);
+        else hipLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, o, words);
     });
     printf("  %-34s %7.2f us  %7.1f GB/s  (pitched bytes %.1f MB)\n", name, us, (double)P * W * 8 / us * 1e-3, words * 8e-6);
 }
 
 int main() {
     const uint32_t shapes[][2] = {{100000, 79}, {125000, 157}, {125000, 782}};
+    for (int rot = 0; rot < 2; ++rot)
     for (auto &sh : shapes) {
         const uint32_t P = sh[0], W = sh[1];
-        uint64_t *out;
-        CK(hipMalloc(&out, (size_t)P * ((W + 15u) & ~15u) * 8 + 4096));
-        printf("--- mask %u x %u words = %.1f MB algorithmic (rows pitched to 128 B; kernel time from dispatch events)\n", P, W, (double)P * W * 8e-6);
+        const size_t bytes = (size_t)P * ((W + 15u) & ~15u) * 8 + 4096;
+        g_nrot = rot ? (int)std::min<size_t>(16, ((size_t)320 << 20) / bytes + 1) : 1;
+        if (rot && g_nrot == 1) continue;  // one buffer already exceeds the cache
+        for (int i = 0; i < g_nrot; ++i) CK(hipMalloc(&g_rot[i], bytes));
+        uint64_t *out = g_rot[0];
+        printf("--- mask %u x %u words = %.1f MB algorithmic (rows pitched to 128 B; kernel time from dispatch events; output %s)\n", P, W, (double)P * W * 8e-6,
+               rot ? "ROTATED over > 256 MiB of buffers" : "in place");
+        run_tiles<8, 0>("tile 8 words (64 B) plain", out, P, W);
+        run_tiles<8, 1>("tile 8 words (64 B) sc1", out, P, W);
+        run_tiles<8, 2>("tile 8 words (64 B) nt", out, P, W);
         run_flat<0>("flat plain", out, P, W);
         run_flat<1>("flat sc1", out, P, W);
         run_flat<2>("flat nt", out, P, W);
@@ -137,7 +153,7 @@ int main() {
         run_tiles<32, 1>("tile 32 words sc1", out, P, W);
         run_tiles<64, 0>("tile 64 words plain", out, P, W);
         run_tiles<64, 1>("tile 64 words sc1", out, P, W);
-        CK(hipFree(out));
+        for (int i = 0; i < g_nrot; ++i) CK(hipFree(g_rot[i]));
     }
     return 0;
 }
