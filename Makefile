@@ -25,6 +25,7 @@ HOST_SRCS := $(wildcard $(HOST)/*.cpp)
 HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/ksched.h
 HOST_TEST := tests/cpp/host_tests
 OBJ_TOOL := tests/cpp/objects_eval
+FAKE_RCCL := tests/cpp/libfake_rccl.so
 INDEX_TEST := tests/cpp/index_tests
 
 .PHONY: all lib host oracle clean
@@ -34,7 +35,10 @@ lib: $(LIB_HIP)
 $(LIB_HIP): $(CSRC)/ksched_api.hip $(wildcard $(CSRC)/*.hpp) include/ksched.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ksched_api.hip
 
-host: $(LIB_HOST) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL)
+host: $(LIB_HOST) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL) $(FAKE_RCCL)
+# TEST-ONLY stand-in for librccl (n ranks on one GPU; loaded only with KSCHED_TEST_HOOKS=1 + KSCHED_RCCL_LIB, see csrc/comm_rccl.hpp)
+$(FAKE_RCCL): tests/cpp/fake_rccl.cpp
+	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -shared -o $@ tests/cpp/fake_rccl.cpp -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 # host-only check of the bitmap index arithmetic (no GPU, no HIP runtime call): tests/test_index_host.py runs it
 $(INDEX_TEST): tests/cpp/index_tests.cpp $(CSRC)/tile_index.hpp
 	$(CXX) -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -o $@ tests/cpp/index_tests.cpp
@@ -42,7 +46,7 @@ $(LIB_HOST): $(HOST_SRCS) $(HOST_HDRS) $(LIB_HIP)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRCS) -L$(PKG) -lksched_hip -Wl,-rpath,'$$ORIGIN' -lpthread
 # C++ tests of the host mirror (tests/cpp/host_tests.cpp; driven by tests/test_host_mirror.py)
 $(HOST_TEST): tests/cpp/host_tests.cpp $(LIB_HOST) $(HOST_HDRS)
-	$(CXX) $(CXXFLAGS) -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o $@ tests/cpp/host_tests.cpp -L$(PKG) -lksched_host -lksched_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -Wl,-rpath,/opt/rocm/lib -lpthread
+	$(CXX) $(CXXFLAGS) -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o $@ tests/cpp/host_tests.cpp -L$(PKG) -lksched_host -lksched_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -Wl,-rpath,/opt/rocm/lib -lpthread -ldl
 
 # objects JSON -> host encoder -> device, printed for the Python parity tests (tests/test_gpu_objects.py)
 $(OBJ_TOOL): tests/cpp/objects_eval.cpp tests/cpp/json_min.hpp $(LIB_HOST) $(HOST_HDRS)
@@ -53,4 +57,4 @@ $(LIB_ORA): oracle/oracle.c oracle/oracle.h
 	$(CC) $(CFLAGS) -shared -o $@ oracle/oracle.c
 
 clean:
-	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL)
+	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL) $(FAKE_RCCL)

@@ -76,7 +76,7 @@ def algorithmic_bytes(P, N, n_keys, taint, masks=1, pick_attempts=0):
     return P * b_pod + N * b_node + P * W * 8 * masks + (P * 4 if pick_attempts else 0)
 
 
-def cpu_baseline(c, flags_names, budget_s=12.0):
+def cpu_baseline(c, flags_names, budget_s=12.0, p_cap=None):
     """Time the oracle (object-level C restatement, per-pair string/map evaluation; quantities parsed
     once, LIST once per node) on all host cores on a bounded sample of this workload's pods."""
     from oracle import capi
@@ -93,10 +93,11 @@ def cpu_baseline(c, flags_names, budget_s=12.0):
         capi.eval_objects(pods, nodes, bound, flags, threads=th, prebuilt=(s, cp, cn, cb))
         return time.perf_counter() - t0
 
-    probe = min(c.P, 64 * max(1, threads))
+    P_all = min(c.P, p_cap or c.P)  # (the cluster may hold several input batches: the sample stays inside the first)
+    probe = min(P_all, 64 * max(1, threads))
     t = run(probe, threads)
     rate = probe * c.N / max(t, 1e-9)
-    P_s = int(min(c.P, max(probe, rate * budget_s / c.N)))
+    P_s = int(min(P_all, max(probe, rate * budget_s / c.N)))
     t = run(P_s, threads)
     value = P_s * c.N / t
     # single core, smaller sample
@@ -104,7 +105,7 @@ def cpu_baseline(c, flags_names, budget_s=12.0):
     t1 = run(P_1, 1)
     # second, stronger CPU baseline: scalar loop on the encoded integer columns
     t0 = time.perf_counter()
-    P_e = min(c.P, 20_000)
+    P_e = min(P_all, 20_000)
     capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels if c.n_keys else None, c.node_taints if c.n_taints else None,
                       c.req_cpu[:P_e], c.req_mem[:P_e], c.pod_sel[:, :P_e] if c.n_keys else None,
                       c.pod_tol[:P_e] if c.n_taints else None, None, flags, threads=threads)
@@ -230,6 +231,8 @@ def main():
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the self-check after the timed region (the last timed step's bindings -- all of this rank's pods -- and >= 4096 of its "
                          "mask rows against the oracle's integer loop; the run exits non-zero on a mismatch)")
+    ap.add_argument("--allow-unchecked", action="store_true",
+                    help="exit 0 even when the self-check itself could not run (e.g. oracle/liboracle.so missing); the default exits 3: an unverified number is not reported as a good one")
     ap.add_argument("--parity-rows", type=int, default=4096, help="mask rows the self-check compares word for word (spread evenly over the rank's pods)")
     ap.add_argument("--packed", action="store_true",
                     help="mask rows packed at W words (default: rows pitched to ksched_mask_pitch(n) = W rounded up to 128 B)")
@@ -240,6 +243,10 @@ def main():
     ap.add_argument("--no-rotate", action="store_true",
                     help="rewrite ONE mask buffer every step (the Infinity Cache then absorbs part of the stores at C3 / C4s); the default "
                          "rotates over enough buffers to exceed it and reports the in-place figure as config.in_place")
+    ap.add_argument("--input-batches", type=int, default=6,
+                    help="the timed loop cycles over this many DIFFERENT seeded pod batches resident in HBM (a scheduler never sees the same "
+                         "batch twice; one batch evaluated every step would have its 6.8 MB of operands served from L2), like it cycles over "
+                         "mask buffers.  Batch 0 is the workload's standard batch; the self-check checks whichever batch the last timed step evaluated")
     ap.add_argument("--no-others", action="store_true",
                     help="N = 1, default workload: skip config.other_workloads (C4s, C5s measured in the same process, a few hundred ms) "
                          "and config.in_place")
@@ -277,6 +284,19 @@ def main():
                     help="with --depth >= 2: mask kernels on one HIP stream, pick kernels (+ all-gather) on another (ksched_pipe)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly (`python bench.py --gpus 8 ...`): become the launcher -- one process per GPU under torch.distributed.run on
+        # this node, the same command line, rendezvous on 127.0.0.1 (the container's hostname may not resolve)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: re-launching as `%s`\n" % (args.gpus, " ".join(cmd)))
+        sys.stderr.flush()
+        os.execv(sys.executable, cmd)
+
     import torch
     import torch.distributed as dist
 
@@ -287,8 +307,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
         raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
@@ -327,9 +345,12 @@ def main():
     class Rig:
         """This rank's shard of one P_total x N workload: evaluator, resident inputs, loops."""
 
-        def __init__(self, cfg, P_total, N, flag_names, pick):
+        def __init__(self, cfg, P_total, N, flag_names, pick, n_batches=None):
             self.P_total, self.N, self.flag_names, self.pick = P_total, N, flag_names, pick
-            c = synth.make_config(cfg, P=P_total, N=N)  # same seeded cluster on every rank; each takes its rows
+            # same seeded cluster on every rank; each takes its rows.  B pod batches of P_total pods each: the generator's streams are
+            # prefixes of one another, so batch 0 is exactly the P_total-pod workload and batches 1.. are further pods of the same distribution
+            self.B = B = max(1, n_batches or args.input_batches)
+            c = synth.make_config(cfg, P=P_total * B, N=N)
             self.c = c
             flags = sum(getattr(L, f) for f in flag_names)
             flags |= L.PICK_SAMPLED if pick == "sampled" else L.PICK_BESTFIT
@@ -345,11 +366,20 @@ def main():
             self.lo, self.hi, _ = shard_bounds(P_total, world, rank)
             lo, hi = self.lo, self.hi
             t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
-            self.d_cpu, self.d_mem = t(c.req_cpu[lo:hi], np.int64), t(c.req_mem[lo:hi], np.int64)
-            self.d_sel = t(c.pod_sel[:, lo:hi], np.int32) if c.n_keys else None
-            self.d_tol = t(c.pod_tol[lo:hi], np.int64) if self.taint else None
-            self.d_smp = t(c.samples[lo:hi], np.int32) if pick == "sampled" else None
+            self.batches = []  # per input batch: (req_cpu, req_mem, sel, tol, samples) of THIS rank's rows, resident
+            for b in range(B):
+                r0, r1 = b * P_total + lo, b * P_total + hi
+                self.batches.append((t(c.req_cpu[r0:r1], np.int64), t(c.req_mem[r0:r1], np.int64),
+                                     t(c.pod_sel[:, r0:r1], np.int32) if c.n_keys else None,
+                                     t(c.pod_tol[r0:r1], np.int64) if self.taint else None,
+                                     t(c.samples[r0:r1], np.int32) if pick == "sampled" else None))
+            self.d_cpu, self.d_mem, self.d_sel, self.d_tol, self.d_smp = self.batches[0]
+            self.input_bytes = sum(int(x.numel() * x.element_size()) for bt in self.batches for x in bt if x is not None)
             self.comm, self.comm_note = None, None
+
+        def rows(self, b):
+            """numpy rows of input batch b that belong to this rank"""
+            return slice(b * self.P_total + self.lo, b * self.P_total + self.hi)
 
         def make_comm(self):
             """ksched_comm_create: the C ABI's RCCL communicator.  Its creation is collective; if it fails on ANY rank (e.g. no
@@ -407,8 +437,9 @@ def main():
     class Loop:
         """One configuration of the step loop: scheduler (sharding + gather), buffers, pre-marshalled launches."""
 
-        def __init__(self, rig, G, depth=depth, two_stream=None, rotate=True, alternate=False):
+        def __init__(self, rig, G, depth=depth, two_stream=None, rotate=True, alternate=False, inputs_rotate=True):
             ev = rig.ev
+            self.rig = rig
             self.alternate = alternate and G == 1 and depth % 2 == 0
             n_loc = rig.hi - rig.lo
             pipelined = depth > 1 and not args.no_mask
@@ -442,31 +473,47 @@ def main():
                 slot_outs = {(0, 0): sched.local[: n_loc]}
             keys = sorted(slot_outs)
             # sequential form: ONE (pre-marshalled) library call per step on one stream
-            bound = ev.bind_eval_device(rig.d_cpu, rig.d_mem, rig.d_sel, rig.d_tol, rig.d_smp, rig.flags,
-                                        out_feasible=None if args.no_mask else (self.masks if self.pipe is None else self.masks[0]),
-                                        out_bindings=[slot_outs[k] for k in keys])
+            # one pre-marshalled call per INPUT batch (the loop cycles over rig.B resident pod batches as it cycles over mask buffers)
+            nb = rig.B if inputs_rotate else 1
+            self.n_inputs = nb
+            bounds = [ev.bind_eval_device(*rig.batches[b], rig.flags,
+                                          out_feasible=None if args.no_mask else (self.masks if self.pipe is None else self.masks[0]),
+                                          out_bindings=[slot_outs[k] for k in keys]) for b in range(nb)]
             index_of = {slot_outs[k].data_ptr(): i for i, k in enumerate(keys)}
-            submit = None
+            submits = None
             if self.pipe is not None:  # pre-marshalled ksched_pipe_submit: mask kernel -> the pipe's mask stream, pick -> its pick stream
-                submit = self.pipe.bind(rig.d_cpu, rig.d_mem, rig.d_sel, rig.d_tol, rig.d_smp, rig.flags, self.masks, [slot_outs[k] for k in keys])  # pipe slot = k * G + g
+                submits = [self.pipe.bind(*rig.batches[b], rig.flags, self.masks, [slot_outs[k] for k in keys]) for b in range(nb)]  # pipe slot = k * G + g
             n_rot = max(1, self.R) if self.pipe is None and not args.no_mask else 1
             k_rot = [0]
-            self.last_mask = 0  # index into self.masks of the buffer the latest step wrote (the self-check reads it back)
+            self.last_mask = 0   # index into self.masks of the buffer the latest step wrote (the self-check reads it back)
+            self.last_batch = 0  # ... and which input batch it evaluated
 
             def local_eval(binding_out):
-                self.last_mask = k_rot[0] % n_rot
-                bound(index_of[binding_out.data_ptr()], self.last_mask)
+                self.last_mask, self.last_batch = k_rot[0] % n_rot, k_rot[0] % nb
+                bounds[self.last_batch](index_of[binding_out.data_ptr()], self.last_mask)
                 k_rot[0] += 1
 
             def run(slot, binding_out):  # pipelined form: bindings and masks are per slot
-                if submit is not None:
+                self.last_batch = k_rot[0] % nb
+                if submits is not None:
                     self.last_mask = slot
-                    submit(slot)
+                    submits[self.last_batch](slot)
                 else:
                     self.last_mask = k_rot[0] % n_rot
-                    bound(index_of[binding_out.data_ptr()], self.last_mask)
-                    k_rot[0] += 1
+                    bounds[self.last_batch](index_of[binding_out.data_ptr()], self.last_mask)
+                k_rot[0] += 1
+            self.submits = submits
             self.step = (lambda: sched.step(run)) if pipelined else (lambda: sched.step(local_eval))
+
+        def reference(self, b):
+            """bindings of input batch b by ONE sequential library call on the current stream (what the other legs' last steps are compared with)"""
+            n_loc = self.rig.hi - self.rig.lo
+            out = torch.full((n_loc,), -3, dtype=torch.int32, device=dev)
+            self.drain()
+            torch.cuda.synchronize()
+            self.ev.bind_eval_device(*self.rig.batches[b], self.rig.flags, out_feasible=None if args.no_mask else self.masks[0], out_bindings=[out])(0, 0)
+            torch.cuda.synchronize()
+            return out
 
         def use(self):
             """KSCHED_OPT_PIPE_MODE is a property of the evaluator, read by every ksched_pipe_submit: set it to this loop's mode before
@@ -566,30 +613,33 @@ def main():
             from oracle import capi
             torch.cuda.synchronize()
             n_loc = hi - lo
-            sel_all = c.pod_sel[:, lo:hi] if (c.n_keys and "SEL" in flag_names) else None
+            bsl = rig.rows(loop.last_batch)  # the input batch the last timed step evaluated (this rank's rows of it)
+            b_cpu, b_mem, b_tol, b_smp = c.req_cpu[bsl], c.req_mem[bsl], c.pod_tol[bsl], c.samples[bsl]
+            sel_all = c.pod_sel[:, bsl] if (c.n_keys and "SEL" in flag_names) else None
             o_flags = sum(getattr(capi, f) for f in flag_names) | (capi.PICK_SAMPLED if pick == "sampled" else capi.PICK_BESTFIT)
             oracle_args = dict(avail_cpu=c.avail_cpu, avail_mem=c.avail_mem, label_ids=c.node_labels if sel_all is not None else None,
                                taints=c.node_taints if taint else None)
             # bindings: every pod of the shard when the host has the cores for it, else the first pods of the shard
             threads = capi.num_threads()
             n_b = n_loc if threads >= 8 else min(n_loc, max(1, int(2e9 / max(N, 1))))
-            _, _, want_b = capi.eval_encoded(**oracle_args, req_cpu=c.req_cpu[lo:lo + n_b], req_mem=c.req_mem[lo:lo + n_b],
-                                             sel_ids=None if sel_all is None else sel_all[:, :n_b], tolerations=c.pod_tol[lo:lo + n_b] if taint else None,
-                                             samples=c.samples[lo:lo + n_b] if pick == "sampled" else None, flags=o_flags, want_mask=False)
+            _, _, want_b = capi.eval_encoded(**oracle_args, req_cpu=b_cpu[:n_b], req_mem=b_mem[:n_b],
+                                             sel_ids=None if sel_all is None else np.ascontiguousarray(sel_all[:, :n_b]), tolerations=b_tol[:n_b] if taint else None,
+                                             samples=b_smp[:n_b] if pick == "sampled" else None, flags=o_flags, want_mask=False)
             got_b = bindings[lo:lo + n_b].cpu().numpy() if bindings.numel() >= hi else bindings[:n_b].cpu().numpy()
             bad_b = int((got_b != want_b).sum())
             bad_w = rows_checked = words = 0
             if not args.no_mask and n_loc > 0:
                 rows = np.unique(np.linspace(0, n_loc - 1, num=min(n_loc, max(1, args.parity_rows))).astype(np.int64))
-                want_m, _, _ = capi.eval_encoded(**oracle_args, req_cpu=c.req_cpu[lo:hi][rows], req_mem=c.req_mem[lo:hi][rows],
+                want_m, _, _ = capi.eval_encoded(**oracle_args, req_cpu=b_cpu[rows], req_mem=b_mem[rows],
                                                  sel_ids=None if sel_all is None else np.ascontiguousarray(sel_all[:, rows]),
-                                                 tolerations=c.pod_tol[lo:hi][rows] if taint else None, samples=None,
+                                                 tolerations=b_tol[rows] if taint else None, samples=None,
                                                  flags=o_flags & ~(capi.PICK_SAMPLED | capi.PICK_BESTFIT), want_mask=True)
                 got_m = loop.masks[loop.last_mask][torch.from_numpy(rows).to(dev)].cpu().numpy().view(np.uint64)
                 bad_w = int((got_m != want_m).sum())
                 rows_checked, words = int(rows.size), int(want_m.size)
             parity = {"checked": "the last timed step's outputs against oracle.c ora_eval_encoded (scalar loop on the encoded columns)",
-                      "bindings": int(n_b), "binding_mismatches": bad_b, "rows": rows_checked, "words": words, "word_mismatches": bad_w,
+                      "input_batch": int(loop.last_batch), "bindings": int(n_b), "bindings_of": int(n_loc), "partial": bool(n_b < n_loc),
+                      "binding_mismatches": bad_b, "rows": rows_checked, "words": words, "word_mismatches": bad_w,
                       "mismatches": bad_b + bad_w}
         except Exception as e:  # noqa: BLE001 -- the CHECKER could not run (e.g. oracle/liboracle.so missing on this box): said in the line, not a mismatch
             parity = {"error": f"{type(e).__name__}: {e}", "mismatches": None}
@@ -679,7 +729,7 @@ def main():
                 loop_ov.step()
             loop_ov.drain()
             e_ov, last_ov = loop_ov.timed(k_ov)
-            same = bool(torch.equal(last_ov.wait(), bindings))
+            same = bool(torch.equal(last_ov.wait(), loop.reference(loop_ov.last_batch)))  # the same input batch through ONE sequential call
             alg_ov = algorithmic_bytes(hi - lo, N, c.n_keys if "SEL" in flag_names else 0, taint,
                                        pick_attempts=int(c.samples.shape[1]) if (ev.last_pick.startswith("fused") and pick == "sampled") else 0)
             overlapped = {"value": float(P_total) * N * k_ov / e_ov, "ms_per_step": e_ov / k_ov * 1e3, "steps": k_ov,
@@ -700,14 +750,14 @@ def main():
         lp.drain()
         lp.use()
         outs = [lp.sched.binding_buffer(k, g) for k in range(lp.depth) for g in range(lp.G)]
-        sub = lp.pipe.bind(rg.d_cpu, rg.d_mem, rg.d_sel, rg.d_tol, rg.d_smp, rg.flags, lp.masks, outs)
-        nslot = lp.depth * lp.G
+        subs = [lp.pipe.bind(*rg.batches[b], rg.flags, lp.masks, outs) for b in range(lp.n_inputs)]
+        nslot, nb_ = lp.depth * lp.G, lp.n_inputs
         for j in range(32):
-            sub(j % nslot)
+            subs[j % nb_](j % nslot)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         for j in range(args.steps):
-            sub(j % nslot)
+            subs[j % nb_](j % nslot)
         torch.cuda.synchronize()
         e_solo = max_over_ranks(time.perf_counter() - t2)
         return {"per_gpu_value_max_time": float(rg.hi - rg.lo) * rg.N * args.steps / e_solo, "ms_per_step": e_solo / args.steps * 1e3,
@@ -720,7 +770,7 @@ def main():
         try:
             loop.drain()
             cfg4, _, N4, fn4, pick4, _ = WORKLOADS["C4s"]
-            rig4 = Rig(cfg4, 1_000_000, N4, fn4, pick4)
+            rig4 = Rig(cfg4, 1_000_000, N4, fn4, pick4, n_batches=1)  # (a million pods per batch: one resident batch)
             rig4.comm = rig.comm  # one communicator per process is enough (same ranks, same device)
             lp4 = Loop(rig4, 1, alternate=alt_default)
             for _ in range(16):
@@ -794,6 +844,10 @@ def main():
                        "mask_rotation_note": (f"the loop writes {loop.R} mask buffers of {loop.mask_bytes / 2**20:.0f} MiB in turn "
                                               f"({loop.R * loop.mask_bytes / 2**20:.0f} MiB > the 256 MiB Infinity Cache)" if loop.R > 1 else
                                               "one mask buffer" + (" (already larger than the 256 MiB Infinity Cache)" if loop.mask_bytes > L3_BYTES else "")),
+                       "input_rotation": {"batches": loop.n_inputs, "bytes_resident": rig.input_bytes,
+                                          "note": f"the loop cycles over {loop.n_inputs} different seeded pod batches resident in HBM ({rig.input_bytes / 1e6:.1f} MB of operand "
+                                                  "columns: more than the 8 x 4 MiB of L2), batch 0 = the workload's standard batch; the self-check reads the batch the last "
+                                                  "timed step evaluated (parity_check.input_batch)"},
                        "step_frac_of_hbm_peak": (alg / step_s / 1e9 / HBM_PEAK_GBS) if world == 1 else None,
                        "step_frac_note": "algorithmic bytes of one step (mask + draws + bindings) / ms_per_step / 8 TB/s",
                        "repeat_ms_per_step": repeats, "in_place": in_place, "other_workloads": others,
@@ -830,7 +884,7 @@ def main():
         }
         out["parity_check"] = parity
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(c, flag_names)
+            out["cpu_baseline"] = cpu_baseline(c, flag_names, p_cap=P_total)
         else:
             out["cpu_baseline"] = None
     if multi:
@@ -849,6 +903,10 @@ def main():
     if parity is not None and (parity.get("mismatches_all_ranks") or parity.get("mismatches") or 0) > 0:
         sys.stderr.write(f"bench.py: the self-check FAILED on rank {rank}: {parity}\n")
         sys.exit(1)
+    # a checker that could not run leaves the number unverified: that is a failure too, unless explicitly allowed
+    if parity is not None and not args.allow_unchecked and (parity.get("mismatches") is None or (parity.get("ranks_unchecked") or 0) > 0):
+        sys.stderr.write(f"bench.py: the self-check could NOT RUN on rank {rank} (the line above is unverified; --allow-unchecked accepts that): {parity}\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

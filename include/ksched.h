@@ -374,7 +374,12 @@ int ksched_explain(ksched_ctx *ctx, uint32_t p, const int64_t *req_cpu_milli, co
  *   last shard with -1).  Enqueue it on the stream the pick was launched on and no host sync or event is needed.
  * With one process driving n devices the n calls of one collective must be issued together:
  * ksched_allgather_bindings_local wraps them in ncclGroupStart/End (local[i], gathered[i], hip_streams[i] belong to comms[i]).
+ * If any of the n calls (or the group's end) fails, the collective is at best half issued: the library then aborts the whole clique
+ * (ncclCommAbort), the handles stay valid only for ksched_comm_destroy, and every later call with them returns KSCHED_E_INVAL --
+ * create a new clique.  The streams carry no stuck collective afterwards: ksched_eval_end on them returns.
  * RCCL is loaded on first use (dlopen "librccl.so.1"); a process that never calls these never loads it.
+ * Test hook (never in production): with $KSCHED_TEST_HOOKS=1, $KSCHED_RCCL_LIB names the library to load instead
+ * (tests/cpp/fake_rccl.cpp: n ranks on one GPU); $KSCHED_RCCL_LIB without the switch makes every ksched_comm_* call fail.
  */
 #define KSCHED_COMM_ID_BYTES 128u
 typedef struct ksched_comm ksched_comm;

@@ -6,8 +6,13 @@
 // single-GPU caller never loads it, and inside a process that already carries an RCCL (e.g. PyTorch's bundled
 // librccl.so.1) the same library instance is reused instead of a second copy being mapped next to it.  The header is
 // only used for its types and prototypes.
+//
+// Test hook: with BOTH $KSCHED_TEST_HOOKS=1 and $KSCHED_RCCL_LIB=<path> that library is loaded instead -- tests/cpp/fake_rccl.cpp,
+// which lets one GPU stand for n ranks so that the multi-device host's exchange runs with n > 1 on a one-GPU box.  $KSCHED_RCCL_LIB
+// without the hook switch is an error, never a silent substitute.
 #pragma once
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -21,12 +26,14 @@ struct RcclApi {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;  // optional: used to give up a clique whose collective was only half issued
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok = false;
     std::string error;
+    std::string substitute;  // path of the test stand-in, empty = the real RCCL
 };
 
 inline RcclApi &rccl_api() {
@@ -34,12 +41,26 @@ inline RcclApi &rccl_api() {
     static std::once_flag once;
     std::call_once(once, [] {
         void *h = nullptr;
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names)
-            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!h) {
-            api.error = std::string("cannot load librccl.so.1: ") + dlerror();
-            return;
+        if (const char *over = getenv("KSCHED_RCCL_LIB")) {
+            const char *hooks = getenv("KSCHED_TEST_HOOKS");
+            if (!hooks || std::string(hooks) != "1") {
+                api.error = "KSCHED_RCCL_LIB is set but KSCHED_TEST_HOOKS=1 is not: refusing a substitute for RCCL";
+                return;
+            }
+            h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!h) {
+                api.error = std::string("cannot load $KSCHED_RCCL_LIB: ") + dlerror();
+                return;
+            }
+            api.substitute = over;
+        } else {
+            const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char *n : names)
+                if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+            if (!h) {
+                api.error = std::string("cannot load librccl.so.1: ") + dlerror();
+                return;
+            }
         }
         bool all = true;
         auto sym = [&](const char *name) -> void * {
@@ -59,6 +80,7 @@ inline RcclApi &rccl_api() {
         api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
         api.ok = all;
+        api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(h, "ncclCommAbort"));
     });
     return api;
 }

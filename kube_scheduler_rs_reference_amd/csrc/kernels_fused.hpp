@@ -711,6 +711,51 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
     // round r and awaited after them, from ONE load site and ONE wait site (no register copies can be
     // scheduled between a load and its wait).  The tile is staged inside the first trip, after the
     // first operand loads have been issued.
+    // ---- operand prefetch ------------------------------------------------------------------------------------------
+    // A scheduler never evaluates the same batch twice, so a round's operand lines (64 pods x 68 bytes at C3: 34 lines of 128 bytes
+    // over ten columns) come from HBM, not from the L2 an earlier launch left warm -- and the pipeline below issues a round's loads
+    // only ONE trip ahead, behind a queue of mask stores: with the bench cycling over different resident batches the C3 step read
+    // 24.2 us against 19.7 us with one batch evaluated over and over (session r5c).  So before anything else the wave touches the
+    // lines of the rounds AFTER its first one -- ONE load instruction per round, lane l fetching a dword of line l of the round -- which
+    // brings them into the XCD's L2 while the tile is staged; the real loads of those rounds then hit.  The touched values are never
+    // used and take no register: the loads are LDS-DMA loads (global_load_lds_dword) into the wave's own record area, which phase 1
+    // overwrites after the staging barrier -- whose wait covers them, vector-memory operations return in order.  At most
+    // kPrefetchRounds rounds ahead (a launch with longer waves is bound by its stores, not by this latency).
+    constexpr uint32_t kPrefetchRounds = 6;
+    // (session r5d, inputs rotated: C3 23.9 -> 20.2 us per step, the C4 shard 54.8 -> 42.3; the C5 shard, 24 rounds per wave and bound by
+    // its stores, 222.5 -> 224.7: waves with more rounds than the prefetch reaches skip it)
+    if ((FIT || SEL || TAINT) && u + 8u * (kPrefetchRounds + 2u) >= u_hi && !(a.debug & 0x20000000u)) {
+        // where the touched dwords land: this wave's own record area, which nobody reads before phase 1 has written it (after the barrier)
+        const uint32_t dump = (uint32_t)__builtin_amdgcn_readfirstlane((int)((FIT ? a.off_fit + wave * 1024u : SEL ? a.off_lab + wave * 1024u : a.off_trow + wave * 512u)));
+        // lane -> line of the round: [0,4) cpu, [4,8) memory, [8,24) the eight selector columns (two lines each), [24,34) the draws, [34,38) tolerations
+        const uint32_t li = opaque(lane);
+        for (uint32_t r = 1; r <= kPrefetchRounds; ++r) {
+            const uint32_t pu = u + 8u * r;
+            if (pu >= u_hi) break;  // wave-uniform
+            const uint32_t pod0 = pu * 8u;
+            const uint32_t pe = a.p - 1u;
+            // integer addresses throughout (no selects between pointers), the lane's index made opaque first: the compiler cannot fold the
+            // selection into something wave-uniform that it would hand to the "v" operand as a scalar pair
+            const uint32_t e8 = min(pod0 + (li & 3u) * 16u, pe);  // element of an 8-byte column: line (li & 3) of the round
+            uint64_t a64 = reinterpret_cast<uint64_t>(a.zero64);  // lanes without a line of their own touch the zero word
+            if (FIT && li < 4u) a64 = reinterpret_cast<uint64_t>(g_pcpu + e8);
+            if (FIT && li >= 4u && li < 8u) a64 = reinterpret_cast<uint64_t>(g_pmem + e8);
+            if (SEL && a.nkeys && li >= 8u && li < 24u) {
+                const uint32_t k = min((li - 8u) >> 1, min(a.nkeys, 8u) - 1u);
+                a64 = reinterpret_cast<uint64_t>(g_psel + (size_t)k * a.p + min(pod0 + (li & 1u) * 32u, pe));
+            }
+            if (PICK == 2 && li >= 24u && li < 34u) {
+                a64 = reinterpret_cast<uint64_t>(sa.samples + min((size_t)pod0 * kPickAttempts + (li - 24u) * 32u, (size_t)a.p * kPickAttempts - 1u));
+            }
+            if (TAINT && a.has_tol && li >= 34u && li < 38u) {
+                a64 = reinterpret_cast<uint64_t>(g_ptol + e8);
+            }
+            // (M0 = the LDS destination of an LDS-DMA load; the compiler manages M0 itself -- the staging below -- so the statement
+            // puts back what it found)
+            uint32_t m0_saved;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_saved) : "v"(a64), "s"(dump) : "memory");
+        }
+    }
     bool more = u < u_hi, have_prev = false, first = true, stamped4 = false;
     uint32_t prev_u = 0, prev_nu = 0;
     uint64_t prev_over = 0;

@@ -1946,8 +1946,21 @@ int ksched_allgather_bindings_local(ksched_comm *const *comms, int n, const int3
         if (r != ncclSuccess && first == ncclSuccess) first = r;
     }
     r = api.GroupEnd();
-    if (first != ncclSuccess) return comm_fail("ncclAllGather", first);
-    return r == ncclSuccess ? KSCHED_OK : comm_fail("ncclGroupEnd", r);
+    if (first != ncclSuccess || r != ncclSuccess) {
+        // The collective is at best half issued: ranks that did enqueue it would wait for the others for ever, and whoever then
+        // synchronises their stream hangs with them.  Give the whole clique up -- ncclCommAbort takes its outstanding work down --
+        // and leave the handles empty: every later call with them fails with KSCHED_E_INVAL, ksched_comm_destroy still frees them.
+        for (int i = 0; i < n; ++i) {
+            DeviceGuard g(comms[i]->device);
+            if (api.CommAbort) (void)api.CommAbort(comms[i]->comm);
+            else (void)api.CommDestroy(comms[i]->comm);
+            comms[i]->comm = nullptr;
+        }
+        const int rc = first != ncclSuccess ? comm_fail("ncclAllGather", first) : comm_fail("ncclGroupEnd", r);
+        g_comm_error += " -- the communicator clique has been aborted; create a new one";
+        return rc;
+    }
+    return KSCHED_OK;
 } KSCHED_ABI_CATCH_COMM
 
 int ksched_index_checksum(ksched_ctx *c, uint64_t *out) try {

@@ -300,6 +300,14 @@ class PipelinedScheduler:
         out = self.binding_buffer(k, g)
         if self.n_local > 0:
             run(k * self.gather_every + g if self.pipe is not None else k, out)
+            if self._alternate and not self._used[k]:
+                # The slot's all-gather is pre-bound to stream (k mod 2) and relies on the pick having gone onto that very stream.
+                # ksched_pipe_submit falls back to its split mode when the pick reads the mask (KSCHED_OPT_PICK_FROM_MASK, a best-fit
+                # pick without the bitmap index): the pick is then on the pick stream whatever the slot.  Ask the pipe once per slot.
+                used = self.pipe.slot_stream(k)
+                if used is None or used.cuda_stream != self._streams2[k & 1].cuda_stream:
+                    raise RuntimeError("PipelinedScheduler(alternate=True): the pipe ran this request in its split mode (the pick reads the mask), so the "
+                                       "slot's all-gather would not be ordered behind its pick; use alternate=False for this request")
             self._used[k] = True
         self._fill[k] = g + 1
         pending = PendingBindings(self, k, g)

@@ -73,8 +73,9 @@ void ShardedContext::eval(const PodColumns &pc, const uint32_t *samples, uint32_
     const uint32_t cpr = shard_bounds(p, n, 0).count_per_rank;
     std::vector<int32_t *> local(n, nullptr), gathered(n, nullptr);
     std::vector<void *> streams(n, nullptr);
-    uint32_t begun = 0;
+    uint32_t touched = 0;  // devices a call of this batch has entered -- the failing one included: its copies may already be under way
     std::string failure;
+    if (broken_) throw EncodeError("ShardedContext: the communicator was aborted after a failed exchange; build a new context");
     // 1. every device gets its rows: copies in and kernels enqueued on the device's own stream, the host does not wait
     for (uint32_t r = 0; r < n && failure.empty(); ++r) {
         const ShardBounds b = shard_bounds(p, n, r);
@@ -85,10 +86,9 @@ void ShardedContext::eval(const PodColumns &pc, const uint32_t *samples, uint32_
                                          (flags & KSCHED_PICK_SAMPLED) ? samples + (size_t)lo * attempts : nullptr, attempts, flags,
                                          out_feasible ? out_feasible + (size_t)lo * W : nullptr, out_fit ? out_fit + (size_t)lo * W : nullptr, cpr, &local[r],
                                          &streams[r]);
+        ++touched;
         if (rc != KSCHED_OK)
             failure = "ksched_eval_begin on shard " + std::to_string(r) + ": " + ksched_strerror(rc) + " (" + ksched_last_error(devs_[r]->handle()) + ")";
-        else
-            ++begun;
     }
     // 2. the exchange: one all-gather of ceil(p / n) int32 per device over xGMI, enqueued behind each device's pick on its own stream
     if (failure.empty() && pick && exchange_ == Exchange::Rccl) {
@@ -98,13 +98,17 @@ void ShardedContext::eval(const PodColumns &pc, const uint32_t *samples, uint32_
         }
         if (failure.empty()) {
             const int rc = ksched_allgather_bindings_local(comms_.data(), (int)n, local.data(), gathered.data(), cpr, streams.data());
-            if (rc != KSCHED_OK) failure = std::string("ksched_allgather_bindings_local: ") + ksched_strerror(rc) + " (" + ksched_comm_last_error() + ")";
+            if (rc != KSCHED_OK) {  // the library has aborted the clique (nothing half issued is left on the streams): this context is done for
+                failure = std::string("ksched_allgather_bindings_local: ") + ksched_strerror(rc) + " (" + ksched_comm_last_error() + ")";
+                broken_ = true;
+            }
         }
     }
     // 3. the table comes back in one copy from device 0 (every device holds it); the other devices only finish their streams --
-    //    whatever happened above, every device that was given work is waited for before this function returns or throws
+    //    whatever happened above, every device a call has entered is waited for before this function returns or throws (the
+    //    inputs must stay alive until ksched_eval_end, include/ksched.h -- also for a shard whose ksched_eval_begin failed half way)
     if (pick) table_.resize((size_t)n * cpr);
-    for (uint32_t r = 0; r < begun; ++r) {
+    for (uint32_t r = 0; r < touched; ++r) {
         const int32_t *src = nullptr;
         int32_t *dst = nullptr;
         uint32_t count = 0;

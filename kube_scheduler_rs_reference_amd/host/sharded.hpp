@@ -63,6 +63,7 @@ public:
               uint64_t *out_fit, int32_t *out_binding);
 
     uint64_t batches() const { return batches_; }  // observability: evaluations that went through the exchange
+    bool broken() const { return broken_; }        // a failed exchange aborted the communicator: every further eval throws
 
 private:
     std::vector<std::shared_ptr<DeviceEvaluator>> devs_;
@@ -70,6 +71,7 @@ private:
     Exchange exchange_;
     std::vector<int32_t> table_;  // [n][count_per_rank], host copy of the gathered bindings
     uint64_t batches_ = 0;
+    bool broken_ = false;  // a failed exchange aborted the communicator clique
 };
 
 }  // namespace ksched_host

@@ -40,9 +40,17 @@ PodResources total_pod_resources(const corev1::Pod &pod) {
 
 void Context::refresh_snapshot() {
     if (!snapshot) {
-        const std::vector<int> devs = devices.empty() ? devices_from_env(std::getenv("KSCHED_DEVICES"), device) : devices;
+        std::vector<int> devs_env = devices.empty() ? devices_from_env(std::getenv("KSCHED_DEVICES"), device) : devices;
         const char *force = std::getenv("KSCHED_SHARDED");
         const bool sharded = force && *force && *force != '0';
+        // test hook (with $KSCHED_TEST_HOOKS=1 only; the exchange then needs the stand-in of $KSCHED_RCCL_LIB): KSCHED_SHARDED=k, k >= 2,
+        // with ONE device = k evaluators on that device, so that a one-GPU box runs the mirror through a k-way row shard
+        const char *hooks = std::getenv("KSCHED_TEST_HOOKS");
+        if (sharded && hooks && std::string(hooks) == "1" && devs_env.size() == 1) {
+            const long k = std::strtol(force, nullptr, 10);
+            if (k >= 2 && k <= 64) devs_env.assign((size_t)k, devs_env[0]);
+        }
+        const std::vector<int> &devs = devs_env;
         snapshot = (devs.size() > 1 || sharded) ? std::make_shared<Snapshot>(devs, sharded) : std::make_shared<Snapshot>(devs[0]);
     }
     snapshot->rebuild(node_store, client.get());

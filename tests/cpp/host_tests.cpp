@@ -22,6 +22,7 @@
 #include "../../kube_scheduler_rs_reference_amd/host/encoder.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/predicates.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/sharded.hpp"
+#include <dlfcn.h>
 #include "../../kube_scheduler_rs_reference_amd/host/scheduler.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/util.hpp"
 
@@ -1356,14 +1357,223 @@ static void sharded_tests() {
     });
 }
 
+// The exchange with n > 1 on a one-GPU box.  Needs $KSCHED_TEST_HOOKS=1 and $KSCHED_RCCL_LIB=tests/cpp/libfake_rccl.so
+// (tests/test_host_mirror.py sets both): the library then loads the TEST-ONLY stand-in of tests/cpp/fake_rccl.cpp, whose ncclCommInitAll
+// accepts one device n times and whose grouped ncclAllGather is n x n stream-ordered copies -- so the product sequence
+//     ksched_comm_create_local -> ksched_eval_begin x n -> ksched_gather_buffer x n -> ksched_allgather_bindings_local -> ksched_eval_end(gathered_0)
+// runs through Exchange::Rccl with n = 2 .. 8, which Exchange::HostCopies bypasses.  Not covered: the real xGMI transport.
+static void sharded_rccl_tests() {
+    struct Cluster {
+        uint32_t n, keys;
+        std::vector<int64_t> ncpu, nmem;
+        std::vector<uint32_t> nlab;
+    };
+    auto make_cluster = [](uint32_t n, uint32_t keys, SplitMixChooser &rng) {
+        Cluster c{n, keys, std::vector<int64_t>(n), std::vector<int64_t>(n), std::vector<uint32_t>((size_t)keys * n)};
+        for (uint32_t i = 0; i < n; ++i) {
+            c.ncpu[i] = 500 + (int64_t)*rng.choose(8000);
+            c.nmem[i] = (int64_t)1 << (20 + *rng.choose(14));
+            for (uint32_t k = 0; k < keys; ++k) c.nlab[(size_t)k * n + i] = (uint32_t)*rng.choose(4 + k);
+        }
+        return c;
+    };
+    auto make_pods = [](uint32_t p, const Cluster &c, uint32_t attempts, SplitMixChooser &rng, PodColumns &pc, std::vector<uint32_t> &samples) {
+        pc = PodColumns{};
+        pc.p = p;
+        pc.n_keys = c.keys;
+        pc.req_cpu_milli.resize(p);
+        pc.req_mem_bytes.resize(p);
+        pc.sel_val_ids.assign((size_t)c.keys * p, 0u);
+        samples.assign((size_t)p * attempts, 0u);
+        for (uint32_t i = 0; i < p; ++i) {
+            pc.req_cpu_milli[i] = 100 + (int64_t)*rng.choose(6000);
+            pc.req_mem_bytes[i] = (int64_t)1 << (18 + *rng.choose(14));
+            for (uint32_t k = 0; k < c.keys; ++k)
+                if (*rng.choose(5) == 0) pc.sel_val_ids[(size_t)k * p + i] = (*rng.choose(20) == 0) ? KSCHED_SEL_NEVER : 1u + (uint32_t)*rng.choose(3 + k);
+            for (uint32_t t = 0; t < attempts; ++t) samples[(size_t)i * attempts + t] = (uint32_t)*rng.choose(c.n + 2);
+        }
+    };
+    auto replicas = [](uint32_t shards, const Cluster &c) {
+        std::vector<std::shared_ptr<DeviceEvaluator>> devs;
+        for (uint32_t r = 0; r < shards; ++r) {
+            devs.push_back(std::make_shared<DeviceEvaluator>(0));
+            CHECK(ksched_set_nodes(devs.back()->handle(), c.n, c.ncpu.data(), c.nmem.data(), c.keys ? c.nlab.data() : nullptr, c.keys, nullptr) == KSCHED_OK);
+        }
+        return devs;
+    };
+    run("the stand-in is what the library loaded (and only because the test hooks are switched on)", [] {
+        const char *lib = std::getenv("KSCHED_RCCL_LIB"), *hooks = std::getenv("KSCHED_TEST_HOOKS");
+        CHECK(lib && *lib && hooks && std::string(hooks) == "1");
+        std::vector<std::shared_ptr<DeviceEvaluator>> devs = {std::make_shared<DeviceEvaluator>(0), std::make_shared<DeviceEvaluator>(0)};
+        ShardedContext sh(devs);  // the real RCCL refuses this ("a communicator over one device named twice", sharded_tests)
+        CHECK(sh.size() == 2 && sh.exchange() == ShardedContext::Exchange::Rccl);
+    });
+    run("Exchange::Rccl with 2 .. 8 shards on one GPU == one ksched_eval of the whole batch (masks, fit masks, bindings; empty and ragged shards)", [&] {
+        SplitMixChooser rng(515);
+        const Cluster c = make_cluster(1500, 3, rng);
+        const uint32_t W = ksched_mask_words(c.n), attempts = ATTEMPTS;
+        for (uint32_t shards : {2u, 3u, 4u, 5u, 8u})
+            for (uint32_t p : {1u, 7u, 1001u, 20000u}) {
+                PodColumns pc;
+                std::vector<uint32_t> samples;
+                make_pods(p, c, attempts, rng, pc, samples);
+                auto devs = replicas(shards, c);
+                ShardedContext sh(devs);
+                const uint32_t flags = KSCHED_FIT | KSCHED_SEL | KSCHED_PICK_SAMPLED | KSCHED_WANT_FIT_MASK;
+                std::vector<uint64_t> feas((size_t)p * W, 0xABull), fit((size_t)p * W, 0xCDull), feas1((size_t)p * W), fit1((size_t)p * W);
+                std::vector<int32_t> bind(p, 12345), bind1(p);
+                sh.eval(pc, samples.data(), attempts, flags, W, feas.data(), fit.data(), bind.data());
+                CHECK(ksched_eval(devs[0]->handle(), p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), pc.sel_val_ids.data(), nullptr, samples.data(), attempts, flags,
+                                  feas1.data(), fit1.data(), bind1.data()) == KSCHED_OK);
+                CHECK(feas == feas1 && fit == fit1 && bind == bind1);
+                std::vector<int32_t> bind2(p, 777);
+                sh.eval(pc, samples.data(), attempts, KSCHED_FIT | KSCHED_SEL | KSCHED_PICK_SAMPLED, W, nullptr, nullptr, bind2.data());
+                CHECK(bind2 == bind1);
+                std::vector<int32_t> bind3(p, 778);  // best fit: its own launches ahead of the gather on each device's stream
+                sh.eval(pc, nullptr, 0, KSCHED_FIT | KSCHED_SEL | KSCHED_PICK_BESTFIT, W, nullptr, nullptr, bind3.data());
+                CHECK(ksched_eval(devs[0]->handle(), p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), pc.sel_val_ids.data(), nullptr, nullptr, 0,
+                                  KSCHED_FIT | KSCHED_SEL | KSCHED_PICK_BESTFIT, nullptr, nullptr, bind1.data()) == KSCHED_OK);
+                CHECK(bind3 == bind1);
+            }
+    });
+    run("Exchange::Rccl, 4 shards: forty batches back to back through ONE context (stream order between a device's pick, the gather and the next batch's copies in)", [&] {
+        SplitMixChooser rng(99);
+        const Cluster c = make_cluster(2300, 2, rng);
+        const uint32_t W = ksched_mask_words(c.n), attempts = ATTEMPTS;
+        auto devs = replicas(4, c);
+        ShardedContext sh(devs);
+        for (int b = 0; b < 40; ++b) {
+            const uint32_t p = 1u + (uint32_t)*rng.choose(6000);
+            PodColumns pc;
+            std::vector<uint32_t> samples;
+            make_pods(p, c, attempts, rng, pc, samples);
+            std::vector<int32_t> got(p, -5), want(p);
+            sh.eval(pc, samples.data(), attempts, KSCHED_FIT | KSCHED_SEL | KSCHED_PICK_SAMPLED, W, nullptr, nullptr, got.data());
+            CHECK(ksched_eval(devs[(size_t)b % 4]->handle(), p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), pc.sel_val_ids.data(), nullptr, samples.data(), attempts,
+                              KSCHED_FIT | KSCHED_SEL | KSCHED_PICK_SAMPLED, nullptr, nullptr, want.data()) == KSCHED_OK);
+            CHECK(got == want);
+        }
+        CHECK(sh.batches() == 40);
+    });
+    run("Exchange::Rccl, 3 shards: a shard failing inside the library (KSCHED_OPT_FAULT) -> EncodeError, every device drained, no collective issued, the next batch whole", [&] {
+        SplitMixChooser rng(404);
+        const Cluster c = make_cluster(900, 0, rng);
+        const uint32_t p = 2000, attempts = ATTEMPTS;
+        PodColumns pc;
+        std::vector<uint32_t> samples;
+        make_pods(p, c, attempts, rng, pc, samples);
+        auto devs = replicas(3, c);
+        ShardedContext sh(devs);
+        const uint32_t flags = KSCHED_FIT | KSCHED_PICK_SAMPLED;
+        std::vector<int32_t> want(p), got(p, 31337);
+        CHECK(ksched_eval(devs[0]->handle(), p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), nullptr, nullptr, samples.data(), attempts, flags, nullptr, nullptr,
+                          want.data()) == KSCHED_OK);
+        for (int victim : {0, 1, 2}) {
+            CHECK(ksched_set_option(devs[(size_t)victim]->handle(), KSCHED_OPT_FAULT, 2) == KSCHED_OK);
+            std::fill(got.begin(), got.end(), 31337);
+            CHECK_THROWS(sh.eval(pc, samples.data(), attempts, flags, ksched_mask_words(c.n), nullptr, nullptr, got.data()));
+            for (int32_t b : got) CHECK(b == 31337);
+            CHECK(!sh.broken());  // the exchange was never started: the communicator is intact
+            sh.eval(pc, samples.data(), attempts, flags, ksched_mask_words(c.n), nullptr, nullptr, got.data());
+            CHECK(got == want);
+        }
+    });
+    run("Exchange::Rccl, 3 shards: the collective fails for one rank inside the group -> EncodeError, the clique aborted, nothing hangs, a new context works", [&] {
+        SplitMixChooser rng(405);
+        const Cluster c = make_cluster(700, 0, rng);
+        const uint32_t p = 900, attempts = ATTEMPTS;
+        PodColumns pc;
+        std::vector<uint32_t> samples;
+        make_pods(p, c, attempts, rng, pc, samples);
+        auto devs = replicas(3, c);
+        const uint32_t flags = KSCHED_FIT | KSCHED_PICK_SAMPLED;
+        std::vector<int32_t> want(p), got(p, 31337);
+        CHECK(ksched_eval(devs[0]->handle(), p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), nullptr, nullptr, samples.data(), attempts, flags, nullptr, nullptr,
+                          want.data()) == KSCHED_OK);
+        {
+            ShardedContext sh(devs);
+            sh.eval(pc, samples.data(), attempts, flags, ksched_mask_words(c.n), nullptr, nullptr, got.data());
+            CHECK(got == want);
+            // the stand-in counts ncclAllGather calls per process: make the SECOND rank's call of the next batch fail (rank 0 has then
+            // already put its part of the collective into the group)
+            void *fake = dlopen(std::getenv("KSCHED_RCCL_LIB"), RTLD_NOW | RTLD_NOLOAD);
+            CHECK(fake != nullptr);
+            auto calls = fake ? reinterpret_cast<long (*)()>(dlsym(fake, "fake_rccl_allgather_calls")) : nullptr;
+            auto collectives = fake ? reinterpret_cast<long (*)()>(dlsym(fake, "fake_rccl_collectives")) : nullptr;
+            CHECK(calls && collectives && collectives() > 0);  // the batches above did go through the stand-in's grouped all-gather
+            const long done_before = collectives ? collectives() : 0;
+            if (calls) setenv("FAKE_RCCL_FAIL_ALLGATHER", std::to_string(calls() + 2).c_str(), 1);
+            bool failed = false;
+            std::fill(got.begin(), got.end(), 31337);
+            try {
+                sh.eval(pc, samples.data(), attempts, flags, ksched_mask_words(c.n), nullptr, nullptr, got.data());
+            } catch (const EncodeError &e) {
+                failed = true;
+                CHECK(std::string(e.what()).find("aborted") != std::string::npos);
+                for (int32_t b : got) CHECK(b == 31337);  // nothing half-written comes back
+            }
+            CHECK(collectives && collectives() == done_before);  // nothing was enqueued for the half-issued collective
+            unsetenv("FAKE_RCCL_FAIL_ALLGATHER");
+            CHECK(failed && sh.broken());
+            CHECK_THROWS(sh.eval(pc, samples.data(), attempts, flags, ksched_mask_words(c.n), nullptr, nullptr, got.data()));  // for good
+        }
+        ShardedContext again(devs);  // the evaluators themselves are fine: a new clique over them works
+        std::fill(got.begin(), got.end(), 31337);
+        again.eval(pc, samples.data(), attempts, flags, ksched_mask_words(c.n), nullptr, nullptr, got.data());
+        CHECK(got == want);
+    });
+    run("the mirror's own entry points over THREE replicas of one device: select_nodes_for_pods / reconcile_batch == the single-device path", [] {
+        std::vector<corev1::Node> nodes;
+        std::vector<corev1::Pod> bound;
+        for (int i = 0; i < 41; ++i) {
+            corev1::Node n = node_with("node-" + std::to_string(100 + (i * 7) % 41), (i % 3) ? "4" : "2", "8589934592");
+            n.metadata.labels = corev1::StringMap{{"zone", (i % 2) ? "a" : "b"}, {"tier", std::to_string(i % 4)}};
+            if (i % 5 == 0) n.metadata.labels.reset();
+            nodes.push_back(n);
+            bound.push_back(pod_with("load-" + std::to_string(i), {container((i % 4) ? "1500m" : "3900m", "1073741824")}, corev1::name_any(n.metadata).c_str()));
+        }
+        std::vector<corev1::Pod> pods;
+        for (int i = 0; i < 333; ++i) {
+            corev1::Pod p = pod_with("pod-" + std::to_string(i), {container((i % 3) ? "500m" : "2500m", "2147483648")});
+            if (i % 4 == 1) p.spec->node_selector = corev1::StringMap{{"zone", "a"}};
+            if (i % 4 == 2) p.spec->node_selector = corev1::StringMap{{"zone", "b"}, {"tier", "2"}};
+            if (i % 10 == 3) p.spec->node_selector = corev1::StringMap{{"gpu", "yes"}};
+            pods.push_back(p);
+        }
+        std::vector<const corev1::Pod *> ptrs;
+        for (auto &p : pods) ptrs.push_back(&p);
+        Context plain = make_ctx(nodes, bound), sharded = make_ctx(nodes, bound);
+        plain.snapshot = std::make_shared<Snapshot>(0);
+        plain.snapshot->rebuild(plain.node_store, plain.client.get());
+        sharded.snapshot = std::make_shared<Snapshot>(std::vector<int>{0, 0, 0});
+        sharded.snapshot->rebuild(sharded.node_store, sharded.client.get());
+        CHECK(sharded.snapshot->sharded() != nullptr && sharded.snapshot->sharded()->size() == 3);
+        for (bool want_rejected : {false, true}) {
+            SplitMixChooser c1(7), c2(7);
+            const BatchSelection a = select_nodes_for_pods(ptrs, plain, c1, want_rejected), b = select_nodes_for_pods(ptrs, sharded, c2, want_rejected);
+            CHECK(a.node_store_index == b.node_store_index);
+            CHECK(a.validity.binding == b.validity.binding && a.validity.feasible == b.validity.feasible && a.validity.fit == b.validity.fit);
+        }
+        RecordingSink s1, s2;
+        SplitMixChooser c1(99), c2(99);
+        const auto o1 = reconcile_batch(ptrs, plain, c1, s1), o2 = reconcile_batch(ptrs, sharded, c2, s2);
+        CHECK(s1.posts == s2.posts && !s1.posts.empty());
+        for (size_t i = 0; i < o1.size(); ++i) CHECK(o1[i].ok == o2[i].ok && o1[i].bound_to == o2[i].bound_to);
+        CHECK(plain.snapshot->columns().avail_cpu_milli == sharded.snapshot->columns().avail_cpu_milli);
+        SplitMixChooser d1(5), d2(5);  // the bindings of that batch reached every replica (ksched_update_nodes on each)
+        CHECK(select_nodes_for_pods(ptrs, plain, d1).node_store_index == select_nodes_for_pods(ptrs, sharded, d2).node_store_index);
+    });
+}
+
 int main(int argc, char **argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (mode == "cpu") cpu_tests();
     else if (mode == "gpu") gpu_tests();
     else if (mode == "comm") comm_tests();
     else if (mode == "sharded") sharded_tests();
+    else if (mode == "sharded_rccl") sharded_rccl_tests();
     else {
-        std::printf("usage: host_tests cpu|gpu|comm|sharded\n");
+        std::printf("usage: host_tests cpu|gpu|comm|sharded|sharded_rccl\n");
         return 2;
     }
     std::printf("%d test(s), %d failed check(s)\n", g_run, g_fail);

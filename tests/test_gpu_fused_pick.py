@@ -367,3 +367,35 @@ def test_grid_cus_option_is_validated_and_changes_nothing_in_the_results(evaluat
             assert np.array_equal(r.feasible, feas) and np.array_equal(r.binding, base), cus
     finally:
         ev.set_option(_lib.OPT_GRID_CUS, 0)
+
+
+def test_alternate_scheduler_refuses_a_request_the_pipe_runs_in_split_mode(evaluator):
+    """with a pick that reads the mask (KSCHED_OPT_PICK_FROM_MASK) ksched_pipe_submit falls back to its split mode -- the pick on the
+    pick stream whatever the slot -- so an all-gather pre-bound to stream (slot mod 2) would not be ordered behind it.  The scheduler asks the
+    pipe which stream carried the slot (ksched_pipe_slot_stream) and refuses loudly instead of gathering stale bindings."""
+    import torch
+    from kube_scheduler_rs_reference_amd.dist import AbiComm, PipelinedScheduler
+    ev = evaluator
+    c = synth.make_cluster(3000, 2600, n_keys=8, n_taints=0, seed=77)
+    ev.set_nodes(**c.node_columns())
+    dev = torch.device("cuda", ev.device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    d = dict(cpu=t(c.req_cpu, np.int64), mem=t(c.req_mem, np.int64), sel=t(c.pod_sel, np.int32), smp=t(c.samples, np.int32))
+    comm = AbiComm(ev)
+    ev.set_option(_lib.OPT_PIPE_MODE, 1)
+    ev.set_option(_lib.OPT_PICK_FROM_MASK, 1)
+    pipe = ev.pipe(2)
+    try:
+        sched = PipelinedScheduler(c.P, dev, depth=2, pipe=pipe, gather_always=True, gather_every=1, comm=comm, alternate=True)
+        masks = [ev.alloc_mask(c.P) for _ in range(2)]
+
+        def run(slot, out):
+            pipe.submit(slot, d["cpu"], d["mem"], d["sel"], None, d["smp"], FIT | SEL | PICK_SAMPLED, masks[slot], out)
+        with pytest.raises(RuntimeError, match="split mode"):
+            sched.step(run)  # slot 0: its pick went onto the pick stream, not onto stream 0
+        torch.cuda.synchronize()
+    finally:
+        pipe.close()
+        ev.set_option(_lib.OPT_PICK_FROM_MASK, 0)
+        ev.set_option(_lib.OPT_PIPE_MODE, 0)
+        comm.close()

@@ -61,3 +61,35 @@ def test_host_mirror_gpu_through_the_sharded_path():
     reconciler and the sequential accounting all run through the multi-device code path."""
     out = _run("gpu", env={"KSCHED_SHARDED": "1"})
     assert "test_does_node_selector_match_true (KAT-S3)" in out
+
+
+FAKE_RCCL = os.path.join(ROOT, "tests", "cpp", "libfake_rccl.so")
+HOOKS = {"KSCHED_TEST_HOOKS": "1", "KSCHED_RCCL_LIB": FAKE_RCCL}
+
+
+@pytest.mark.gpu
+def test_sharded_exchange_with_more_than_one_rank_through_the_stand_in():
+    """The product sequence ksched_comm_create_local -> ksched_eval_begin x n -> ksched_gather_buffer x n -> ksched_allgather_bindings_local
+    -> ksched_eval_end(gathered_0) with n = 2 .. 8 on ONE GPU: Exchange::Rccl over the TEST-ONLY librccl stand-in (tests/cpp/fake_rccl.cpp,
+    loaded only because KSCHED_TEST_HOOKS=1 and KSCHED_RCCL_LIB are both set); failures inside a shard and inside the collective."""
+    _build()
+    assert os.path.exists(FAKE_RCCL)
+    out = _run("sharded_rccl", env=HOOKS)
+    assert out.count("ok  ") >= 6
+
+
+@pytest.mark.gpu
+def test_host_mirror_gpu_through_a_three_way_shard_on_one_gpu():
+    """Every device test of the mirror with KSCHED_SHARDED=3 under the test hooks: Context builds its snapshot over THREE evaluators on the
+    device, so the KATs, the derived vectors, the batching reconciler and the sequential accounting run through a real three-way row shard,
+    the grouped all-gather and the merge."""
+    out = _run("gpu", env=dict(HOOKS, KSCHED_SHARDED="3"))
+    assert "test_does_node_selector_match_true (KAT-S3)" in out
+
+
+@pytest.mark.gpu
+def test_a_substitute_rccl_is_refused_without_the_test_hook_switch():
+    _build()
+    r = subprocess.run([BIN, "sharded_rccl"], capture_output=True, text=True, timeout=600, env=dict(os.environ, KSCHED_RCCL_LIB=FAKE_RCCL, KSCHED_TEST_HOOKS="0"))
+    assert r.returncode != 0
+    assert "refusing a substitute for RCCL" in (r.stdout + r.stderr)
