@@ -299,6 +299,11 @@ uint32_t ksched_mask_pitch(uint32_t n_nodes);
 int ksched_pick_device(ksched_ctx *ctx, uint32_t p, const uint64_t *feasible, uint32_t mask_pitch_words,
                        const int64_t *req_mem_bytes, const uint32_t *samples, uint32_t attempts, uint32_t flags,
                        int32_t *out_binding, void *hip_stream);
+/* The same from HOST masks (rows packed at ksched_mask_words(n) words): copies in, picks on the ctx's own stream, copies the bindings out and
+ * waits.  For hosts that combine masks themselves -- the mirror ANDs the masks of a pod whose selector has more keys than one call takes
+ * (KSCHED_MAX_KEYS; the reference has no limit, src/predicates.rs:48-53) and lets the device pick from the result. */
+int ksched_pick(ksched_ctx *ctx, uint32_t p, const uint64_t *feasible, const int64_t *req_mem_bytes, const uint32_t *samples,
+                uint32_t attempts, uint32_t flags, int32_t *out_binding);
 
 /* ---- pipelined evaluation (throughput form) ------------------------------------------------
  * Consecutive batches do not depend on each other, and within a batch the pick only needs the finished mask.  A

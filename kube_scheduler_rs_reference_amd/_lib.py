@@ -86,6 +86,7 @@ SYMBOLS = {
     "ksched_eval_device_pitched": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     "ksched_mask_pitch": (_u32, [_u32]),
     "ksched_pick_device": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp]),
+    "ksched_pick": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _u32, _u32, _vp]),
     "ksched_pipe_create": (C.c_int, [_vp, _u32, C.POINTER(_vp)]),
     "ksched_pipe_destroy": (None, [_vp]),
     "ksched_pipe_submit": (C.c_int, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _vp]),

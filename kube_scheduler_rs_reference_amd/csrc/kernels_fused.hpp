@@ -95,6 +95,7 @@ struct FusedArgs {
     uint32_t pick_ppb, pick_waves;  // PICK == 1: pods whose sampled pick one block carries, and how many of its waves carry them (the others stage)
     uint64_t *pick_acc;             // PICK == 2: [ceil(p / 8)] accumulators, one per unit of eight pods (count << 40 | 8 x 5 feasible-draw bits), all zero between launches
     uint32_t off_park;              // PICK == 2: LDS byte offset of the per-wave park of the round's draws
+    uint32_t off_pf;                // LDS byte offset of the 256-byte dump area of the operand prefetch, or 0xFFFFFFFF: no room, no prefetch
     uint64_t *trace;  // diagnostics: per-block phase timestamps (100 MHz), or nullptr
 };
 
@@ -103,6 +104,7 @@ struct FusedArgs {
 //               [nlist * 6 KiB: the tile's list keys][per wave x 64 pods: 16 B list record]   (snapshots with list keys only)
 constexpr uint32_t kPickAttempts = 5;  // draws per pod the tile-test pick (PICK == 2) handles: ATTEMPTS of src/main.rs:49
 constexpr uint32_t kPickParkBytes = kFusedWaves * kPickAttempts * 64u * 4u;
+constexpr uint32_t kPrefetchDumpBytes = 256u;  // one dword per lane: where the operand prefetch's LDS-DMA loads land (shared by the block's waves: nobody reads it)
 inline uint32_t fused_lds_bytes(const IndexedLayout &l, bool fit, bool sel, bool taint, FusedArgs *a = nullptr, bool park = false) {
     uint32_t off = l.rows * 128u;
     const uint32_t off_aux = off;
@@ -119,7 +121,14 @@ inline uint32_t fused_lds_bytes(const IndexedLayout &l, bool fit, bool sel, bool
     if (sel && l.nlist) off += kFusedWaves * 64u * kListRecBytes;
     const uint32_t off_park = off;
     if (park) off += kPickParkBytes;
+    // the operand prefetch's dump area: only where it fits (it never decides whether the fused kernel applies)
+    uint32_t off_pf = 0xFFFFFFFFu;
+    if (off + kPrefetchDumpBytes <= kLdsBudget) {
+        off_pf = off;
+        off += kPrefetchDumpBytes;
+    }
     if (a) {
+        a->off_pf = off_pf;
         a->off_park = off_park;
         a->off_list = off_list;
         a->off_lrec = off_lrec;
@@ -715,20 +724,23 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
     // A scheduler never evaluates the same batch twice, so a round's operand lines (64 pods x 68 bytes at C3: 34 lines of 128 bytes
     // over ten columns) come from HBM, not from the L2 an earlier launch left warm -- and the pipeline below issues a round's loads
     // only ONE trip ahead, behind a queue of mask stores: with the bench cycling over different resident batches the C3 step read
-    // 24.2 us against 19.7 us with one batch evaluated over and over (session r5c).  So before anything else the wave touches the
-    // lines of the rounds AFTER its first one -- ONE load instruction per round, lane l fetching a dword of line l of the round -- which
-    // brings them into the XCD's L2 while the tile is staged; the real loads of those rounds then hit.  The touched values are never
-    // used and take no register: the loads are LDS-DMA loads (global_load_lds_dword) into the wave's own record area, which phase 1
-    // overwrites after the staging barrier -- whose wait covers them, vector-memory operations return in order.  At most
-    // kPrefetchRounds rounds ahead (a launch with longer waves is bound by its stores, not by this latency).
+    // 24.2 us against 19.7 us with one batch evaluated over and over (session r5c).  So right behind the staging barrier -- not ahead
+    // of it: the address arithmetic and the cold translations of these loads would sit in front of the staging pieces every wave
+    // waits for -- the wave touches the lines of the rounds AFTER its first one: ONE load instruction per round, lane l fetching a
+    // dword of line l of the round, which brings them into the XCD's L2 while rounds 0 and 1 are computed; the real loads of those
+    // rounds then hit.  The touched values are never used and take no register: the loads are LDS-DMA loads (global_load_lds_dword)
+    // into a 256-byte dump area of their own (FusedArgs::off_pf; no room for it in LDS = no prefetch), issued by inline asm so that
+    // the compiler's wait bookkeeping does not see them; they are older than the next trip's operand loads, whose counted wait
+    // therefore covers them (vector-memory operations return in order).  At most kPrefetchRounds rounds ahead; waves with more rounds
+    // than the prefetch reaches skip it (a launch that long is bound by its stores, not by this latency).
+    // (session r5d, inputs rotated: C3 23.9 -> 20.2 us per step, the C4 shard 54.8 -> 42.3; the C5 shard, 24 rounds per wave, 222.5 -> 224.7 with it)
     constexpr uint32_t kPrefetchRounds = 6;
-    // (session r5d, inputs rotated: C3 23.9 -> 20.2 us per step, the C4 shard 54.8 -> 42.3; the C5 shard, 24 rounds per wave and bound by
-    // its stores, 222.5 -> 224.7: waves with more rounds than the prefetch reaches skip it)
-    if ((FIT || SEL || TAINT) && u + 8u * (kPrefetchRounds + 2u) >= u_hi && !(a.debug & 0x20000000u)) {
-        // where the touched dwords land: this wave's own record area, which nobody reads before phase 1 has written it (after the barrier)
-        const uint32_t dump = (uint32_t)__builtin_amdgcn_readfirstlane((int)((FIT ? a.off_fit + wave * 1024u : SEL ? a.off_lab + wave * 1024u : a.off_trow + wave * 512u)));
+    auto prefetch_rounds = [&]() {
+        if (!(FIT || SEL || TAINT) || a.off_pf == 0xFFFFFFFFu || u + 8u * (kPrefetchRounds + 2u) < u_hi || (a.debug & 0x20000000u)) return;
+        const uint32_t dump = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off_pf);
         // lane -> line of the round: [0,4) cpu, [4,8) memory, [8,24) the eight selector columns (two lines each), [24,34) the draws, [34,38) tolerations
         const uint32_t li = opaque(lane);
+#pragma unroll 1
         for (uint32_t r = 1; r <= kPrefetchRounds; ++r) {
             const uint32_t pu = u + 8u * r;
             if (pu >= u_hi) break;  // wave-uniform
@@ -750,12 +762,12 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
             if (TAINT && a.has_tol && li >= 34u && li < 38u) {
                 a64 = reinterpret_cast<uint64_t>(g_ptol + e8);
             }
-            // (M0 = the LDS destination of an LDS-DMA load; the compiler manages M0 itself -- the staging below -- so the statement
+            // (M0 = the LDS destination of an LDS-DMA load; the compiler manages M0 itself -- the staging -- so the statement
             // puts back what it found)
             uint32_t m0_saved;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_saved) : "v"(a64), "s"(dump) : "memory");
         }
-    }
+    };
     bool more = u < u_hi, have_prev = false, first = true, stamped4 = false;
     uint32_t prev_u = 0, prev_nu = 0;
     uint64_t prev_over = 0;
@@ -845,6 +857,7 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
             // (a pick wave issues no staging piece whose wait would cover them)
             if (PICK == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            prefetch_rounds();  // (behind the barrier: see "operand prefetch" above)
             if (!(a.debug & 128u)) stamp(2);
         }
         if (have_prev) {

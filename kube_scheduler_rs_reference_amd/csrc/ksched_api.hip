@@ -1589,6 +1589,49 @@ int ksched_pick_device(ksched_ctx *c, uint32_t p, const uint64_t *feasible, uint
     return launch_pick(c, p, feasible, mask_pitch_words, req_mem_bytes, samples, attempts, flags, out_binding, s);
 } KSCHED_ABI_CATCH(c)
 
+// The pick alone from HOST masks (packed rows of W words): copies in, ksched_pick_device on the ctx's stream, copies out, waits.
+int ksched_pick(ksched_ctx *c, uint32_t p, const uint64_t *feasible, const int64_t *req_mem_bytes, const uint32_t *samples, uint32_t attempts,
+                uint32_t flags, int32_t *out_binding) try {
+    if (!c) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_nodes) return KSCHED_E_STATE;
+    const bool pick_s = flags & KSCHED_PICK_SAMPLED, pick_b = flags & KSCHED_PICK_BESTFIT;
+    if (pick_s == pick_b || (flags & ~(KSCHED_PICK_SAMPLED | KSCHED_PICK_BESTFIT | KSCHED_FIT | KSCHED_SEL | KSCHED_TAINT))) return KSCHED_E_INVAL;
+    if (!out_binding || (p > 0 && c->n > 0 && !feasible)) return KSCHED_E_INVAL;
+    if (pick_s && (attempts == 0 || attempts > KSCHED_MAX_ATTEMPTS || (p > 0 && !samples))) return KSCHED_E_INVAL;
+    if (pick_b && (flags & KSCHED_FIT) && p > 0 && !req_mem_bytes) return KSCHED_E_INVAL;
+    if (p == 0) return KSCHED_OK;
+    if (c->n == 0) {  // choose() on an empty store yields None on every attempt (src/main.rs:56,70)
+        for (uint32_t i = 0; i < p; ++i) out_binding[i] = -1;
+        return KSCHED_OK;
+    }
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    fault_point(c);
+    hipStream_t s = c->stream;
+    if (pick_b)
+        if (int rcb = ensure_bestfit(c)) return rcb;
+    if (int rce = stream_enter(c, s)) return rce;  // behind the latest snapshot change
+    const size_t W = c->W;
+    HIPCHK(c, c->feas.reserve((size_t)p * W));
+    HIPCHK(c, c->binding.reserve(p));
+    HIPCHK(c, hipMemcpyAsync(c->feas.ptr, feasible, (size_t)p * W * 8, hipMemcpyHostToDevice, s));
+    if (req_mem_bytes) {
+        HIPCHK(c, c->pmem.reserve(p));
+        HIPCHK(c, hipMemcpyAsync(c->pmem.ptr, req_mem_bytes, (size_t)p * 8, hipMemcpyHostToDevice, s));
+    }
+    if (pick_s) {
+        HIPCHK(c, c->psamples.reserve((size_t)p * attempts));
+        HIPCHK(c, hipMemcpyAsync(c->psamples.ptr, samples, (size_t)p * attempts * 4, hipMemcpyHostToDevice, s));
+    }
+    if (int rc = launch_pick(c, p, c->feas.ptr, (uint32_t)W, req_mem_bytes ? c->pmem.ptr : nullptr, pick_s ? c->psamples.ptr : nullptr, attempts, flags,
+                             c->binding.ptr, s))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(out_binding, c->binding.ptr, (size_t)p * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return KSCHED_OK;
+} KSCHED_ABI_CATCH(c)
+
 // ---- the host-pointer evaluation in two halves (include/ksched.h "one host thread, several devices") -------------------------
 // eval_begin_locked: copy the batch in, enqueue the evaluation and the copies of the masks back -- all on the ctx's own stream, no
 // host wait.  The bindings stay in a ctx-owned device buffer of `capacity` >= p entries; entries [p, capacity) are -1 (the padding

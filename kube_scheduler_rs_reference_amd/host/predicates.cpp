@@ -2,6 +2,7 @@
 
 #include "sharded.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include <set>
@@ -20,8 +21,16 @@ const char *debug_name(InvalidNodeReason r) {
 
 namespace {
 
+std::vector<corev1::Pod> split_wide_pod(const corev1::Pod &pod);
+bool is_wide(const corev1::Pod &pod) { return pod.spec && pod.spec->node_selector && pod.spec->node_selector->size() > KSCHED_MAX_KEYS; }
+
 // One-pod x one-node evaluation on the device: bit 0 of the single mask word.
 bool eval_pair(Snapshot &snap, const corev1::Pod &pod, uint32_t flags) {
+    if (is_wide(pod)) {  // more selector keys than one call takes: group by group, every group must hold (a conjunction, src/predicates.rs:48-53)
+        bool ok = true;
+        for (const corev1::Pod &part : split_wide_pod(pod)) ok = eval_pair(snap, part, flags) && ok;
+        return ok;
+    }
     PodColumns pc = snap.encode_pods({&pod});  // may add label columns -> re-upload
     uint64_t word = 0;
     DeviceEvaluator &dev = snap.device();
@@ -65,13 +74,20 @@ Validity check_node_validity(const corev1::Pod &pod, const corev1::Node &node, C
     // One device call gives both masks; the order of the reasons is the reference's (:68-74).
     Snapshot &snap = pair_snapshot(ctx);
     snap.rebuild({node}, ctx.client.get());
-    PodColumns pc = snap.encode_pods({&pod});
-    uint64_t feas = 0, fit = 0;
+    uint64_t feas = ~0ull, fit = 0;
     DeviceEvaluator &dev = snap.device();
-    dev.check(ksched_eval(dev.handle(), 1, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(),
-                          pc.n_keys ? pc.sel_val_ids.data() : nullptr, nullptr, nullptr, 0,
-                          KSCHED_FIT | KSCHED_SEL | KSCHED_WANT_FIT_MASK, &feas, &fit, nullptr),
-              "ksched_eval");
+    std::vector<corev1::Pod> groups;
+    if (is_wide(pod)) groups = split_wide_pod(pod);  // (more selector keys than one call takes: the groups' feasible bits ANDed)
+    for (size_t g = 0; g < std::max<size_t>(1, groups.size()); ++g) {
+        const corev1::Pod &part = groups.empty() ? pod : groups[g];
+        PodColumns pc = snap.encode_pods({&part});
+        uint64_t f = 0;
+        dev.check(ksched_eval(dev.handle(), 1, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(),
+                              pc.n_keys ? pc.sel_val_ids.data() : nullptr, nullptr, nullptr, 0,
+                              KSCHED_FIT | KSCHED_SEL | KSCHED_WANT_FIT_MASK, &f, &fit, nullptr),
+                  "ksched_eval");
+        feas &= f;
+    }
     const int r = ksched_reason(&feas, &fit, 0, KSCHED_FIT | KSCHED_SEL);
     if (r == KSCHED_REASON_OK) return std::nullopt;
     return r == KSCHED_REASON_NOT_ENOUGH_RESOURCES ? InvalidNodeReason::NotEnoughResources : InvalidNodeReason::NodeSelectorMismatch;
@@ -94,6 +110,90 @@ uint64_t BatchValidity::feasible_count(uint32_t pod) const {
 }
 
 namespace {
+
+// The device takes at most KSCHED_MAX_KEYS label columns per call; the reference has no limit on selector keys
+// (src/predicates.rs:48-53).  A batch is therefore cut into consecutive pod ranges whose distinct selector keys fit the budget (a new
+// range re-uploads the label columns it needs), and a single pod with MORE keys than one call takes is a range of its own, marked wide:
+// it is evaluated once per group of KSCHED_MAX_KEYS keys and the groups' masks are ANDed (a selector is a conjunction).
+struct KeyRange {
+    size_t lo, hi;
+    bool wide;
+};
+std::vector<KeyRange> key_ranges(const std::vector<const corev1::Pod *> &pods) {
+    std::vector<KeyRange> out;
+    size_t lo = 0;
+    std::set<std::string> keys;
+    auto close = [&](size_t hi) {
+        if (hi > lo) out.push_back({lo, hi, false});
+        lo = hi;
+        keys.clear();
+    };
+    for (size_t i = 0; i < pods.size(); ++i) {
+        const corev1::Pod &pod = *pods[i];
+        if (!pod.spec || !pod.spec->node_selector || pod.spec->node_selector->empty()) continue;  // (most pods: nothing is built for them)
+        const auto &selector = *pod.spec->node_selector;  // (a map: its keys are distinct)
+        if (selector.size() > KSCHED_MAX_KEYS) {
+            close(i);
+            out.push_back({i, i + 1, true});
+            lo = i + 1;
+            continue;
+        }
+        size_t adds = 0;
+        for (const auto &kv : selector) adds += keys.find(kv.first) == keys.end() ? 1u : 0u;
+        if (!adds) continue;
+        if (keys.size() + adds > KSCHED_MAX_KEYS) close(i);
+        for (const auto &kv : selector) keys.insert(kv.first);
+    }
+    close(pods.size());
+    return out;
+}
+// the pod once per group of at most KSCHED_MAX_KEYS of its selector's keys (every copy carries the whole pod otherwise: requests, tolerations)
+std::vector<corev1::Pod> split_wide_pod(const corev1::Pod &pod) {
+    std::vector<corev1::Pod> out;
+    const auto &selector = *pod.spec->node_selector;
+    corev1::StringMap group;
+    auto flush = [&] {
+        corev1::Pod part = pod;
+        part.spec->node_selector = group;
+        out.push_back(std::move(part));
+        group.clear();
+    };
+    for (const auto &kv : selector) {
+        group.insert(kv);
+        if (group.size() == KSCHED_MAX_KEYS) flush();
+    }
+    if (!group.empty()) flush();
+    return out;
+}
+
+// A pod whose selector has more keys than one call takes (row `i` of `out`): one device evaluation per key group against that group's
+// label columns, the groups' feasible masks ANDed (does_node_selector_match is a conjunction over the keys, src/predicates.rs:48-53;
+// the fit mask is the same in every group), and the pick made by the device from the combined mask (ksched_pick).  On the first
+// device of a multi-device snapshot: such pods are rare, and every device holds the whole snapshot.
+void eval_wide_pod(Snapshot &snap, const corev1::Pod &pod, size_t i, uint32_t pick, const std::vector<uint32_t> *samples, uint32_t attempts,
+                   BatchValidity &out, bool want_masks) {
+    const uint32_t W = out.W;
+    std::vector<uint64_t> feas(W, ~0ull), fit(W, 0ull), f(W), ft(W);
+    DeviceEvaluator &dev = snap.device();
+    int64_t req_mem = 0;
+    for (const corev1::Pod &part : split_wide_pod(pod)) {
+        PodColumns pc = snap.encode_pods({&part});  // (re-uploads the label columns of this group's keys)
+        dev.check(ksched_eval(dev.handle(), 1, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), pc.n_keys ? pc.sel_val_ids.data() : nullptr,
+                              (out.flags & KSCHED_TAINT) ? pc.tolerations.data() : nullptr, nullptr, 0, out.flags | KSCHED_WANT_FIT_MASK, f.data(), ft.data(), nullptr),
+                  "ksched_eval");
+        for (uint32_t w = 0; w < W; ++w) feas[w] &= f[w];
+        fit = ft;
+        req_mem = pc.req_mem_bytes[0];
+    }
+    if (want_masks) {
+        std::copy(feas.begin(), feas.end(), out.feasible.begin() + (std::ptrdiff_t)(i * W));
+        std::copy(fit.begin(), fit.end(), out.fit.begin() + (std::ptrdiff_t)(i * W));
+    }
+    if (pick)
+        dev.check(ksched_pick(dev.handle(), 1, feas.data(), &req_mem, (pick & KSCHED_PICK_SAMPLED) ? samples->data() + i * attempts : nullptr, attempts,
+                              pick | (out.flags & (KSCHED_FIT | KSCHED_SEL | KSCHED_TAINT)), out.binding.data() + i),
+                  "ksched_pick");
+}
 
 // One device call for pods [lo, hi) of the batch, written into rows [lo, hi) of `out`.
 void eval_range(Snapshot &snap, const std::vector<const corev1::Pod *> &pods, size_t lo, size_t hi, uint32_t pick,
@@ -140,29 +240,12 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
     if (out.p == 0 || out.n == 0) return out;  // no pods, or an empty store: nothing is feasible
     if ((pick & KSCHED_PICK_SAMPLED) && (!samples || samples->size() != (size_t)out.p * attempts))
         throw EncodeError("check_node_validity_batch: samples must hold p * attempts indices");
-    // The device takes at most KSCHED_MAX_KEYS label columns per call.  The reference has no limit on selector keys, so a batch
-    // that uses more distinct keys is evaluated in consecutive pod ranges, each within the budget (a new range re-uploads the
-    // label columns it needs).  Only a single pod with more than KSCHED_MAX_KEYS selector keys is refused.
-    size_t lo = 0;
-    std::set<std::string> keys;
-    for (size_t i = 0; i < pods.size(); ++i) {
-        const corev1::Pod &pod = *pods[i];
-        if (!pod.spec || !pod.spec->node_selector || pod.spec->node_selector->empty()) continue;  // (most pods: nothing is built for them)
-        const auto &selector = *pod.spec->node_selector;  // (a map: its keys are distinct)
-        if (selector.size() > KSCHED_MAX_KEYS)  // a per-pod failure raised before anything of the batch was evaluated or POSTed: PodEncodeError, so that
-                                                // run_batches isolates the offender instead of the exception taking the scheduling loop down
-            throw PodEncodeError("pod " + full_name(pod.metadata) + ": more than KSCHED_MAX_KEYS nodeSelector keys on one pod");
-        size_t adds = 0;
-        for (const auto &kv : selector) adds += keys.find(kv.first) == keys.end() ? 1u : 0u;
-        if (!adds) continue;
-        if (keys.size() + adds > KSCHED_MAX_KEYS) {
-            eval_range(snap, pods, lo, i, pick, samples, attempts, out, want_masks);
-            lo = i;
-            keys.clear();
-        }
-        for (const auto &kv : selector) keys.insert(kv.first);
+    // (key_ranges: consecutive pod ranges within the device's budget of label columns per call; a pod with more keys than that is
+    // evaluated group by group and ANDed -- no input the reference schedules is refused)
+    for (const KeyRange &r : key_ranges(pods)) {
+        if (r.wide) eval_wide_pod(snap, *pods[r.lo], r.lo, pick, samples, attempts, out, want_masks);
+        else eval_range(snap, pods, r.lo, r.hi, pick, samples, attempts, out, want_masks);
     }
-    eval_range(snap, pods, lo, pods.size(), pick, samples, attempts, out, want_masks);
     return out;
 }
 
@@ -173,27 +256,54 @@ std::vector<Validity> explain_pairs(const std::vector<const corev1::Pod *> &pods
     if (taints && snap.has_taints()) snap.enable_taints();
     std::vector<Validity> out(pairs.size());
     if (pairs.empty()) return out;
-    PodColumns pc = snap.encode_pods(pods);  // (one call: at most KSCHED_MAX_KEYS distinct selector keys among `pods`)
-    std::vector<uint32_t> pp(pairs.size()), pn(pairs.size());
-    for (size_t i = 0; i < pairs.size(); ++i) {
-        pp[i] = pairs[i].first;
-        pn[i] = pairs[i].second;
-    }
-    std::vector<int32_t> reason(pairs.size());
     const uint32_t flags = KSCHED_FIT | KSCHED_SEL | ((taints && snap.has_taints()) ? KSCHED_TAINT : 0u);
     DeviceEvaluator &dev = snap.device();
-    dev.check(ksched_explain(dev.handle(), pc.p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), pc.n_keys ? pc.sel_val_ids.data() : nullptr,
-                             (flags & KSCHED_TAINT) ? pc.tolerations.data() : nullptr, (uint32_t)pairs.size(), pp.data(), pn.data(), flags,
-                             reason.data()),
-              "ksched_explain");
-    for (size_t i = 0; i < pairs.size(); ++i) {
-        switch (reason[i]) {
-            case KSCHED_REASON_OK: out[i] = std::nullopt; break;
-            case KSCHED_REASON_NOT_ENOUGH_RESOURCES: out[i] = InvalidNodeReason::NotEnoughResources; break;
-            case KSCHED_REASON_TAINT_NOT_TOLERATED: out[i] = InvalidNodeReason::TaintNotTolerated; break;
-            default: out[i] = InvalidNodeReason::NodeSelectorMismatch;
+    auto to_validity = [](int32_t r) -> Validity {
+        switch (r) {
+            case KSCHED_REASON_OK: return std::nullopt;
+            case KSCHED_REASON_NOT_ENOUGH_RESOURCES: return InvalidNodeReason::NotEnoughResources;
+            case KSCHED_REASON_TAINT_NOT_TOLERATED: return InvalidNodeReason::TaintNotTolerated;
+            default: return InvalidNodeReason::NodeSelectorMismatch;
         }
+    };
+    // pairs by pod range (the same key-budget ranges the evaluation uses: one ksched_explain per range that has pairs)
+    std::vector<size_t> order(pairs.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return pairs[a].first < pairs[b].first; });
+    size_t next = 0;
+    for (const KeyRange &r : key_ranges(pods)) {
+        std::vector<size_t> mine;
+        while (next < order.size() && pairs[order[next]].first < r.hi) mine.push_back(order[next++]);
+        if (mine.empty()) continue;
+        std::vector<uint32_t> pp(mine.size()), pn(mine.size());
+        std::vector<int32_t> reason(mine.size());
+        for (size_t k = 0; k < mine.size(); ++k) {
+            if (pairs[mine[k]].first < r.lo) throw EncodeError("explain_pairs: a pair names a pod outside the batch");
+            pp[k] = pairs[mine[k]].first - (uint32_t)r.lo;
+            pn[k] = pairs[mine[k]].second;
+        }
+        // a wide pod: group by group; the first failure in the reference's order wins (resources, src/predicates.rs:68-70, say the same
+        // in every group; then any group's selector mismatch, :72-74)
+        std::vector<corev1::Pod> groups;
+        std::vector<std::vector<const corev1::Pod *>> calls;
+        if (r.wide) {
+            groups = split_wide_pod(*pods[r.lo]);
+            for (const corev1::Pod &g : groups) calls.push_back({&g});
+        } else {
+            calls.emplace_back(pods.begin() + (std::ptrdiff_t)r.lo, pods.begin() + (std::ptrdiff_t)r.hi);
+        }
+        std::vector<int32_t> combined(mine.size(), KSCHED_REASON_OK);
+        for (const auto &part : calls) {
+            PodColumns pc = snap.encode_pods(part);
+            dev.check(ksched_explain(dev.handle(), pc.p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), pc.n_keys ? pc.sel_val_ids.data() : nullptr,
+                                     (flags & KSCHED_TAINT) ? pc.tolerations.data() : nullptr, (uint32_t)mine.size(), pp.data(), pn.data(), flags, reason.data()),
+                      "ksched_explain");
+            for (size_t k = 0; k < mine.size(); ++k)
+                if (combined[k] == KSCHED_REASON_OK) combined[k] = reason[k];
+        }
+        for (size_t k = 0; k < mine.size(); ++k) out[mine[k]] = to_validity(combined[k]);
     }
+    if (next != order.size()) throw EncodeError("explain_pairs: a pair names a pod outside the batch");
     return out;
 }
 

@@ -43,7 +43,9 @@ std::optional<corev1::Node> select_node_for_pod(const corev1::Pod &pod, Context 
         const corev1::Node &candidate = ctx.node_store[*idx];
         const predicates::Validity v = predicates::check_node_validity(pod, candidate, ctx);  // :61
         if (v) {
-            if (rejected) rejected->push_back({corev1::name_any(candidate.metadata), *v});  // the WARN line at :62
+            const RejectedCandidate r{corev1::name_any(candidate.metadata), *v};
+            if (ctx.warn) ctx.warn(rejected_line(pod, r));  // the WARN line at :62
+            if (rejected) rejected->push_back(r);
         } else {
             node = candidate;  // :64-65
             break;
@@ -67,6 +69,7 @@ BatchSelection select_nodes_for_pods(const std::vector<const corev1::Pod *> &pod
             const std::optional<size_t> idx = chooser.choose(ctx.node_store.size());
             if (idx) samples[(size_t)i * ATTEMPTS + t] = snap.canonical_index((uint32_t)*idx);
         }
+    out.samples = samples;
     if (n == 0 || p == 0) return out;
     // (the masks only when the caller wants the rejected draws' reasons: a batch's bindings alone need no mask kernel and no mask copy)
     out.validity = predicates::check_node_validity_batch(pods, ctx, /*taints=*/false, KSCHED_PICK_SAMPLED, &samples, ATTEMPTS, /*want_masks=*/want_rejected);
@@ -84,6 +87,39 @@ BatchSelection select_nodes_for_pods(const std::vector<const corev1::Pod *> &pod
         }
     }
     return out;
+}
+
+std::vector<std::vector<RejectedCandidate>> explain_rejected(const std::vector<const corev1::Pod *> &pods, Context &ctx, const BatchSelection &sel) {
+    const uint32_t p = (uint32_t)pods.size();
+    std::vector<std::vector<RejectedCandidate>> out(p);
+    if (!ctx.snapshot || p == 0 || sel.samples.size() != (size_t)p * ATTEMPTS || sel.validity.binding.size() != p) return out;
+    Snapshot &snap = *ctx.snapshot;
+    const uint32_t n = snap.n();
+    std::vector<std::pair<uint32_t, uint32_t>> pairs;
+    for (uint32_t i = 0; i < p; ++i) {
+        const int32_t won = sel.validity.binding[i];
+        for (uint32_t t = 0; t < ATTEMPTS; ++t) {
+            const uint32_t s = sel.samples[(size_t)i * ATTEMPTS + t];
+            if (s >= n) continue;                       // no draw (empty store)
+            if (won >= 0 && s == (uint32_t)won) break;  // the first feasible draw wins (src/main.rs:61-65): everything before it was refused
+            pairs.emplace_back(i, s);
+        }
+    }
+    const std::vector<predicates::Validity> why = predicates::explain_pairs(pods, ctx, pairs);
+    for (size_t k = 0; k < pairs.size(); ++k)
+        if (why[k]) out[pairs[k].first].push_back({snap.columns().names[pairs[k].second], *why[k]});
+    return out;
+}
+
+std::string rejected_line(const corev1::Pod &pod, const RejectedCandidate &r) {
+    return "Node " + r.node_name + " failed validity check for pod " + full_name(pod.metadata) + ": " + predicates::debug_name(r.reason);
+}
+
+void warn_rejected(const std::vector<const corev1::Pod *> &pods, Context &ctx, const BatchSelection &sel) {
+    if (!ctx.warn) return;  // the level is off: a quiet cluster pays nothing
+    const auto rejected = sel.rejected.size() == pods.size() ? sel.rejected : explain_rejected(pods, ctx, sel);
+    for (size_t i = 0; i < pods.size(); ++i)
+        for (const RejectedCandidate &r : rejected[i]) ctx.warn(rejected_line(*pods[i], r));
 }
 
 Action error_policy(const corev1::Pod &, ReconcileError) { return Action::RequeueAfter5Min; }  // src/main.rs:122-125
@@ -174,6 +210,7 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
     const bool timing = std::getenv("KSCHED_HOST_TIMING") != nullptr;  // (tools/host_loop.py: where a batch's host time goes, to stderr)
     const auto t0 = std::chrono::steady_clock::now();
     const BatchSelection sel = select_nodes_for_pods(pending, ctx, chooser);
+    warn_rejected(pending, ctx, sel);  // src/main.rs:62, for the whole batch (one ksched_explain call; skipped when nobody listens)
     const auto t1 = std::chrono::steady_clock::now();
     std::vector<const corev1::Node *> chosen(pending.size(), nullptr);
     for (size_t j = 0; j < pending.size(); ++j)
@@ -222,6 +259,7 @@ std::vector<ReconcileOutcome> reconcile_batch_sequential(const std::vector<const
         std::vector<const corev1::Pod *> batch;
         for (size_t i : pending) batch.push_back(pods[i]);
         const BatchSelection sel = select_nodes_for_pods(batch, ctx, chooser);  // one device evaluation + pick
+        warn_rejected(batch, ctx, sel);
         std::vector<size_t> next;
         std::vector<bool> taken(ctx.node_store.size(), false);
         std::vector<std::pair<const corev1::Pod *, const std::string *>> landed;  // (pod, the node it was bound to), for the snapshot update

@@ -66,9 +66,19 @@ struct BatchSelection {
     std::vector<int32_t> node_store_index;             // [p] index into ctx.node_store or -1
     std::vector<std::vector<RejectedCandidate>> rejected;  // [p] candidates tried and refused, in order (filled on request)
     predicates::BatchValidity validity;                // the bindings; with want_rejected also both masks (canonical node order): without it no mask is computed or copied
+    std::vector<uint32_t> samples;                     // [p][ATTEMPTS] the draws as canonical node indices (n = "no draw": empty store)
 };
 BatchSelection select_nodes_for_pods(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
                                      bool want_rejected = false);
+
+// The candidates a batch's pods tried and were refused, in draw order, WITHOUT the two masks: the draws ahead of each pod's winning one
+// (all of them when none won) go to the device as (pod, node) pairs and come back with check_node_validity's reason (ksched_explain).  What
+// select_node_for_pod logs at WARN (src/main.rs:62); costs one small device call per batch instead of two P x N masks.
+std::vector<std::vector<RejectedCandidate>> explain_rejected(const std::vector<const corev1::Pod *> &pods, Context &ctx, const BatchSelection &sel);
+// the reference's line for one of them: "Node {} failed validity check for pod {}: {:?}" (src/main.rs:62)
+std::string rejected_line(const corev1::Pod &pod, const RejectedCandidate &r);
+// emits them through ctx.warn, pod by pod, draw by draw (nothing happens -- and nothing is asked of the device -- when the level is off)
+void warn_rejected(const std::vector<const corev1::Pod *> &pods, Context &ctx, const BatchSelection &sel);
 
 // ---- reconcile ------------------------------------------------------------------------------------
 

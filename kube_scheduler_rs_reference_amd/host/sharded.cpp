@@ -31,10 +31,16 @@ std::vector<int> devices_from_env(const char *value, int fallback) {
     }
     std::set<int> seen;
     const char *s = value;
+    // the same reading as the Rust twin's parse_device_ids (rust/src/ksched.rs): entries separated by commas, blanks around an entry ignored,
+    // an empty entry ("0,1," or "0,,1") is an error like anything else that is not a number
     while (*s) {
+        while (*s == ' ' || *s == '\t') ++s;
         char *end = nullptr;
-        const long d = std::strtol(s, &end, 10);
-        if (end == s || d < 0 || (*end != ',' && *end != '\0')) throw EncodeError(std::string("KSCHED_DEVICES: cannot read '") + value + "' (expected e.g. 0,1,2,3 or all)");
+        const bool digit = *s >= '0' && *s <= '9';  // (strtol would also take a sign and leading white space of its own)
+        const long d = digit ? std::strtol(s, &end, 10) : -1;
+        while (end && (*end == ' ' || *end == '\t')) ++end;
+        if (!digit || end == s || d < 0 || (*end != ',' && *end != '\0') || (*end == ',' && end[1] == '\0'))
+            throw EncodeError(std::string("KSCHED_DEVICES: cannot read '") + value + "' (expected e.g. 0,1,2,3 or all)");
         if (d >= visible) throw EncodeError("KSCHED_DEVICES names device " + std::to_string(d) + ", the process sees " + std::to_string(visible));
         if (!seen.insert((int)d).second) throw EncodeError("KSCHED_DEVICES lists device " + std::to_string(d) + " twice");
         out.push_back((int)d);

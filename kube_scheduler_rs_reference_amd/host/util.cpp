@@ -1,5 +1,6 @@
 #include "util.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "encoder.hpp"
@@ -36,6 +37,12 @@ PodResources total_pod_resources(const corev1::Pod &pod) {
         }
     }
     return r;
+}
+
+std::function<void(const std::string &)> Context::default_warn_sink() {
+    const char *lvl = std::getenv("KSCHED_LOG");
+    if (lvl && (std::string(lvl) == "off" || std::string(lvl) == "error")) return nullptr;
+    return [](const std::string &line) { std::fprintf(stderr, " WARN %s\n", line.c_str()); };
 }
 
 void Context::refresh_snapshot() {

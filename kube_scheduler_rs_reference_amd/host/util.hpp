@@ -9,6 +9,7 @@
 // `kube::Client` is reduced to the one call the predicate path makes on it: the LIST of pods with
 // field selector spec.nodeName=<node> (src/predicates.rs:21-25,34) -> PodLister.
 #pragma once
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -56,8 +57,16 @@ struct Context {
     // one-node scratch snapshot used by the per-pair predicates::* entry points
     std::shared_ptr<Snapshot> pair_snapshot;
 
+    // tracing's WARN level: where the reference's warn!() lines go -- one per rejected candidate (src/main.rs:62: "Node {} failed validity
+    // check for pod {}: {:?}") and one per failed reconcile (:123).  The reference's subscriber prints everything up to INFO (:128), so the
+    // default writes them to stderr; $KSCHED_LOG=off (or =error) or an empty function switches the level off, and then NOTHING is computed
+    // for it: the batched path asks the device for the rejected draws' reasons (ksched_explain) only when somebody listens.
+    std::function<void(const std::string &)> warn = default_warn_sink();
+
     // (Re)build `snapshot` from node_store and one LIST per node.
     void refresh_snapshot();
+
+    static std::function<void(const std::string &)> default_warn_sink();
 };
 
 bool is_pod_bound(const corev1::Pod &pod);

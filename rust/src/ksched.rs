@@ -15,6 +15,7 @@
 //   * nodes in canonical order = ascending metadata.name; column index == mask bit.
 //   * label values -> dense dictionary ids per key (1..), 0 = key absent on the node; a selector value that no node
 //     carries -> KSCHED_SEL_NEVER.  Exact interning, never a hash.
+use crate::predicates::InvalidNodeReason;
 use std::collections::{BTreeMap, BTreeSet, HashMap};
 use std::ffi::CStr;
 use std::sync::Arc;
@@ -102,7 +103,12 @@ pub fn parse_device_ids(text: Option<&str>, visible: i32) -> Result<Vec<i32>, St
     }
     let mut ids: Vec<i32> = Vec::new();
     for part in text.split(',') {
-        let d: i32 = part.trim().parse().map_err(|_| format!("KSCHED_DEVICES: cannot read '{}' (expected e.g. 0,1,2,3 or all)", text))?;
+        // (digits only -- `parse` alone would take "+0" --: the same reading as devices_from_env, whose vectors tests/cpp/host_tests.cpp holds)
+        let item = part.trim_matches(|c| c == ' ' || c == '\t');
+        if item.is_empty() || !item.bytes().all(|b| b.is_ascii_digit()) {
+            return Err(format!("KSCHED_DEVICES: cannot read '{}' (expected e.g. 0,1,2,3 or all)", text));
+        }
+        let d: i32 = item.parse().map_err(|_| format!("KSCHED_DEVICES: cannot read '{}' (expected e.g. 0,1,2,3 or all)", text))?;
         if d < 0 || d >= visible {
             return Err(format!("KSCHED_DEVICES names device {}, the process sees {}", d, visible));
         }
@@ -132,6 +138,7 @@ pub struct Devices {
     evaluators: Vec<Evaluator>,
     comms: Vec<*mut sys::ksched_comm>, // one per device; empty with a single device (plain ksched_eval, no exchange)
     table: Vec<i32>,                   // [n][count_per_rank]: the gathered bindings, host copy
+    broken: bool,                      // a failed exchange: the library aborted the communicator clique (ksched.h), nothing more can be gathered
 }
 unsafe impl Send for Devices {}
 
@@ -162,7 +169,7 @@ impl Devices {
                 return Err(KschedError { code: rc, message: format!("ksched_comm_create_local: {} ({})", strerror(rc), detail) });
             }
         }
-        return Ok(Devices { evaluators, comms, table: Vec::new() });
+        return Ok(Devices { evaluators, comms, table: Vec::new(), broken: false });
     }
 
     pub fn len(&self) -> usize {
@@ -214,13 +221,16 @@ impl Devices {
             ev.check(rc, "ksched_eval")?;
             return Ok(binding);
         }
+        if self.broken {
+            return Err(KschedError { code: sys::KSCHED_E_RCCL, message: "the communicator was aborted after a failed exchange; restart the scheduler".into() });
+        }
         let n = self.evaluators.len() as u32;
         let count_per_rank = shard_bounds(p, n, 0).2;
         let mut local: Vec<*const i32> = vec![std::ptr::null(); n as usize];
         let mut gathered: Vec<*mut i32> = vec![std::ptr::null_mut(); n as usize];
         let mut streams: Vec<*mut std::os::raw::c_void> = vec![std::ptr::null_mut(); n as usize];
         let mut failure: Option<KschedError> = None;
-        let mut begun = 0usize;
+        let mut touched = 0usize; // devices a call of this batch has entered -- the failing one included: its copies may already be under way
         // 1. every device gets its rows: copies in and kernels enqueued on the device's own stream, no host wait
         for r in 0..n {
             let (lo, hi, _) = shard_bounds(p, n, r);
@@ -233,12 +243,12 @@ impl Devices {
                     &mut streams[r as usize],
                 )
             };
+            touched += 1;
             if let Err(e) = ev.check(rc, "ksched_eval_begin") {
                 failure = Some(e);
                 break;
             }
             local[r as usize] = dev_binding as *const i32;
-            begun += 1;
         }
         // 2. ONE all-gather of ceil(p / n) int32 per device over xGMI, enqueued behind each device's pick on its own stream
         if failure.is_none() {
@@ -258,11 +268,13 @@ impl Devices {
             if rc != sys::KSCHED_OK {
                 let detail = unsafe { CStr::from_ptr(sys::ksched_comm_last_error()) }.to_string_lossy().into_owned();
                 failure = Some(KschedError { code: rc, message: format!("ksched_allgather_bindings_local: {} ({})", strerror(rc), detail) });
+                self.broken = true; // (the library has aborted the clique: no stream carries a half-issued collective, the waits below return)
             }
         }
-        // 3. the table comes back in one copy from device 0; whatever happened above, every device that was given work is waited for
+        // 3. the table comes back in one copy from device 0; whatever happened above, every device a call has entered is waited for
+        // (the inputs must stay alive until ksched_eval_end, also for a shard whose ksched_eval_begin failed half way)
         self.table.resize((n * count_per_rank) as usize, -1);
-        for r in 0..begun {
+        for r in 0..touched {
             let ev = &self.evaluators[r];
             let rc = if r == 0 && failure.is_none() {
                 unsafe { sys::ksched_eval_end(ev.raw(), gathered[0] as *const i32, n * count_per_rank, self.table.as_mut_ptr()) }
@@ -282,6 +294,55 @@ impl Devices {
             binding[lo as usize..hi as usize].copy_from_slice(&self.table[from..from + (hi - lo) as usize]);
         }
         return Ok(binding);
+    }
+}
+
+impl Devices {
+    /// Both masks of an encoded batch from the FIRST device (every device holds the whole snapshot): [p][words] feasible, fit.
+    /// For the rare pods that need more than one call -- a selector with more keys than KSCHED_MAX_KEYS is evaluated group by group
+    /// and the groups' feasible masks ANDed (twin of eval_wide_pod, host/predicates.cpp).
+    pub fn masks(&self, cols: &PodColumns, words: u32) -> Result<(Vec<u64>, Vec<u64>), KschedError> {
+        let ev = &self.evaluators[0];
+        let mut feasible = vec![0u64; (cols.p * words) as usize];
+        let mut fit = vec![0u64; (cols.p * words) as usize];
+        let rc = unsafe {
+            sys::ksched_eval(
+                ev.raw(), cols.p, cols.req_cpu_milli.as_ptr(), cols.req_mem_bytes.as_ptr(),
+                if cols.n_keys > 0 { cols.sel_val_ids.as_ptr() } else { std::ptr::null() }, std::ptr::null(), std::ptr::null(), 0,
+                sys::KSCHED_FIT | sys::KSCHED_SEL | sys::KSCHED_WANT_FIT_MASK, feasible.as_mut_ptr(), fit.as_mut_ptr(), std::ptr::null_mut(),
+            )
+        };
+        ev.check(rc, "ksched_eval")?;
+        return Ok((feasible, fit));
+    }
+
+    /// The sampled pick from masks the host has combined (ksched_pick): `feasible` = [p][words], `samples` = [p][attempts] canonical indices.
+    pub fn pick_from_masks(&self, p: u32, feasible: &[u64], req_mem_bytes: &[i64], samples: &[u32], attempts: u32) -> Result<Vec<i32>, KschedError> {
+        let ev = &self.evaluators[0];
+        let mut binding = vec![-1i32; p as usize];
+        let rc = unsafe {
+            sys::ksched_pick(ev.raw(), p, feasible.as_ptr(), req_mem_bytes.as_ptr(), samples.as_ptr(), attempts, sys::KSCHED_FIT | sys::KSCHED_SEL | sys::KSCHED_PICK_SAMPLED, binding.as_mut_ptr())
+        };
+        ev.check(rc, "ksched_pick")?;
+        return Ok(binding);
+    }
+
+    /// check_node_validity's reason (KSCHED_REASON_*) for listed (row of `cols`, canonical node) pairs, decided on the first device
+    /// (ksched_explain): what the reference logs at WARN for every rejected candidate (src/main.rs:62).
+    pub fn explain(&self, cols: &PodColumns, pair_pod: &[u32], pair_node: &[u32]) -> Result<Vec<i32>, KschedError> {
+        let ev = &self.evaluators[0];
+        let mut reason = vec![0i32; pair_pod.len()];
+        if pair_pod.is_empty() {
+            return Ok(reason);
+        }
+        let rc = unsafe {
+            sys::ksched_explain(
+                ev.raw(), cols.p, cols.req_cpu_milli.as_ptr(), cols.req_mem_bytes.as_ptr(), if cols.n_keys > 0 { cols.sel_val_ids.as_ptr() } else { std::ptr::null() },
+                std::ptr::null(), pair_pod.len() as u32, pair_pod.as_ptr(), pair_node.as_ptr(), sys::KSCHED_FIT | sys::KSCHED_SEL, reason.as_mut_ptr(),
+            )
+        };
+        ev.check(rc, "ksched_explain")?;
+        return Ok(reason);
     }
 }
 
@@ -901,45 +962,55 @@ impl ClusterState {
 
     /// select_node_for_pod (src/main.rs:51-71) for a batch of pending pods in ONE evaluation over the process's devices: `draws` holds
     /// `attempts` indices into `nodes` (the store's own order; u32::MAX = no draw: empty store) per pod, made up front by the caller;
-    /// the first feasible draw wins.  Returns the chosen index into `nodes` per pod, -1 = none (NoNodeFound in reconcile).  A pod whose
-    /// requests cannot be encoded (the reference's .expect("invalid pod spec") panics on it) or that alone names more than
-    /// KSCHED_MAX_KEYS selector keys gets -1 and a warning; the other pods of the batch are evaluated as usual.  The reference has no
-    /// limit on selector keys: a batch that uses more than KSCHED_MAX_KEYS distinct ones is evaluated in consecutive pod ranges, each
-    /// within the budget (twin of check_node_validity_batch's walk in the C++ host mirror, host/predicates.cpp).
-    pub fn pick_batch(&mut self, devices: &mut Devices, nodes: &[Arc<corev1::Node>], pods: &[Arc<corev1::Pod>], draws: &[u32], attempts: u32) -> Result<Vec<i32>, String> {
+    /// the first feasible draw wins.  Returns the chosen index into `nodes` per pod, -1 = none (NoNodeFound in reconcile) and -- with
+    /// `want_rejected` -- the candidates that were tried and refused as (pod, index into `nodes`, reason), pod by pod in draw order:
+    /// what the reference logs at WARN (src/main.rs:62).  A pod whose requests cannot be encoded (the reference's
+    /// .expect("invalid pod spec") panics on it) gets -1 and a warning; the other pods of the batch are evaluated as usual.  The reference
+    /// has no limit on selector keys (src/predicates.rs:48-53): a batch that uses more than KSCHED_MAX_KEYS distinct ones is evaluated in
+    /// consecutive pod ranges, each within the budget, and a single pod with more keys than that group by group, the groups' masks ANDed
+    /// and the pick made by the device from the result (twins of key_ranges / eval_wide_pod in the C++ host mirror, host/predicates.cpp).
+    pub fn pick_batch(
+        &mut self, devices: &mut Devices, nodes: &[Arc<corev1::Node>], pods: &[Arc<corev1::Pod>], draws: &[u32], attempts: u32, want_rejected: bool,
+    ) -> Result<(Vec<i32>, Vec<(usize, usize, InvalidNodeReason)>), String> {
         if draws.len() != pods.len() * attempts as usize {
             return Err("draws must hold attempts indices per pod".into());
         }
         let mut chosen = vec![-1i32; pods.len()];
+        let mut rejected: Vec<(usize, usize, InvalidNodeReason)> = Vec::new();
         if nodes.is_empty() || pods.is_empty() {
-            return Ok(chosen); // choose() on an empty store yields None on every attempt (src/main.rs:56,70)
+            return Ok((chosen, rejected)); // choose() on an empty store yields None on every attempt (src/main.rs:56,70)
         }
         let snap = self.snapshot_for(nodes)?;
         let mut canonical_of_store = vec![0u32; nodes.len()];
         for (canonical, &store) in snap.store_index.iter().enumerate() {
             canonical_of_store[store] = canonical as u32;
         }
+        let keys_of = |p: &corev1::Pod| match &p.spec {
+            Some(corev1::PodSpec { node_selector: Some(sel), .. }) => sel.len(),
+            _ => 0,
+        };
         // the pods that can be encoded
         let mut which: Vec<usize> = Vec::with_capacity(pods.len());
         for (i, p) in pods.iter().enumerate() {
-            let keys_of_pod = match &p.spec {
-                Some(corev1::PodSpec { node_selector: Some(sel), .. }) => sel.len(),
-                _ => 0,
-            };
-            if keys_of_pod > sys::KSCHED_MAX_KEYS as usize {
-                tracing::warn!("pod {} cannot be scheduled: {} nodeSelector keys on one pod (limit {})", pod_key(p), keys_of_pod, sys::KSCHED_MAX_KEYS);
-                continue;
-            }
             match total_pod_resources_nanos(p).and_then(|(c, m)| ceil_to_i64(c, snap.cpu_unit, "cpu request").and(ceil_to_i64(m, snap.mem_unit, "memory request"))) {
                 Ok(_) => which.push(i),
                 Err(e) => tracing::warn!("pod {} cannot be scheduled: {}", pod_key(p), e),
             }
         }
-        // consecutive ranges of `which`, each with at most KSCHED_MAX_KEYS distinct selector keys
+        // consecutive ranges of `which`, each with at most KSCHED_MAX_KEYS distinct selector keys; a pod with more keys is a range of its own
         let mut ranges: Vec<(usize, usize)> = Vec::new();
         let mut lo = 0usize;
         let mut keys: BTreeSet<&str> = BTreeSet::new();
         for (j, &i) in which.iter().enumerate() {
+            if keys_of(&pods[i]) > sys::KSCHED_MAX_KEYS as usize {
+                if lo < j {
+                    ranges.push((lo, j));
+                }
+                ranges.push((j, j + 1));
+                lo = j + 1;
+                keys.clear();
+                continue;
+            }
             if let Some(corev1::PodSpec { node_selector: Some(sel), .. }) = &pods[i].spec {
                 let adds = sel.keys().filter(|k| !keys.contains(k.as_str())).count();
                 if adds > 0 && keys.len() + adds > sys::KSCHED_MAX_KEYS as usize {
@@ -955,9 +1026,9 @@ impl ClusterState {
         if lo < which.len() {
             ranges.push((lo, which.len()));
         }
+        let words = unsafe { sys::ksched_mask_words(snap.n()) };
         for (from, to) in ranges {
             let part = &which[from..to];
-            let refs: Vec<&corev1::Pod> = part.iter().map(|&i| pods[i].as_ref()).collect();
             // the range's draws in canonical column indices
             let mut samples: Vec<u32> = Vec::with_capacity(part.len() * attempts as usize);
             for &i in part {
@@ -966,14 +1037,86 @@ impl ClusterState {
                     samples.push(if (d as usize) < nodes.len() { canonical_of_store[d as usize] } else { u32::MAX });
                 }
             }
-            let cols = snap.encode_and_upload(devices, &refs)?; // (a new range re-uploads the label columns it needs)
-            let binding = devices.pick_sampled(&cols, &samples, attempts).map_err(|e| e.to_string())?;
+            // what one device call can take: the pods of the range as they are, or -- a pod with more selector keys than one call
+            // takes -- that pod once per group of KSCHED_MAX_KEYS keys
+            let wide = part.len() == 1 && keys_of(&pods[part[0]]) > sys::KSCHED_MAX_KEYS as usize;
+            let mut groups: Vec<corev1::Pod> = Vec::new();
+            if wide {
+                let whole = pods[part[0]].as_ref();
+                let selector = whole.spec.as_ref().and_then(|s| s.node_selector.as_ref()).expect("a wide pod has a selector");
+                let entries: Vec<(&String, &String)> = selector.iter().collect();
+                for group in entries.chunks(sys::KSCHED_MAX_KEYS as usize) {
+                    let mut copy = whole.clone();
+                    copy.spec.as_mut().expect("a wide pod has a spec").node_selector = Some(group.iter().map(|(k, v)| ((*k).clone(), (*v).clone())).collect());
+                    groups.push(copy);
+                }
+            }
+            let binding: Vec<i32>;
+            // reasons of the refused draws, by (row of the range, canonical node)
+            let mut pair_pod: Vec<u32> = Vec::new();
+            let mut pair_node: Vec<u32> = Vec::new();
+            let pairs_for = |binding: &[i32], pair_pod: &mut Vec<u32>, pair_node: &mut Vec<u32>| {
+                for j in 0..part.len() {
+                    for a in 0..attempts as usize {
+                        let s = samples[j * attempts as usize + a];
+                        if s == u32::MAX {
+                            continue; // no draw (empty store)
+                        }
+                        if binding[j] >= 0 && s == binding[j] as u32 {
+                            break; // the first feasible draw wins (src/main.rs:61-65): everything before it was refused
+                        }
+                        pair_pod.push(j as u32);
+                        pair_node.push(s);
+                    }
+                }
+            };
+            let mut reasons: Vec<i32> = Vec::new();
+            if wide {
+                let mut feasible = vec![!0u64; words as usize];
+                let mut req_mem = vec![0i64; 1];
+                for g in &groups {
+                    let cols = snap.encode_and_upload(devices, &[g])?; // (re-uploads the label columns of this group's keys)
+                    let (f, _fit) = devices.masks(&cols, words).map_err(|e| e.to_string())?;
+                    for w in 0..words as usize {
+                        feasible[w] &= f[w]; // does_node_selector_match is a conjunction over the keys (src/predicates.rs:48-53)
+                    }
+                    req_mem[0] = cols.req_mem_bytes[0];
+                }
+                binding = devices.pick_from_masks(1, &feasible, &req_mem, &samples, attempts).map_err(|e| e.to_string())?;
+                if want_rejected {
+                    pairs_for(&binding, &mut pair_pod, &mut pair_node);
+                    reasons = vec![sys::KSCHED_REASON_OK; pair_pod.len()];
+                    for g in &groups {
+                        // the first failure in the reference's order: resources say the same in every group (src/predicates.rs:68-70), then any group's selector (:72-74)
+                        let cols = snap.encode_and_upload(devices, &[g])?;
+                        let r = devices.explain(&cols, &pair_pod, &pair_node).map_err(|e| e.to_string())?;
+                        for k in 0..reasons.len() {
+                            if reasons[k] == sys::KSCHED_REASON_OK {
+                                reasons[k] = r[k];
+                            }
+                        }
+                    }
+                }
+            } else {
+                let refs: Vec<&corev1::Pod> = part.iter().map(|&i| pods[i].as_ref()).collect();
+                let cols = snap.encode_and_upload(devices, &refs)?; // (a new range re-uploads the label columns it needs)
+                binding = devices.pick_sampled(&cols, &samples, attempts).map_err(|e| e.to_string())?;
+                if want_rejected {
+                    pairs_for(&binding, &mut pair_pod, &mut pair_node);
+                    reasons = devices.explain(&cols, &pair_pod, &pair_node).map_err(|e| e.to_string())?;
+                }
+            }
             for (j, &i) in part.iter().enumerate() {
                 if binding[j] >= 0 {
                     chosen[i] = snap.store_index[binding[j] as usize] as i32;
                 }
             }
+            for k in 0..reasons.len() {
+                if let Err(why) = crate::predicates::reason_of(reasons[k]) {
+                    rejected.push((part[pair_pod[k] as usize], snap.store_index[pair_node[k] as usize], why));
+                }
+            }
         }
-        return Ok(chosen);
+        return Ok((chosen, rejected));
     }
 }

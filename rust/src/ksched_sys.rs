@@ -109,6 +109,10 @@ extern "C" {
         ctx: *mut ksched_ctx, p: u32, feasible: *const u64, mask_pitch_words: u32, req_mem_bytes: *const i64,
         samples: *const u32, attempts: u32, flags: u32, out_binding: *mut i32, hip_stream: *mut c_void,
     ) -> c_int;
+    pub fn ksched_pick(
+        ctx: *mut ksched_ctx, p: u32, feasible: *const u64, req_mem_bytes: *const i64, samples: *const u32, attempts: u32, flags: u32,
+        out_binding: *mut i32,
+    ) -> c_int;
     // ---- pipelined evaluation
     pub fn ksched_pipe_create(ctx: *mut ksched_ctx, depth: u32, out: *mut *mut ksched_pipe) -> c_int;
     pub fn ksched_pipe_destroy(pipe: *mut ksched_pipe);
@@ -177,6 +181,7 @@ pub fn symbol_table() -> Vec<(&'static str, usize)> {
         ("ksched_eval_device_pitched", ksched_eval_device_pitched as usize),
         ("ksched_mask_pitch", ksched_mask_pitch as usize),
         ("ksched_pick_device", ksched_pick_device as usize),
+        ("ksched_pick", ksched_pick as usize),
         ("ksched_pipe_create", ksched_pipe_create as usize),
         ("ksched_pipe_destroy", ksched_pipe_destroy as usize),
         ("ksched_pipe_submit", ksched_pipe_submit as usize),

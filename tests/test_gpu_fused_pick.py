@@ -323,6 +323,7 @@ def test_pipe_k_streams_on_a_share_of_the_chip_equals_oracle(evaluator, k, cus, 
     try:
         masks = [ev.alloc_mask(c.P) for _ in range(depth)]
         outs = [torch.full((c.P,), -7, dtype=torch.int32, device=dev) for _ in range(depth)]
+        torch.cuda.synchronize()  # (the fills run on torch's stream; the pipe's streams are non-blocking ones and are not ordered behind it)
         assert pipe.slot_stream(0) is None
         for j in range(steps):
             slot = j % depth

@@ -107,6 +107,49 @@ def test_more_than_32_selector_keys_in_one_batch(tmp_path):
     assert 0 < np.unpackbits(feas.view(np.uint8)).sum() < np.unpackbits(fit.view(np.uint8)).sum()
 
 
+def test_a_pod_with_forty_selector_keys_equals_the_object_level_oracle(tmp_path):
+    """the reference walks any selector map (src/predicates.rs:48-53); the device takes 32 label columns per call.  A pod
+    with 40 (and 41, and 65) keys is evaluated group by group and the groups' masks ANDed: same masks as the object-level oracle, and the
+    reconciler schedules it (first feasible draw of the ANDed row) instead of refusing it."""
+    c = synth.make_cluster(P=48, N=90, n_keys=4, n_taints=0, seed=0x40E1)
+    pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()
+    for i, n in enumerate(nodes):
+        lab = n["metadata"].setdefault("labels", {})
+        for k in range(70):
+            if (i * 3 + k) % 11:          # most nodes carry most keys ...
+                lab[f"wide{k:02d}"] = "v" if (i + k) % 29 else "w"  # ... with a sprinkling of other values
+    for i in (5, 6, 7, 20, 33):
+        for k in range(70):
+            nodes[i]["metadata"]["labels"][f"wide{k:02d}"] = "v"  # a few nodes match everything
+    wide = {f"wide{k:02d}": "v" for k in range(40)}
+    pods[2]["spec"]["nodeSelector"] = dict(wide)
+    pods[11]["spec"]["nodeSelector"] = dict(wide, **{"wide40": "v"})                      # 41 keys
+    pods[12]["spec"]["nodeSelector"] = {f"wide{k:02d}": "v" for k in range(65)}           # three groups
+    pods[30]["spec"]["nodeSelector"] = dict(wide, **{"wide39": "nobody"})                 # never matches
+    pods[31]["spec"]["nodeSelector"] = dict(wide, **(pods[31]["spec"].get("nodeSelector") or {}))  # wide + its ordinary keys
+    path = tmp_path / "objs.json"
+    write_objects(path, pods, nodes, bound)
+    got = tool("masks", path)
+    W = (c.N + 63) // 64
+    feas, fit = expect_masks(pods, nodes, bound, False, cache=True)
+    assert np.array_equal(unhex(got["fit"], W), fit)
+    assert np.array_equal(unhex(got["feasible"], W), feas)
+    bits = lambda r: int(np.unpackbits(feas[r].view(np.uint8)).sum())  # noqa: E731
+    assert 0 < bits(2) <= 5 and 0 < bits(12) <= 5 and bits(30) == 0
+    # ... and through the reconciler: outcomes == the oracle's restatement of the batched reference execution, POST by POST
+    got = tool("batch", path, 77)
+    want, posted = R.reconcile_batch(pods, list(reversed(nodes)), bound, R.SplitMixChooser(77), fail_every=0)  # (the tool's store order is reversed canonical)
+    assert [(o["ok"], o["error"], o["bound_to"]) for o in got["outcomes"]] == [(o["ok"], o["error"], o["bound_to"]) for o in want]
+    assert [tuple(x) for x in got["posted"]] == posted
+    names = [n["metadata"]["name"] for n in nodes]
+    for i in (2, 11, 12, 31):
+        b = got["outcomes"][i]["bound_to"]
+        if b:
+            j = names.index(b)
+            assert (feas[i, j // 64] >> np.uint64(j % 64)) & np.uint64(1), "a wide pod is bound to a node its ANDed mask allows"
+    assert not got["outcomes"][30]["bound_to"]
+
+
 def small_cluster(seed, P=60, N=12, tight=False):
     c = synth.make_cluster(P=P, N=N, n_keys=4, n_taints=0, seed=seed, binary_suffixes=True)
     pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()

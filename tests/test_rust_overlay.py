@@ -190,7 +190,12 @@ def test_the_batched_pick_is_wired_into_the_running_binary(tmp_path):
     assert '#[cfg(feature = "ksched")]\nasync fn select_node_for_pod(pod: &Arc<corev1::Pod>, ctx: &Context) -> Option<corev1::Node>' in main_rs
     assert strip_rust(main_rs).count("select_node_for_pod(&pod, &ctx).await") == 1 and "select_node_for_pod(&pod, &ctx).await" in ref_main
     # the batch task: ready_chunks -> one device call per batch -> replies; spawned from main(); the pod watch too
-    for needle in ("work.ready_chunks(MAX_BATCH)", "state.pick_batch(&mut devices, &nodes_b, &pods, &draws, ATTEMPTS)", "tokio::task::spawn_blocking",
+    for needle in ("work.ready_chunks(MAX_BATCH)", "state.pick_batch(&mut devices, &nodes_b, &pods_b, &draws, ATTEMPTS, want_rejected)", "tokio::task::spawn_blocking",
+                   # the reference's WARN line for every rejected candidate (src/main.rs:62), asked of the device only when the level is on
+                   "let want_rejected = tracing::enabled!(tracing::Level::WARN);",
+                   'warn!("Node {} failed validity check for pod {}: {:?}", nodes[index].name_any(), full_name(pods[i].deref()), reason);',
+                   # at most MAX_BATCH pods per device call, whatever piled up while the watch was syncing
+                   "let rest = waiting.split_off(waiting.len().min(MAX_BATCH));",
                    "tokio::spawn(run_pick_batches(work, node_store.clone(), devices));",
                    "tokio::spawn(watch_bound_pods(client.clone(), picker.clone()));", "watcher::Event::Applied(pod)", "watcher::Event::Deleted(pod)",
                    "watcher::Event::Restarted(pods)", "ctx.picker.unbounded_send(Work::Pick(pod.clone(), reply))",
@@ -211,6 +216,16 @@ def test_the_batched_pick_is_wired_into_the_running_binary(tmp_path):
     for item in ("pub fn pick_batch(", "pub fn observe(", "pub fn resync(", "pub fn is_synced(", "pub fn counted_pods(", "pub enum PodEvent", "pub struct ClusterState",
                  "pub enum ClusterEvent", "pub fn apply(", "pub struct Devices", "pub fn from_env(", "pub fn pick_sampled("):
         assert item in ksched_rs, item
+    # the reference's own format string, character for character
+    assert 'warn!("Node {} failed validity check for pod {}: {:?}", candidate.name_any(), full_name(pod), e);' in ref_main
+    # a pod with more selector keys than one device call takes is evaluated group by group, never refused (src/predicates.rs:48-53 has no limit)
+    pick = ksched_rs[ksched_rs.index("pub fn pick_batch("):]
+    assert "cannot be scheduled: {} nodeSelector keys" not in ksched_rs
+    for needle in ("entries.chunks(sys::KSCHED_MAX_KEYS as usize)", "feasible[w] &= f[w];", "devices.pick_from_masks(1, &feasible, &req_mem, &samples, attempts)",
+                   "devices.explain(&cols, &pair_pod, &pair_node)", "crate::predicates::reason_of(reasons[k])"):
+        assert needle in pick, needle
+    pred = (out / "src" / "predicates.rs").read_text()
+    assert '#[cfg(feature = "ksched")]\npub fn reason_of(code: i32) -> Result<(), InvalidNodeReason>' in pred
     for call in re.findall(r"\bksched::(\w+)", main_rs):
         assert re.search(r"pub (?:struct|enum|fn|type) %s\b" % call, ksched_rs), call
 

@@ -53,6 +53,8 @@ def kernels(asm: str):
     meta = {}
     for m in re.finditer(r"\.name:\s+(_ZN6ksched12k_eval_fused\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", asm):
         meta[m.group(1)] = {"vgpr_spill": int(m.group(2))}
+    for m in re.finditer(r"\.name:\s+(_ZN6ksched12k_eval_fused\S+)\n(?:.*\n)*?\s+\.sgpr_count:\s+(\d+)\n\s+\.sgpr_spill_count:\s+(\d+)", asm):
+        meta.setdefault(m.group(1), {}).update(sgpr=int(m.group(2)), sgpr_spill=int(m.group(3)))
     for m in re.finditer(r"\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.symbol:\s+(_ZN6ksched12k_eval_fused\S+)\.kd", asm):
         meta.setdefault(m.group(2), {})["scratch"] = int(m.group(1))
     for m in re.finditer(r"^(_ZN6ksched12k_eval_fused\S+):.*?\n(.*?)\n\s+s_endpgm", asm, re.S | re.M):
@@ -136,6 +138,16 @@ def audit_kernel(name: str, lines: list[str], meta: dict) -> list[str]:
     return errs
 
 
+def scalar_side(lines: list[str], meta: dict) -> dict:
+    """what the scalar side of an instantiation costs -- SGPRs the back end parked in VGPR lanes (sgpr_spill_count), and how many
+    v_readlane / v_writelane instructions sit INSIDE the round loop (everything from the Depth=1 loop header on; the prologue's run once)."""
+    hdr = next((i for i, ln in enumerate(lines) if "Loop Header: Depth=1" in ln), len(lines))
+    body = [ln.split(";")[0] for ln in lines[hdr:]]
+    return {"sgpr_count": meta.get("sgpr"), "sgpr_spill_count": meta.get("sgpr_spill"), "instructions": sum(1 for ln in lines if re.match(r"\s+[sv]_|\s+(ds|global|buffer|scratch)_", ln)),
+            "loop_readlane": sum("v_readlane_b32" in ln for ln in body), "loop_writelane": sum("v_writelane_b32" in ln for ln in body),
+            "prologue_readlane": sum("v_readlane_b32" in ln for ln in lines[:hdr]), "prologue_writelane": sum("v_writelane_b32" in ln for ln in lines[:hdr])}
+
+
 def audit_kernarg_warm(asm: str) -> list[str]:
     """csrc/kernarg.hpp: the hot kernels open with ONE group of scalar loads that touches every 64-byte line of the kernarg segment
     (s_load_dword at 0x0, 0x40, ... inside one asm statement, one wait) ahead of the first branch."""
@@ -199,6 +211,7 @@ def audit_bestfit_loads(asm: str) -> list[str]:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--keep", default=None)
+    ap.add_argument("--scalar-report", action="store_true", help="per instantiation: SGPR spills and the v_readlane / v_writelane count inside the round loop (reported, not gated)")
     args = ap.parse_args()
     wd = args.keep or tempfile.mkdtemp(prefix="ksched_audit_")
     os.makedirs(wd, exist_ok=True)
@@ -212,6 +225,10 @@ def main() -> int:
         if errs:
             bad += 1
             print(f"FAIL {tag}: " + "; ".join(errs[:4]))
+        if args.scalar_report:
+            sc = scalar_side(lines, meta)
+            print(f"scalar {tag:34s} sgprs {sc['sgpr_count']:>3} spilled {sc['sgpr_spill_count']:>3}  round loop: {sc['loop_readlane']:>3} v_readlane {sc['loop_writelane']:>3} v_writelane"
+                  f"  prologue: {sc['prologue_readlane']:>3} / {sc['prologue_writelane']:>3}  ({sc['instructions']} instructions)")
     kw = audit_kernarg_warm(asm)
     for e in kw:
         print("FAIL kernarg warm-up:", e)

@@ -10,13 +10,15 @@ from bench import WORKLOADS
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="C3"); ap.add_argument("--pods", type=int, default=None)
+ap.add_argument("--rotate", type=int, default=1, help="cycle over this many different pod batches AND mask buffers before the traced launch (the bench's form: operands and outputs cold)")
 ap.add_argument("--profile", action="store_true", help="library built with -DKSCHED_PROFILE=1: trace words 1..4 are wave 0's cycle totals");
 ap.add_argument("--pick", action="store_true", help="with the sampled pick riding in the launch (KSCHED_OPT_FUSED_PICK)"); ap.add_argument("--debug", type=int, default=0); ap.add_argument("--packed", action="store_true"); ap.add_argument("--nodes", type=int, default=None); ap.add_argument("--kill", type=int, default=0, help="make the last K nodes infeasible")
 a = ap.parse_args()
 cfg, P, N, flag_names, pick, desc = WORKLOADS[a.workload]
 P = a.pods or P
 N = a.nodes or N
-c = synth.make_config(cfg, P=P, N=N)
+B = max(1, a.rotate)
+c = synth.make_config(cfg, P=P * B, N=N)
 flags = sum(getattr(L, f) for f in flag_names)
 if a.kill:
     c.avail_cpu[-a.kill:] = -1
@@ -25,19 +27,25 @@ dev = torch.device("cuda:0")
 ev = Evaluator(0); ev.set_kernel("fused"); ev.set_nodes(**c.node_columns())
 if a.debug: ev.set_option(L.OPT_DEBUG, a.debug)
 t = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x).view(dt)).to(dev)
-d_cpu, d_mem = t(c.req_cpu, np.int64), t(c.req_mem, np.int64)
-d_sel = t(c.pod_sel, np.int32) if c.n_keys else None
-d_tol = t(c.pod_tol, np.int64) if "TAINT" in flag_names else None
-mask = ev.alloc_mask(P, pitched=not a.packed)
-d_smp = d_out = None
+bt = []
+for b in range(B):
+    r = slice(b * P, (b + 1) * P)
+    bt.append((t(c.req_cpu[r], np.int64), t(c.req_mem[r], np.int64), t(c.pod_sel[:, r], np.int32) if c.n_keys else None,
+               t(c.pod_tol[r], np.int64) if "TAINT" in flag_names else None, t(c.samples[r], np.int32) if a.pick else None))
+masks = [ev.alloc_mask(P, pitched=not a.packed) for _ in range(B)]
+d_out = None
 if a.pick:
     flags |= L.PICK_SAMPLED
-    d_smp = t(c.samples, np.int32); d_out = torch.empty((P,), dtype=torch.int32, device=dev)
-for i in range(5):
-    ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=mask, out_binding=d_out)
+    d_out = torch.empty((P,), dtype=torch.int32, device=dev)
+def launch(i):
+    d_cpu, d_mem, d_sel, d_tol, d_smp = bt[i % B]
+    ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=masks[i % B], out_binding=d_out)
+for i in range(5 * B):
+    launch(i)
 torch.cuda.synchronize()
 ev.set_option(L.OPT_TRACE, 1)
-ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=mask, out_binding=d_out)
+for i in range(5 * B, 6 * B + 1):  # (every launch is traced; the buffer keeps the last one: a launch in the middle of the rotation)
+    launch(i)
 torch.cuda.synchronize()
 tr = ev.trace_read()
 live = tr[:, 0] > 0
