@@ -50,9 +50,15 @@
 // uses the defaults below, chosen from the measurements under profiles/):
 //   KSCHED_STORE_POLICY  mask stores: 0 = plain (write-back L2), 1 = nt, 2 = sc1 (write-through: no dirty lines are
 //                        left for the end-of-kernel L2 flush), 3 = sc0 sc1, 4 = sc1 nt, 5 = sc0 sc1 nt
+//                        Shipped: 5.  Rounds 1 - 4 shipped 2, chosen with ONE mask buffer rewritten in place (the Infinity Cache absorbing part of
+//                        the stream).  With the outputs rotated over more than the cache AND fresh inputs every step (round 5: what a scheduler does)
+//                        the non-temporal write-through forms win everywhere -- the mask is never read again by this kernel, and lines that do not
+//                        linger in the caches leave them to the operands and the tile index: C3 20.1 -> 18.4 us per step, the C4 shard 42.5 -> 38.1,
+//                        the C5 shard 220 -> 196 (sessions r5g, r5h: profiles/r05_r5h_store_policy.txt; 4 and 5 within noise of each other except at
+//                        the C5 shard, where 5 is 2 - 3 % ahead); in place nothing changes (19.9 - 20.5 us either way).
 //   KSCHED_FUSED_THREADS threads per block (waves x 64)
 #ifndef KSCHED_STORE_POLICY
-#define KSCHED_STORE_POLICY 2
+#define KSCHED_STORE_POLICY 5
 #endif
 #ifndef KSCHED_FUSED_THREADS
 #define KSCHED_FUSED_THREADS 1024

@@ -400,3 +400,4 @@ def test_alternate_scheduler_refuses_a_request_the_pipe_runs_in_split_mode(evalu
         ev.set_option(_lib.OPT_PICK_FROM_MASK, 0)
         ev.set_option(_lib.OPT_PIPE_MODE, 0)
         comm.close()
+

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Randomised differential test of the HIP path against the oracle (GPU box): random shapes, key counts and cardinalities (incl.
 list keys and > 8 keys), taints, predicate subsets, both picks, snapshot updates between evaluations, both kernels, per-pair reasons (ksched_explain),
-the two halves of ksched_eval over 1 .. 5 row shards (ksched_shard_bounds / ksched_eval_begin / ksched_eval_end).
+the two halves of ksched_eval over 1 .. 5 row shards (ksched_shard_bounds / ksched_eval_begin / ksched_eval_end) and -- with the test hooks on
+(KSCHED_TEST_HOOKS=1 KSCHED_RCCL_LIB=tests/cpp/libfake_rccl.so) -- the whole multi-device sequence over 2 .. 4 evaluators on the one GPU:
+ksched_comm_create_local, ksched_eval_begin on every replica, ksched_gather_buffer, ksched_allgather_bindings_local, ksched_eval_end(gathered_0).
 usage: python tools/fuzz_parity.py [seconds] [seed]       prints one line per failure and a summary; exit code 1 on any failure"""
 import os, sys, time
 import numpy as np
@@ -13,6 +15,9 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ev = Evaluator(0)
+# the multi-device sequence with n > 1 needs the TEST-ONLY librccl stand-in (one GPU stands for n ranks): replicas + one clique per n, made on first use
+HOOKS = os.environ.get("KSCHED_TEST_HOOKS") == "1" and bool(os.environ.get("KSCHED_RCCL_LIB"))
+replicas, cliques = [], {}
 t_end = time.time() + budget
 cases = fails = 0
 picks = {}
@@ -126,6 +131,71 @@ while time.time() < t_end:
                 fails += 1
                 print(f"FAIL sharded halves case seed {cs}: N={N} P={P} K={K} nt={nt} flags={flags:#x} shards={n_sh}", flush=True)
             picks["sharded-halves"] = picks.get("sharded-halves", 0) + 1
+        if HOOKS and pick and r.random() < 0.35:
+            import ctypes as C
+            n_sh = int(r.choice([2, 3, 4]))
+            while len(replicas) < n_sh:
+                replicas.append(Evaluator(0))
+            reps = replicas[:n_sh]
+            lib = ev._lib
+            if n_sh not in cliques:
+                ctxs = (C.c_void_p * n_sh)(*[e._h for e in reps])
+                comms = (C.c_void_p * n_sh)()
+                rcode = lib.ksched_comm_create_local(ctxs, n_sh, comms)
+                if rcode != 0:
+                    raise L.KschedError(rcode, "ksched_comm_create_local", lib.ksched_comm_last_error().decode())
+                cliques[n_sh] = comms
+            comms = cliques[n_sh]
+            for e in reps:  # the snapshot is replicated (the current values: the updates above are in cpu / mem)
+                e.set_option(L.OPT_BESTFIT_STAGES, int(r.choice([0, 1, 2])))
+                e.set_nodes(cpu, mem, lab, taints)
+            W = ev.W
+            lo_, hi_, cpr_ = C.c_uint32(), C.c_uint32(), C.c_uint32()
+            rc_c, rm_c = np.ascontiguousarray(rc), np.ascontiguousarray(rm)
+            sel_c = np.ascontiguousarray(sel) if K else None
+            tol_c = np.ascontiguousarray(tol) if (preds & L.TAINT) else None
+            smp_c = np.ascontiguousarray(smp)
+            feas_s, fit_s = np.zeros((P, W), dtype=np.uint64), np.zeros((P, W), dtype=np.uint64)
+            local, gathered, streams = (C.c_void_p * n_sh)(), (C.c_void_p * n_sh)(), (C.c_void_p * n_sh)()
+            lib.ksched_shard_bounds(P, n_sh, 0, C.byref(lo_), C.byref(hi_), C.byref(cpr_))
+            cpr = cpr_.value
+            for rank, e in enumerate(reps):
+                lib.ksched_shard_bounds(P, n_sh, rank, C.byref(lo_), C.byref(hi_), C.byref(cpr_))
+                lo, hi = lo_.value, hi_.value
+                dev_b, stream = C.c_void_p(), C.c_void_p()
+                rcode = lib.ksched_eval_begin(
+                    e._h, hi - lo, C.c_void_p(rc_c.ctypes.data + 8 * lo), C.c_void_p(rm_c.ctypes.data + 8 * lo),
+                    C.c_void_p(sel_c.ctypes.data + 4 * lo) if K else None, P, C.c_void_p(tol_c.ctypes.data + 8 * lo) if tol_c is not None else None,
+                    C.c_void_p(smp_c.ctypes.data + 20 * lo) if pick == L.PICK_SAMPLED else None, 5 if pick == L.PICK_SAMPLED else 0, flags,
+                    C.c_void_p(feas_s.ctypes.data + 8 * W * lo), C.c_void_p(fit_s.ctypes.data + 8 * W * lo) if flags & L.WANT_FIT_MASK else None, cpr,
+                    C.byref(dev_b), C.byref(stream))
+                if rcode != 0:
+                    raise L.KschedError(rcode, "ksched_eval_begin", lib.ksched_last_error(e._h).decode())
+                local[rank], streams[rank] = dev_b.value, stream.value
+                g = C.c_void_p()
+                rcode = lib.ksched_gather_buffer(e._h, n_sh * cpr, C.byref(g))
+                if rcode != 0:
+                    raise L.KschedError(rcode, "ksched_gather_buffer", lib.ksched_last_error(e._h).decode())
+                gathered[rank] = g.value
+            rcode = lib.ksched_allgather_bindings_local(comms, n_sh, local, gathered, cpr, streams)
+            if rcode != 0:
+                raise L.KschedError(rcode, "ksched_allgather_bindings_local", lib.ksched_comm_last_error().decode())
+            table = np.full((n_sh * cpr,), 555, dtype=np.int32)
+            for rank, e in enumerate(reps):
+                rcode = lib.ksched_eval_end(e._h, C.c_void_p(gathered[0]) if rank == 0 else None, n_sh * cpr if rank == 0 else 0,
+                                            table.ctypes.data_as(C.c_void_p) if rank == 0 else None)
+                if rcode != 0:
+                    raise L.KschedError(rcode, "ksched_eval_end", lib.ksched_last_error(e._h).decode())
+            bind_s = np.full((P,), 777, dtype=np.int32)
+            pad_ok = True
+            for rank in range(n_sh):
+                lib.ksched_shard_bounds(P, n_sh, rank, C.byref(lo_), C.byref(hi_), C.byref(cpr_))
+                bind_s[lo_.value:hi_.value] = table[rank * cpr: rank * cpr + hi_.value - lo_.value]
+                pad_ok = pad_ok and bool((table[rank * cpr + hi_.value - lo_.value: (rank + 1) * cpr] == -1).all())
+            if not (pad_ok and np.array_equal(feas_s, want[0]) and (not (flags & L.WANT_FIT_MASK) or np.array_equal(fit_s, want[1])) and np.array_equal(bind_s, want[2])):
+                fails += 1
+                print(f"FAIL multi-device sequence case seed {cs}: N={N} P={P} K={K} nt={nt} flags={flags:#x} replicas={n_sh}", flush=True)
+            picks[f"gathered-over-{n_sh}"] = picks.get(f"gathered-over-{n_sh}", 0) + 1
         if r.random() < 0.3:  # ksched_explain on random pairs == the reason rebuilt from three single-predicate oracle masks
             from kube_scheduler_rs_reference_amd.evaluator import unpack_mask
             one = lambda f: unpack_mask(capi.eval_encoded(cpu, mem, lab, taints, rc, rm, sel, tol, None, f)[0], N)  # noqa: E731
