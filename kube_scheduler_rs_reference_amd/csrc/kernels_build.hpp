@@ -452,9 +452,11 @@ __global__ __launch_bounds__(1024) void k_sort_runs(const SortArgs a) {
 __global__ __launch_bounds__(256) void k_merge_pass(const SortArgs a) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.n) return;
-    const uint32_t span = 2u * a.run, base = (g / span) * span, off = g - base;
+    // (64-bit span arithmetic: 2 * run and base + span must not wrap for n beyond 2^31 -- ADVICE r4; the host side also refuses such an n)
+    const uint64_t span = 2ull * a.run;
+    const uint32_t base = (uint32_t)(((uint64_t)g / span) * span), off = g - base;
     const bool in_a = off < a.run;
-    const uint32_t b_lo = min(a.n, base + a.run), b_hi = (uint32_t)min((uint64_t)a.n, (uint64_t)base + span);
+    const uint32_t b_lo = (uint32_t)min((uint64_t)a.n, (uint64_t)base + a.run), b_hi = (uint32_t)min((uint64_t)a.n, (uint64_t)base + span);
     const uint32_t s_lo = in_a ? b_lo : base, s_hi = in_a ? b_hi : b_lo;  // the sibling run
     const int64_t m0 = a.k0_in[g], m1 = a.k1_in ? a.k1_in[g] : 0;
     const uint32_t mi = a.idx_in[g];

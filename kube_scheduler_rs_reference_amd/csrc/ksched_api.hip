@@ -446,6 +446,10 @@ int build_bestfit(ksched_ctx *c) {
         HIPCHK(c, c->srt_idx[b].reserve(n));
     }
     auto device_sort = [&](const int64_t *k0, const int64_t *k1, int64_t *dst_k0, uint32_t *dst_idx) -> int {
+        if (n > (1u << 31)) {  // (the merge passes index records with 32 bits; no snapshot of that size fits a GPU's memory anyway)
+            c->last_error = "best-fit structures: more than 2^31 nodes";
+            return KSCHED_E_INVAL;
+        }
         uint32_t passes = 0;
         for (uint64_t run = 1024; run < n; run <<= 1) ++passes;
         // buffer of pass i's output: the destination arrays for the last one, the ping-pong sets before it

@@ -812,3 +812,30 @@ def test_eval_in_two_halves_equals_ksched_eval(evaluator):
     assert lib.ksched_gather_buffer(h, 4096, C.byref(g)) == 0 and g.value
     g2 = C.c_void_p()
     assert lib.ksched_gather_buffer(h, 100, C.byref(g2)) == 0 and g2.value == g.value  # grown on demand, reused
+
+
+@pytest.mark.parametrize("N,distinct", [(1025, 3), (2049, 7), (3001, 7), (5000, 2), (4097, 4097)])
+def test_bestfit_orders_with_ragged_sizes_and_duplicate_keys(evaluator, N, distinct):
+    """the best-fit structures' two orders come from the hand-written merge sort (k_sort_runs + k_merge_pass).  Node counts that are not
+    a multiple of a run (1024) and `available` columns with only a handful of distinct values -- long runs of equal (mem, cpu) keys, ordered by the
+    node index alone -- must give the oracle's best-fit binding for every pod (the tie-break IS the order), one stage and two stages."""
+    from kube_scheduler_rs_reference_amd import PICK_BESTFIT
+    ev = evaluator
+    r = np.random.default_rng(N * 31 + distinct)
+    vals_c = r.integers(500, 9000, distinct).astype(np.int64)
+    vals_m = r.integers(1 << 20, 1 << 34, distinct).astype(np.int64)
+    pick = r.integers(0, distinct, N)
+    cpu, mem = vals_c[pick], vals_m[r.integers(0, distinct, N)]
+    P = 30_000
+    rc = r.integers(100, 9500, P).astype(np.int64)
+    rm = r.integers(1 << 19, 1 << 34, P).astype(np.int64)
+    ev.set_nodes(cpu, mem, None, None)
+    want = capi.eval_encoded(cpu, mem, None, None, rc, rm, None, None, None, FIT | PICK_BESTFIT)
+    try:
+        for stages in (1, 2):
+            ev.set_option(_lib.OPT_BESTFIT_STAGES, stages)
+            got = ev.eval(rc, rm, None, None, None, FIT | PICK_BESTFIT)
+            assert np.array_equal(got.binding, want[2]), stages
+            assert np.array_equal(got.feasible, want[0])
+    finally:
+        ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
