@@ -177,11 +177,21 @@ class SingleRig:
         torch.cuda.synchronize()
         # clock ramp, like the graded loop's: this rig's cluster was just generated on the host (seconds of an idle GPU), and a handful of
         # warm-up steps ends long before the clocks are back up (the C5 shard read 175 us per mask kernel here against 141 us in its own run)
+        # (... and a store-bound launch of hundreds of microseconds keeps getting faster for a few hundred ms of sustained load -- the C5 shard's mask
+        # kernel reads 171 us after 170 ms and 141 us after 360 ms, session r5m --: bursts until two in a row agree within 2 %, 60 ms at least, 0.6 s at most)
         t_r = time.perf_counter()
-        while time.perf_counter() - t_r < 0.06:
-            for _ in range(16):
+        prev = None
+        while True:
+            t_b = time.perf_counter()
+            for _ in range(32):
                 step()
             torch.cuda.synchronize()
+            now = time.perf_counter()
+            burst = now - t_b
+            settled = prev is not None and abs(burst - prev) <= 0.02 * prev
+            prev = burst
+            if (now - t_r >= 0.06 and settled) or now - t_r >= 0.6:
+                break
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
