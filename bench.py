@@ -367,7 +367,12 @@ def main():
             # same seeded cluster on every rank; each takes its rows.  B pod batches of P_total pods each: the generator's streams are
             # prefixes of one another, so batch 0 is exactly the P_total-pod workload and batches 1.. are further pods of the same distribution
             self.B = B = max(1, n_batches or args.input_batches)
-            c = synth.make_config(cfg, P=P_total * B, N=N)
+            self.lo, self.hi, _ = shard_bounds(P_total, world, rank)
+            lo, hi = self.lo, self.hi
+            # (a rank generates only ITS rows of every batch: pods [b * P_total + lo, b * P_total + hi) of the seed's pod sequence, synth pod_offset;
+            # at N = 8 everybody's rows of six batches would be 4.8 M pods and 11 s of host time per rank)
+            self.cs = [synth.make_config(cfg, P=hi - lo, N=N, pod_offset=b * P_total + lo) for b in range(B)]
+            c = self.cs[0]
             self.c = c
             flags = sum(getattr(L, f) for f in flag_names)
             flags |= L.PICK_SAMPLED if pick == "sampled" else L.PICK_BESTFIT
@@ -380,23 +385,16 @@ def main():
                 ev.set_option(L.OPT_DEBUG, args.debug)
             ev.set_nodes(**c.node_columns())
             self.ev = ev
-            self.lo, self.hi, _ = shard_bounds(P_total, world, rank)
-            lo, hi = self.lo, self.hi
             t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
             self.batches = []  # per input batch: (req_cpu, req_mem, sel, tol, samples) of THIS rank's rows, resident
-            for b in range(B):
-                r0, r1 = b * P_total + lo, b * P_total + hi
-                self.batches.append((t(c.req_cpu[r0:r1], np.int64), t(c.req_mem[r0:r1], np.int64),
-                                     t(c.pod_sel[:, r0:r1], np.int32) if c.n_keys else None,
-                                     t(c.pod_tol[r0:r1], np.int64) if self.taint else None,
-                                     t(c.samples[r0:r1], np.int32) if pick == "sampled" else None))
+            for cb in self.cs:
+                self.batches.append((t(cb.req_cpu, np.int64), t(cb.req_mem, np.int64),
+                                     t(cb.pod_sel, np.int32) if cb.n_keys else None,
+                                     t(cb.pod_tol, np.int64) if self.taint else None,
+                                     t(cb.samples, np.int32) if pick == "sampled" else None))
             self.d_cpu, self.d_mem, self.d_sel, self.d_tol, self.d_smp = self.batches[0]
             self.input_bytes = sum(int(x.numel() * x.element_size()) for bt in self.batches for x in bt if x is not None)
             self.comm, self.comm_note = None, None
-
-        def rows(self, b):
-            """numpy rows of input batch b that belong to this rank"""
-            return slice(b * self.P_total + self.lo, b * self.P_total + self.hi)
 
         def make_comm(self):
             """ksched_comm_create: the C ABI's RCCL communicator.  Its creation is collective; if it fails on ANY rank (e.g. no
@@ -630,9 +628,9 @@ def main():
             from oracle import capi
             torch.cuda.synchronize()
             n_loc = hi - lo
-            bsl = rig.rows(loop.last_batch)  # the input batch the last timed step evaluated (this rank's rows of it)
-            b_cpu, b_mem, b_tol, b_smp = c.req_cpu[bsl], c.req_mem[bsl], c.pod_tol[bsl], c.samples[bsl]
-            sel_all = c.pod_sel[:, bsl] if (c.n_keys and "SEL" in flag_names) else None
+            cb = rig.cs[loop.last_batch]  # the input batch the last timed step evaluated (this rank's rows of it)
+            b_cpu, b_mem, b_tol, b_smp = cb.req_cpu, cb.req_mem, cb.pod_tol, cb.samples
+            sel_all = cb.pod_sel if (c.n_keys and "SEL" in flag_names) else None
             o_flags = sum(getattr(capi, f) for f in flag_names) | (capi.PICK_SAMPLED if pick == "sampled" else capi.PICK_BESTFIT)
             oracle_args = dict(avail_cpu=c.avail_cpu, avail_mem=c.avail_mem, label_ids=c.node_labels if sel_all is not None else None,
                                taints=c.node_taints if taint else None)

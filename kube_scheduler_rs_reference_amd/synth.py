@@ -37,11 +37,12 @@ def _mix(z: np.ndarray) -> np.ndarray:
         return z ^ (z >> np.uint64(31))
 
 
-def stream(seed: int, stream_id: int, n: int) -> np.ndarray:
-    """n SplitMix64 outputs of the counter stream (seed, stream_id)."""
+def stream(seed: int, stream_id: int, n: int, start: int = 0) -> np.ndarray:
+    """outputs [start, start + n) of the counter stream (seed, stream_id): SplitMix64 of a counter, so any window of a stream can be made
+    without the outputs before it"""
     with np.errstate(over="ignore"):
         base = _mix(np.array([np.uint64(seed & 0xFFFFFFFFFFFFFFFF)]) * GOLDEN + np.uint64(stream_id))[0]
-        ctr = (np.arange(1, n + 1, dtype=np.uint64) * GOLDEN) + base
+        ctr = (np.arange(start + 1, start + n + 1, dtype=np.uint64) * GOLDEN) + base
     return _mix(ctr)
 
 
@@ -197,10 +198,12 @@ class Cluster:
 
 
 def make_cluster(P: int, N: int, n_keys: int = 8, n_taints: int = 0, seed: int = 0x5EED0000, attempts: int = 5,
-                 binary_suffixes: bool = False, hostname_key: Optional[int] = None) -> Cluster:
+                 binary_suffixes: bool = False, hostname_key: Optional[int] = None, pod_offset: int = 0) -> Cluster:
     """Build the cluster of SURVEY.md section 8d for P pending pods and N nodes.
     hostname_key = k: label key k is kubernetes.io/hostname-like -- every node carries its own value (cardinality N), and the pods
-    that constrain it (same 15 %) each name one node."""
+    that constrain it (same 15 %) each name one node.
+    pod_offset = o: the pods are pods [o, o + P) of the (unbounded) pod sequence of this seed -- the same pods a cluster of o + P pods holds in
+    rows [o, o + P) -- so a rank can make ITS rows of the b-th batch without generating everybody's (bench.py: input batches, pod-row shards)."""
     if not (0 <= n_keys <= len(KEY_CARDINALITY)):
         raise ValueError("n_keys must be 0..16")
     if not (0 <= n_taints <= 64):
@@ -247,17 +250,18 @@ def make_cluster(P: int, N: int, n_keys: int = 8, n_taints: int = 0, seed: int =
         c.node_taints |= (_bern(S(100 + t, N), 0.05).astype(np.uint64) << np.uint64(t))
 
     # ---- pods ----------------------------------------------------------------------------------
-    c.pod_ncont = 1 + _below(S(200, P), 3)
-    c.pod_has_req = ~_bern(S(201, P), 0.05)
+    SP = lambda sid, n: stream(seed, sid, n, start=pod_offset)  # noqa: E731
+    c.pod_ncont = 1 + _below(SP(200, P), 3)
+    c.pod_has_req = ~_bern(SP(201, P), 0.05)
     c.cont_cpu = np.zeros((P, 3), dtype=np.int64)
     c.cont_mem = np.zeros((P, 3), dtype=np.int64)
     for j in range(3):
         live = (c.pod_ncont > j) & c.pod_has_req
         # log-uniform by octave: cpu 50m..4000m per pod, memory 64 MiB..16 GiB per pod, split over containers
-        oc = _below(S(210 + j, P), 7)
-        cpu = np.minimum(50 * (1 << oc) + _below(S(220 + j, P), 1 << 30) % (50 * (1 << oc)), 4000)
-        om = _below(S(230 + j, P), 8)
-        mem = (64 * MIB) * (1 << om) + _below(S(240 + j, P), 1 << 62) % ((64 * MIB) * (1 << om))
+        oc = _below(SP(210 + j, P), 7)
+        cpu = np.minimum(50 * (1 << oc) + _below(SP(220 + j, P), 1 << 30) % (50 * (1 << oc)), 4000)
+        om = _below(SP(230 + j, P), 8)
+        mem = (64 * MIB) * (1 << om) + _below(SP(240 + j, P), 1 << 62) % ((64 * MIB) * (1 << om))
         c.cont_cpu[:, j] = np.where(live, np.maximum(cpu // c.pod_ncont, 1), 0)
         c.cont_mem[:, j] = np.where(live, np.maximum(mem // c.pod_ncont, 1), 0)
     c.req_cpu = c.cont_cpu.sum(axis=1)
@@ -265,15 +269,15 @@ def make_cluster(P: int, N: int, n_keys: int = 8, n_taints: int = 0, seed: int =
 
     c.pod_sel = np.zeros((n_keys, P), dtype=np.uint32)
     for k in range(n_keys):
-        con = _bern(S(300 + k, P), 0.15)
-        val = 1 + _below(S(320 + k, P), N if (hostname_key is not None and k == hostname_key and N > 0) else KEY_CARDINALITY[k])
-        never = _bern(S(340 + k, P), 0.01)
+        con = _bern(SP(300 + k, P), 0.15)
+        val = 1 + _below(SP(320 + k, P), N if (hostname_key is not None and k == hostname_key and N > 0) else KEY_CARDINALITY[k])
+        never = _bern(SP(340 + k, P), 0.01)
         c.pod_sel[k] = np.where(con, np.where(never, SEL_NEVER, val), 0).astype(np.uint32)
     c.pod_tol = np.zeros(P, dtype=np.uint64)
     for t in range(n_taints):
-        c.pod_tol |= (_bern(S(400 + t, P), 0.3).astype(np.uint64) << np.uint64(t))
+        c.pod_tol |= (_bern(SP(400 + t, P), 0.3).astype(np.uint64) << np.uint64(t))
     if N > 0:
-        c.samples = _below(S(500, P * attempts), N).astype(np.uint32).reshape(P, attempts)
+        c.samples = _below(stream(seed, 500, P * attempts, start=pod_offset * attempts), N).astype(np.uint32).reshape(P, attempts)
     else:
         c.samples = np.zeros((P, attempts), dtype=np.uint32)
     return c
@@ -292,8 +296,8 @@ CONFIGS: Dict[str, dict] = {
 }
 
 
-def make_config(name: str, P: Optional[int] = None, N: Optional[int] = None) -> Cluster:
+def make_config(name: str, P: Optional[int] = None, N: Optional[int] = None, pod_offset: int = 0) -> Cluster:
     cfg = CONFIGS[name]
     idx = list(CONFIGS).index(name)
     return make_cluster(P if P is not None else cfg["P"], N if N is not None else cfg["N"], n_keys=cfg["n_keys"],
-                        n_taints=cfg["n_taints"], seed=0x5EED0000 + idx, hostname_key=cfg.get("hostname_key"))
+                        n_taints=cfg["n_taints"], seed=0x5EED0000 + idx, hostname_key=cfg.get("hostname_key"), pod_offset=pod_offset)

@@ -38,3 +38,25 @@ def test_world_size_that_contradicts_gpus_is_an_error():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2 != --gpus 4" in (r.stderr + r.stdout)
+
+
+def test_a_rank_generates_only_its_rows_of_every_input_batch():
+    """bench.py's input rotation: rank r's rows of batch b are pods [b * P_total + lo_r, b * P_total + hi_r) of the seed's pod sequence.  The generator's
+    streams are counter-based, so a window of pods (synth pod_offset) equals the same rows of a cluster generated whole: the ranks' pieces tile the
+    batches exactly, and batch 0 at N = 1 is the workload's standard batch."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from kube_scheduler_rs_reference_amd import synth
+    for cfg in ("C3", "C5", "C3h"):
+        whole = synth.make_config(cfg, P=3 * 400, N=257)          # three batches of 400 pods
+        for b in range(3):
+            for lo, hi in ((0, 134), (134, 268), (268, 400)):     # three ranks' shards of a batch
+                part = synth.make_config(cfg, P=hi - lo, N=257, pod_offset=b * 400 + lo)
+                rows = slice(b * 400 + lo, b * 400 + hi)
+                for f in ("req_cpu", "req_mem", "pod_tol", "samples", "pod_ncont", "pod_has_req", "cont_cpu", "cont_mem"):
+                    assert np.array_equal(getattr(whole, f)[rows], getattr(part, f)), (cfg, b, lo, f)
+                assert np.array_equal(whole.pod_sel[:, rows], part.pod_sel)
+                assert np.array_equal(whole.avail_cpu, part.avail_cpu) and np.array_equal(whole.avail_mem, part.avail_mem)
+                assert np.array_equal(whole.node_labels, part.node_labels) and np.array_equal(whole.node_taints, part.node_taints)
+        std = synth.make_config(cfg, P=400, N=257)
+        assert np.array_equal(std.req_cpu, whole.req_cpu[:400]) and np.array_equal(std.samples, whole.samples[:400])
