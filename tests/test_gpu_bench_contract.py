@@ -37,6 +37,9 @@ def test_default_line_contract(built):
     assert r["algorithmic_bytes_per_launch"] == 100_000 * (48 + 20) + 5_000 * 48 + 100_000 * 79 * 8 + 100_000 * 4
     assert c["mask_rotation"] >= 5 and c["mask_rotation_bytes"] > 256 * 2**20, "the timed loop must not rewrite a mask the Infinity Cache still holds"
     assert d["ramp_steps"] >= 16 and d["untimed_steps_before_timed_region"] == d["warmup"] + d["ramp_steps"]
+    # ... nor evaluate a pod batch whose operands the previous step left in L2: six different resident batches in turn
+    ir = c["input_rotation"]
+    assert ir["batches"] == 6 and ir["bytes_resident"] == 6 * 100_000 * 68 > 8 * 4 * 2**20
     for leg in ("in_place", "two_batches_in_flight"):
         assert c[leg] and "error" not in c[leg] and c[leg]["ms_per_step"] > 0, leg
     assert c["two_batches_in_flight"]["bindings_equal_sequential"] is True
@@ -54,6 +57,7 @@ def test_default_line_contract(built):
     # the run checks what it timed: the last timed step's bindings -- every pod -- and >= 4096 mask rows against the oracle
     pc = d["parity_check"]
     assert pc == c["parity_check"] and pc["mismatches"] == 0 and pc["bindings"] == 100_000 and pc["rows"] >= 4096 and pc["words"] == pc["rows"] * 79, pc
+    assert pc["partial"] is False and pc["bindings_of"] == 100_000 and 0 <= pc["input_batch"] < 6  # (the batch the LAST timed step evaluated is the one checked)
 
 
 def test_a_wrong_result_fails_the_bench(built):
@@ -64,6 +68,25 @@ def test_a_wrong_result_fails_the_bench(built):
     assert r.returncode != 0, "a bench whose kernel skips the rank searches must not pass its self-check"
     line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert line["parity_check"]["mismatches"] > 0 and "self-check FAILED" in r.stderr
+
+
+def test_an_unverified_number_is_not_reported_as_a_good_one(built, tmp_path):
+    """when the checker itself cannot run (here: no oracle library to load) the line says so AND the process exits 3, unless --allow-unchecked."""
+    import shutil
+    fake_root = tmp_path / "repo"
+    fake_root.mkdir()
+    for item in ("bench.py", "kube_scheduler_rs_reference_amd", "profiles"):
+        src = os.path.join(ROOT, item)
+        (shutil.copytree if os.path.isdir(src) else shutil.copy)(src, fake_root / item)
+    (fake_root / "oracle").mkdir()  # an `oracle` package without its library: the checker raises on import
+    (fake_root / "oracle" / "__init__.py").write_text("")
+    args = [sys.executable, str(fake_root / "bench.py"), "--steps", "20", "--warmup", "2", "--ramp-ms", "2", "--kernel-samples", "4", "--no-cpu-baseline", "--no-others", "--repeats", "0"]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3 and "could NOT RUN" in r.stderr, (r.returncode, r.stderr[-800:])
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["parity_check"]["mismatches"] is None and "error" in line["parity_check"]
+    r = subprocess.run(args + ["--allow-unchecked"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0
 
 
 def test_other_workloads_and_bindings_only(built):
