@@ -315,6 +315,26 @@ class Evaluator:
                                           ptr(out_binding), C.c_void_p(stream.cuda_stream))
         self._check(rc, "ksched_pick_device")
 
+    def pick(self, feasible: np.ndarray, flags: int, req_mem_bytes=None, samples=None) -> np.ndarray:
+        """The pick alone from HOST masks (ksched_pick): `feasible` = [p, W] uint64 rows as `eval` returns them (or as a caller has combined
+        them: ANDed masks of a selector evaluated in key groups).  flags: PICK_SAMPLED (+ samples [p, attempts]) or PICK_BESTFIT (+ FIT and
+        req_mem_bytes when the mask includes the resource fit)."""
+        f = np.ascontiguousarray(feasible, dtype=np.uint64)
+        if f.ndim != 2 or f.shape[1] != self.W:
+            raise ValueError(f"feasible must be [p, {self.W}] uint64")
+        p = f.shape[0]
+        mem = _np(req_mem_bytes, np.int64, "req_mem_bytes")
+        smp = _np(samples, np.uint32, "samples")
+        attempts = 0
+        if flags & L.PICK_SAMPLED:
+            if smp is None or smp.ndim != 2 or smp.shape[0] != p:
+                raise ValueError("samples must be [p][attempts]")
+            attempts = smp.shape[1]
+        out = np.empty((p,), dtype=np.int32)
+        rc = self._lib.ksched_pick(self._h, p, _ptr(f), _ptr(mem), _ptr(smp), attempts, flags, _ptr(out))
+        self._check(rc, "ksched_pick")
+        return out
+
     def pipe(self, depth: int = 2) -> "Pipe":
         """A `depth`-slot two-stream pipeline over this evaluator (ksched_pipe_*)."""
         return Pipe(self, depth)

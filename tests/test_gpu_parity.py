@@ -839,3 +839,30 @@ def test_bestfit_orders_with_ragged_sizes_and_duplicate_keys(evaluator, N, disti
             assert np.array_equal(got.feasible, want[0])
     finally:
         ev.set_option(_lib.OPT_BESTFIT_STAGES, 0)
+
+
+@pytest.mark.parametrize("P,N", [(1, 1), (300, 70), (2000, 1500), (40_000, 3000)])
+def test_pick_from_host_masks_equals_the_pick_of_the_evaluation(evaluator, P, N):
+    """ksched_pick (host-pointer twin of ksched_pick_device, new in ABI 5): the sampled and the best-fit pick from masks the HOST holds -- what the
+    mirror uses for a pod whose selector needs more than one call (the groups' masks ANDed on the host, the pick by the device).  From the masks an
+    evaluation returned it must give that evaluation's bindings; from an ANDed pair of masks the bindings of the conjunction (oracle)."""
+    ev = evaluator
+    c = synth.make_cluster(P, N, n_keys=8, n_taints=0, seed=P * 13 + N)
+    ev.set_nodes(**c.node_columns())
+    for pick in (PICK_SAMPLED, PICK_BESTFIT):
+        want = oracle_eval(c, FIT | SEL | pick)
+        got = ev.eval(c.req_cpu, c.req_mem, c.pod_sel, None, c.samples if pick == PICK_SAMPLED else None, FIT | SEL | pick)
+        assert np.array_equal(got.binding, want[2]) and np.array_equal(got.feasible, want[0])
+        again = ev.pick(got.feasible, FIT | SEL | pick, req_mem_bytes=c.req_mem, samples=c.samples if pick == PICK_SAMPLED else None)
+        assert np.array_equal(again, want[2]), pick
+        # the conjunction of two half-selectors: masks of keys 0..3 and of keys 4..7, ANDed on the host
+        lo, hi = c.pod_sel.copy(), c.pod_sel.copy()
+        lo[4:], hi[:4] = 0, 0
+        m_lo = ev.eval(c.req_cpu, c.req_mem, lo, None, None, FIT | SEL).feasible
+        m_hi = ev.eval(c.req_cpu, c.req_mem, hi, None, None, FIT | SEL).feasible
+        both = ev.pick(m_lo & m_hi, FIT | SEL | pick, req_mem_bytes=c.req_mem, samples=c.samples if pick == PICK_SAMPLED else None)
+        assert np.array_equal(m_lo & m_hi, want[0]) and np.array_equal(both, want[2]), pick
+    with pytest.raises(KschedError):
+        ev.pick(np.zeros((P, ev.W), dtype=np.uint64), PICK_SAMPLED | PICK_BESTFIT, samples=c.samples)
+    with pytest.raises(KschedError):
+        ev.pick(np.zeros((P, ev.W), dtype=np.uint64), FIT, samples=c.samples)
