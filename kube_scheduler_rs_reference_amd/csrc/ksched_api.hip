@@ -1469,10 +1469,13 @@ void ksched_pipe_destroy(ksched_pipe *q) try {
 } catch (...) {  // nothing unwinds across the C ABI
 }
 
-void *ksched_pipe_stream(ksched_pipe *q, int which) {
+void *ksched_pipe_stream(ksched_pipe *q, int which) try {
     if (!q || which < 0) return nullptr;
     if (which < 2) return (void *)(which == 0 ? q->s_mask : q->s_pick);
+    std::lock_guard<std::mutex> lk(q->ctx->mu);  // (ksched_pipe_submit grows `extra` under the same lock)
     return (size_t)(which - 2) < q->extra.size() ? (void *)q->extra[(size_t)(which - 2)] : nullptr;
+} catch (...) {
+    return nullptr;
 }
 
 // the stream that carried the slot's latest evaluation in the alternate mode / its pick in the split mode: what a consumer of the
