@@ -122,7 +122,29 @@ void warn_rejected(const std::vector<const corev1::Pod *> &pods, Context &ctx, c
         for (const RejectedCandidate &r : rejected[i]) ctx.warn(rejected_line(*pods[i], r));
 }
 
+const char *debug_name(ReconcileError e) {
+    switch (e) {
+        case ReconcileError::CreateBindingFailed: return "CreateBindingFailed";
+        case ReconcileError::CreateBindingObjectFailed: return "CreateBindingObjectFailed";
+        case ReconcileError::NoNodeFound: return "NoNodeFound";
+    }
+    return "?";
+}
+
 Action error_policy(const corev1::Pod &, ReconcileError) { return Action::RequeueAfter5Min; }  // src/main.rs:122-125
+Action error_policy(const corev1::Pod &pod, ReconcileError error, Context &ctx) {
+    if (ctx.warn) ctx.warn("reconcile failed on pod " + full_name(pod.metadata) + ": " + debug_name(error));  // :123
+    return error_policy(pod, error);
+}
+
+namespace {
+// what the Controller does with a failed reconcile: error_policy (src/main.rs:141-144) -- here for every failed outcome of a batch, in batch order
+void warn_failed(const std::vector<const corev1::Pod *> &pods, const std::vector<ReconcileOutcome> &out, Context &ctx) {
+    if (!ctx.warn) return;
+    for (size_t i = 0; i < pods.size() && i < out.size(); ++i)
+        if (!out[i].ok) (void)error_policy(*pods[i], out[i].error, ctx);
+}
+}  // namespace
 
 namespace {
 
@@ -194,7 +216,9 @@ std::vector<ReconcileOutcome> post_bindings(const std::vector<const corev1::Pod 
 ReconcileOutcome reconcile(const corev1::Pod &pod, Context &ctx, NodeChooser &chooser, BindingSink &sink) {
     if (is_pod_bound(pod)) return ReconcileOutcome{};  // src/main.rs:74-76
     const std::optional<corev1::Node> chosen = select_node_for_pod(pod, ctx, chooser);
-    return bind(pod, chosen ? &*chosen : nullptr, sink);
+    const ReconcileOutcome r = bind(pod, chosen ? &*chosen : nullptr, sink);
+    if (!r.ok) (void)error_policy(pod, r.error, ctx);  // (the Controller's error_policy call: the WARN line of :123)
+    return r;
 }
 
 std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
@@ -237,6 +261,7 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
             if (!ctx.snapshot->device_stale()) ctx.snapshot.reset();
         }
     }
+    warn_failed(pods, out, ctx);
     if (timing) {
         const auto t3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -285,6 +310,7 @@ std::vector<ReconcileOutcome> reconcile_batch_sequential(const std::vector<const
     }
     for (size_t i : pending) out[i] = bind(*pods[i], nullptr, sink);  // still colliding after max_rounds
     if (stats) *stats = st;
+    warn_failed(pods, out, ctx);
     return out;
 }
 

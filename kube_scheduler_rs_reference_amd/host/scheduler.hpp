@@ -84,6 +84,7 @@ void warn_rejected(const std::vector<const corev1::Pod *> &pods, Context &ctx, c
 
 enum class ReconcileError { CreateBindingFailed, CreateBindingObjectFailed, NoNodeFound };  // src/error.rs:5-15
 const char *error_text(ReconcileError e);  // the #[error("...")] strings
+const char *debug_name(ReconcileError e);  // #[derive(Debug)]: the variant's name, as error_policy prints it ("reconcile failed on pod {}: {:?}", src/main.rs:123)
 
 // corev1::Binding as reconcile builds it (src/main.rs:83-91): the pod's metadata, target = node name
 struct Binding {
@@ -144,7 +145,8 @@ struct SequentialStats {
 std::vector<ReconcileOutcome> reconcile_batch_sequential(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
                                                          BindingSink &sink, uint32_t max_rounds = 64, SequentialStats *stats = nullptr);
 
-// src/main.rs:122-125
+// src/main.rs:122-125: the requeue, and -- with a Context whose WARN level is on -- the reference's line "reconcile failed on pod {}: {:?}" (:123)
 Action error_policy(const corev1::Pod &pod, ReconcileError error);
+Action error_policy(const corev1::Pod &pod, ReconcileError error, Context &ctx);
 
 }  // namespace ksched_host

@@ -1074,8 +1074,11 @@ static void gpu_tests() {
             "Node node-b failed validity check for pod test/picky: NodeSelectorMismatch",
             "Node node-b failed validity check for pod test/picky: NodeSelectorMismatch",
         };
-        CHECK(lines == want);
-        if (lines != want)
+        // ... followed by error_policy's line for the reconcile that found no node (src/main.rs:123)
+        std::vector<std::string> with_policy = want;
+        with_policy.push_back("reconcile failed on pod test/picky: NoNodeFound");
+        CHECK(lines == with_policy);
+        if (lines != with_policy)
             for (const auto &l : lines) std::printf("    got: %s\n", l.c_str());
         // the per-pod path of the reference's own shape says the same for the same draws
         std::vector<std::string> one;
