@@ -249,6 +249,18 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
     return out;
 }
 
+std::vector<DeviceCall> device_calls(const std::vector<const corev1::Pod *> &pods) {
+    std::vector<DeviceCall> out;
+    for (const KeyRange &r : key_ranges(pods)) {
+        DeviceCall c;
+        c.lo = r.lo;
+        c.hi = r.hi;
+        if (r.wide) c.groups = split_wide_pod(*pods[r.lo]);
+        out.push_back(std::move(c));
+    }
+    return out;
+}
+
 std::vector<Validity> explain_pairs(const std::vector<const corev1::Pod *> &pods, Context &ctx,
                                     const std::vector<std::pair<uint32_t, uint32_t>> &pairs, bool taints) {
     if (!ctx.snapshot) ctx.refresh_snapshot();

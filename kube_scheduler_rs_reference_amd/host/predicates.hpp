@@ -64,6 +64,16 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
                                         uint32_t pick_flags = 0, const std::vector<uint32_t> *samples = nullptr,
                                         uint32_t attempts = 0, bool want_masks = true);
 
+// How check_node_validity_batch cuts a batch into device evaluations (no device involved: the host-side plan alone, what the CPU tests
+// check).  The device takes KSCHED_MAX_KEYS label columns per call and the reference has no limit on selector keys
+// (src/predicates.rs:48-53): pods [lo, hi) are one call whose distinct selector keys fit the budget; a pod with more keys than one call
+// takes is a call of its own (hi == lo + 1) with `groups` = that pod once per group of at most KSCHED_MAX_KEYS keys, masks ANDed.
+struct DeviceCall {
+    size_t lo = 0, hi = 0;
+    std::vector<corev1::Pod> groups;
+};
+std::vector<DeviceCall> device_calls(const std::vector<const corev1::Pod *> &pods);
+
 // check_node_validity's result for listed (pod, node) pairs, decided pair by pair on the device (ksched_explain): what the
 // reference logs at WARN for every rejected candidate (src/main.rs:62).  Unlike BatchValidity::validity (two masks) this tells a
 // selector failure from a taint failure when the taint extension is on.  pairs[i] = {index into `pods`, CANONICAL node index}.

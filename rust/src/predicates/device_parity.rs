@@ -17,7 +17,7 @@ fn load<T: serde::de::DeserializeOwned>(doc: &serde_json::Value, key: &str) -> V
 fn device_parity() {
     let dir = std::path::PathBuf::from(std::env::var("KSCHED_GOLDEN_DIR").expect("set KSCHED_GOLDEN_DIR to <ksched repo>/tests/golden"));
     let evaluator = crate::ksched::Devices::new(&[0]).expect("ksched_create (needs an MI355X; there is no CPU fallback)");
-    for name in ["c1_100x20", "ragged_70x130_taints", "one_node_33x1", "binsuffix_60x40"] {
+    for name in ["c1_100x20", "ragged_70x130_taints", "one_node_33x1", "binsuffix_60x40", "wide_selectors_48x90"] {
         let text = std::fs::read_to_string(dir.join(format!("{}_objects.json", name))).expect("objects file");
         let doc: serde_json::Value = serde_json::from_str(&text).expect("json");
         let pods: Vec<corev1::Pod> = load(&doc, "pods");

@@ -204,19 +204,34 @@ int main(int argc, char **argv) {
             // the wire-format step alone, no device: objects -> host/quantity.cpp + host/encoder.cpp -> the integer columns of
             // include/ksched.h (Snapshot::kEncodeOnly uploads nothing).  Runs where there is no GPU.
             bool taints = false;
+            bool plan = false;
             size_t batches = 1;  // batches=K: the pods are encoded as K consecutive batches against ONE snapshot (label columns are a per-batch
                                  // working set: a later batch may evict an earlier batch's keys); one JSON document per batch, one per line
             for (int i = 3; i < argc; ++i) {
                 const std::string a = argv[i];
                 if (a == "taints") taints = true;
                 else if (a.rfind("batches=", 0) == 0) batches = std::max<size_t>(1, std::strtoul(a.c_str() + 8, nullptr, 0));
+                else if (a == "plan") plan = true;
             }
             Snapshot snap(Snapshot::kEncodeOnly);
             snap.rebuild(ctx.node_store, lister.get());
             if (taints) snap.enable_taints();
-            const size_t per = (pp.size() + batches - 1) / batches;
-            for (size_t b0 = 0; b0 < pp.size() || b0 == 0; b0 += std::max<size_t>(per, 1)) {
-            const std::vector<const corev1::Pod *> part(pp.begin() + (std::ptrdiff_t)b0, pp.begin() + (std::ptrdiff_t)std::min(pp.size(), b0 + std::max<size_t>(per, 1)));
+            // plan: one document per device evaluation check_node_validity_batch would make (predicates::device_calls: pod ranges within the
+            // budget of label columns; a pod with more selector keys than one call takes once per key group, masks to be ANDed), each
+            // carrying "rows":[lo,hi) -- the host side of wide selectors without a device
+            std::vector<std::pair<std::pair<size_t, size_t>, std::vector<corev1::Pod>>> parts;  // {rows, the group's pods (wide) or empty}
+            if (plan) {
+                for (const predicates::DeviceCall &c : predicates::device_calls(pp)) {
+                    if (c.groups.empty()) parts.push_back({{c.lo, c.hi}, {}});
+                    for (const corev1::Pod &g : c.groups) parts.push_back({{c.lo, c.hi}, {g}});
+                }
+            } else {
+                const size_t per = std::max<size_t>((pp.size() + batches - 1) / batches, 1);
+                for (size_t b0 = 0; b0 < pp.size() || b0 == 0; b0 += per) parts.push_back({{b0, std::min(pp.size(), b0 + per)}, {}});
+            }
+            for (const auto &pt : parts) {
+            std::vector<const corev1::Pod *> part(pp.begin() + (std::ptrdiff_t)pt.first.first, pp.begin() + (std::ptrdiff_t)pt.first.second);
+            if (!pt.second.empty()) part.assign(1, &pt.second[0]);
             const PodColumns pc = snap.encode_pods(part);
             const NodeColumns &nc = snap.columns();
             auto arr64 = [](const char *k, const std::vector<int64_t> &v) {
@@ -234,7 +249,7 @@ int main(int argc, char **argv) {
                 for (size_t i = 0; i < v.size(); ++i) std::printf("%s%u", i ? "," : "", v[i]);
                 std::printf("]");
             };
-            std::printf("{\"p\":%u,\"n\":%u,\"n_keys\":%u,\"pod_keys\":%u,", pc.p, nc.n, nc.n_keys, pc.n_keys);
+            std::printf("{\"p\":%u,\"n\":%u,\"n_keys\":%u,\"pod_keys\":%u,\"rows\":[%zu,%zu],", pc.p, nc.n, nc.n_keys, pc.n_keys, pt.first.first, pt.first.second);
             std::printf("\"names\":[");
             for (uint32_t i = 0; i < nc.n; ++i) std::printf("%s\"%s\"", i ? "," : "", nc.names[i].c_str());
             std::printf("],\"keys\":[");
@@ -251,7 +266,6 @@ int main(int argc, char **argv) {
             // the unit of the two resource columns, nano-units per column unit (1e6 / 1e9 = milli-cores / bytes unless the cluster holds finer values)
             std::printf(",\"cpu_unit_nanos\":%lld,\"mem_unit_nanos\":%lld", (long long)snap.cpu_unit_nanos(), (long long)snap.mem_unit_nanos());
             std::printf(",\"list_calls\":%llu}\n", (unsigned long long)lister->list_calls);
-            if (pp.empty()) break;
             }
             return 0;
         }

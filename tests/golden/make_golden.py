@@ -149,6 +149,28 @@ SPELLINGS = ["0", "1", "2", "500m", "250m", "100m", "10m", "1500m", "7910m", "0.
              "1073741824", "17179869184", "1n", "100u", "1e3", "1E3", "129e6", "5.", "+5", "-5m"]
 
 
+def wide_case():
+    """Selector maps wider than the device's 32 label columns per call (src/predicates.rs:48-53 walks any map): pods with 40, 41 and 65
+    keys, one that can never match, one with wide + ordinary keys.  Quantities stay in domain D."""
+    c = synth.make_cluster(P=48, N=90, n_keys=4, n_taints=0, seed=0x40E1)
+    pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()
+    for i, n in enumerate(nodes):
+        lab = n["metadata"].setdefault("labels", {})
+        for k in range(70):
+            if (i * 3 + k) % 11:
+                lab[f"wide{k:02d}"] = "v" if (i + k) % 29 else "w"
+    for i in (5, 6, 7, 20, 33):
+        for k in range(70):
+            nodes[i]["metadata"]["labels"][f"wide{k:02d}"] = "v"
+    wide = {f"wide{k:02d}": "v" for k in range(40)}
+    pods[2]["spec"]["nodeSelector"] = dict(wide)
+    pods[11]["spec"]["nodeSelector"] = dict(wide, **{"wide40": "v"})
+    pods[12]["spec"]["nodeSelector"] = {f"wide{k:02d}": "v" for k in range(65)}
+    pods[30]["spec"]["nodeSelector"] = dict(wide, **{"wide39": "nobody"})
+    pods[31]["spec"]["nodeSelector"] = dict(wide, **(pods[31]["spec"].get("nodeSelector") or {}))
+    return pods, nodes, bound, c.samples
+
+
 def dump_readings(name, pods, nodes, bound):
     """Both expectations of the fit mask: exact Kubernetes semantics (what the product implements) and kube_quantity 0.6.1 as
     recalled (oracle_ref.KubeQuantity061).  ref_<name>.json of a real reference run is compared with both (tests/test_quantity_readings.py)."""
@@ -205,6 +227,9 @@ def main():
     pods, nodes, bound, samples = subunit_case()
     dump_objects("subunit_22x8", pods, nodes, bound, samples, "OUTSIDE D: sub-milli CPU (100u, 1500n) and sub-byte memory (100m, 1n) at exact-fit boundaries")
     dump_expected("subunit_22x8", pods, nodes, bound, samples, use_taint=False)
+    pods, nodes, bound, samples = wide_case()
+    dump_objects("wide_selectors_48x90", pods, nodes, bound, samples, "D, selector maps of 40 / 41 / 65 keys (more than the device's 32 label columns per call)")
+    dump_expected("wide_selectors_48x90", pods, nodes, bound, samples, use_taint=False)
     dump_spellings()
     for name, kw in CASES.items():
         c = synth.make_cluster(**kw)

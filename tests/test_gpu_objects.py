@@ -54,7 +54,8 @@ def expect_masks(pods, nodes, bound, use_taint, cache):
 
 
 @pytest.mark.parametrize("name,taints", [("c1_100x20", False), ("ragged_70x130_taints", True), ("one_node_33x1", True),
-                                         ("binsuffix_60x40", False), ("hazard_gi_24x10", False), ("subunit_22x8", False)])
+                                         ("binsuffix_60x40", False), ("hazard_gi_24x10", False), ("subunit_22x8", False),
+                                         ("wide_selectors_48x90", False)])
 def test_golden_objects_through_the_host_encoder(name, taints):
     path = os.path.join(GOLD, name + "_objects.json")
     doc = json.load(open(path))

@@ -104,6 +104,45 @@ def test_golden_objects_through_the_host_encoder_without_a_device(name, taints):
         assert Fraction(c["req_cpu_milli"][i] * cu, 10 ** 9) == rq.cpu and Fraction(c["req_mem_bytes"][i] * mu, 10 ** 9) == rq.memory
 
 
+def test_wide_selectors_are_planned_as_key_groups_whose_masks_and_to_the_oracles(tmp_path):
+    """tests/golden/wide_selectors_48x90: pods with 40 / 41 / 65 selector keys (the reference walks any map, src/predicates.rs:48-53; the device
+    takes 32 label columns per call).  One encoding of the whole batch is refused; predicates::device_calls plans pod ranges within the budget
+    and, for a wide pod, one evaluation per group of 32 keys.  Every planned evaluation is run through the C oracle on the ENCODED columns and
+    the documents covering a pod row ANDed: the object-level expectations, bit for bit.  (The device half: tests/test_gpu_objects.py.)"""
+    path = os.path.join(GOLD, "wide_selectors_48x90_objects.json")
+    doc = json.load(open(path))
+    P, N = doc["p"], doc["n"]
+    r = columns(path, expect_fail=True)
+    assert r.returncode == 1 and "KSCHED_MAX_KEYS" in r.stderr
+    out = subprocess.run([TOOL, "columns", path, "plan"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    docs = [json.loads(line) for line in out.stdout.splitlines()]
+    W = (N + 63) // 64
+    feas = np.full((P, W), ~np.uint64(0), dtype=np.uint64)
+    fit = np.full((P, W), ~np.uint64(0), dtype=np.uint64)
+    covered = np.zeros(P, dtype=int)
+    wide_rows = {}
+    for c in docs:
+        lo, hi = c["rows"]
+        assert c["pod_keys"] <= 32 and c["p"] == hi - lo
+        f, t = masks_of_columns(c, False)
+        feas[lo:hi] &= f.reshape(hi - lo, W)
+        fit[lo:hi] &= t.reshape(hi - lo, W)
+        covered[lo:hi] += 1
+        if hi - lo == 1 and covered[lo] > 1:
+            wide_rows[lo] = covered[lo]
+    assert covered.min() >= 1
+    assert wide_rows == {2: 2, 11: 2, 12: 3, 30: 2, 31: 2}, "40 / 41 / 65 / 40 / 40+ordinary keys in groups of 32"
+    e = json.load(open(os.path.join(GOLD, "wide_selectors_48x90_expected.json")))
+    unhex = lambda rows: np.array([[int(w, 16) for w in row] for row in rows], dtype=np.uint64).reshape(len(rows), W)  # noqa: E731
+    assert np.array_equal(fit, unhex(e["fit"]))
+    assert np.array_equal(feas, unhex(e["feasible_fit_and_sel"]))
+    want_feas, want_fit = expect_masks(doc["pods"], doc["nodes"], doc["bound"], False, cache=True)
+    assert np.array_equal(feas, want_feas) and np.array_equal(fit, want_fit)
+    bits = lambda row: int(np.unpackbits(feas[row].view(np.uint8)).sum())  # noqa: E731
+    assert 0 < bits(2) <= 5 and 0 < bits(12) <= 5 and bits(30) == 0
+
+
 def test_cluster_2000x500_binary_suffixes_12_keys_taints_without_a_device(tmp_path):
     c = synth.make_cluster(P=2000, N=500, n_keys=12, n_taints=16, seed=0x0B1EC7, binary_suffixes=True)
     pods, nodes, bound = c.pod_objects(), c.node_objects(), c.bound_pod_objects()
