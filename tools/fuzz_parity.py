@@ -57,6 +57,7 @@ while time.time() < t_end:
     flags = preds | pick | (L.WANT_FIT_MASK if r.random() < 0.5 else 0)
     try:
         ev.set_option(L.OPT_BESTFIT_STAGES, int(r.choice([0, 1, 2])))
+        ev.set_option(L.OPT_GRID_CUS, int(r.choice([0, 0, 0, 8, 17, 96, 200])))  # fewer compute units per launch: same results
         ev.set_option(L.OPT_FUSED_PICK, int(r.choice([0, 1, 1, 2])))  # 3 (tile tests or E_UNSUPPORTED) below, where it applies
         ev.set_nodes(cpu, mem, lab, taints)
         for step in range(int(r.choice([1, 1, 3]))):
@@ -91,6 +92,21 @@ while time.time() < t_end:
                     picks["tile-unsupported"] = picks.get("tile-unsupported", 0) + 1
                 ev.set_option(L.OPT_FUSED_PICK, 1)
         ev.set_kernel("auto")
+        if pick and r.random() < 0.4:
+            # the pick alone from HOST masks (ksched_pick, what a selector evaluated in key groups uses): from the oracle's mask it is the oracle's
+            # binding; from that mask thinned by random words (an AND with another group's mask) the sampled pick is the first draw whose bit is set
+            got_b = ev.pick(want[0], pick | (preds & L.FIT), req_mem_bytes=rm if (preds & L.FIT) else None, samples=smp if pick == L.PICK_SAMPLED else None)
+            ok = np.array_equal(got_b, want[2])
+            if ok and pick == L.PICK_SAMPLED:
+                thin = want[0] & r.integers(0, 1 << 63, want[0].shape, dtype=np.uint64)
+                got_t = ev.pick(thin, L.PICK_SAMPLED, samples=smp)
+                bit = lambda row, n: n < N and bool((int(thin[row, n >> 6]) >> (n & 63)) & 1)  # noqa: E731
+                want_t = np.array([next((int(x) for x in smp[i] if bit(i, int(x))), -1) for i in range(P)], dtype=np.int32)
+                ok = np.array_equal(got_t, want_t)
+            if not ok:
+                fails += 1
+                print(f"FAIL ksched_pick case seed {cs}: N={N} P={P} K={K} nt={nt} flags={flags:#x}", flush=True)
+            picks["host-masks"] = picks.get("host-masks", 0) + 1
         if pick and r.random() < 0.35:
             # the host-side row shard (include/ksched.h "one host thread, several devices"): the batch cut into 1 .. 5 shards with
             # ksched_shard_bounds, every shard through ksched_eval_begin (selector columns addressed inside the whole batch's array with its
