@@ -10,6 +10,9 @@ a fresh process per runtime setting a latency-sensitive host could choose:
     ROC_ACTIVE_WAIT_TIMEOUT=200     the HIP runtime spins that many us on a signal before it blocks
     hipDeviceScheduleSpin           hipSetDeviceFlags(hipDeviceScheduleSpin) before the context exists
     GPU_MAX_HW_QUEUES=1 / 2         fewer hardware queues
+    HIP_FORCE_DEV_KERNARG=0 / 1     where the kernel-argument segment lives (host / device memory)
+    AMD_DIRECT_DISPATCH=0           launches handed to the runtime's worker thread instead of written by the calling thread
+(FC_ONLY=substr[,substr] runs the matching variants only)
 usage: python tools/fixed_cost.py [workload=C3]            (parent: runs every variant)
 """
 import ctypes
@@ -29,6 +32,9 @@ VARIANTS = [
     ("hipDeviceScheduleBlockingSync", {}, 4),
     ("GPU_MAX_HW_QUEUES=1", {"GPU_MAX_HW_QUEUES": "1"}, None),
     ("spin + ROC_ACTIVE_WAIT_TIMEOUT=200 + HSA_ENABLE_INTERRUPT=0", {"ROC_ACTIVE_WAIT_TIMEOUT": "200", "HSA_ENABLE_INTERRUPT": "0"}, 1),
+    ("HIP_FORCE_DEV_KERNARG=0", {"HIP_FORCE_DEV_KERNARG": "0"}, None),  # kernel arguments in host memory (the kernels' first scalar loads cross PCIe)
+    ("HIP_FORCE_DEV_KERNARG=1", {"HIP_FORCE_DEV_KERNARG": "1"}, None),  # ... in device memory
+    ("AMD_DIRECT_DISPATCH=0", {"AMD_DIRECT_DISPATCH": "0"}, None),  # launches through the runtime's worker thread
 ]
 
 
@@ -118,7 +124,10 @@ def main():
         return child()
     name = sys.argv[1] if len(sys.argv) > 1 else "C3"
     print(f"# tools/fixed_cost.py {name}: T(K steps between synchronizes) = fixed + K x per_step, sequential loop, outputs rotated; medians of 25 regions per K")
+    only = os.environ.get("FC_ONLY")  # comma-separated substrings: run the matching variants only
     for label, env, devflags in VARIANTS:
+        if only and not any(o in label for o in only.split(",")):
+            continue
         e = dict(os.environ, FC_CHILD="1", FC_WORKLOAD=name, **env)
         if devflags is not None:
             e["FC_DEVICE_FLAGS"] = str(devflags)
