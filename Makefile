@@ -5,6 +5,7 @@
 #   make lib        -> kube_scheduler_rs_reference_amd/libksched_hip.so     hipcc, gfx950 only
 #   make host       -> kube_scheduler_rs_reference_amd/libksched_host.so    g++, links libksched_hip.so; + tests/cpp/host_tests
 #   make oracle     -> oracle/liboracle.so                                  gcc, test infrastructure only
+#   make tools      -> tools/pmc_calib                                      hipcc: calibration kernels for the HBM counters
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 CC      ?= gcc
@@ -28,8 +29,15 @@ OBJ_TOOL := tests/cpp/objects_eval
 FAKE_RCCL := tests/cpp/libfake_rccl.so
 INDEX_TEST := tests/cpp/index_tests
 
-.PHONY: all lib host oracle clean
-all: lib host oracle
+PMC_CALIB := tools/pmc_calib
+
+.PHONY: all lib host oracle tools clean
+all: lib host oracle tools
+
+# kernels of KNOWN byte counts for calibrating the HBM counters (bench.py --live-traffic, tools/gpu_round.sh pmc)
+tools: $(PMC_CALIB)
+$(PMC_CALIB): tools/pmc_calib.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ tools/pmc_calib.hip
 
 lib: $(LIB_HIP)
 $(LIB_HIP): $(CSRC)/ksched_api.hip $(wildcard $(CSRC)/*.hpp) include/ksched.h
@@ -57,4 +65,4 @@ $(LIB_ORA): oracle/oracle.c oracle/oracle.h
 	$(CC) $(CFLAGS) -shared -o $@ oracle/oracle.c
 
 clean:
-	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL) $(FAKE_RCCL)
+	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL) $(FAKE_RCCL) $(PMC_CALIB)

@@ -234,6 +234,60 @@ class SingleRig:
         self.ev.close()
 
 
+
+def live_traffic(workload, kernel_arg, extra_args, budget_s=240.0):
+    """HBM bytes per launch of the mask kernel, measured now (the line used to carry a constant from an earlier session and
+    could not notice a traffic regression).  MI355X_MICROARCH.md's recipe: counters in their own passes (--pmc with --kernel-trace only),
+    FETCH_SIZE and WRITE_SIZE separately, each trusted only after calibration on kernels of KNOWN byte counts in the same access pattern
+    (tools/pmc_calib: 512 MiB flat 16 B / lane reads, 128-byte-segment mask-shaped stores; the guide's gfx950 x 2 for wide reads comes out
+    of the calibration).  The passes re-run THIS file with 10 steps of the same workload, kernel and rotation.  -> (record, None) or (None, why)."""
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    calib = os.path.join(ROOT, "tools", "pmc_calib")
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    if not os.path.exists(calib):
+        return None, "tools/pmc_calib not built (make)"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic as PT
+    out = tempfile.mkdtemp(prefix="ksched_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", KSCHED_BENCH_TRAFFIC_CHILD="1")
+    child = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--kernel", kernel_arg, "--steps", "10", "--warmup", "2", "--ramp-ms", "0",
+             "--kernel-samples", "2", "--no-cpu-baseline", "--no-others", "--repeats", "0", "--live-traffic", "off"] + list(extra_args)
+    t_end = time.perf_counter() + budget_s
+    res = {}
+    try:
+        for counter, tag in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            for name, cmd in (("calib_" + tag, [calib]), ("run_" + tag, child)):
+                left = t_end - time.perf_counter()
+                if left < 5:
+                    return None, f"time budget of {budget_s:.0f} s spent before pass {name}"
+                r = subprocess.run([rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(out, name), "-o", "p", "--"] + cmd,
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
+                if r.returncode != 0:
+                    return None, f"pass {name} exited {r.returncode}: {(r.stderr or r.stdout)[-200:]!r}"
+                res[name] = PT.per_kernel(os.path.join(out, name))
+        cf, cw = res["calib_fetch"], res["calib_write"]
+        f_factor = PT.CALIB_BYTES["calib_read_flat16"] / cf["calib_read_flat16"]["FETCH_SIZE"]
+        w_factor = PT.CALIB_BYTES["calib_write_tile128"] / cw["calib_write_tile128"]["WRITE_SIZE"]
+        kf = {k: v for k, v in res["run_fetch"].items() if k.startswith("k_eval")}
+        kw = {k: v for k, v in res["run_write"].items() if k.startswith("k_eval")}
+        if len(kf) != 1 or set(kf) != set(kw):
+            return None, f"expected one mask kernel in the passes, saw {sorted(kf)} / {sorted(kw)}"
+        k = next(iter(kf))
+        fetch_b, write_b = kf[k]["FETCH_SIZE"] * f_factor, kw[k]["WRITE_SIZE"] * w_factor
+        return {"kernel": k, "fetch_bytes": fetch_b, "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b,
+                "dispatches": [kf[k]["_dispatches"], kw[k]["_dispatches"]], "fetch_bytes_per_count": f_factor, "write_bytes_per_count": w_factor}, None
+    except subprocess.TimeoutExpired as e:
+        return None, f"a rocprofv3 pass ran into the time budget ({e.timeout:.0f} s left for it)"
+    except Exception as e:  # noqa: BLE001  (the measurement is optional: the line falls back to the committed figure and says so)
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,6 +321,11 @@ def main():
     ap.add_argument("--no-others", action="store_true",
                     help="N = 1, default workload: skip config.other_workloads (C4s, C5s measured in the same process, a few hundred ms) "
                          "and config.in_place")
+    ap.add_argument("--live-traffic", choices=["auto", "on", "off"], default="auto",
+                    help="roofline.traffic measured by THIS invocation: after the timed region, four short rocprofv3 --pmc passes (FETCH_SIZE and "
+                         "WRITE_SIZE, separately: over tools/pmc_calib -- known byte counts -- and over this command with 10 steps), per launch of the "
+                         "mask kernel.  auto (default): at N = 1, when rocprofv3 and tools/pmc_calib exist and this process is not itself being "
+                         "profiled; a pass that fails or times out falls back to the committed profiles/pmc_traffic.json (traffic_source says which)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip config.configs3_strong (1M pods x 10k nodes split N ways)")
     ap.add_argument("--repeats", type=int, default=4, help="further timed regions of K steps after the graded one (config.repeat_ms_per_step)")
     ap.add_argument("--depth", type=int, default=None,
@@ -832,17 +891,41 @@ def main():
         achieved = alg / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         # HBM traffic per launch comes from SEPARATE rocprofv3 --pmc passes (tools/gpu_pmc.sh -> tools/pmc_traffic.py), not from
         # this run: the counters cannot be collected inside a timing run.  The file names the session it was measured in.
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_committed, traffic_live = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 doc = json.load(open(tpath))
                 rec = doc.get(f"{args.workload}:{kernel_name}")
-                traffic = rec["hbm_bytes_per_launch"] if rec else None
+                traffic = traffic_committed = rec["hbm_bytes_per_launch"] if rec else None
                 if rec:
                     traffic_source = f"profiles/pmc_traffic.json ({doc.get('_session', 'session unnamed')}): separate rocprofv3 --pmc passes, not this run"
             except Exception:
                 traffic = None
+        # ... and measured by this invocation where that is possible (--live-traffic): the committed figure stays beside it for comparison
+        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+        try:  # (the profiler's tool library mapped into this process says it most reliably)
+            profiled = profiled or any("rocprofiler-sdk-tool" in ln or "librocprofv3" in ln for ln in open("/proc/self/maps"))
+        except OSError:
+            pass
+        want_live = args.live_traffic == "on" or (args.live_traffic == "auto" and world == 1 and not profiled and kernel_name in ("fused", "direct")
+                                                   and not args.no_mask and not args.debug and not os.environ.get("KSCHED_BENCH_FORCE_DIST"))
+        if want_live and world == 1:
+            passthrough = []
+            for flag, on in (("--no-rotate", args.no_rotate), ("--packed", args.packed)):
+                if on:
+                    passthrough.append(flag)
+            passthrough += ["--fused-pick", str(args.fused_pick), "--input-batches", str(args.input_batches)]
+            rec_live, why = live_traffic(args.workload, args.kernel, passthrough)
+            if rec_live and kernel_name and rec_live["kernel"].replace("k_eval_", "") == kernel_name:
+                traffic_live = rec_live
+                traffic = rec_live["hbm_bytes_per_launch"]
+                traffic_source = ("this invocation: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command (10 steps, %d dispatches) "
+                                  "and over tools/pmc_calib (known byte counts)" % rec_live["dispatches"][0])
+            else:
+                traffic_live = {"error": why or f"the passes saw kernel {rec_live['kernel']}, the run timed {kernel_name}"}
+                if traffic_source:
+                    traffic_source += "; the live passes failed: " + traffic_live["error"]
         step_s = elapsed / args.steps
         per_gpu_solo = solo["per_gpu_value_max_time"] if solo else None
         out = {
@@ -883,7 +966,7 @@ def main():
                        "snapshot_refresh": ({"every_steps": args.refresh_every, "nodes_per_update": args.refresh_nodes,
                                              "updates_issued": refresh["calls"]} if args.refresh_every > 0 else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_committed": traffic_committed, "traffic_live": traffic_live,
                          "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                          "kernel": f"mask kernel ({kernel_name}" + (", the sampled pick rides in it)" if pick_how.startswith("fused") else ")"),
                          "algorithmic_bytes_per_launch": alg,

@@ -4,7 +4,7 @@
 TAG=${1:-ab}; VARS=${2:-"s0p0 s1p0"}; WLS=${3:-"C3 C4s"}
 REPO=$PWD; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 for v in $VARS; do for wl in $WLS; do
-  KSCHED_LIB=$REPO/build/variants/libksched_hip_$v.so timeout 300 python bench.py --workload $wl --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 > $OUT/ab_${v}_${wl}.json
+  KSCHED_LIB=$REPO/build/variants/libksched_hip_$v.so timeout 300 python bench.py --workload $wl --steps 40 --warmup 5 --no-cpu-baseline --live-traffic off 2>&1 | tail -1 > $OUT/ab_${v}_${wl}.json
   python - <<PY
 import json
 try:

@@ -5,7 +5,7 @@ OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; REPO=$PWD
 cd /tmp
 rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ|TCC|TCP|TA|GRBM)_[A-Z0-9_]+\b" | sort -u > $OUT/counters.txt; wc -l $OUT/counters.txt
 run() { name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $REPO/bench.py --workload $WL --kernel $K --steps 10 --warmup 2 --no-cpu-baseline $BENCH_EXTRA > $OUT/$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $REPO/bench.py --workload $WL --kernel $K --steps 10 --warmup 2 --no-cpu-baseline --live-traffic off $BENCH_EXTRA > $OUT/$name.log 2>&1
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" <<'PY'
 import csv,sys,collections

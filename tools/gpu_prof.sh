@@ -3,7 +3,7 @@
 TAG=${1:-p}; WL=${2:-C3}; K=${3:-fused}; shift 3
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; REPO=$PWD
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${WL}_${K} -o r -- python $REPO/bench.py --workload $WL --kernel $K --steps 50 --warmup 5 --no-cpu-baseline "$@" > $OUT/prof_${WL}_${K}.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${WL}_${K} -o r -- python $REPO/bench.py --workload $WL --kernel $K --steps 50 --warmup 5 --no-cpu-baseline --live-traffic off "$@" > $OUT/prof_${WL}_${K}.log 2>&1
 cd $REPO
 tail -1 $OUT/prof_${WL}_${K}.log | python -c "
 import json,sys

@@ -5,7 +5,7 @@ TAG=${1:-q}; WLS=${2:-"C3 C4s C5s C2"}; KERNELS=${3:-"fused"}; NOTEST=$4
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 if [ -z "$NOTEST" ]; then echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -8; fi
 for k in $KERNELS; do for wl in $WLS; do
-  timeout 600 python bench.py --workload $wl --kernel $k --steps 30 --warmup 3 --no-cpu-baseline $BENCH_EXTRA 2>&1 | tail -1 > $OUT/bench_${wl}_${k}.json
+  timeout 600 python bench.py --workload $wl --kernel $k --steps 30 --warmup 3 --no-cpu-baseline --live-traffic off $BENCH_EXTRA 2>&1 | tail -1 > $OUT/bench_${wl}_${k}.json
   python - <<PY
 import json
 try:

@@ -43,7 +43,7 @@ if has prof; then
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -o r -- python $REPO/bench.py > $OUT/prof_default.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_driver_form -o r -- python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/prof_driver_form.log 2>&1
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5s -o r -- python $REPO/bench.py --workload C5s --no-cpu-baseline --no-others > $OUT/prof_c5s.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5s -o r -- python $REPO/bench.py --workload C5s --no-cpu-baseline --live-traffic off --no-others > $OUT/prof_c5s.log 2>&1
   cd $REPO
   grep "^{\"metric" $OUT/prof_default.log > $OUT/prof_default_bench.json
   grep "^{\"metric" $OUT/prof_driver_form.log > $OUT/prof_driver_form_bench.json
@@ -65,11 +65,11 @@ if has pmc; then
   timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -o p -- $REPO/tools/pmc_calib > $OUT/calib_fetch.log 2>&1
   timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -o p -- $REPO/tools/pmc_calib > $OUT/calib_write.log 2>&1
   for wl in ${PMC_WLS:-C3 C4s}; do
-    timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${wl}_fetch -o p -- python $REPO/bench.py --workload $wl --steps 10 --warmup 2 --ramp-ms 0 --kernel-samples 2 --no-cpu-baseline > $OUT/${wl}_fetch.log 2>&1
-    timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${wl}_write -o p -- python $REPO/bench.py --workload $wl --steps 10 --warmup 2 --ramp-ms 0 --kernel-samples 2 --no-cpu-baseline > $OUT/${wl}_write.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${wl}_fetch -o p -- python $REPO/bench.py --workload $wl --steps 10 --warmup 2 --ramp-ms 0 --kernel-samples 2 --no-cpu-baseline --live-traffic off > $OUT/${wl}_fetch.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${wl}_write -o p -- python $REPO/bench.py --workload $wl --steps 10 --warmup 2 --ramp-ms 0 --kernel-samples 2 --no-cpu-baseline --live-traffic off > $OUT/${wl}_write.log 2>&1
   done
   # a third pass: SQ activity of the mask kernel (VALU / LDS / wait split) on the default workload
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/C3_sq -o p -- python $REPO/bench.py --steps 10 --warmup 2 --ramp-ms 0 --kernel-samples 2 --no-cpu-baseline > $OUT/C3_sq.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/C3_sq -o p -- python $REPO/bench.py --steps 10 --warmup 2 --ramp-ms 0 --kernel-samples 2 --no-cpu-baseline --live-traffic off > $OUT/C3_sq.log 2>&1
   cd $REPO
   python tools/pmc_traffic.py $OUT ${PMC_WLS:-C3 C4s} > $OUT/pmc_traffic.log 2>&1; tail -30 $OUT/pmc_traffic.log
   # drop the bulky raw traces, keep the counter csvs
@@ -78,7 +78,7 @@ fi
 if has lines; then
   stamp "bench lines of the other workloads"
   for wl in ${LINE_WLS:-C2 C3h C4s C5s}; do
-    timeout 600 python bench.py --workload $wl --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_${wl}.json
+    timeout 600 python bench.py --workload $wl --no-cpu-baseline --live-traffic off 2>&1 | tail -1 > $OUT/bench_${wl}.json
     python - <<PY
 import json
 try:
@@ -92,7 +92,7 @@ fi
 if has ab; then
   stamp "A/B: bench with kernel debug bits ${AB_BITS:-64} (results of a debug run are not valid outputs; timing only)"
   for wl in ${AB_WLS:-C3 C4s}; do for bits in ${AB_BITS:-64}; do
-    timeout 600 python bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline --debug $bits 2>&1 | tail -1 > $OUT/ab_${wl}_${bits}.json
+    timeout 600 python bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline --live-traffic off --debug $bits 2>&1 | tail -1 > $OUT/ab_${wl}_${bits}.json
     python - <<PY
 import json
 try:
@@ -105,7 +105,7 @@ PY
 fi
 if has dist; then
   stamp "N > 1 bench path in a ONE-rank RCCL group (KSCHED_BENCH_FORCE_DIST=1): C ABI communicator vs torch, pipe vs one stream"
-  KSCHED_BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline 2>$OUT/dist_default.err | tail -1 > $OUT/dist_default.json
+  KSCHED_BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --live-traffic off 2>$OUT/dist_default.err | tail -1 > $OUT/dist_default.json
   python - <<PY
 import json
 try:
@@ -115,7 +115,7 @@ except Exception as e:
     print("default N>1 path FAILED", e); print(open("$OUT/dist_default.err").read()[-1500:])
 PY
   for wl in C3 C4s; do for mode in "" "--torch-gather" "--one-stream"; do
-    KSCHED_BENCH_FORCE_DIST=1 timeout 300 python bench.py --workload $wl --no-cpu-baseline $mode 2>&1 | tail -1 > $OUT/dist_${wl}_${mode#--}.json
+    KSCHED_BENCH_FORCE_DIST=1 timeout 300 python bench.py --workload $wl --no-cpu-baseline --live-traffic off $mode 2>&1 | tail -1 > $OUT/dist_${wl}_${mode#--}.json
     python - <<PY
 import json
 try:
@@ -129,7 +129,7 @@ fi
 if has evflags; then
   stamp "A/B of the HIP event flags of the per-dispatch kernel timing (bench.py post-pass) vs rocprofv3 (the prof step)"
   for f in 0x0 0x20000000 0x40000000; do
-    KSCHED_TIMING_EVENT_FLAGS=$f timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 > $OUT/evflags_$f.json
+    KSCHED_TIMING_EVENT_FLAGS=$f timeout 300 python bench.py --no-cpu-baseline --live-traffic off 2>&1 | tail -1 > $OUT/evflags_$f.json
     python -c "
 import json; r=json.load(open('$OUT/evflags_$f.json'))['roofline']; print('flags $f: mean %.2f median %.2f min %.2f max %.2f us' % (r['avg_kernel_us'], r['median_kernel_us'], r['min_kernel_us'], r['max_kernel_us']))"
   done
@@ -137,11 +137,11 @@ fi
 if has abpick; then
   stamp "A/B of the picks (KSCHED_OPT_DEBUG): sampled pick eager draws (bits 8-9), best-fit one stage (bit 10) / lane words (bits 12-15); bindings-only steps"
   for wl in C3 C2; do for dbg in 0 256 512 768; do
-    timeout 200 python bench.py --workload $wl --no-cpu-baseline --no-mask --debug $dbg 2>&1 | tail -1 | python -c "
+    timeout 200 python bench.py --workload $wl --no-cpu-baseline --live-traffic off --no-mask --debug $dbg 2>&1 | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$wl debug=$dbg: bindings-only step %.2f us' % (d['ms_per_step']*1e3))"
   done; done
   for dbg in 1024 4096 8192 16384 32768; do
-    timeout 200 python bench.py --workload C5s --no-cpu-baseline --no-mask --debug $dbg --steps 300 2>&1 | tail -1 | python -c "
+    timeout 200 python bench.py --workload C5s --no-cpu-baseline --live-traffic off --no-mask --debug $dbg --steps 300 2>&1 | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('C5s debug=$dbg: bindings-only step %.1f us' % (d['ms_per_step']*1e3))"
   done
 fi
