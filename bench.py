@@ -175,10 +175,10 @@ class SingleRig:
         for _ in range(max(8, 2 * R)):
             step()
         torch.cuda.synchronize()
-        # clock ramp, like the graded loop's: this rig's cluster was just generated on the host (seconds of an idle GPU), and a handful of
-        # warm-up steps ends long before the clocks are back up (the C5 shard read 175 us per mask kernel here against 141 us in its own run)
-        # (... and a store-bound launch of hundreds of microseconds keeps getting faster for a few hundred ms of sustained load -- the C5 shard's mask
-        # kernel reads 171 us after 170 ms and 141 us after 360 ms, session r5m --: bursts until two in a row agree within 2 %, 60 ms at least, 0.6 s at most)
+        # untimed run-in, like the graded loop's: bursts until two in a row agree within 2 %, 60 ms at least, 0.6 s at most.  (It was added on the belief
+        # that a store-bound launch keeps getting faster for a few hundred ms of sustained load -- the C5 shard's mask kernel read 171 us in one
+        # measurement and 141 us in another.  tools/clock_ramp.py and tools/placement_probe.py have since shown the rate to be flat in time from the
+        # first milliseconds and the two values to be a property of the mask ALLOCATION, profiles/r05_bimodal_by_allocation.md; the run-in is harmless.)
         t_r = time.perf_counter()
         prev = None
         while True:
