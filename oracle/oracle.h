@@ -18,7 +18,7 @@
  *     (CPU "<n>" / "<n>m", memory plain integer bytes, optionally Ki/Mi) every reading of the
  *     crate agrees with it.  Neither the build container nor the GPU box has cargo/rustc (profiles/
  *     r02_a_toolchain_probe_gpu_box.txt), so there is no oracle/_ref.  Pinning is one command for anyone who has cargo:
- *     rust/pin_parity.sh runs the reference's OWN fits() / does_node_selector_match on tests/golden/*_objects.json and
+ *     rust/pin_parity.sh runs the reference's OWN fits() / does_node_selector_match on tests/golden/<name>_objects.json and
  *     tests/test_reference_fixtures.py compares the result with the fixtures this oracle reproduces.
  *     Outside D the unpinned half is BRACKETED: oracle_ref.py carries a second reading (kube_quantity 0.6.1 as the surveyor recalls
  *     it: f32 scale factors kept to 7 digits) and tests/test_quantity_readings.py states, per spelling, where the two agree (D, Ki,
