@@ -5,7 +5,7 @@ in the next, flat in time within each -- tools/clock_ramp.py -- so it is not a c
 One process, one evaluator, one workload: the mask buffer(s) are re-allocated several times -- behind spacers of different sizes, so that the virtual
 and physical placement moves -- and carved out of their allocation at different byte offsets; every placement is timed with HIP events on the mask kernel
 (mean of `n` dispatches after a warm-up).  Prints the device address next to the time.
-    python tools/placement_probe.py [workload=C5s] [n=48] [offsets|sizes]
+    python tools/placement_probe.py [workload=C5s] [n=48] [offsets|sizes|sticky|select]
 """
 import os
 import sys
@@ -52,7 +52,36 @@ def timed(masks):
 spacers = []
 rows = P * pitch
 mode = sys.argv[3] if len(sys.argv) > 3 else "offsets"
-if mode == "sticky":
+if mode == "select":
+    # can the fast allocations be PICKED?  K candidate buffers alive at once, every one timed inside a rotation over all of them (so that no
+    # buffer is rewritten while the Infinity Cache still holds it), twice; then the standard loop over the R fastest and over the R slowest
+    K = max(3 * R, 6)
+    cands = [ev.alloc_mask(P) for _ in range(K)]
+
+    def per_buffer(reps=10):
+        run = ev.bind_eval_device(*rig.d, rig.flags, out_feasible=cands, out_bindings=[rig.out])
+        for i in range(2 * K):
+            run(0, i % K)
+        torch.cuda.synchronize()
+        ev.set_timing(True, every=1)
+        ev.kernel_time_samples(4096)
+        for _ in range(reps):
+            for i in range(K):
+                run(0, i)
+        torch.cuda.synchronize()
+        us = ev.kernel_time_samples(4096) * 1e3
+        ev.set_timing(False)
+        return np.median(us.reshape(reps, K), axis=0)
+    a, b = per_buffer(), per_buffer()
+    print("per-buffer median us, pass 1: " + " ".join(f"{x:.1f}" for x in a))
+    print("per-buffer median us, pass 2: " + " ".join(f"{x:.1f}" for x in b))
+    print(f"correlation between the passes {np.corrcoef(a, b)[0, 1]:.2f}; spread of pass 1: min {a.min():.2f} median {np.median(a):.2f} max {a.max():.2f}")
+    order = np.argsort(a + b)
+    for label, idx in (("fastest", order[:R]), ("slowest", order[-R:]), ("fastest again", order[:R]), ("first allocated", np.arange(R))):
+        mean, med, lo = timed([cands[i] for i in idx])
+        print(f"loop over the {R} {label:16s} buffers {list(map(int, idx))}: mask kernel mean {mean:.2f} us, median {med:.2f}, min {lo:.2f}", flush=True)
+    plan = []
+elif mode == "sticky":
     # is the mode a property of the ALLOCATION?  One mask allocation timed repeatedly, with other allocations coming and going in between and the
     # operand columns re-allocated (cloned) half-way; then the next mask allocation
     import itertools
