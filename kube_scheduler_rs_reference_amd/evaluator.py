@@ -289,9 +289,10 @@ class Evaluator:
         tails = [(ptr(b), pitch, C.c_void_p(stream.cuda_stream)) for b in outs]
         keep = (req_cpu_milli, req_mem_bytes, sel_val_ids, tolerations, samples, masks, out_fit, outs)
         fn, check = self._lib.ksched_eval_device_pitched, self._check
+        calls = [[head + mid + tail for mid in mids] for tail in tails]  # the whole argument tuple per (binding buffer, mask buffer), built once
 
         def run(i: int = 0, m: int = 0, _keep=keep):
-            rc = fn(*head, *mids[m], *tails[i])
+            rc = fn(*calls[i][m])
             if rc:
                 check(rc, "ksched_eval_device_pitched")
         return run
