@@ -310,8 +310,11 @@ std::vector<Validity> explain_pairs(const std::vector<const corev1::Pod *> &pods
             dev.check(ksched_explain(dev.handle(), pc.p, pc.req_cpu_milli.data(), pc.req_mem_bytes.data(), pc.n_keys ? pc.sel_val_ids.data() : nullptr,
                                      (flags & KSCHED_TAINT) ? pc.tolerations.data() : nullptr, (uint32_t)mine.size(), pp.data(), pn.data(), flags, reason.data()),
                       "ksched_explain");
+            // (over the groups of a wide pod the strongest reason in check_node_validity's order wins: resources, then ANY group's selector
+            // mismatch, then -- extension E2 -- the taints; a taint verdict of an early group must not hide a later group's selector mismatch)
+            auto rank = [](int32_t r) { return r == KSCHED_REASON_NOT_ENOUGH_RESOURCES ? 3 : r == KSCHED_REASON_NODE_SELECTOR_MISMATCH ? 2 : r == KSCHED_REASON_OK ? 0 : 1; };
             for (size_t k = 0; k < mine.size(); ++k)
-                if (combined[k] == KSCHED_REASON_OK) combined[k] = reason[k];
+                if (rank(reason[k]) > rank(combined[k])) combined[k] = reason[k];
         }
         for (size_t k = 0; k < mine.size(); ++k) out[mine[k]] = to_validity(combined[k]);
     }

@@ -1042,6 +1042,32 @@ static void gpu_tests() {
                 CHECK(why[i][k].node_name == sel.rejected[i][k].node_name && why[i][k].reason == sel.rejected[i][k].reason);
         }
         CHECK(lines > 10);
+        // with the taint extension on: a node that is tainted AND fails a key of the wide pod's LAST group is a selector mismatch (the reference's
+        // order, then E2), whatever the earlier groups say
+        {
+            std::vector<corev1::Node> tn = nodes;
+            for (auto &n : tn) {
+                if (!n.spec) n.spec = corev1::NodeSpec{};
+                n.spec->taints = std::vector<corev1::Taint>{corev1::Taint{"dedicated", std::string("gpu"), "NoSchedule"}};
+            }
+            Context tctx = make_ctx(tn);
+            std::vector<std::pair<uint32_t, uint32_t>> pairs;
+            for (uint32_t j = 0; j < (uint32_t)tn.size(); ++j) pairs.push_back({1u, j});  // pod 1: all forty keys = "v"
+            const auto reasons = predicates::explain_pairs(ptrs, tctx, pairs, true);
+            tctx.refresh_snapshot();
+            const auto &names = tctx.snapshot->columns().names;
+            size_t taint_only = 0, mismatch = 0;
+            for (uint32_t j = 0; j < (uint32_t)tn.size(); ++j) {
+                size_t store = 0;
+                while (tn[store].metadata.name.value_or("") != names[j]) ++store;
+                const bool sel_ok = does_node_selector_match(pods[1], tn[store]);
+                const bool fit_ok = can_pod_fit(pods[1], tn[store], tctx);
+                if (!fit_ok) CHECK(reasons[j] && *reasons[j] == InvalidNodeReason::NotEnoughResources);
+                else if (!sel_ok) { CHECK(reasons[j] && *reasons[j] == InvalidNodeReason::NodeSelectorMismatch); ++mismatch; }
+                else { CHECK(reasons[j] && *reasons[j] == InvalidNodeReason::TaintNotTolerated); ++taint_only; }
+            }
+            CHECK(taint_only > 0 && mismatch > 0);
+        }
         // best fit over a wide pod: the device picks from the combined mask
         const predicates::BatchValidity bf = predicates::check_node_validity_batch(ptrs, ctx, false, KSCHED_PICK_BESTFIT, nullptr, 0, true);
         for (size_t i = 0; i < pods.size(); ++i) {
