@@ -927,6 +927,8 @@ def main():
                 if on:
                     passthrough.append(flag)
             passthrough += ["--fused-pick", str(args.fused_pick), "--input-batches", str(args.input_batches)]
+            if args.pods:
+                passthrough += ["--pods", str(args.pods)]
             rec_live, why = live_traffic(args.workload, args.kernel, passthrough)
             if rec_live and kernel_name and rec_live["kernel"].replace("k_eval_", "") == kernel_name:
                 traffic_live = rec_live
