@@ -46,7 +46,7 @@ $(LIB_HIP): $(CSRC)/ksched_api.hip $(wildcard $(CSRC)/*.hpp) include/ksched.h
 host: $(LIB_HOST) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL) $(FAKE_RCCL)
 # TEST-ONLY stand-in for librccl (n ranks on one GPU; loaded only with KSCHED_TEST_HOOKS=1 + KSCHED_RCCL_LIB, see csrc/comm_rccl.hpp)
 $(FAKE_RCCL): tests/cpp/fake_rccl.cpp
-	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -shared -o $@ tests/cpp/fake_rccl.cpp -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
+	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -shared -o $@ tests/cpp/fake_rccl.cpp -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lrt -lpthread
 # host-only check of the bitmap index arithmetic (no GPU, no HIP runtime call): tests/test_index_host.py runs it
 $(INDEX_TEST): tests/cpp/index_tests.cpp $(CSRC)/tile_index.hpp
 	$(CXX) -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -o $@ tests/cpp/index_tests.cpp

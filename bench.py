@@ -386,15 +386,29 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    # TEST HOOK (KSCHED_TEST_HOOKS=1 + KSCHED_BENCH_ONE_GPU=1, tests/test_gpu_bench_contract.py): the N ranks of `--gpus N` all sit on device 0 of a
+    # one-GPU box, so that the N > 1 code of this file -- row shards with lo > 0, the communicator behind the C ABI with nranks > 1, the gathered
+    # table, the cross-rank self-check, the strong-scaling leg -- runs end to end before an 8-GPU node sees it.  RCCL refuses a device twice
+    # in one communicator: the library then talks to the TEST-ONLY stand-in ($KSCHED_RCCL_LIB = tests/cpp/libfake_rccl.so, a blocking all-gather
+    # through shared memory) and the control group is gloo on host tensors.  The line says so (`config.one_gpu_stand_in`); its value is NOT a scaling figure.
+    one_gpu = os.environ.get("KSCHED_BENCH_ONE_GPU") == "1"
+    if one_gpu and not (os.environ.get("KSCHED_TEST_HOOKS") == "1" and os.environ.get("KSCHED_RCCL_LIB")):
+        raise SystemExit("KSCHED_BENCH_ONE_GPU=1 is a test hook: it needs KSCHED_TEST_HOOKS=1 and KSCHED_RCCL_LIB=<the RCCL stand-in>")
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if one_gpu else dev  # where the control collectives' tensors live (gloo moves host tensors)
     # KSCHED_BENCH_FORCE_DIST=1 (self-test): run the N > 1 code path -- RCCL process group, asynchronous all-gather of the
     # bindings, barrier, MAX all-reduce of the elapsed time -- in a one-rank group on the one GPU there is
     multi = world > 1 or bool(os.environ.get("KSCHED_BENCH_FORCE_DIST"))
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     default_workload = args.workload is None
     if default_workload:
@@ -414,7 +428,7 @@ def main():
     def max_over_ranks(x: float) -> float:
         if not multi:
             return x
-        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        tt = torch.tensor([x], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
@@ -465,7 +479,7 @@ def main():
                 ok = 1
             except Exception as e:  # noqa: BLE001
                 self.comm, ok, self.comm_note = None, 0, f"AbiComm failed on rank {rank}: {e}"
-            okt = torch.tensor([ok], dtype=torch.int32, device=dev)
+            okt = torch.tensor([ok], dtype=torch.int32, device=cdev)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             if int(okt.item()) == 0:
                 if self.comm is not None:
@@ -665,7 +679,7 @@ def main():
     t16 = burst(16)
     more = int(min(50_000, max(0.0, args.ramp_ms * 1e-3 - t16) / max(t16 / 16, 1e-7)))
     if multi:
-        mt = torch.tensor([more], dtype=torch.int64, device=dev)
+        mt = torch.tensor([more], dtype=torch.int64, device=cdev)
         dist.all_reduce(mt, op=dist.ReduceOp.MAX)
         more = int(mt.item())
     if more:
@@ -724,9 +738,21 @@ def main():
         except Exception as e:  # noqa: BLE001 -- the CHECKER could not run (e.g. oracle/liboracle.so missing on this box): said in the line, not a mismatch
             parity = {"error": f"{type(e).__name__}: {e}", "mismatches": None}
         if multi:  # every rank checks its own shard; the line carries the sum (a rank whose checker could not run counts as unchecked, not as a mismatch)
-            pm = torch.tensor([parity["mismatches"] or 0, 0 if parity["mismatches"] is not None else 1], dtype=torch.int64, device=dev)
+            pm = torch.tensor([parity["mismatches"] or 0, 0 if parity["mismatches"] is not None else 1], dtype=torch.int64, device=cdev)
             dist.all_reduce(pm, op=dist.ReduceOp.SUM)
             parity["mismatches_all_ranks"], parity["ranks_unchecked"] = int(pm[0].item()), int(pm[1].item())
+            # ... and every rank must hold the SAME gathered table (each checks its own rows against the oracle above; the other ranks' rows it only
+            # has from the all-gather): an order-sensitive sum per shard of the table, the vectors of all ranks compared -- a checksum of checksums
+            if bindings.numel() >= P_total and P_total > 0:
+                wts = (torch.arange(P_total, device=dev, dtype=torch.int64) % 1000003) + 1
+                prod = (bindings[:P_total].to(torch.int64) + 2) * wts
+                mine = torch.stack([prod[slice(*shard_bounds(P_total, world, r)[:2])].sum() for r in range(world)]).to(cdev)
+                everyone = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(everyone, mine)
+                diffs = sum(int((h != everyone[0]).sum().item()) for h in everyone)
+                parity["gathered_table"] = {"rows": int(P_total), "shards_hashed": world, "shard_sums_differing_between_ranks": diffs}
+                if diffs:
+                    parity["mismatches_all_ranks"] += diffs
     # further regions of the same K steps: how much one region of K steps moves from run to run (the graded one is the first)
     repeats = []
     for _ in range(max(0, args.repeats)):
@@ -947,6 +973,8 @@ def main():
             "untimed_steps_before_timed_region": args.warmup + ramp_steps, "ms_per_step": step_s * 1e3, "timed_region_split": region_split,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": desc, "pods_per_gpu": P_gpu, "pods_total": P_total, "nodes": N,
+                       **({"one_gpu_stand_in": "TEST HOOK: the %d ranks share ONE GPU and gather through the RCCL stand-in; a check of the N > 1 code, not a scaling figure" % world}
+                          if one_gpu else {}),
                        "predicates": "+".join(flag_names), "pick": pick, "mask_written": not args.no_mask,
                        "mask_row_pitch_words": pitch, "mask_words": W,
                        "kernel": kernel_name, "pick_launch": pick_how,

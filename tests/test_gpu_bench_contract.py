@@ -128,3 +128,42 @@ def test_multi_gpu_path_in_a_one_rank_group(built):
     s = c["configs3_strong"]
     assert s and "error" not in s and s["pods_total"] == 1_000_000 and s["nodes"] == 10_000 and s["value"] > 1e12
     assert 0.05 < c["bound_fraction"] < 1.0
+
+
+FAKE_RCCL = os.path.join(ROOT, "tests", "cpp", "libfake_rccl.so")
+
+
+def test_two_ranks_on_one_gpu_run_the_n_greater_one_code_end_to_end(built):
+    """`python bench.py --gpus 2`, started plainly, on a ONE-GPU box (test hook KSCHED_BENCH_ONE_GPU=1 under KSCHED_TEST_HOOKS=1): the file launches itself under
+    torch.distributed.run, both ranks sit on device 0, the communicator behind the C ABI is created with nranks = 2 over the RCCL stand-in (a blocking
+    all-gather through shared memory; RCCL itself refuses one device twice), and everything the driver's N = 2, 4, 8 runs execute runs: row shards with
+    lo > 0, ksched_allgather_bindings per batch, the table check across ranks, the every-4 and no-gather legs, configs[3] split two ways.  The value is
+    not a scaling figure and the line says so."""
+    assert os.path.exists(FAKE_RCCL), "make host"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(KSCHED_TEST_HOOKS="1", KSCHED_RCCL_LIB=FAKE_RCCL, KSCHED_BENCH_ONE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--ramp-ms", "5", "--kernel-samples", "8",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "re-launching as" in r.stderr and "--nproc-per-node=2" in r.stderr
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and c["pods_per_gpu"] == 100_000 and c["pods_total"] == 200_000 and "one_gpu_stand_in" in c
+    assert c["allgather"].startswith("ksched_allgather_bindings") and c["steps_per_allgather"] == 1
+    pc = d["parity_check"]
+    assert pc["mismatches"] == 0 and pc["mismatches_all_ranks"] == 0 and pc["ranks_unchecked"] == 0 and pc["bindings"] == 100_000
+    assert pc["gathered_table"] == {"rows": 200_000, "shards_hashed": 2, "shard_sums_differing_between_ranks": 0}
+    assert abs(d["value"] - 200_000 * 5_000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    for leg in ("allgather_every_4", "no_allgather"):
+        assert c[leg] and c[leg]["ms_per_step"] > 0, leg
+    s = c["configs3_strong"]
+    assert s and "error" not in s and s["pods_total"] == 1_000_000 and "500000 pods on this rank" in s["workload"]
+
+
+def test_the_one_gpu_hook_is_refused_without_the_test_switch(built):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KSCHED_TEST_HOOKS")}
+    env.update(KSCHED_BENCH_ONE_GPU="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "is a test hook" in (r.stderr + r.stdout)
