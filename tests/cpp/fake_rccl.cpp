@@ -14,6 +14,8 @@
 //     rank's stream has reached the collective (the send buffers are then complete), copies the n contributions into its receive
 //     buffer (hipMemcpyAsync device -> device, peer copies across devices), and no rank's stream runs past the collective before every
 //     rank has finished reading (a send buffer may be overwritten right behind it).  Nothing blocks the host.
+//   * $FAKE_RCCL_CORRUPT_RANK=r (clique of processes): rank r's copy of the gathered table gets one wrong word in a peer's part -- what only a
+//     comparison ACROSS ranks can notice (bench.py parity_check.gathered_table);
 //   * $FAKE_RCCL_FAIL_ALLGATHER=k makes the k-th ncclAllGather call of the process fail (ncclInternalError) -- inside a group that
 //     leaves the collective half-issued, which is what the library's abort path is for.
 // What it does NOT cover: the xGMI transport, RCCL's own kernels and their interaction with the evaluator's kernels on the CUs.
@@ -159,6 +161,11 @@ ncclResult_t gather_across_processes(ncclComm *c, const void *send, void *recv, 
         r = ncclSystemError;
     for (int j = 0; j < n && r == ncclSuccess; ++j)
         if (hipMemcpy(static_cast<char *>(recv) + (size_t)j * bytes, slots + (size_t)j * kSlotBytes, bytes, hipMemcpyHostToDevice) != hipSuccess) r = ncclUnhandledCudaError;
+    if (const char *bad = std::getenv("FAKE_RCCL_CORRUPT_RANK"))  // fault injection: THIS rank receives a wrong word in a peer's part of the table
+        if (r == ncclSuccess && n > 1 && std::atoi(bad) == c->rank) {
+            const int32_t wrong = -7;
+            (void)hipMemcpy(static_cast<char *>(recv) + (size_t)((c->rank + 1) % n) * bytes, &wrong, sizeof wrong, hipMemcpyHostToDevice);
+        }
     m->left[c->rank].store(seq, std::memory_order_release);
     if (!wait_for([&] {  // nobody writes its next contribution before everybody has read this one
             for (int j = 0; j < n; ++j)

@@ -167,3 +167,17 @@ def test_the_one_gpu_hook_is_refused_without_the_test_switch(built):
     env.update(KSCHED_BENCH_ONE_GPU="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "is a test hook" in (r.stderr + r.stdout)
+
+
+def test_a_rank_whose_gathered_table_differs_fails_the_bench(built):
+    """Every rank checks its OWN rows against the oracle; the other ranks' rows it only has from the all-gather.  With the stand-in told to hand rank 1 one
+    wrong word in rank 0's part of the table, both ranks' own rows are still right -- the per-shard sums compared across ranks are what notices, and the
+    run exits non-zero."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(KSCHED_TEST_HOOKS="1", KSCHED_RCCL_LIB=FAKE_RCCL, KSCHED_BENCH_ONE_GPU="1", FAKE_RCCL_CORRUPT_RANK="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--ramp-ms", "5", "--kernel-samples", "8",
+                        "--no-cpu-baseline", "--no-strong-leg", "--repeats", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0, "a table that differs between the ranks must fail the run"
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    pc = d["parity_check"]
+    assert pc["mismatches"] == 0 and pc["gathered_table"]["shard_sums_differing_between_ranks"] > 0 and pc["mismatches_all_ranks"] > 0
