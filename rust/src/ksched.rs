@@ -814,38 +814,113 @@ impl BatchValidity {
 /// sampled pick of select_node_for_pod (src/main.rs:51-71): `samples` = [p][attempts] canonical node indices.
 #[cfg(test)]
 pub fn eval_batch(devices: &Devices, snap: &mut Snapshot, pods: &[&corev1::Pod], samples: Option<(&[u32], u32)>) -> Result<BatchValidity, String> {
-    let ev = devices.first(); // (both masks of the whole batch from one device: the test builds' view)
-    let cols = snap.encode_and_upload(devices, pods)?;
+    // (both masks of the whole batch from the first device: the test builds' view.  Like the C++ mirror's check_node_validity_batch the batch is
+    // evaluated in consecutive pod ranges within the device's budget of label columns per call, and a pod with more selector keys than one call
+    // takes once per group of KSCHED_MAX_KEYS keys, the groups' feasible masks ANDed: the reference walks any selector map, src/predicates.rs:48-53)
     let n = snap.n();
     let words = unsafe { sys::ksched_mask_words(n) };
-    let mut out = BatchValidity { p: cols.p, n, words, feasible: vec![0u64; (cols.p * words) as usize], fit: vec![0u64; (cols.p * words) as usize], binding: Vec::new() };
-    if cols.p == 0 || n == 0 {
-        if samples.is_some() {
-            out.binding = vec![-1; cols.p as usize]; // choose() on an empty store: None on every attempt (src/main.rs:56,70)
+    let p = pods.len() as u32;
+    let mut out = BatchValidity { p, n, words, feasible: vec![0u64; (p * words) as usize], fit: vec![0u64; (p * words) as usize], binding: Vec::new() };
+    if let Some((s, a)) = samples {
+        if s.len() != (p * a) as usize {
+            return Err("samples must hold p * attempts indices".into());
         }
+        out.binding = vec![-1; p as usize]; // (also what choose() on an empty store yields on every attempt: None, src/main.rs:56,70)
+    }
+    if p == 0 || n == 0 {
         return Ok(out);
     }
-    let mut flags = sys::KSCHED_FIT | sys::KSCHED_SEL | sys::KSCHED_WANT_FIT_MASK;
-    let (smp_ptr, attempts) = match samples {
-        Some((s, a)) => {
-            if s.len() != (cols.p * a) as usize {
-                return Err("samples must hold p * attempts indices".into());
+    let w = words as usize;
+    for (lo, hi, wide) in key_ranges(pods) {
+        if wide {
+            let mut feasible = vec![!0u64; w];
+            let mut req_mem = vec![0i64; 1];
+            for group in split_wide_pod(pods[lo]) {
+                let cols = snap.encode_and_upload(devices, &[&group])?; // (re-uploads the label columns of this group's keys)
+                let (f, fit) = devices.masks(&cols, words).map_err(|e| e.to_string())?;
+                for k in 0..w {
+                    feasible[k] &= f[k];
+                }
+                out.fit[lo * w..(lo + 1) * w].copy_from_slice(&fit); // (the same in every group)
+                req_mem[0] = cols.req_mem_bytes[0];
             }
-            flags |= sys::KSCHED_PICK_SAMPLED;
-            out.binding = vec![-1; cols.p as usize];
-            (s.as_ptr(), a)
-        },
-        None => (std::ptr::null(), 0),
-    };
-    let rc = unsafe {
-        sys::ksched_eval(
-            ev.raw(), cols.p, cols.req_cpu_milli.as_ptr(), cols.req_mem_bytes.as_ptr(),
-            if cols.n_keys > 0 { cols.sel_val_ids.as_ptr() } else { std::ptr::null() }, std::ptr::null(), smp_ptr, attempts, flags,
-            out.feasible.as_mut_ptr(), out.fit.as_mut_ptr(), if out.binding.is_empty() { std::ptr::null_mut() } else { out.binding.as_mut_ptr() },
-        )
-    };
-    ev.check(rc, "ksched_eval").map_err(|e| e.to_string())?;
+            out.feasible[lo * w..(lo + 1) * w].copy_from_slice(&feasible);
+            if let Some((s, a)) = samples {
+                let row = &s[lo * a as usize..(lo + 1) * a as usize];
+                out.binding[lo] = devices.pick_from_masks(1, &feasible, &req_mem, row, a).map_err(|e| e.to_string())?[0];
+            }
+            continue;
+        }
+        let cols = snap.encode_and_upload(devices, &pods[lo..hi])?; // (a new range re-uploads the label columns it needs)
+        let ev = devices.first();
+        let mut flags = sys::KSCHED_FIT | sys::KSCHED_SEL | sys::KSCHED_WANT_FIT_MASK;
+        let (smp_ptr, attempts, bind_ptr) = match samples {
+            Some((s, a)) => {
+                flags |= sys::KSCHED_PICK_SAMPLED;
+                (s[lo * a as usize..].as_ptr(), a, out.binding[lo..].as_mut_ptr())
+            },
+            None => (std::ptr::null(), 0, std::ptr::null_mut()),
+        };
+        let rc = unsafe {
+            sys::ksched_eval(
+                ev.raw(), cols.p, cols.req_cpu_milli.as_ptr(), cols.req_mem_bytes.as_ptr(),
+                if cols.n_keys > 0 { cols.sel_val_ids.as_ptr() } else { std::ptr::null() }, std::ptr::null(), smp_ptr, attempts, flags,
+                out.feasible[lo * w..].as_mut_ptr(), out.fit[lo * w..].as_mut_ptr(), bind_ptr,
+            )
+        };
+        ev.check(rc, "ksched_eval").map_err(|e| e.to_string())?;
+    }
     return Ok(out);
+}
+
+/// Consecutive pod ranges [lo, hi) whose distinct selector keys fit one device call; a pod with more keys than a call takes is a range of
+/// its own, marked wide (twin of key_ranges, host/predicates.cpp).
+fn key_ranges(pods: &[&corev1::Pod]) -> Vec<(usize, usize, bool)> {
+    let mut out: Vec<(usize, usize, bool)> = Vec::new();
+    let mut lo = 0usize;
+    let mut keys: BTreeSet<&str> = BTreeSet::new();
+    for (i, pod) in pods.iter().enumerate() {
+        let sel = match &pod.spec {
+            Some(corev1::PodSpec { node_selector: Some(sel), .. }) if !sel.is_empty() => sel,
+            _ => continue, // (most pods: nothing is built for them)
+        };
+        if sel.len() > sys::KSCHED_MAX_KEYS as usize {
+            if lo < i {
+                out.push((lo, i, false));
+            }
+            out.push((i, i + 1, true));
+            lo = i + 1;
+            keys.clear();
+            continue;
+        }
+        let adds = sel.keys().filter(|k| !keys.contains(k.as_str())).count();
+        if adds > 0 && keys.len() + adds > sys::KSCHED_MAX_KEYS as usize {
+            out.push((lo, i, false));
+            lo = i;
+            keys.clear();
+        }
+        for k in sel.keys() {
+            keys.insert(k.as_str());
+        }
+    }
+    if lo < pods.len() {
+        out.push((lo, pods.len(), false));
+    }
+    return out;
+}
+
+/// The pod once per group of at most KSCHED_MAX_KEYS of its selector's keys; every copy carries the whole pod otherwise (twin of
+/// split_wide_pod, host/predicates.cpp).
+fn split_wide_pod(pod: &corev1::Pod) -> Vec<corev1::Pod> {
+    let selector = pod.spec.as_ref().and_then(|s| s.node_selector.as_ref()).expect("a wide pod has a selector");
+    let entries: Vec<(&String, &String)> = selector.iter().collect();
+    let mut out: Vec<corev1::Pod> = Vec::new();
+    for group in entries.chunks(sys::KSCHED_MAX_KEYS as usize) {
+        let mut copy = pod.clone();
+        copy.spec.as_mut().expect("a wide pod has a spec").node_selector = Some(group.iter().map(|(k, v)| ((*k).clone(), (*v).clone())).collect());
+        out.push(copy);
+    }
+    return out;
 }
 
 // ---- the cluster as the watches see it (SURVEY.md section 8f n1 + n2) ----------------------------------------------------
