@@ -25,10 +25,15 @@ in-place figure (one buffer rewritten every step) is reported next to it (`confi
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant (mask) kernel: algorithmic bytes
 per launch / its mean HIP-event duration, measured live in this run on the launch stream: events on
-every mask kernel dispatch of a post-pass of --kernel-samples further steps right after the timed
-region (events cost launch gap, so the timed steps carry none).
+every mask kernel dispatch of a post-pass of --kernel-samples further steps behind the same untimed run-in
+as the timed region (events cost launch gap, so the timed steps carry none).  `roofline.traffic` is measured
+by this invocation too (--live-traffic: separate calibrated rocprofv3 --pmc passes behind the timed region;
+the committed profiles/pmc_traffic.json figure stays beside it and is the fallback).
 `cpu_baseline` is the oracle (CPU restatement, kind "port") timed on this box's host cores on a
 bounded sample of the same workload; it is a reported baseline, never the thing measured above.
+`python bench.py --gpus N` without WORLD_SIZE launches its N ranks itself (torch.distributed.run, 127.0.0.1).
+Test hook: KSCHED_TEST_HOOKS=1 KSCHED_RCCL_LIB=tests/cpp/libfake_rccl.so KSCHED_BENCH_ONE_GPU=1 puts all N ranks
+on device 0 (the N > 1 code end to end on a one-GPU box; the line says it is not a scaling figure).
 """
 from __future__ import annotations
 
