@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define KSCHED_ABI_VERSION 5u
+#define KSCHED_ABI_VERSION 6u
 
 /* at most this many label-key columns per batch */
 #define KSCHED_MAX_KEYS 32u
@@ -287,6 +287,29 @@ int ksched_eval_device_pitched(ksched_ctx *ctx, uint32_t p, const int64_t *req_c
                                uint32_t attempts, uint32_t flags, uint64_t *out_feasible, uint64_t *out_fit,
                                int32_t *out_binding, uint32_t mask_pitch_words, void *hip_stream);
 uint32_t ksched_mask_pitch(uint32_t n_nodes);
+
+/* ---- mask buffers allocated by the library (ABI 6) ---------------------------------------------
+ * The reference never materialises a mask (check_node_validity answers one pair at a time, src/predicates.rs:63-77); the batched
+ * path's mask is its own artefact and 92 % of its HBM traffic, and on MI355X the rate at which the mask kernel runs depends on the
+ * PHYSICAL placement of the buffer it writes (two rates, 4 % apart at 100k x 5k and 20 % apart at 125k x 50k:
+ * profiles/r05_bimodal_by_allocation.md, profiles/r06_mask_alloc.md).  A caller may keep allocating its own masks (any device pointer works);
+ * ksched_mask_alloc hands out [p] rows at the pitch ksched_mask_pitch(n) gives, placed the way the measurements found fastest.
+ *   how            : KSCHED_MASK_ALLOC_AUTO, or one specific path (for re-measuring the choice: tools/alloc_probe.py)
+ *   out_pitch_words: receives the row pitch in 64-bit words (pass it to ksched_eval_device_pitched / ksched_pipe_submit); may be NULL
+ * KSCHED_E_STATE before ksched_set_nodes (the pitch follows the node count); a snapshot with a different node count needs new masks.
+ * ksched_mask_free waits for the device before it unmaps; ksched_destroy frees what the caller left. */
+#define KSCHED_MASK_ALLOC_AUTO 0u
+#define KSCHED_MASK_ALLOC_PLAIN 1u      /* hipMalloc */
+#define KSCHED_MASK_ALLOC_VMM 2u        /* hipMemCreate in one piece at the recommended granularity, VA aligned to 2 MiB */
+#define KSCHED_MASK_ALLOC_VMM_1G 3u     /* the same, VA aligned to 1 GiB */
+#define KSCHED_MASK_ALLOC_VMM_MIN 4u    /* the same at the minimum granularity, default VA alignment */
+#define KSCHED_MASK_ALLOC_CONTIGUOUS 5u /* hipExtMallocWithFlags(hipDeviceMallocContiguous) */
+#define KSCHED_MASK_ALLOC_UNCACHED 6u   /* hipExtMallocWithFlags(hipDeviceMallocUncached) */
+#define KSCHED_MASK_ALLOC_POOL 7u       /* hipMallocFromPoolAsync, a pool that never releases */
+#define KSCHED_MASK_ALLOC_LAST 7u
+#define KSCHED_MASK_ALLOC_AUTO_IS KSCHED_MASK_ALLOC_PLAIN /* what AUTO resolves to in this build */
+int ksched_mask_alloc(ksched_ctx *ctx, uint32_t p, uint32_t how, uint64_t **out_mask, uint32_t *out_pitch_words);
+int ksched_mask_free(ksched_ctx *ctx, uint64_t *mask);
 
 /* The pick alone, from a feasibility mask already on the device (a previous ksched_eval_device* call): lets a caller
  * run the mask kernel of batch i + 1 and the pick of batch i on different HIP streams (the two do not depend on each

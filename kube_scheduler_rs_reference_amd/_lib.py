@@ -14,7 +14,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KSCHED_LIB") or os.path.join(_PKG_DIR, "libksched_hip.so")
 
 # --- constants mirrored from include/ksched.h --------------------------------------------------
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_KEYS = 32
 MAX_ATTEMPTS = 64
 SEL_NEVER = 0xFFFFFFFF
@@ -59,6 +59,16 @@ TRACE_WORDS = 8
 KERNEL_AUTO = 0
 KERNEL_DIRECT = 1
 KERNEL_FUSED = 3
+MASK_ALLOC_AUTO = 0
+MASK_ALLOC_PLAIN = 1
+MASK_ALLOC_VMM = 2
+MASK_ALLOC_VMM_1G = 3
+MASK_ALLOC_VMM_MIN = 4
+MASK_ALLOC_CONTIGUOUS = 5
+MASK_ALLOC_UNCACHED = 6
+MASK_ALLOC_POOL = 7
+MASK_ALLOC_LAST = 7
+MASK_ALLOC_NAMES = {0: "auto", 1: "plain", 2: "vmm", 3: "vmm-1g", 4: "vmm-min", 5: "contiguous", 6: "uncached", 7: "pool"}
 
 # every symbol include/ksched.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
@@ -85,6 +95,8 @@ SYMBOLS = {
     "ksched_eval_device": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "ksched_eval_device_pitched": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     "ksched_mask_pitch": (_u32, [_u32]),
+    "ksched_mask_alloc": (C.c_int, [_vp, _u32, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
+    "ksched_mask_free": (C.c_int, [_vp, _vp]),
     "ksched_pick_device": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp]),
     "ksched_pick": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _u32, _u32, _vp]),
     "ksched_pipe_create": (C.c_int, [_vp, _u32, C.POINTER(_vp)]),

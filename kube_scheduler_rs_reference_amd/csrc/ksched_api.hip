@@ -23,6 +23,7 @@
 #include "kernels_build.hpp"
 #include "kernels_direct.hpp"
 #include "kernels_fused.hpp"
+#include "mask_alloc.hpp"
 #include "tile_index.hpp"
 
 using namespace ksched;
@@ -1118,6 +1119,15 @@ void ksched_destroy(ksched_ctx *c) try {
         if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
         if (c->ev_scratch) (void)hipEventDestroy(c->ev_scratch);
         indexed_release(c->idx);
+        {  // masks the caller never handed back (ksched_mask_alloc)
+            MaskRegistry &reg = mask_registry();
+            std::lock_guard<std::mutex> rl(reg.mu);
+            for (size_t i = reg.live.size(); i-- > 0;)
+                if (reg.live[i].owner == c) {
+                    (void)mask_release(reg.live[i]);
+                    reg.live.erase(reg.live.begin() + (long)i);
+                }
+        }
         for (auto &ep : c->ev_pool) {
             (void)hipEventDestroy(ep.a);
             (void)hipEventDestroy(ep.b);
@@ -1752,6 +1762,109 @@ int ksched_eval_begin(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int6
     rc = eval_begin_locked(c, p, pcpu, pmem, psel, sel_stride, ptol, samples, attempts, flags, out_feas, out_fit, binding_capacity, binding_dev);
     if (rc) return rc;
     *hip_stream = (void *)c->stream;
+    return KSCHED_OK;
+} KSCHED_ABI_CATCH(c)
+
+// ---- mask buffers owned by the library (mask_alloc.hpp; profiles/r06_mask_alloc.md) ---------------------------------------------
+int ksched_mask_alloc(ksched_ctx *c, uint32_t p, uint32_t how, uint64_t **out_mask, uint32_t *out_pitch_words) try {
+    if (!c || !out_mask) return KSCHED_E_INVAL;
+    *out_mask = nullptr;
+    if (how > KSCHED_MASK_ALLOC_LAST) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_nodes) {
+        c->last_error = "ksched_mask_alloc before ksched_set_nodes: the row pitch follows the node count";
+        return KSCHED_E_STATE;
+    }
+    fault_point(c);
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    const uint32_t pitch = ksched_mask_pitch(c->n);
+    if (out_pitch_words) *out_pitch_words = pitch;
+    const size_t bytes = std::max<size_t>((size_t)p * pitch * 8u, 128u);
+    MaskAllocation a;
+    a.bytes = bytes;
+    a.device = c->device;
+    a.owner = c;
+    const uint32_t eff = how == KSCHED_MASK_ALLOC_AUTO ? (uint32_t)KSCHED_MASK_ALLOC_AUTO_IS : how;
+    a.how = eff;
+    hipError_t e = hipSuccess;
+    switch (eff) {
+        case KSCHED_MASK_ALLOC_PLAIN:
+            e = hipMalloc(&a.ptr, bytes);
+            a.mapped = bytes;
+            break;
+        case KSCHED_MASK_ALLOC_VMM: e = mask_alloc_vmm(c->device, bytes, 2u << 20, true, &a); break;
+        case KSCHED_MASK_ALLOC_VMM_1G: e = mask_alloc_vmm(c->device, bytes, 1u << 30, true, &a); break;
+        case KSCHED_MASK_ALLOC_VMM_MIN: e = mask_alloc_vmm(c->device, bytes, 0, false, &a); break;
+        case KSCHED_MASK_ALLOC_CONTIGUOUS:
+            e = hipExtMallocWithFlags(&a.ptr, bytes, hipDeviceMallocContiguous);
+            a.mapped = bytes;
+            break;
+        case KSCHED_MASK_ALLOC_UNCACHED:
+            e = hipExtMallocWithFlags(&a.ptr, bytes, hipDeviceMallocUncached);
+            a.mapped = bytes;
+            break;
+        case KSCHED_MASK_ALLOC_POOL: {
+            MaskRegistry &reg = mask_registry();
+            std::lock_guard<std::mutex> rl(reg.mu);
+            hipMemPool_t pool = nullptr;
+            for (auto &pp : reg.pools)
+                if (pp.first == c->device) pool = pp.second;
+            if (!pool) {
+                hipMemPoolProps props{};
+                props.allocType = hipMemAllocationTypePinned;
+                props.location.type = hipMemLocationTypeDevice;
+                props.location.id = c->device;
+                e = hipMemPoolCreate(&pool, &props);
+                if (e == hipSuccess) {
+                    uint64_t never = ~0ull;
+                    e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &never);
+                    reg.pools.emplace_back(c->device, pool);
+                }
+            }
+            if (e == hipSuccess) e = hipMallocFromPoolAsync(&a.ptr, bytes, pool, nullptr);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+            a.mapped = bytes;
+            a.pooled = true;
+            break;
+        }
+        default: return KSCHED_E_INVAL;
+    }
+    if (e != hipSuccess || !a.ptr) {
+        c->last_error = std::string("ksched_mask_alloc: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? KSCHED_E_NOMEM : KSCHED_E_HIP;
+    }
+    {
+        MaskRegistry &reg = mask_registry();
+        std::lock_guard<std::mutex> rl(reg.mu);
+        reg.live.push_back(a);
+    }
+    *out_mask = (uint64_t *)a.ptr;
+    return KSCHED_OK;
+} KSCHED_ABI_CATCH(c)
+
+int ksched_mask_free(ksched_ctx *c, uint64_t *mask) try {
+    if (!c) return KSCHED_E_INVAL;
+    if (!mask) return KSCHED_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    if (!g.ok) return KSCHED_E_HIP;
+    MaskAllocation a;
+    {
+        MaskRegistry &reg = mask_registry();
+        std::lock_guard<std::mutex> rl(reg.mu);
+        auto it = std::find_if(reg.live.begin(), reg.live.end(), [&](const MaskAllocation &m) { return m.ptr == (void *)mask; });
+        if (it == reg.live.end()) {
+            c->last_error = "ksched_mask_free: not a pointer ksched_mask_alloc returned (or freed already)";
+            return KSCHED_E_INVAL;
+        }
+        a = *it;
+        reg.live.erase(it);
+    }
+    // evaluations still writing it (any stream of the device) finish first: unmapping under a running kernel is a fault
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, mask_release(a));
     return KSCHED_OK;
 } KSCHED_ABI_CATCH(c)
 

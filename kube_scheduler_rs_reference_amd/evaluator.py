@@ -340,15 +340,20 @@ class Evaluator:
         """A `depth`-slot two-stream pipeline over this evaluator (ksched_pipe_*)."""
         return Pipe(self, depth)
 
-    def alloc_mask(self, p: int, pitched: bool = True):
-        """A [p, W] int64 mask tensor on this device.  pitched=True pads the row pitch to
-        ksched_mask_pitch(n) words (cache-line aligned rows: the fast layout); the returned tensor
-        is the [p, W] view of it."""
+    def alloc_mask(self, p: int, pitched: bool = True, how=None):
+        """A [p, W] int64 mask tensor on this device.  pitched=True: rows at the pitch ksched_mask_pitch(n) gives (cache-line aligned rows: the
+        fast layout), the memory ALLOCATED BY THE LIBRARY (ksched_mask_alloc: the placement the measurements found fastest, profiles/r06_mask_alloc.md)
+        and handed back to it when the tensor dies; `how` = one of _lib.MASK_ALLOC_* (default AUTO).  pitched=False: a packed torch tensor."""
         import torch
         W = self.W
-        pitch = int(self._lib.ksched_mask_pitch(self.n)) if pitched else W
-        buf = torch.empty((p, max(pitch, 1)), dtype=torch.int64, device=f"cuda:{self.device}")
-        return buf[:, :W]
+        if not pitched:
+            return torch.empty((p, max(W, 1)), dtype=torch.int64, device=f"cuda:{self.device}")[:, :W]
+        ptr, pitch = C.c_void_p(), C.c_uint32(0)
+        self._check(self._lib.ksched_mask_alloc(self._h, int(p), int(L.MASK_ALLOC_AUTO if how is None else how), C.byref(ptr), C.byref(pitch)), "ksched_mask_alloc")
+        pitch = max(int(pitch.value), 1)
+        owner = _LibraryMask(self, ptr.value, (max(int(p), 1), pitch))
+        buf = torch.as_tensor(owner, device=f"cuda:{self.device}")  # zero-copy (__cuda_array_interface__); the tensor keeps `owner` alive
+        return buf[:int(p), :W]
 
     # -- reasons -------------------------------------------------------------------------------------
     def explain(self, req_cpu_milli, req_mem_bytes, sel_val_ids, tolerations, pair_pod, pair_node, flags: int) -> np.ndarray:
@@ -372,6 +377,23 @@ class Evaluator:
         f = np.ascontiguousarray(feasible_row, dtype=np.uint64)
         r = None if fit_row is None else np.ascontiguousarray(fit_row, dtype=np.uint64)
         return self._lib.ksched_reason(_ptr(f), _ptr(r), int(node), int(flags))
+
+
+class _LibraryMask:
+    """Owner of one ksched_mask_alloc buffer, seen by torch through __cuda_array_interface__; ksched_mask_free when the last tensor over it dies."""
+
+    def __init__(self, ev: "Evaluator", ptr: int, shape):
+        self._ev, self._ptr = ev, ptr
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<i8", "data": (int(ptr), False), "version": 3, "strides": None}
+
+    def __del__(self):
+        ev, ptr = self._ev, self._ptr
+        self._ptr = None
+        if ptr and getattr(ev, "_h", None):  # (a closed evaluator has freed it already: ksched_destroy)
+            try:
+                ev._lib.ksched_mask_free(ev._h, C.c_void_p(ptr))
+            except Exception:  # pragma: no cover
+                pass
 
 
 class Pipe:

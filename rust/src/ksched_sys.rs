@@ -17,7 +17,7 @@ pub struct ksched_comm {
     _private: [u8; 0],
 }
 
-pub const KSCHED_ABI_VERSION: u32 = 5;
+pub const KSCHED_ABI_VERSION: u32 = 6;
 pub const KSCHED_MAX_KEYS: u32 = 32;
 pub const KSCHED_MAX_ATTEMPTS: u32 = 64;
 pub const KSCHED_SEL_NEVER: u32 = 0xFFFF_FFFF;
@@ -57,6 +57,9 @@ pub const KSCHED_OPT_FAULT: c_int = 10;
 pub const KSCHED_OPT_PIPE_MODE: c_int = 11;
 pub const KSCHED_PIPE_MAX_STREAMS: u32 = 8;
 pub const KSCHED_OPT_GRID_CUS: c_int = 12;
+pub const KSCHED_MASK_ALLOC_AUTO: u32 = 0;
+pub const KSCHED_MASK_ALLOC_PLAIN: u32 = 1;
+pub const KSCHED_MASK_ALLOC_VMM: u32 = 2;
 
 extern "C" {
     // ---- lifetime
@@ -105,6 +108,8 @@ extern "C" {
         out_binding: *mut i32, mask_pitch_words: u32, hip_stream: *mut c_void,
     ) -> c_int;
     pub fn ksched_mask_pitch(n_nodes: u32) -> u32;
+    pub fn ksched_mask_alloc(ctx: *mut ksched_ctx, p: u32, how: u32, out_mask: *mut *mut u64, out_pitch_words: *mut u32) -> c_int;
+    pub fn ksched_mask_free(ctx: *mut ksched_ctx, mask: *mut u64) -> c_int;
     pub fn ksched_pick_device(
         ctx: *mut ksched_ctx, p: u32, feasible: *const u64, mask_pitch_words: u32, req_mem_bytes: *const i64,
         samples: *const u32, attempts: u32, flags: u32, out_binding: *mut i32, hip_stream: *mut c_void,
@@ -180,6 +185,8 @@ pub fn symbol_table() -> Vec<(&'static str, usize)> {
         ("ksched_eval_device", ksched_eval_device as usize),
         ("ksched_eval_device_pitched", ksched_eval_device_pitched as usize),
         ("ksched_mask_pitch", ksched_mask_pitch as usize),
+        ("ksched_mask_alloc", ksched_mask_alloc as usize),
+        ("ksched_mask_free", ksched_mask_free as usize),
         ("ksched_pick_device", ksched_pick_device as usize),
         ("ksched_pick", ksched_pick as usize),
         ("ksched_pipe_create", ksched_pipe_create as usize),
@@ -248,5 +255,8 @@ pub fn constant_table() -> Vec<(&'static str, i64)> {
         ("KSCHED_OPT_PIPE_MODE", KSCHED_OPT_PIPE_MODE as i64),
         ("KSCHED_PIPE_MAX_STREAMS", KSCHED_PIPE_MAX_STREAMS as i64),
         ("KSCHED_OPT_GRID_CUS", KSCHED_OPT_GRID_CUS as i64),
+        ("KSCHED_MASK_ALLOC_AUTO", KSCHED_MASK_ALLOC_AUTO as i64),
+        ("KSCHED_MASK_ALLOC_PLAIN", KSCHED_MASK_ALLOC_PLAIN as i64),
+        ("KSCHED_MASK_ALLOC_VMM", KSCHED_MASK_ALLOC_VMM as i64),
     ];
 }

@@ -1,0 +1,119 @@
+#!/usr/bin/env python
+"""Which allocation path gives the mask kernel its fast rate, and which hardware counter separates the two rates?
+(the finding it follows up: profiles/r05_bimodal_by_allocation.md.)
+
+    python tools/alloc_probe.py <workload=C5s> survey [k=4] [hows=1,2,3,4,5,7] [n=24]
+        k mask buffers (sets of R buffers where the workload rotates) per allocation path of ksched_mask_alloc, each timed with HIP events on the
+        mask kernel; a fragmenting pattern of spacer allocations runs between the paths so that the plain path sees used memory.
+    python tools/alloc_probe.py <workload> pmc [k=6] [hows=1,2] [n=16]
+        the same candidates; then a FINAL PHASE of n launches into each candidate in turn, and one `PLAN {json}` line that says which of the
+        process's last launches wrote which candidate and what the events read -- run it under `rocprofv3 --kernel-trace --pmc <counters>` and give
+        the csv to tools/alloc_pmc_summary.py: per-candidate counter values next to per-candidate times.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from kube_scheduler_rs_reference_amd import Evaluator, _lib as L, synth  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C5s"
+mode = sys.argv[2] if len(sys.argv) > 2 else "survey"
+kw = dict(a.split("=", 1) for a in sys.argv[3:] if "=" in a)
+K = int(kw.get("k", 4))
+N = int(kw.get("n", 24))
+hows = [int(h) for h in kw.get("hows", "1,2,3,4,5,7").split(",")]
+frag = int(kw.get("frag", 1))
+dev = torch.device("cuda:0")
+rig = bench.SingleRig(torch, L, synth, Evaluator, dev, name)
+ev, P = rig.ev, rig.P
+pitch = int(ev._lib.ksched_mask_pitch(ev.n))
+R = bench.rotation_for(pitch * 8 * P, True)
+print(f"# {rig.desc}: {P} rows at a pitch of {pitch} words = {pitch * 8 * P / 2**20:.0f} MiB per buffer, {R} buffer(s) per candidate set", flush=True)
+
+
+def bound(masks):
+    return ev.bind_eval_device(*rig.d, rig.flags, out_feasible=masks, out_bindings=[rig.out])
+
+
+def timed(masks, n=N):
+    run = bound(masks)
+    k = 0
+    for _ in range(max(8, 2 * len(masks))):
+        run(0, k % len(masks)); k += 1
+    torch.cuda.synchronize()
+    ev.set_timing(True, every=1)
+    ev.kernel_time_samples(8192)
+    for _ in range(n):
+        run(0, k % len(masks)); k += 1
+    torch.cuda.synchronize()
+    us = ev.kernel_time_samples(8192) * 1e3
+    ev.set_timing(False)
+    return float(np.mean(us)), float(np.median(us)), float(np.min(us))
+
+
+def fragment(seed):
+    """Leave holes: allocate many odd-sized blocks through the plain path, free every other one.  Returned blocks stay alive."""
+    rng = np.random.default_rng(seed)
+    blocks = [torch.empty(int(rng.integers(3, 90)) << 20, dtype=torch.uint8, device=dev) for _ in range(48)]
+    keep = blocks[::2]
+    del blocks
+    torch.cuda.empty_cache()
+    return keep
+
+
+cands = []  # (how, index, [masks])
+spacers = []
+for hi, how in enumerate(hows):
+    if frag:
+        spacers.append(fragment(hi))
+    for i in range(K):
+        try:
+            masks = [ev.alloc_mask(P, how=how) for _ in range(R)]
+        except L.KschedError as e:
+            print(f"how {how} ({L.MASK_ALLOC_NAMES[how]}): allocation failed: {e}", flush=True)
+            break
+        cands.append((how, i, masks))
+
+res = []
+for how, i, masks in cands:
+    mean, med, lo = timed(masks)
+    res.append((how, i, mean, med, lo, masks[0].data_ptr()))
+    print(f"how {how} {L.MASK_ALLOC_NAMES[how]:10s} candidate {i}: first buffer at {masks[0].data_ptr():#x}: mask kernel mean {mean:7.2f} us, median {med:7.2f}, min {lo:7.2f}", flush=True)
+print("# second pass (is a candidate's rate its own?)")
+for j, (how, i, masks) in enumerate(cands):
+    mean, med, lo = timed(masks)
+    print(f"how {how} {L.MASK_ALLOC_NAMES[how]:10s} candidate {i}: mean {mean:7.2f} us (first pass {res[j][2]:7.2f})", flush=True)
+    res[j] = res[j] + (mean,)
+for how in hows:
+    r = [x for x in res if x[0] == how]
+    if r:
+        a = np.array([[x[2], x[6]] for x in r])
+        print(f"== how {how} {L.MASK_ALLOC_NAMES[how]:10s}: mean over candidates {a.mean():7.2f} us, fastest {a.min():7.2f}, slowest {a.max():7.2f}")
+
+if mode == "pmc":
+    # final phase: n launches per candidate, nothing else on the device; the csv's LAST len(cands) * n mask-kernel dispatches are these
+    plan = []
+    ev.set_timing(True, every=1)
+    for how, i, masks in cands:
+        run = bound(masks)
+        for k in range(2 * len(masks)):
+            run(0, k % len(masks))
+        torch.cuda.synchronize()
+    ev.kernel_time_samples(8192)
+    torch.cuda.synchronize()
+    for how, i, masks in cands:
+        run = bound(masks)
+        for k in range(N):
+            run(0, k % len(masks))
+        torch.cuda.synchronize()
+        us = ev.kernel_time_samples(8192) * 1e3
+        plan.append({"how": how, "name": L.MASK_ALLOC_NAMES[how], "candidate": i, "launches": N, "event_mean_us": float(np.mean(us)), "ptr": masks[0].data_ptr()})
+    ev.set_timing(False)
+    print("PLAN " + json.dumps({"workload": name, "per_candidate_launches": N, "kernel_prefix": "k_eval_fused", "candidates": plan}), flush=True)
+del cands
+rig.close()
