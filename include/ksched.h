@@ -151,6 +151,14 @@ extern "C" {
  * alternate mode) and 256 / k compute units each, one batch's fill hides under the others' stores.  A throughput setting:
  * a single batch's own latency grows.  Results do not depend on it. */
 #define KSCHED_OPT_GRID_CUS 12
+/* KSCHED_OPT_MASK_PROBE: candidates ksched_mask_alloc's probe-and-keep path allocates and times (1 .. 16, default 6; 1 = no probing). */
+#define KSCHED_OPT_MASK_PROBE 13
+/* KSCHED_OPT_ROUND_ORDER: which pods the fused mask kernel's waves take in which order.  A launch cuts the batch into rounds of 64 pods and has
+ * chunks * 16 waves per tile working at once.  0 (default) = interleaved, wave-major: round g goes to stream g mod (chunks * 16), neighbouring
+ * rounds to different blocks -- the chip writes one moving window of the mask; 2 = interleaved, chunk-major (a block's 16 waves take 16
+ * neighbouring rounds); 1 = blocked: every wave owns one contiguous pod range (rounds 1 .. 5's order: chunks * 16 write streams megabytes apart).
+ * Results do not depend on it (tests/test_gpu_fullsize.py runs all three); rates do: profiles/r06_round_order.md. */
+#define KSCHED_OPT_ROUND_ORDER 14
 
 typedef struct ksched_ctx ksched_ctx;
 
@@ -306,10 +314,20 @@ uint32_t ksched_mask_pitch(uint32_t n_nodes);
 #define KSCHED_MASK_ALLOC_CONTIGUOUS 5u /* hipExtMallocWithFlags(hipDeviceMallocContiguous) */
 #define KSCHED_MASK_ALLOC_UNCACHED 6u   /* hipExtMallocWithFlags(hipDeviceMallocUncached) */
 #define KSCHED_MASK_ALLOC_POOL 7u       /* hipMallocFromPoolAsync, a pool that never releases */
-#define KSCHED_MASK_ALLOC_LAST 7u
-#define KSCHED_MASK_ALLOC_AUTO_IS KSCHED_MASK_ALLOC_PLAIN /* what AUTO resolves to in this build */
+#define KSCHED_MASK_ALLOC_SCATTER_2M 8u  /* physical pieces of 2 MiB created one by one (a quarter more than needed), shuffled, mapped at consecutive addresses */
+#define KSCHED_MASK_ALLOC_SCATTER_16M 9u /* the same with pieces of 16 MiB */
+#define KSCHED_MASK_ALLOC_SCATTER_64K 10u /* the same with pieces of 64 KiB (large masks: tens of thousands of mappings) */
+#define KSCHED_MASK_ALLOC_PROBE 11u /* probe-and-keep: KSCHED_OPT_MASK_PROBE candidates over several of the paths above, all alive at once; the fused
+                                     * mask kernel is timed into each (fit only, zero requests, the current snapshot); the fastest is kept */
+#define KSCHED_MASK_ALLOC_LAST 11u
+/* AUTO = PROBE for masks of at least KSCHED_MASK_PROBE_MIN_BYTES when the snapshot has its bitmap index, PLAIN otherwise: no allocation path selects
+ * the fast placement (profiles/r06_mask_alloc.md), and below that size a buffer's own rate does not stand out of the run-to-run noise */
+#define KSCHED_MASK_PROBE_MIN_BYTES 0x8000000u /* 128 MiB */
 int ksched_mask_alloc(ksched_ctx *ctx, uint32_t p, uint32_t how, uint64_t **out_mask, uint32_t *out_pitch_words);
 int ksched_mask_free(ksched_ctx *ctx, uint64_t *mask);
+/* What the latest probe-and-keep allocation of this ctx measured: microseconds per mask kernel launch into each candidate, in candidate order
+ * (the kept one is the smallest).  Returns the number of candidates written (<= cap), 0 when the latest ksched_mask_alloc did not probe. */
+int ksched_mask_probe_report(ksched_ctx *ctx, double *out_us, uint32_t cap);
 
 /* The pick alone, from a feasibility mask already on the device (a previous ksched_eval_device* call): lets a caller
  * run the mask kernel of batch i + 1 and the pick of batch i on different HIP streams (the two do not depend on each

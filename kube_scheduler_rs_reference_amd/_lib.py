@@ -55,6 +55,8 @@ OPT_FAULT = 10
 OPT_PIPE_MODE = 11
 PIPE_MAX_STREAMS = 8
 OPT_GRID_CUS = 12
+OPT_MASK_PROBE = 13
+OPT_ROUND_ORDER = 14
 TRACE_WORDS = 8
 KERNEL_AUTO = 0
 KERNEL_DIRECT = 1
@@ -67,8 +69,13 @@ MASK_ALLOC_VMM_MIN = 4
 MASK_ALLOC_CONTIGUOUS = 5
 MASK_ALLOC_UNCACHED = 6
 MASK_ALLOC_POOL = 7
-MASK_ALLOC_LAST = 7
-MASK_ALLOC_NAMES = {0: "auto", 1: "plain", 2: "vmm", 3: "vmm-1g", 4: "vmm-min", 5: "contiguous", 6: "uncached", 7: "pool"}
+MASK_ALLOC_SCATTER_2M = 8
+MASK_ALLOC_SCATTER_16M = 9
+MASK_ALLOC_SCATTER_64K = 10
+MASK_ALLOC_PROBE = 11
+MASK_ALLOC_LAST = 11
+MASK_PROBE_MIN_BYTES = 128 << 20
+MASK_ALLOC_NAMES = {0: "auto", 1: "plain", 2: "vmm", 3: "vmm-1g", 4: "vmm-min", 5: "contiguous", 6: "uncached", 7: "pool", 8: "scatter-2m", 9: "scatter-16m", 10: "scatter-64k", 11: "probe"}
 
 # every symbol include/ksched.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
@@ -97,6 +104,7 @@ SYMBOLS = {
     "ksched_mask_pitch": (_u32, [_u32]),
     "ksched_mask_alloc": (C.c_int, [_vp, _u32, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
     "ksched_mask_free": (C.c_int, [_vp, _vp]),
+    "ksched_mask_probe_report": (C.c_int, [_vp, _vp, _u32]),
     "ksched_pick_device": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp]),
     "ksched_pick": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _u32, _u32, _vp]),
     "ksched_pipe_create": (C.c_int, [_vp, _u32, C.POINTER(_vp)]),

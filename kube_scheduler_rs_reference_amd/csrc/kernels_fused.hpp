@@ -93,6 +93,9 @@ struct FusedArgs {
     const uint64_t *zero64;            // eight zero bytes in device memory
     uint32_t p, units, chunks, run;    // units = ceil(p / 8); run = (chunk, tile) pairs per XCD
     uint32_t unit_q, unit_rem, tiles_rcp;  // units / chunks, units % chunks, floor(2^32 / tiles)
+    uint32_t wave_major;               // interleaved order: 1 = stream index wave * chunks + chunk, 0 = chunk * waves + wave
+    uint32_t u_stride;                 // units between a wave's consecutive rounds: 8 = every wave owns a contiguous pod range (blocked); chunks * waves * 8 =
+                                       // the launch's rounds are dealt round-robin over its (chunk, wave) streams (interleaved: the chip writes ONE moving window)
     uint32_t off_aux, off_fit, off_lab, off_trow;  // LDS byte offsets of the regions after the bitmap rows
     uint32_t nlist, list_mask8, off_list, off_lrec;  // list keys (tile_index.hpp): count, which of the first eight columns are lists, LDS offsets
     uint32_t list_col[kMaxListKeys];                 // their label columns
@@ -248,7 +251,19 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
     const uint32_t c_lo = chunk * a.unit_q + min(chunk, a.unit_rem);
     const uint32_t c_n = a.unit_q + (chunk < a.unit_rem ? 1u : 0u);
     uint32_t u = c_lo + (wave * c_n) / kFusedWaves;
-    const uint32_t u_hi = c_lo + ((wave + 1u) * c_n) / kFusedWaves;
+    uint32_t u_hi = c_lo + ((wave + 1u) * c_n) / kFusedWaves;
+    const uint32_t u_stride = a.u_stride;  // (a kernel argument: uniform; the back end may keep it or load it again)
+    if (u_stride != 8u) {
+        // interleaved (the default): round g of the launch (64 pods) belongs to stream g mod (chunks * waves); stream = wave * chunks + chunk
+        // (wave-major: neighbouring rounds are written by different blocks, hence different compute units and mostly different XCDs) or
+        // chunk * waves + wave (chunk-major: a block's sixteen waves write sixteen neighbouring rounds).  The chip then writes ONE moving window
+        // of chunks * 16 rounds instead of chunks * 16 streams that each sweep a range of their own megabytes apart: session r6j / r6k, same box,
+        // blocked -> chunk-major -> wave-major: C3 19.66 -> 18.73 -> 18.0 us per step, C4 shard 40.9 -> 38.8 -> 37.5, the C5 shard's mask kernel
+        // 173 -> 165 -> 152 us (profiles/r06_round_order.md).  Every tile-block of a chunk still sees the same pods in the same units (the
+        // tile-test pick's accumulators count on it); only the round at the very end of the batch can be short, and it is its wave's last.
+        u = (a.wave_major ? wave * a.chunks + chunk : chunk * kFusedWaves + wave) * 8u;
+        u_hi = a.units;
+    }
 
     // ---- pod operands ---------------------------------------------------------------------------
     // Loaded with inline-asm global loads that the compiler's s_waitcnt bookkeeping does not see, and
@@ -742,13 +757,13 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
     // (session r5d, inputs rotated: C3 23.9 -> 20.2 us per step, the C4 shard 54.8 -> 42.3; the C5 shard, 24 rounds per wave, 222.5 -> 224.7 with it)
     constexpr uint32_t kPrefetchRounds = 6;
     auto prefetch_rounds = [&]() {
-        if (!(FIT || SEL || TAINT) || a.off_pf == 0xFFFFFFFFu || u + 8u * (kPrefetchRounds + 2u) < u_hi || (a.debug & 0x20000000u)) return;
+        if (!(FIT || SEL || TAINT) || a.off_pf == 0xFFFFFFFFu || u + u_stride * (kPrefetchRounds + 2u) < u_hi || (a.debug & 0x20000000u)) return;
         const uint32_t dump = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off_pf);
         // lane -> line of the round: [0,4) cpu, [4,8) memory, [8,24) the eight selector columns (two lines each), [24,34) the draws, [34,38) tolerations
         const uint32_t li = opaque(lane);
 #pragma unroll 1
         for (uint32_t r = 1; r <= kPrefetchRounds; ++r) {
-            const uint32_t pu = u + 8u * r;
+            const uint32_t pu = u + u_stride * r;
             if (pu >= u_hi) break;  // wave-uniform
             const uint32_t pod0 = pu * 8u;
             const uint32_t pe = a.p - 1u;
@@ -769,9 +784,11 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
                 a64 = reinterpret_cast<uint64_t>(g_ptol + e8);
             }
             // (M0 = the LDS destination of an LDS-DMA load; the compiler manages M0 itself -- the staging -- so the statement
-            // puts back what it found)
+            // puts back what it found.  gfx9 wants one wait state between an SALU write of M0 and an LDS-DMA instruction that reads it, the
+            // hardware does not interlock and the hazard recogniser does not look inside inline asm: the s_nop on either side of the load
+            // is that wait state, for the statement's own M0 write and for the load against the restore -- ADVICE r5; tools/audit_asm.py checks it.)
             uint32_t m0_saved;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_saved) : "v"(a64), "s"(dump) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_nop 0\n\ts_mov_b32 m0, %0\n\ts_nop 0" : "=&s"(m0_saved) : "v"(a64), "s"(dump) : "memory");
         }
     };
     bool more = u < u_hi, have_prev = false, first = true, stamped4 = false;
@@ -1018,7 +1035,7 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
             prev_u = u;
             prev_nu = min(8u, u_hi - u);
             have_prev = true;
-            u += 8u;
+            u += u_stride;
             more = u < u_hi;
         }
         if (PICK == 2 && !had_more && have_prev) {  // the wave's last round: nothing else is in flight behind its atomic
@@ -1120,7 +1137,7 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
                             const uint64_t *ptol, uint32_t flags, uint64_t *out_feas, uint64_t *out_fit, uint32_t pitch, hipStream_t stream,
                             uint32_t debug = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint64_t *trace = nullptr,
                             uint32_t trace_blocks = 0, const SelectArgs *pick = nullptr, int pick_form = 1, uint64_t *pick_acc = nullptr,
-                            uint32_t grid_cus = 0) {
+                            uint32_t grid_cus = 0, int round_order = 0) {
     const IndexedLayout &l = s.lay;
     FusedArgs a{};
     a.W = l.W;
@@ -1170,6 +1187,9 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     a.chunks = std::max(1u, std::min((cus * blocks_per_cu) / l.tiles, want));
     a.unit_q = a.units / a.chunks;
     a.unit_rem = a.units % a.chunks;
+    // KSCHED_OPT_ROUND_ORDER: 0 = interleaved, wave-major (default); 1 = blocked; 2 = interleaved, chunk-major
+    a.u_stride = round_order == 1 ? 8u : a.chunks * kFusedWaves * 8u;
+    a.wave_major = round_order == 2 ? 0u : 1u;
     a.tiles_rcp = (uint32_t)std::min<uint64_t>((1ull << 32) / l.tiles, 0xFFFFFFFFull);
     const uint32_t total = a.chunks * l.tiles;
     a.run = (total + 7u) / 8u;

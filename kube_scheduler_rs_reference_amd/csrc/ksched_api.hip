@@ -149,6 +149,9 @@ struct ksched_ctx {
     };
     std::vector<PickAcc> pick_acc;
     int opt_pipe_mode = 0;        // KSCHED_OPT_PIPE_MODE: 0 split (mask stream / pick stream), m >= 1 alternate (whole steps, stream = slot % max(2, m))
+    int opt_round_order = 0;      // KSCHED_OPT_ROUND_ORDER: 0 interleaved wave-major (default), 1 blocked, 2 interleaved chunk-major
+    uint32_t opt_mask_probe = 6;  // KSCHED_OPT_MASK_PROBE: candidates of ksched_mask_alloc's probe-and-keep path
+    double mask_probe_us[16] = {};  // what the latest probe measured per candidate (diagnostics: ksched_last_error carries them as text)
     uint32_t opt_grid_cus = 0;    // KSCHED_OPT_GRID_CUS: compute units ONE fused mask launch may occupy (0 = the whole chip)
     uint32_t fault_kind = 0, fault_skip = 0;  // KSCHED_OPT_FAULT (test hook of the no-unwind rule)
     int opt_bestfit_stages = 0;  // KSCHED_OPT_BESTFIT_STAGES: 0 auto, 1 one stage, 2 two stages
@@ -1012,7 +1015,7 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
         hipError_t e = run_fused(c->idx, p, pcpu, pmem, psel, ptol, flags, feas, out_fit, pitch, s, c->opt_debug,
                                  timed ? c->ev_pool[slot].a : nullptr, timed ? c->ev_pool[slot].b : nullptr,
                                  c->opt_trace ? c->trace.ptr : nullptr, kTraceBlocks, pick_rides ? &ride : nullptr, ride_form, ride_acc,
-                                 c->opt_grid_cus);
+                                 c->opt_grid_cus, c->opt_round_order);
         if (e != hipSuccess) return fail_hip(c, e, "run_fused");
         c->last_kernel = "fused";
         if (pick_rides) c->last_pick = ride_form == 2 ? "fused-tile" : "fused";
@@ -1189,6 +1192,14 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) try {
         case KSCHED_OPT_GRID_CUS:
             if (value != 0 && (value < 8 || value > 256)) return KSCHED_E_INVAL;
             c->opt_grid_cus = (uint32_t)value;
+            return KSCHED_OK;
+        case KSCHED_OPT_ROUND_ORDER:
+            if (value < 0 || value > 2) return KSCHED_E_INVAL;
+            c->opt_round_order = (int)value;
+            return KSCHED_OK;
+        case KSCHED_OPT_MASK_PROBE:
+            if (value < 1 || value > 16) return KSCHED_E_INVAL;
+            c->opt_mask_probe = (uint32_t)value;
             return KSCHED_OK;
         case KSCHED_OPT_FAULT:  // low byte: 0 off, 1 std::bad_alloc, 2 std::runtime_error; bits 8..: fault points to pass first
             if (value < 0 || (value & 0xFF) > 2 || value > 0xFFFFFF) return KSCHED_E_INVAL;
@@ -1766,6 +1777,136 @@ int ksched_eval_begin(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int6
 } KSCHED_ABI_CATCH(c)
 
 // ---- mask buffers owned by the library (mask_alloc.hpp; profiles/r06_mask_alloc.md) ---------------------------------------------
+namespace {
+// one buffer through one allocation path (never AUTO / PROBE)
+hipError_t mask_alloc_path(ksched_ctx *c, size_t bytes, uint32_t how, MaskAllocation &a) {
+    a = MaskAllocation();
+    a.bytes = bytes;
+    a.device = c->device;
+    a.owner = c;
+    a.how = how;
+    a.mapped = bytes;
+    switch (how) {
+        case KSCHED_MASK_ALLOC_PLAIN: return hipMalloc(&a.ptr, bytes);
+        case KSCHED_MASK_ALLOC_VMM: return mask_alloc_vmm(c->device, bytes, 2u << 20, true, &a);
+        case KSCHED_MASK_ALLOC_VMM_1G: return mask_alloc_vmm(c->device, bytes, 1u << 30, true, &a);
+        case KSCHED_MASK_ALLOC_VMM_MIN: return mask_alloc_vmm(c->device, bytes, 0, false, &a);
+        case KSCHED_MASK_ALLOC_SCATTER_2M: return mask_alloc_scattered(c->device, bytes, 2u << 20, 25, &a);
+        case KSCHED_MASK_ALLOC_SCATTER_16M: return mask_alloc_scattered(c->device, bytes, 16u << 20, 25, &a);
+        case KSCHED_MASK_ALLOC_SCATTER_64K: return mask_alloc_scattered(c->device, bytes, 64u << 10, 25, &a);
+        case KSCHED_MASK_ALLOC_CONTIGUOUS: return hipExtMallocWithFlags(&a.ptr, bytes, hipDeviceMallocContiguous);
+        case KSCHED_MASK_ALLOC_UNCACHED: return hipExtMallocWithFlags(&a.ptr, bytes, hipDeviceMallocUncached);
+        case KSCHED_MASK_ALLOC_POOL: {
+            MaskRegistry &reg = mask_registry();
+            std::lock_guard<std::mutex> rl(reg.mu);
+            hipMemPool_t pool = nullptr;
+            for (auto &pp : reg.pools)
+                if (pp.first == c->device) pool = pp.second;
+            hipError_t e = hipSuccess;
+            if (!pool) {
+                hipMemPoolProps props{};
+                props.allocType = hipMemAllocationTypePinned;
+                props.location.type = hipMemLocationTypeDevice;
+                props.location.id = c->device;
+                e = hipMemPoolCreate(&pool, &props);
+                if (e != hipSuccess) return e;
+                uint64_t never = ~0ull;
+                e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &never);
+                reg.pools.emplace_back(c->device, pool);
+                if (e != hipSuccess) return e;
+            }
+            e = hipMallocFromPoolAsync(&a.ptr, bytes, pool, nullptr);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+            a.pooled = true;
+            return e;
+        }
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// Probe-and-keep (KSCHED_MASK_ALLOC_PROBE).  The rate of the mask kernel into a buffer is a property of the buffer's physical placement
+// (HBM-side write stalls, TCC_EA0_WRREQ_DRAM_CREDIT_STALL: profiles/r06_mask_alloc.md) that no allocation path selects and user space
+// cannot see -- but it is sticky per allocation and the kernel itself measures it: `k` candidates over different paths, ALL alive at once
+// (a freed buffer's pages come straight back), the fused mask kernel timed into each (fit only, zero requests: every pair feasible
+// or not by the node's sign, the same 128-byte segments at the same addresses as any other instantiation), the fastest kept.
+int mask_alloc_probe(ksched_ctx *c, uint32_t p, uint32_t pitch, size_t bytes, MaskAllocation &best) {
+    static const uint32_t paths[] = {KSCHED_MASK_ALLOC_VMM_MIN, KSCHED_MASK_ALLOC_PLAIN, KSCHED_MASK_ALLOC_SCATTER_16M, KSCHED_MASK_ALLOC_VMM};
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+    const uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(c->opt_mask_probe, free_b / 4 / std::max<size_t>(bytes, 1)));
+    std::vector<MaskAllocation> cand;
+    auto release_all = [&](size_t keep) {
+        for (size_t i = 0; i < cand.size(); ++i)
+            if (i != keep) (void)mask_release(cand[i]);
+    };
+    for (uint32_t i = 0; i < k; ++i) {
+        MaskAllocation a;
+        hipError_t e = mask_alloc_path(c, bytes, paths[i % 4u], a);
+        if (e != hipSuccess || !a.ptr) {
+            (void)hipGetLastError();
+            if (!cand.empty()) break;  // fewer candidates than asked for
+            e = mask_alloc_path(c, bytes, KSCHED_MASK_ALLOC_PLAIN, a);
+            if (e != hipSuccess || !a.ptr) {
+                c->last_error = std::string("ksched_mask_alloc: ") + hipGetErrorString(e);
+                (void)hipGetLastError();
+                return e == hipErrorOutOfMemory ? KSCHED_E_NOMEM : KSCHED_E_HIP;
+            }
+        }
+        cand.push_back(a);
+    }
+    size_t keep = 0;
+    std::fill(std::begin(c->mask_probe_us), std::end(c->mask_probe_us), 0.0);
+    if (cand.size() > 1) {
+        // zero requests for `p` pods in the ctx's own operand scratch (the host-pointer path's; nothing else uses it while the ctx is locked)
+        hipError_t e = c->pcpu.reserve(p);
+        if (e == hipSuccess) e = c->pmem.reserve(p);
+        if (e == hipSuccess) e = hipMemsetAsync(c->pcpu.ptr, 0, (size_t)p * 8u, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c->pmem.ptr, 0, (size_t)p * 8u, c->stream);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        const uint32_t timing = c->opt_timing;
+        const int kern = c->opt_kernel;
+        c->opt_timing = 0;
+        c->opt_kernel = KSCHED_KERNEL_FUSED;
+        int rc = e == hipSuccess ? KSCHED_OK : KSCHED_E_HIP;
+        double best_us = 0;
+        constexpr int kReps = 4;
+        for (int pass = 0; pass < 2 && rc == KSCHED_OK; ++pass)  // two passes: the first candidates of the first pass carry the warm-up
+            for (size_t i = 0; i < cand.size() && rc == KSCHED_OK; ++i) {
+                rc = eval_on_device(c, p, c->pcpu.ptr, c->pmem.ptr, nullptr, nullptr, nullptr, 0, KSCHED_FIT, (uint64_t *)cand[i].ptr, nullptr, nullptr, pitch, c->stream);
+                if (rc) break;
+                if (hipEventRecord(e0, c->stream) != hipSuccess) rc = KSCHED_E_HIP;
+                for (int r = 0; r < kReps && rc == KSCHED_OK; ++r)
+                    rc = eval_on_device(c, p, c->pcpu.ptr, c->pmem.ptr, nullptr, nullptr, nullptr, 0, KSCHED_FIT, (uint64_t *)cand[i].ptr, nullptr, nullptr, pitch, c->stream);
+                if (rc == KSCHED_OK && (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = KSCHED_E_HIP;
+                float ms = 0;
+                if (rc == KSCHED_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = KSCHED_E_HIP;
+                if (rc == KSCHED_OK && pass == 1) {
+                    const double us = (double)ms * 1e3 / kReps;
+                    if (i < 16) c->mask_probe_us[i] = us;
+                    if (i == 0 || us < best_us) {
+                        best_us = us;
+                        keep = i;
+                    }
+                }
+            }
+        c->opt_timing = timing;
+        c->opt_kernel = kern;
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipStreamSynchronize(c->stream);
+        if (rc != KSCHED_OK) {  // the probe could not run (no bitmap index for this snapshot, ...): the first candidate as it is
+            (void)hipGetLastError();
+            keep = 0;
+        }
+    }
+    release_all(keep);
+    best = cand[keep];
+    return KSCHED_OK;
+}
+}  // namespace
+
 int ksched_mask_alloc(ksched_ctx *c, uint32_t p, uint32_t how, uint64_t **out_mask, uint32_t *out_pitch_words) try {
     if (!c || !out_mask) return KSCHED_E_INVAL;
     *out_mask = nullptr;
@@ -1781,59 +1922,20 @@ int ksched_mask_alloc(ksched_ctx *c, uint32_t p, uint32_t how, uint64_t **out_ma
     const uint32_t pitch = ksched_mask_pitch(c->n);
     if (out_pitch_words) *out_pitch_words = pitch;
     const size_t bytes = std::max<size_t>((size_t)p * pitch * 8u, 128u);
+    uint32_t eff = how;
+    if (how == KSCHED_MASK_ALLOC_AUTO) eff = (bytes >= KSCHED_MASK_PROBE_MIN_BYTES && c->idx.built && c->opt_mask_probe > 1u) ? KSCHED_MASK_ALLOC_PROBE : KSCHED_MASK_ALLOC_PLAIN;
     MaskAllocation a;
-    a.bytes = bytes;
-    a.device = c->device;
-    a.owner = c;
-    const uint32_t eff = how == KSCHED_MASK_ALLOC_AUTO ? (uint32_t)KSCHED_MASK_ALLOC_AUTO_IS : how;
-    a.how = eff;
-    hipError_t e = hipSuccess;
-    switch (eff) {
-        case KSCHED_MASK_ALLOC_PLAIN:
-            e = hipMalloc(&a.ptr, bytes);
-            a.mapped = bytes;
-            break;
-        case KSCHED_MASK_ALLOC_VMM: e = mask_alloc_vmm(c->device, bytes, 2u << 20, true, &a); break;
-        case KSCHED_MASK_ALLOC_VMM_1G: e = mask_alloc_vmm(c->device, bytes, 1u << 30, true, &a); break;
-        case KSCHED_MASK_ALLOC_VMM_MIN: e = mask_alloc_vmm(c->device, bytes, 0, false, &a); break;
-        case KSCHED_MASK_ALLOC_CONTIGUOUS:
-            e = hipExtMallocWithFlags(&a.ptr, bytes, hipDeviceMallocContiguous);
-            a.mapped = bytes;
-            break;
-        case KSCHED_MASK_ALLOC_UNCACHED:
-            e = hipExtMallocWithFlags(&a.ptr, bytes, hipDeviceMallocUncached);
-            a.mapped = bytes;
-            break;
-        case KSCHED_MASK_ALLOC_POOL: {
-            MaskRegistry &reg = mask_registry();
-            std::lock_guard<std::mutex> rl(reg.mu);
-            hipMemPool_t pool = nullptr;
-            for (auto &pp : reg.pools)
-                if (pp.first == c->device) pool = pp.second;
-            if (!pool) {
-                hipMemPoolProps props{};
-                props.allocType = hipMemAllocationTypePinned;
-                props.location.type = hipMemLocationTypeDevice;
-                props.location.id = c->device;
-                e = hipMemPoolCreate(&pool, &props);
-                if (e == hipSuccess) {
-                    uint64_t never = ~0ull;
-                    e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &never);
-                    reg.pools.emplace_back(c->device, pool);
-                }
-            }
-            if (e == hipSuccess) e = hipMallocFromPoolAsync(&a.ptr, bytes, pool, nullptr);
-            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-            a.mapped = bytes;
-            a.pooled = true;
-            break;
+    std::fill(std::begin(c->mask_probe_us), std::end(c->mask_probe_us), 0.0);
+    if (eff == KSCHED_MASK_ALLOC_PROBE) {
+        const int rc = mask_alloc_probe(c, p, pitch, bytes, a);
+        if (rc) return rc;
+    } else {
+        const hipError_t e = mask_alloc_path(c, bytes, eff, a);
+        if (e != hipSuccess || !a.ptr) {
+            c->last_error = std::string("ksched_mask_alloc: ") + hipGetErrorString(e);
+            (void)hipGetLastError();
+            return e == hipErrorOutOfMemory ? KSCHED_E_NOMEM : KSCHED_E_HIP;
         }
-        default: return KSCHED_E_INVAL;
-    }
-    if (e != hipSuccess || !a.ptr) {
-        c->last_error = std::string("ksched_mask_alloc: ") + hipGetErrorString(e);
-        (void)hipGetLastError();
-        return e == hipErrorOutOfMemory ? KSCHED_E_NOMEM : KSCHED_E_HIP;
     }
     {
         MaskRegistry &reg = mask_registry();
@@ -1842,6 +1944,16 @@ int ksched_mask_alloc(ksched_ctx *c, uint32_t p, uint32_t how, uint64_t **out_ma
     }
     *out_mask = (uint64_t *)a.ptr;
     return KSCHED_OK;
+} KSCHED_ABI_CATCH(c)
+
+int ksched_mask_probe_report(ksched_ctx *c, double *out_us, uint32_t cap) try {
+    if (!c || (cap && !out_us)) return KSCHED_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    uint32_t n = 0;
+    while (n < 16u && c->mask_probe_us[n] > 0.0) ++n;
+    n = std::min(n, cap);
+    for (uint32_t i = 0; i < n; ++i) out_us[i] = c->mask_probe_us[i];
+    return (int)n;
 } KSCHED_ABI_CATCH(c)
 
 int ksched_mask_free(ksched_ctx *c, uint64_t *mask) try {

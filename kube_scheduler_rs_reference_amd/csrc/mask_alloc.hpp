@@ -25,6 +25,8 @@ struct MaskAllocation {
     int device = 0;
     hipMemGenericAllocationHandle_t handle{};  // VMM forms
     bool vmm = false;
+    std::vector<hipMemGenericAllocationHandle_t> pieces;  // the scattered form: one handle per piece, mapped at consecutive addresses
+    size_t piece_bytes = 0;
     bool pooled = false;                       // pool form (the device's pool below)
     const void *owner = nullptr;               // the ctx that allocated it (ksched_destroy frees what its caller left)
 };
@@ -87,10 +89,92 @@ inline hipError_t mask_alloc_vmm(int device, size_t bytes, size_t va_align, bool
     return hipSuccess;
 }
 
+// Scattered: the buffer is built from `piece`-sized physical allocations made one by one -- more of them than needed are created, in an
+// order shuffled by a fixed generator, and the surplus is released -- and mapped at consecutive virtual addresses: what the memory
+// channels see behind a linear sweep of the mask is then a pseudo-random walk over the pieces instead of one physical run
+// (profiles/r06_mask_alloc.md: one contiguous physical range is reliably in the SLOW half of the rates).
+inline hipError_t mask_alloc_scattered(int device, size_t bytes, size_t piece, uint32_t surplus_pct, MaskAllocation *out) {
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    if (gran == 0) gran = 4096;
+    piece = round_up(std::max(piece, gran), gran);
+    const size_t n = (std::max<size_t>(bytes, 1) + piece - 1) / piece, total = n * piece;
+    const size_t make = n + n * surplus_pct / 100;
+    std::vector<hipMemGenericAllocationHandle_t> all;
+    all.reserve(make);
+    auto drop = [&](size_t from) {
+        for (size_t i = from; i < all.size(); ++i) (void)hipMemRelease(all[i]);
+        all.resize(std::min(all.size(), from));
+    };
+    for (size_t i = 0; i < make; ++i) {
+        hipMemGenericAllocationHandle_t h{};
+        e = hipMemCreate(&h, piece, &prop, 0);
+        if (e != hipSuccess) {
+            if (all.size() >= n) break;  // the surplus is optional
+            drop(0);
+            return e;
+        }
+        all.push_back(h);
+    }
+    // Fisher-Yates with a fixed xorshift: which pieces are kept and in which order they are mapped
+    uint64_t x = 0x9E3779B97F4A7C15ull ^ (uint64_t)all.size();
+    for (size_t i = all.size(); i > 1; --i) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        std::swap(all[i - 1], all[(size_t)(x % i)]);
+    }
+    drop(n);
+    void *va = nullptr;
+    e = hipMemAddressReserve(&va, total, 0, nullptr, 0);
+    if (e != hipSuccess) {
+        drop(0);
+        return e;
+    }
+    size_t mapped = 0;
+    for (; mapped < n && e == hipSuccess; ++mapped) e = hipMemMap((char *)va + mapped * piece, piece, 0, all[mapped], 0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc{};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, total, &acc, 1);
+    } else {
+        --mapped;  // the piece whose map failed
+    }
+    if (e != hipSuccess) {
+        for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap((char *)va + i * piece, piece);
+        (void)hipMemAddressFree(va, total);
+        drop(0);
+        return e;
+    }
+    out->ptr = va;
+    out->mapped = total;
+    out->vmm = true;
+    out->pieces = std::move(all);
+    out->piece_bytes = piece;
+    return hipSuccess;
+}
+
 inline hipError_t mask_release(MaskAllocation &a) {
     hipError_t e = hipSuccess;
     if (!a.ptr) return e;
-    if (a.vmm) {
+    if (a.vmm && !a.pieces.empty()) {
+        for (size_t i = 0; i < a.pieces.size(); ++i) {
+            hipError_t e1 = hipMemUnmap((char *)a.ptr + i * a.piece_bytes, a.piece_bytes);
+            if (e == hipSuccess) e = e1;
+        }
+        hipError_t e2 = hipMemAddressFree(a.ptr, a.mapped);
+        if (e == hipSuccess) e = e2;
+        for (auto h : a.pieces) {
+            hipError_t e3 = hipMemRelease(h);
+            if (e == hipSuccess) e = e3;
+        }
+        a.pieces.clear();
+    } else if (a.vmm) {
         e = hipMemUnmap(a.ptr, a.mapped);
         hipError_t e2 = hipMemAddressFree(a.ptr, a.mapped);
         hipError_t e3 = hipMemRelease(a.handle);

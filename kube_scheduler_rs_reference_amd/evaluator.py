@@ -355,6 +355,14 @@ class Evaluator:
         buf = torch.as_tensor(owner, device=f"cuda:{self.device}")  # zero-copy (__cuda_array_interface__); the tensor keeps `owner` alive
         return buf[:int(p), :W]
 
+    def mask_probe_report(self) -> np.ndarray:
+        """Microseconds per mask kernel launch into each candidate of this evaluator's latest probe-and-keep allocation (empty: it did not probe)."""
+        out = np.zeros((16,), dtype=np.float64)
+        n = self._lib.ksched_mask_probe_report(self._h, out.ctypes.data_as(C.c_void_p), 16)
+        if n < 0:
+            self._check(n, "ksched_mask_probe_report")
+        return out[:n]
+
     # -- reasons -------------------------------------------------------------------------------------
     def explain(self, req_cpu_milli, req_mem_bytes, sel_val_ids, tolerations, pair_pod, pair_node, flags: int) -> np.ndarray:
         """ksched_explain: REASON_* of check_node_validity for the listed (pod, node) pairs, decided on the device."""

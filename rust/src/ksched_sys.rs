@@ -60,6 +60,9 @@ pub const KSCHED_OPT_GRID_CUS: c_int = 12;
 pub const KSCHED_MASK_ALLOC_AUTO: u32 = 0;
 pub const KSCHED_MASK_ALLOC_PLAIN: u32 = 1;
 pub const KSCHED_MASK_ALLOC_VMM: u32 = 2;
+pub const KSCHED_MASK_ALLOC_PROBE: u32 = 11;
+pub const KSCHED_OPT_MASK_PROBE: c_int = 13;
+pub const KSCHED_OPT_ROUND_ORDER: c_int = 14;
 
 extern "C" {
     // ---- lifetime
@@ -110,6 +113,7 @@ extern "C" {
     pub fn ksched_mask_pitch(n_nodes: u32) -> u32;
     pub fn ksched_mask_alloc(ctx: *mut ksched_ctx, p: u32, how: u32, out_mask: *mut *mut u64, out_pitch_words: *mut u32) -> c_int;
     pub fn ksched_mask_free(ctx: *mut ksched_ctx, mask: *mut u64) -> c_int;
+    pub fn ksched_mask_probe_report(ctx: *mut ksched_ctx, out_us: *mut f64, cap: u32) -> c_int;
     pub fn ksched_pick_device(
         ctx: *mut ksched_ctx, p: u32, feasible: *const u64, mask_pitch_words: u32, req_mem_bytes: *const i64,
         samples: *const u32, attempts: u32, flags: u32, out_binding: *mut i32, hip_stream: *mut c_void,
@@ -187,6 +191,7 @@ pub fn symbol_table() -> Vec<(&'static str, usize)> {
         ("ksched_mask_pitch", ksched_mask_pitch as usize),
         ("ksched_mask_alloc", ksched_mask_alloc as usize),
         ("ksched_mask_free", ksched_mask_free as usize),
+        ("ksched_mask_probe_report", ksched_mask_probe_report as usize),
         ("ksched_pick_device", ksched_pick_device as usize),
         ("ksched_pick", ksched_pick as usize),
         ("ksched_pipe_create", ksched_pipe_create as usize),
@@ -258,5 +263,8 @@ pub fn constant_table() -> Vec<(&'static str, i64)> {
         ("KSCHED_MASK_ALLOC_AUTO", KSCHED_MASK_ALLOC_AUTO as i64),
         ("KSCHED_MASK_ALLOC_PLAIN", KSCHED_MASK_ALLOC_PLAIN as i64),
         ("KSCHED_MASK_ALLOC_VMM", KSCHED_MASK_ALLOC_VMM as i64),
+        ("KSCHED_MASK_ALLOC_PROBE", KSCHED_MASK_ALLOC_PROBE as i64),
+        ("KSCHED_OPT_MASK_PROBE", KSCHED_OPT_MASK_PROBE as i64),
+        ("KSCHED_OPT_ROUND_ORDER", KSCHED_OPT_ROUND_ORDER as i64),
     ];
 }

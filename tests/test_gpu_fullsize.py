@@ -156,6 +156,98 @@ def test_full_size_the_variant_the_bench_times(evaluator, name):
         assert np.array_equal(bind[lo:hi].cpu().numpy(), o_bind), f"bindings != oracle in rows [{lo}, {hi})"
 
 
+@pytest.mark.parametrize("name", ["C3", "C4s"])
+def test_operand_prefetch_on_and_off_write_the_same_words(evaluator, name):
+    """the operand prefetch (kernels_fused.hpp `prefetch_rounds`) issues LDS-DMA loads whose destination comes from M0, written by the
+    same inline-asm statement; a load that read a stale M0 would overwrite 256 bytes of the staged tile index and some mask words would come out
+    wrong.  The launch the bench times (pick riding as tile tests), with the prefetch (default) and without it (KSCHED_OPT_DEBUG bit 0x20000000),
+    six times each over different pod orders: every word and every binding identical between the two, and the first pair == the oracle."""
+    import torch
+    from kube_scheduler_rs_reference_amd import _lib
+    cfg, P, N, preds, pick = CASES[name]
+    c = synth.make_config(cfg, P=P, N=N)
+    ev = evaluator
+    dev = torch.device("cuda", ev.device)
+    ev.set_nodes(**c.node_columns())
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    d_cpu, d_mem, d_sel, d_smp = t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.samples, np.int32)
+    flags = preds | pick
+    ev.set_kernel("auto")
+    rng = np.random.default_rng(11)
+    try:
+        for rep in range(6):
+            if rep == 0:
+                cols = (d_cpu, d_mem, d_sel, d_smp)
+            else:
+                perm = torch.from_numpy(rng.permutation(P)).to(dev)
+                cols = (d_cpu[perm].contiguous(), d_mem[perm].contiguous(), d_sel[:, perm].contiguous(), d_smp[perm].contiguous())
+            out = []
+            for dbg in (0, 0x20000000):
+                ev.set_option(_lib.OPT_DEBUG, dbg)
+                feas = ev.alloc_mask(P, pitched=True)
+                bind = torch.full((P,), -7, dtype=torch.int32, device=dev)
+                ev.eval_device(cols[0], cols[1], cols[2], None, cols[3], flags, out_feasible=feas, out_binding=bind)
+                torch.cuda.synchronize()
+                assert ev.last_kernel == "fused" and ev.last_pick == "fused-tile", (ev.last_kernel, ev.last_pick)
+                out.append((feas, bind))
+            assert torch.equal(out[0][0], out[1][0]), f"repeat {rep}: the mask differs with the operand prefetch on / off"
+            assert torch.equal(out[0][1], out[1][1]), f"repeat {rep}: the bindings differ with the operand prefetch on / off"
+            if rep == 0:
+                feas, bind = out[0]
+                for lo in range(0, P, CHUNK_ROWS):
+                    hi = min(P, lo + CHUNK_ROWS)
+                    o_feas, _, o_bind = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, None, c.req_cpu[lo:hi], c.req_mem[lo:hi],
+                                                          np.ascontiguousarray(c.pod_sel[:, lo:hi]), None, np.ascontiguousarray(c.samples[lo:hi]), flags)
+                    assert np.array_equal(feas[lo:hi].contiguous().cpu().numpy().view(np.uint64), o_feas), f"feasible != oracle in rows [{lo}, {hi})"
+                    assert np.array_equal(bind[lo:hi].cpu().numpy(), o_bind), f"bindings != oracle in rows [{lo}, {hi})"
+            del out
+    finally:
+        ev.set_option(_lib.OPT_DEBUG, 0)
+
+
+@pytest.mark.parametrize("name,P", [("C3", 100_000), ("C4s", 125_000), ("C5s", 125_000), ("C3", 1), ("C3", 63), ("C3", 65), ("C3", 8_191), ("C4s", 12_345), ("C5s", 20_001)])
+def test_round_orders_write_the_same_words(evaluator, name, P):
+    """KSCHED_OPT_ROUND_ORDER (round 6): the fused kernel's waves take the batch's rounds interleaved (wave-major: the default; chunk-major) or as
+    one contiguous pod range each (blocked, the order of rounds 1 - 5).  Same words, same bindings, whatever the order -- full BASELINE sizes and
+    ragged ones (fewer rounds than streams, a short last round); the default order == the oracle on the ragged sizes here (the full sizes are
+    compared with the oracle word for word by the tests above, which run the default order)."""
+    import torch
+    from kube_scheduler_rs_reference_amd import _lib
+    cfg, _, N, preds, pick = CASES[name]
+    c = synth.make_config(cfg, P=P, N=N)
+    ev = evaluator
+    dev = torch.device("cuda", ev.device)
+    ev.set_nodes(**c.node_columns())
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    d_cpu, d_mem, d_sel = t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32)
+    d_tol = t(c.pod_tol, np.int64) if preds & TAINT else None
+    d_smp = t(c.samples, np.int32) if pick == PICK_SAMPLED else None
+    flags = preds | pick
+    ev.set_kernel("fused")
+    out = {}
+    try:
+        for order in (0, 1, 2):
+            ev.set_option(_lib.OPT_ROUND_ORDER, order)
+            feas = ev.alloc_mask(P, pitched=True)
+            bind = torch.full((P,), -7, dtype=torch.int32, device=dev)
+            ev.eval_device(d_cpu, d_mem, d_sel, d_tol, d_smp, flags, out_feasible=feas, out_binding=bind)
+            torch.cuda.synchronize()
+            assert ev.last_kernel == "fused"
+            out[order] = (feas, bind)
+    finally:
+        ev.set_option(_lib.OPT_ROUND_ORDER, 0)
+        ev.set_kernel("auto")
+    for order in (1, 2):
+        assert torch.equal(out[0][0], out[order][0]), f"round order {order}: the mask differs from the default order's"
+        assert torch.equal(out[0][1], out[order][1]), f"round order {order}: the bindings differ from the default order's"
+    if P <= 20_001:
+        o_feas, _, o_bind = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, c.node_taints if preds & TAINT else None, c.req_cpu, c.req_mem,
+                                              np.ascontiguousarray(c.pod_sel), c.pod_tol if preds & TAINT else None,
+                                              np.ascontiguousarray(c.samples) if pick == PICK_SAMPLED else None, flags)
+        assert np.array_equal(out[0][0].contiguous().cpu().numpy().view(np.uint64), o_feas)
+        assert np.array_equal(out[0][1].cpu().numpy(), o_bind)
+
+
 def test_mask_larger_than_4_gib(evaluator):
     """One evaluation whose mask does not fit 32-bit byte offsets: 700k pods x 50k nodes (C5's predicates, pitched rows of 784 words)
     = 4.39 GB of feasible mask, more than half of BASELINE.json's configs[4] on ONE GPU.  Every word and every binding == the oracle

@@ -58,6 +58,7 @@ while time.time() < t_end:
     try:
         ev.set_option(L.OPT_BESTFIT_STAGES, int(r.choice([0, 1, 2])))
         ev.set_option(L.OPT_GRID_CUS, int(r.choice([0, 0, 0, 8, 17, 96, 200])))  # fewer compute units per launch: same results
+        ev.set_option(L.OPT_ROUND_ORDER, int(r.choice([0, 0, 1, 2])))  # which wave takes which round: same results
         ev.set_option(L.OPT_FUSED_PICK, int(r.choice([0, 1, 1, 2])))  # 3 (tile tests or E_UNSUPPORTED) below, where it applies
         ev.set_nodes(cpu, mem, lab, taints)
         for step in range(int(r.choice([1, 1, 3]))):

@@ -37,4 +37,20 @@ if has pmc; then
     python tools/alloc_pmc_summary.py $OUT/pmc_$i.log $OUT/pmc_$i > $OUT/pmc_${i}_summary.txt 2>&1; grep "corr with time" $OUT/pmc_${i}_summary.txt | cut -c1-170
   done
 fi
+if has debugfs; then
+  stamp "can the physical placement be seen? (debugfs)"
+  { mount | grep -i debug; ls /sys/kernel/debug 2>&1 | head; ls /sys/kernel/debug/dri 2>&1 | head; for f in /sys/kernel/debug/dri/*/amdgpu_vram_mm; do echo "== $f"; head -40 $f; done; } > $OUT/debugfs.txt 2>&1; head -12 $OUT/debugfs.txt
+fi
+if has repeat; then
+  for rep in ${REPEAT_IDS:-1 2 3}; do for wl in ${REPEAT_WLS:-C5s}; do
+    stamp "fresh process $rep: survey $wl, passes=${REPEAT_PASSES:-4}"
+    timeout 600 python tools/alloc_probe.py $wl survey k=${REPEAT_K:-4} hows=${REPEAT_HOWS:-1,4,7,2} passes=${REPEAT_PASSES:-4} > $OUT/repeat_${wl}_$rep.txt 2>&1; grep "^==\|failed\|Error" $OUT/repeat_${wl}_$rep.txt | head -20
+  done; done
+fi
+if has pitch; then
+  for wl in ${PITCH_WLS:-C5s C4s C3}; do
+    stamp "row pitch sweep $wl"
+    timeout 600 python tools/alloc_probe.py $wl pitch k=${PITCH_K:-3} passes=2 > $OUT/pitch_$wl.txt 2>&1; grep "^pitch\|Error" $OUT/pitch_$wl.txt | cut -c1-260
+  done
+fi
 stamp done
