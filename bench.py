@@ -126,6 +126,59 @@ def cpu_baseline(c, flags_names, budget_s=12.0, p_cap=None):
     }
 
 
+def end_to_end(torch, L, Evaluator, dev, c, flag_names, pick, objects=True, reps=24):
+    """"Separately report end-to-end including H2D/D2H".  Three figures per batch of this workload, none of them the metric's `value`
+    (that one is quoted with the inputs resident in HBM):
+      host_arrays_to_bindings   numpy columns in pageable host memory -> ksched_eval -> the int32 bindings back in host memory (no mask copy):
+                                what the drop-in's reconciler asks for (copies in, ONE launch, 4 bytes per pod out); median of `reps` calls
+      host_arrays_to_mask       the same call with the feasibility mask copied back too (63 MB at C3, pageable): what a caller pays that wants the matrix
+      objects                   corev1 objects (pods with quantity strings and selector maps) -> reconcile_batch of the C++ host mirror
+                                (draws, encode, device, binding POSTs through a recording sink, the snapshot update) -- tests/cpp/objects_eval
+                                on a cluster of this workload's shape, best and median of 5 batches each against a fresh snapshot, the WARN level off."""
+    flags = sum(getattr(L, f) for f in flag_names) | (L.PICK_SAMPLED if pick == "sampled" else L.PICK_BESTFIT)
+    out = {"workload": f"{c.P} pods x {c.N} nodes per batch", "host_cores": os.cpu_count()}
+    try:
+        ev = Evaluator(dev.index)
+        ev.set_nodes(**c.node_columns())
+        args = (c.req_cpu, c.req_mem, c.pod_sel if c.n_keys else None, c.pod_tol if "TAINT" in flag_names else None, c.samples if pick == "sampled" else None, flags)
+        for key, want_mask, n in (("host_arrays_to_bindings", False, reps), ("host_arrays_to_mask", True, max(5, reps // 3))):
+            ev.eval(*args, want_mask=want_mask)  # (scratch allocations of the host-pointer path)
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                ev.eval(*args, want_mask=want_mask)
+                ts.append(time.perf_counter() - t0)
+            med = float(np.median(ts))
+            out[key] = {"ms_per_batch": med * 1e3, "min_ms": float(np.min(ts)) * 1e3, "calls": n, "evals_per_s": float(c.P) * c.N / med}
+        ev.close()
+    except Exception as e:  # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    if objects:
+        try:
+            import importlib.util
+            import re
+            spec = importlib.util.spec_from_file_location("ksched_host_loop", os.path.join(ROOT, "tools", "host_loop.py"))
+            hl = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(hl)
+            path = hl.objects_file(c.P, c.N)
+            try:
+                d, timing, _ = hl.run("batch", path, reps=5)
+            finally:
+                os.unlink(path)
+            secs = sorted(d["seconds_all"])
+            split = None
+            rows = [re.findall(r"([0-9.]+) ms", ln) for ln in timing if ln.startswith("reconcile_batch")]
+            if rows:
+                a = np.median(np.array([[float(x) for x in r[:4]] for r in rows if len(r) >= 4]), axis=0)
+                split = {"draws_encode_device_ms": float(a[0]), "posts_with_the_update_staged_beside_them_ms": float(a[1]), "snapshot_update_committed_ms": float(a[2]), "warn_lines_ms": float(a[3])}
+            out["objects"] = {"what": "corev1 objects -> reconcile_batch (C++ host mirror) -> bindings POSTed to a recording sink -> snapshot updated; per batch, fresh snapshot each",
+                              "best_ms_per_batch": secs[0] * 1e3, "median_ms_per_batch": secs[len(secs) // 2] * 1e3, "batches": len(secs), "pods_bound": d["posted_count"],
+                              "pods_per_s": c.P / secs[0], "median_split": split}
+        except Exception as e:  # noqa: BLE001
+            out["objects"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def rotation_for(mask_bytes: int, want: bool) -> int:
     """Mask buffers the timed loop rotates over: enough that their total exceeds the Infinity Cache by a quarter (a step's
     stores then cannot land in lines the cache still holds from the step that last wrote the same buffer)."""
@@ -302,7 +355,7 @@ def main():
                     help="default: C3 per GPU at every N (configs[2], the largest single-GPU configuration; weak scaling)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "fused"])
     ap.add_argument("--pods", type=int, default=None, help="override pods per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-side legs: cpu_baseline and the objects leg of config.end_to_end")
     ap.add_argument("--no-mask", action="store_true", help="bindings only (not the graded form)")
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the self-check after the timed region (the last timed step's bindings -- all of this rank's pods -- and >= 4096 of its "
@@ -326,6 +379,8 @@ def main():
     ap.add_argument("--no-others", action="store_true",
                     help="N = 1, default workload: skip config.other_workloads (C4s, C5s measured in the same process, a few hundred ms) "
                          "and config.in_place")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="N = 1: skip config.end_to_end (host arrays -> bindings / mask, and objects -> reconcile_batch through the C++ host mirror: ~25 s)")
     ap.add_argument("--live-traffic", choices=["auto", "on", "off"], default="auto",
                     help="roofline.traffic measured by THIS invocation: after the timed region, four short rocprofv3 --pmc passes (FETCH_SIZE and "
                          "WRITE_SIZE, separately: over tools/pmc_calib -- known byte counts -- and over this command with 10 steps), per launch of the "
@@ -920,6 +975,14 @@ def main():
             except Exception as e:  # noqa: BLE001
                 others[name] = {"error": f"{type(e).__name__}: {e}"}
 
+    # ---- N = 1: the end-to-end figures SURVEY.md 8d asks for, beside (never instead of) the resident-input metric ------------------
+    e2e = None
+    if not multi and not args.no_end_to_end and not args.no_mask and not args.pods and not args.debug:
+        # (the objects leg -- 25 s: a cluster's worth of JSON is made and parsed -- with the default workload's full line only: --no-cpu-baseline, the
+        # switch of every quick run, skips it like it skips the other host-side leg; the profiler's child runs skip everything)
+        if not os.environ.get("KSCHED_BENCH_TRAFFIC_CHILD"):
+            e2e = end_to_end(torch, L, Evaluator, dev, c, flag_names, pick, objects=default_workload and not args.no_cpu_baseline)
+
     # sanity inside the bench: the fraction of pods the last timed step bound (a degenerate workload would show 0 or 1)
     bound_frac = float((bindings >= 0).float().mean().item())
 
@@ -994,7 +1057,7 @@ def main():
                                                   "timed step evaluated (parity_check.input_batch)"},
                        "step_frac_of_hbm_peak": (alg / step_s / 1e9 / HBM_PEAK_GBS) if world == 1 else None,
                        "step_frac_note": "algorithmic bytes of one step (mask + draws + bindings) / ms_per_step / 8 TB/s",
-                       "repeat_ms_per_step": repeats, "in_place": in_place, "other_workloads": others,
+                       "repeat_ms_per_step": repeats, "in_place": in_place, "other_workloads": others, "end_to_end": e2e,
                        "steps_in_flight": depth if pipelined else 1, "two_stream": pipe is not None,
                        "pipe_mode": (("alternate: whole steps + their all-gather on stream (slot mod 2)" if loop.alternate else
                                       "split: mask kernels on one stream, pick -> all-gather on the other") if pipe is not None else None),

@@ -1,4 +1,5 @@
 #include "encoder.hpp"
+#include "pool.hpp"
 
 #include "sharded.hpp"
 
@@ -11,12 +12,6 @@
 #include <thread>
 
 namespace ksched_host {
-
-// worker threads for the per-pod string work (KSCHED_HOST_THREADS overrides the hardware's count: 1 = everything on the caller's thread)
-static uint32_t host_threads() {
-    if (const char *e = std::getenv("KSCHED_HOST_THREADS")) return std::max(1u, (uint32_t)std::strtoul(e, nullptr, 0));
-    return std::max(1u, std::thread::hardware_concurrency());
-}
 
 // ---- the unit of a resource column (encoder.hpp: cpu_unit_nanos) ------------------------------------------------------------------
 namespace {
@@ -105,7 +100,7 @@ void Snapshot::rebuild(const std::vector<corev1::Node> &nodes, PodLister *client
     std::vector<uint32_t> canonical_of_store(n, 0u);
     for (uint32_t i = 0; i < n; ++i) canonical_of_store[order[i]] = i;
     NodeColumns c;
-    std::unordered_map<std::string, Counted> counted;
+    CountedTable counted;
     std::vector<__int128> cpu_nanos(n, 0), mem_nanos(n, 0);
     c.n = n;
     c.names.resize(n);
@@ -369,25 +364,60 @@ size_t Snapshot::observe_bound(const std::vector<std::pair<const corev1::Pod *, 
     return observe_impl(ev);
 }
 
-size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
-    // Stage everything first (the new bookkeeping entries, the exact per-node change in nano-units), validate, then commit: an
-    // EncodeError leaves the snapshot as it was.
-    // Per-event string work first -- the pod's key and the sum of its requests (quantity parsing) --, fanned out over threads for a
-    // large batch like encode_pods: it is what this call spends its time on, and the events are independent until they are merged.
+size_t Snapshot::observe_bound(const std::vector<Bound> &bound) {
+    const std::shared_ptr<StagedUpdate> staged = stage_bound(bound);
+    return commit_staged(*staged);
+}
+
+// What observe_impl has worked out before it touches the snapshot (encoder.hpp: stage_bound / commit_staged).
+struct Snapshot::StagedUpdate {
     struct Pre {
         std::string key;
+        size_t hash = 0;
         int idx = -1;
         __int128 cpu = 0, mem = 0;
         std::string error;
     };
-    std::vector<Pre> pre(events.size());
-    auto prepare = [&](size_t lo, size_t hi) {
+    struct Entry {
+        std::optional<Counted> entry;  // nullopt = not counted any more
+        size_t last = 0;               // the latest event of this key: its string is MOVED into the bookkeeping at the commit
+    };
+    std::vector<Pre> pre;  // one per event; never resized once filled (the maps below hold views into its strings)
+    std::array<std::unordered_map<std::string_view, Entry>, CountedTable::kShards> staged;  // per shard: key -> its entry after these events
+    std::vector<uint32_t> touched;                      // nodes whose `available` changes, ascending
+    std::vector<std::pair<__int128, __int128>> fresh;   // their new exact values
+    size_t changed = 0;
+    uint64_t generation = 0;  // of the snapshot the update was staged against
+    bool committed = false;
+};
+
+std::shared_ptr<Snapshot::StagedUpdate> Snapshot::stage_impl(const std::vector<Observed> &events) {
+    // Stage everything first (the new bookkeeping entries, the exact per-node change in nano-units), validate, then commit: an
+    // EncodeError leaves the snapshot as it was.  Three passes, the first two on the worker threads for a batch's worth of events:
+    //   1. per event: the pod's key + its hash, the node's index, the sum of its requests (quantity parsing unless the caller has it);
+    //   2. per SHARD of the bookkeeping (key hash): the shard's events in event order against the shard's table -- what is counted
+    //      now, what will be, the change per node;
+    //   3. serial: the shards' per-node changes summed into the new `available` values.
+    using Pre = StagedUpdate::Pre;
+    auto out = std::make_shared<StagedUpdate>();
+    StagedUpdate &S = *out;
+    S.generation = generation_;
+    S.pre.resize(events.size());
+    PhaseClock clock("observe");
+    const uint32_t parts = events.size() >= 4096 ? WorkerPool::parts_for(events.size()) : 1u;
+    WorkerPool::instance().run(events.size(), parts, [&](size_t lo, size_t hi, uint32_t) {
         for (size_t i = lo; i < hi; ++i) {
             const Observed &e = events[i];
-            Pre &p = pre[i];
+            Pre &p = S.pre[i];
             p.key = full_name(e.pod->metadata);
-            p.idx = e.node ? index_of(*e.node) : -1;
+            p.hash = CountedTable::hash_of(p.key);
+            p.idx = e.node_index >= -1 ? e.node_index : (e.node ? index_of(*e.node) : -1);
             if (p.idx < 0) continue;
+            if (e.have_requests) {  // (summed by encode_pods a moment ago)
+                p.cpu = e.cpu_nanos;
+                p.mem = e.mem_nanos;
+                continue;
+            }
             try {
                 const PodResources r = total_pod_resources(*e.pod);  // the sum the LIST loop subtracts (src/predicates.rs:37)
                 p.cpu = r.cpu.nanos();
@@ -396,105 +426,156 @@ size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
                 p.error = "pod " + p.key + ": invalid pod spec: " + x.what();
             }
         }
-    };
-    const uint32_t hw = host_threads();
-    const uint32_t nthreads = events.size() >= 4096 ? std::min<uint32_t>({hw, 32u, (uint32_t)(events.size() / 1024)}) : 1u;
-    if (nthreads <= 1) {
-        prepare(0, events.size());
-    } else {
-        std::vector<std::thread> pool;
-        for (uint32_t t = 0; t < nthreads; ++t)
-            pool.emplace_back([&, t] { prepare(events.size() * t / nthreads, events.size() * (t + 1) / nthreads); });
-        for (auto &th : pool) th.join();
-    }
-    // key -> its entry after these events (nullopt = not counted).  The keys are views into `pre` (not resized any more): no string
-    // is copied until the commit.
-    struct Staged {
-        std::optional<Counted> entry;
-        size_t last = 0;  // the latest event of this key: its string is MOVED into the bookkeeping at the commit
-    };
-    std::unordered_map<std::string_view, Staged> staged;
-    staged.reserve(events.size());
-    // node -> change of available (cpu, mem) in nano-units: a dense table for a batch's worth of events, a map for the watch's single ones
-    struct Delta {
-        bool dense;
-        std::vector<std::pair<__int128, __int128>> tab;
-        std::vector<uint8_t> seen;
-        std::vector<uint32_t> nodes;
-        std::map<uint32_t, std::pair<__int128, __int128>> sparse;
-        std::pair<__int128, __int128> &operator[](uint32_t node) {
-            if (!dense) return sparse[node];
-            if (!seen[node]) {
-                seen[node] = 1;
-                nodes.push_back(node);
-            }
-            return tab[node];
+    });
+    clock.lap("keys + requests of the events (threads)");
+    // the events of each shard, in event order (a counting sort)
+    constexpr size_t K = CountedTable::kShards;
+    std::array<uint32_t, K + 1> first{};
+    for (const Pre &p : S.pre) ++first[CountedTable::shard_of(p.hash) + 1];
+    for (size_t k = 0; k < K; ++k) first[k + 1] += first[k];
+    std::vector<uint32_t> by_shard(events.size());
+    {
+        std::array<uint32_t, K> fill{};
+        for (size_t i = 0; i < S.pre.size(); ++i) {
+            const size_t k = CountedTable::shard_of(S.pre[i].hash);
+            by_shard[first[k] + fill[k]++] = (uint32_t)i;
         }
-        // (node, change) in ascending node order
-        std::vector<std::pair<uint32_t, std::pair<__int128, __int128>>> sorted() {
-            std::vector<std::pair<uint32_t, std::pair<__int128, __int128>>> out;
+    }
+    struct Change {
+        uint32_t node;
+        __int128 cpu, mem;
+    };
+    struct ShardOut {
+        std::vector<Change> changes;
+        size_t changed = 0;
+        size_t error_at = SIZE_MAX;  // the first event of the shard whose requests do not parse
+    };
+    std::array<ShardOut, K> so;
+    WorkerPool::instance().run(K, events.size() >= 4096 ? std::min<uint32_t>((uint32_t)K, WorkerPool::parts_for(events.size())) : 1u, [&](size_t klo, size_t khi, uint32_t) {
+        for (size_t k = klo; k < khi; ++k) {
+            auto &staged = S.staged[k];
+            const auto &table = counted_.shard[k];
+            ShardOut &o = so[k];
+            staged.reserve(first[k + 1] - first[k]);
+            for (uint32_t j = first[k]; j < first[k + 1]; ++j) {
+                const size_t i = by_shard[j];
+                const Pre &p = S.pre[i];
+                std::optional<Counted> was;
+                if (auto st = staged.find(std::string_view(p.key)); st != staged.end()) {
+                    was = st->second.entry;
+                } else if (auto it = table.find(p.key); it != table.end()) {
+                    was = it->second;
+                }
+                if (p.idx < 0) {  // deleted, not bound, or bound to a node this snapshot does not hold: counted nowhere from now on
+                    if (!was) continue;
+                    o.changes.push_back({was->node, was->cpu_nanos, was->mem_nanos});
+                    staged[std::string_view(p.key)] = StagedUpdate::Entry{std::nullopt, i};
+                    ++o.changed;
+                    continue;
+                }
+                if (!p.error.empty()) {
+                    o.error_at = i;
+                    break;  // (nothing of this update will be committed)
+                }
+                const Counted now{(uint32_t)p.idx, p.cpu, p.mem};
+                if (was && was->node == now.node && was->cpu_nanos == now.cpu_nanos && was->mem_nanos == now.mem_nanos) continue;  // already counted
+                if (was) o.changes.push_back({was->node, was->cpu_nanos, was->mem_nanos});
+                o.changes.push_back({now.node, -now.cpu_nanos, -now.mem_nanos});
+                staged[std::string_view(p.key)] = StagedUpdate::Entry{now, i};
+                ++o.changed;
+            }
+        }
+    });
+    size_t error_at = SIZE_MAX;
+    for (const ShardOut &o : so) error_at = std::min(error_at, o.error_at);
+    if (error_at != SIZE_MAX) throw EncodeError(S.pre[error_at].error);  // (the first one in event order, like a sequential walk)
+    clock.lap("events merged per shard of the bookkeeping (threads)");
+    // node -> change of available (cpu, mem) in nano-units, ascending node order
+    std::map<uint32_t, std::pair<__int128, __int128>> sparse;
+    std::vector<std::pair<__int128, __int128>> tab;
+    std::vector<uint32_t> nodes;
+    const bool dense = events.size() >= 64 && cols_.n <= (1u << 22);
+    if (dense) tab.assign(cols_.n, {0, 0});
+    std::vector<uint8_t> seen(dense ? cols_.n : 0, 0);
+    for (const ShardOut &o : so) {
+        S.changed += o.changed;
+        for (const Change &c : o.changes) {
             if (!dense) {
-                out.assign(sparse.begin(), sparse.end());
-            } else {
-                std::sort(nodes.begin(), nodes.end());
-                for (uint32_t node : nodes) out.emplace_back(node, tab[node]);
+                auto &d = sparse[c.node];
+                d.first += c.cpu;
+                d.second += c.mem;
+                continue;
             }
-            return out;
+            if (!seen[c.node]) {
+                seen[c.node] = 1;
+                nodes.push_back(c.node);
+            }
+            tab[c.node].first += c.cpu;
+            tab[c.node].second += c.mem;
         }
-    } delta;
-    delta.dense = events.size() >= 64 && cols_.n <= (1u << 22);
-    if (delta.dense) {
-        delta.tab.assign(cols_.n, {0, 0});
-        delta.seen.assign(cols_.n, 0);
     }
-    auto current = [&](const Pre &p) -> std::optional<Counted> {
-        auto st = staged.find(std::string_view(p.key));
-        if (st != staged.end()) return st->second.entry;
-        auto it = counted_.find(p.key);
-        if (it == counted_.end()) return std::nullopt;
-        return it->second;
+    auto add = [&](uint32_t node, const std::pair<__int128, __int128> &d) {
+        if (d.first == 0 && d.second == 0) return;
+        S.touched.push_back(node);
+        S.fresh.emplace_back(avail_cpu_nanos_[node] + d.first, avail_mem_nanos_[node] + d.second);
     };
-    size_t changed = 0;
-    for (size_t i = 0; i < events.size(); ++i) {
-        const Pre &p = pre[i];
-        const std::optional<Counted> was = current(p);
-        if (p.idx < 0) {  // deleted, not bound, or bound to a node this snapshot does not hold: counted nowhere from now on
-            if (!was) continue;
-            delta[was->node].first += was->cpu_nanos;
-            delta[was->node].second += was->mem_nanos;
-            staged[std::string_view(p.key)] = Staged{std::nullopt, i};
-            ++changed;
-            continue;
-        }
-        if (!p.error.empty()) throw EncodeError(p.error);  // (in event order, like the sequential walk)
-        const Counted now{(uint32_t)p.idx, p.cpu, p.mem};
-        if (was && was->node == now.node && was->cpu_nanos == now.cpu_nanos && was->mem_nanos == now.mem_nanos) continue;  // already counted
-        if (was) {
-            delta[was->node].first += was->cpu_nanos;
-            delta[was->node].second += was->mem_nanos;
-        }
-        delta[now.node].first -= now.cpu_nanos;
-        delta[now.node].second -= now.mem_nanos;
-        staged[std::string_view(p.key)] = Staged{now, i};
-        ++changed;
+    if (dense) {
+        std::sort(nodes.begin(), nodes.end());
+        for (uint32_t node : nodes) add(node, tab[node]);
+    } else {
+        for (const auto &[node, d] : sparse) add(node, d);
     }
-    std::vector<uint32_t> touched;
-    std::vector<std::pair<__int128, __int128>> fresh;
-    for (const auto &[node, d] : delta.sorted()) {
-        if (d.first == 0 && d.second == 0) continue;
-        touched.push_back(node);
-        fresh.emplace_back(avail_cpu_nanos_[node] + d.first, avail_mem_nanos_[node] + d.second);
-    }
+    clock.lap("per-node change summed");
+    return out;
+}
+
+size_t Snapshot::commit_staged(StagedUpdate &S) {
+    if (S.committed) throw EncodeError("commit_staged: this update has been committed already");
+    if (S.generation != generation_) throw EncodeError("commit_staged: the snapshot has changed since the update was staged");
+    PhaseClock clock("observe");
     auto commit = [&] {  // (no lookup in `staged` after this: its keys are views into the strings moved here)
-        counted_.reserve(counted_.size() + staged.size());
-        for (auto &[key, st] : staged) {
-            if (st.entry) counted_.insert_or_assign(std::move(pre[st.last].key), *st.entry);
-            else counted_.erase(pre[st.last].key);
-        }
+        size_t n = 0;
+        for (const auto &m : S.staged) n += m.size();
+        WorkerPool::instance().run(CountedTable::kShards, n >= 4096 ? std::min<uint32_t>((uint32_t)CountedTable::kShards, WorkerPool::parts_for(n)) : 1u, [&](size_t klo, size_t khi, uint32_t) {
+            for (size_t k = klo; k < khi; ++k) {
+                auto &table = counted_.shard[k];
+                table.reserve(table.size() + S.staged[k].size());
+                for (auto &[key, st] : S.staged[k]) {
+                    if (st.entry) table.insert_or_assign(std::move(S.pre[st.last].key), *st.entry);
+                    else table.erase(S.pre[st.last].key);
+                }
+            }
+        });
+        S.committed = true;
     };
-    if (touched.empty()) commit();  // (changes that cancel out: the table still moves)
-    else store_available(touched, fresh, commit);  // validates first: on EncodeError nothing -- table, columns, device -- has changed
-    return changed;
+    if (S.touched.empty()) {
+        commit();  // (changes that cancel out: the table still moves)
+        ++generation_;
+    } else {
+        store_available(S.touched, S.fresh, commit);  // validates first: on EncodeError nothing -- table, columns, device -- has changed
+    }
+    clock.lap("commit + columns + ksched_update_nodes");
+    return S.changed;
+}
+
+std::shared_ptr<Snapshot::StagedUpdate> Snapshot::stage_bound(const std::vector<Bound> &bound) {
+    std::vector<Observed> ev;
+    ev.reserve(bound.size());
+    for (const Bound &b : bound)
+        if (b.pod) {
+            Observed o{b.pod, nullptr};
+            o.node_index = b.node < cols_.n ? (int)b.node : -1;
+            o.have_requests = true;
+            o.cpu_nanos = b.cpu_nanos;
+            o.mem_nanos = b.mem_nanos;
+            ev.push_back(o);
+        }
+    return stage_impl(ev);
+}
+
+size_t Snapshot::observe_impl(const std::vector<Observed> &events) {
+    const std::shared_ptr<StagedUpdate> staged = stage_impl(events);
+    return commit_staged(*staged);
 }
 
 bool Snapshot::apply_bound_pod(const corev1::Pod &pod) { return apply_pod_events({{&pod, true}}) == 1; }
@@ -528,25 +609,37 @@ int Snapshot::index_of(const std::string &node_name) const {
     return (int)(it - cols_.names.begin());
 }
 
-PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
-    // the batch's selector keys: every worker collects its range's (a handful of distinct strings), merged afterwards -- one serial
-    // walk over 100 k pods inserting into one set was a third of this call's time
-    const uint32_t hw0 = host_threads();
-    const uint32_t kthreads = pods.size() >= 4096 ? std::min<uint32_t>({hw0, 32u, (uint32_t)(pods.size() / 1024)}) : 1u;
+std::set<std::string> Snapshot::batch_selector_keys(const std::vector<const corev1::Pod *> &pods, bool *any_wide) {
+    // every worker collects its range's keys (a handful of distinct strings), merged afterwards -- one serial walk over 100 k pods
+    // inserting into one set was a third of encode_pods' time
+    const uint32_t kthreads = pods.size() >= 4096 ? WorkerPool::parts_for(pods.size()) : 1u;
     std::vector<std::set<std::string>> part(std::max(1u, kthreads));
-    auto collect = [&](uint32_t t) {
-        const size_t lo = pods.size() * t / part.size(), hi = pods.size() * (t + 1) / part.size();
-        for (size_t i = lo; i < hi; ++i) selector_keys(*pods[i], part[t]);
-    };
-    if (kthreads <= 1) {
-        collect(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (uint32_t t = 0; t < kthreads; ++t) pool.emplace_back(collect, t);
-        for (auto &th : pool) th.join();
-    }
+    std::vector<uint8_t> wide(part.size(), 0);
+    WorkerPool::instance().run(pods.size(), kthreads, [&](size_t lo, size_t hi, uint32_t t) {
+        std::set<std::string> &mine = part[t];
+        const std::string *last = nullptr;  // (consecutive pods mostly name keys already seen: one comparison instead of a tree walk)
+        for (size_t i = lo; i < hi; ++i) {
+            const corev1::Pod &pod = *pods[i];
+            if (!pod.spec || !pod.spec->node_selector) continue;
+            if (pod.spec->node_selector->size() > KSCHED_MAX_KEYS) wide[t] = 1;
+            for (const auto &kv : *pod.spec->node_selector) {
+                if (last && *last == kv.first) continue;
+                last = &*mine.insert(kv.first).first;
+            }
+        }
+    });
     std::set<std::string> keys;
     for (auto &s : part) keys.insert(s.begin(), s.end());
+    if (any_wide) *any_wide = std::find(wide.begin(), wide.end(), (uint8_t)1) != wide.end();
+    return keys;
+}
+
+PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods, const std::set<std::string> *known_keys) {
+    PhaseClock clock("encode_pods");
+    std::set<std::string> collected;
+    if (!known_keys) collected = batch_selector_keys(pods);
+    const std::set<std::string> &keys = known_keys ? *known_keys : collected;
+    clock.lap("selector keys of the batch (threads)");
     ensure_keys(keys);
 
     PodColumns pc;
@@ -556,6 +649,8 @@ PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
     pc.req_mem_bytes.resize(pc.p);
     pc.sel_val_ids.assign((size_t)pc.n_keys * pc.p, 0u);
     pc.tolerations.assign(pc.p, 0ull);
+    pc.req_cpu_nanos.resize(pc.p);
+    pc.req_mem_nanos.resize(pc.p);
     // column index of every key once (the batch's keys all have a column now)
     std::map<std::string, uint32_t> col_of;
     for (uint32_t k = 0; k < cols_.n_keys; ++k) col_of.emplace(cols_.keys[k], k);
@@ -569,6 +664,8 @@ PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
                 if (!fits_i64(qc) || !fits_i64(qm)) throw QuantityError("the request does not fit int64 in the snapshot's unit");
                 pc.req_cpu_milli[i] = (int64_t)qc;
                 pc.req_mem_bytes[i] = (int64_t)qm;
+                pc.req_cpu_nanos[i] = r.cpu.nanos();
+                pc.req_mem_nanos[i] = r.memory.nanos();
             } catch (const QuantityError &e) {
                 throw PodEncodeError("pod " + full_name(pod.metadata) + ": invalid pod spec: " + e.what());
             }
@@ -591,25 +688,11 @@ PodColumns Snapshot::encode_pods(const std::vector<const corev1::Pod *> &pods) {
     };
     // The wire-format step is per-pod string work (quantity parsing, dictionary lookups): for a large batch it is what the host
     // spends its time on, and the pods are independent -- fan it out over threads (each writes only its own rows).
-    const uint32_t hw = host_threads();
-    const uint32_t nthreads = pc.p >= 4096u ? std::min<uint32_t>({hw, 32u, pc.p / 1024u}) : 1u;
-    if (nthreads <= 1) {
-        encode_range(0, pc.p);
-    } else {
-        std::vector<std::thread> pool;
-        std::vector<std::string> errors(nthreads);
-        for (uint32_t t = 0; t < nthreads; ++t)
-            pool.emplace_back([&, t] {
-                try {
-                    encode_range((uint32_t)((uint64_t)pc.p * t / nthreads), (uint32_t)((uint64_t)pc.p * (t + 1) / nthreads));
-                } catch (const PodEncodeError &e) {
-                    errors[t] = e.what();
-                }  // (anything else -- std::bad_alloc, a logic error -- is not a bad pod: it terminates, as it would on one thread)
-            });
-        for (auto &th : pool) th.join();
-        for (const auto &e : errors)
-            if (!e.empty()) throw PodEncodeError(e);  // the lowest pod range's error, like the sequential walk would have raised first
-    }
+    clock.lap("ensure_keys + columns allocated");
+    // (a PodEncodeError of the lowest pod range is the one rethrown, like the sequential walk would have raised first)
+    WorkerPool::instance().run(pc.p, pc.p >= 4096u ? WorkerPool::parts_for(pc.p) : 1u,
+                               [&](size_t lo, size_t hi, uint32_t) { encode_range((uint32_t)lo, (uint32_t)hi); });
+    clock.lap("requests + selector ids (threads)");
     return pc;
 }
 

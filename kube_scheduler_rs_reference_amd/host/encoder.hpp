@@ -5,12 +5,14 @@
 // int64 milli-cores / bytes, label strings become dictionary ids (exact interning, never a
 // hash), taints become bit positions.  Nodes are put in canonical order (ascending name).
 #pragma once
+#include <array>
 #include <cstdint>
 #include <functional>
 #include <map>
 #include <memory>
 #include <set>
 #include <string>
+#include <string_view>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -52,6 +54,9 @@ struct PodColumns {
     std::vector<int64_t> req_cpu_milli, req_mem_bytes;
     std::vector<uint32_t> sel_val_ids;  // [n_keys][p]
     std::vector<uint64_t> tolerations;  // [p]
+    // the exact sums behind the two request columns, in nano-units (total_pod_resources, src/util.rs:54-75): what a snapshot update of the
+    // batch's bindings subtracts from `available` -- kept so that the pods' quantity strings are parsed once per batch, not twice
+    std::vector<__int128> req_cpu_nanos, req_mem_nanos;  // [p]
 };
 
 // Encoded node snapshot (the arguments of ksched_set_nodes), host copy.
@@ -120,6 +125,14 @@ public:
     // The bindings a batch has just created: pod i now runs on node_names[i] (the pod objects themselves still carry no nodeName --
     // no copies are made).  Same bookkeeping and guarantees as observe_pods with Applied events of those pods bound to those nodes.
     size_t observe_bound(const std::vector<std::pair<const corev1::Pod *, const std::string *>> &bound);
+    // The same for a batch this snapshot has just evaluated: the node as its CANONICAL INDEX (what the device returned) and the pod's exact
+    // requests as encode_pods summed them (PodColumns::req_*_nanos) -- no name lookup, no second parse of the quantity strings.
+    struct Bound {
+        const corev1::Pod *pod;
+        uint32_t node;  // canonical index
+        __int128 cpu_nanos, mem_nanos;
+    };
+    size_t observe_bound(const std::vector<Bound> &bound);
     size_t counted_pods() const { return counted_.size(); }
 
     // Make sure every label key in `keys` (the selector keys of ONE batch) has a column; re-uploads the label columns when the
@@ -138,7 +151,10 @@ public:
 
     // Encode pods against this snapshot's dictionaries.  Adds columns for selector keys that
     // have none yet (ensure_keys).  A selector value no node carries becomes KSCHED_SEL_NEVER.
-    PodColumns encode_pods(const std::vector<const corev1::Pod *> &pods);
+    // `known_keys`: the distinct selector keys of `pods` when the caller has collected them already (check_node_validity_batch's plan).
+    PodColumns encode_pods(const std::vector<const corev1::Pod *> &pods, const std::set<std::string> *known_keys = nullptr);
+    // The distinct nodeSelector keys of a batch, collected by the worker threads; *any_wide = some pod names more than KSCHED_MAX_KEYS keys.
+    static std::set<std::string> batch_selector_keys(const std::vector<const corev1::Pod *> &pods, bool *any_wide = nullptr);
 
     const NodeColumns &columns() const { return cols_; }
     // The unit of the resource columns, in nano-units per column unit: 1 000 000 (milli-cores) and 1 000 000 000 (bytes) unless
@@ -195,14 +211,45 @@ private:
         uint32_t node;  // canonical index
         __int128 cpu_nanos, mem_nanos;
     };
-    std::unordered_map<std::string, Counted> counted_;  // namespace/name -> what `available` currently holds against that pod
+    // namespace/name -> what `available` currently holds against that pod.  Cut into shards by the key's hash so that a batch's worth of
+    // events (50 000 bindings of a C3-size batch) is merged and committed by the worker threads, one shard each, instead of one serial walk.
+    struct CountedTable {
+        static constexpr size_t kShards = 64;
+        std::array<std::unordered_map<std::string, Counted>, kShards> shard;
+        static size_t hash_of(std::string_view key) { return std::hash<std::string_view>{}(key); }
+        static size_t shard_of(size_t hash) { return (hash >> 7) % kShards; }  // (not the bits the maps' own buckets use)
+        size_t size() const {
+            size_t n = 0;
+            for (const auto &m : shard) n += m.size();
+            return n;
+        }
+        Counted &operator[](const std::string &key) { return shard[shard_of(hash_of(key))][key]; }
+    };
+    CountedTable counted_;
     void push_rows(const std::vector<uint32_t> &touched);
     // one event of observe_pods / observe_bound: the pod, and the node it runs on now (nullptr = none: deleted / unbound)
     struct Observed {
         const corev1::Pod *pod;
         const std::string *node;
+        int node_index = -2;  // >= -1: the canonical index is known (-1 = none) and `node` is not looked up
+        bool have_requests = false;
+        __int128 cpu_nanos = 0, mem_nanos = 0;
     };
     size_t observe_impl(const std::vector<Observed> &events);
+
+public:
+    // observe_bound in two halves, so that a caller can do the first -- everything that only READS the snapshot: keys, lookups, the
+    // per-node change, validation inputs -- while the batch's binding POSTs are still in flight, and the second, the commit, when it knows
+    // they all landed.  stage_bound never changes the snapshot; commit_staged applies exactly what was staged (returns the number of events
+    // that changed `available`) and throws EncodeError -- leaving the snapshot as it was -- when the snapshot has changed in between or
+    // the change leaves the exact integer domain.  A caller whose POSTs did not all land drops the staged update and calls observe_bound
+    // with the ones that did.
+    struct StagedUpdate;
+    std::shared_ptr<StagedUpdate> stage_bound(const std::vector<Bound> &bound);
+    size_t commit_staged(StagedUpdate &staged);
+
+private:
+    std::shared_ptr<StagedUpdate> stage_impl(const std::vector<Observed> &events);
 };
 
 // K8s ToleratesTaint (extension E2): does toleration `t` tolerate taint `x`?

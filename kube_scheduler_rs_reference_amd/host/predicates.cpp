@@ -1,5 +1,6 @@
 #include "predicates.hpp"
 
+#include "pool.hpp"
 #include "sharded.hpp"
 
 #include <algorithm>
@@ -119,8 +120,20 @@ struct KeyRange {
     size_t lo, hi;
     bool wide;
 };
-std::vector<KeyRange> key_ranges(const std::vector<const corev1::Pod *> &pods) {
+std::vector<KeyRange> key_ranges(const std::vector<const corev1::Pod *> &pods, std::optional<std::set<std::string>> *whole_batch_keys = nullptr) {
     std::vector<KeyRange> out;
+    // The common case first, on the worker threads: the whole batch names at most KSCHED_MAX_KEYS distinct keys and no pod is wide -- ONE
+    // range, and its key set goes on to the encoder.  (The serial walk below was 17 of a C3-size batch's 25 ms on the way to the device,
+    // profiles/r06_host_loop.txt; it is still what cuts a batch that needs cutting.)
+    if (pods.size() >= 4096) {
+        bool any_wide = false;
+        std::set<std::string> all = Snapshot::batch_selector_keys(pods, &any_wide);
+        if (!any_wide && all.size() <= KSCHED_MAX_KEYS) {
+            out.push_back({0, pods.size(), false});
+            if (whole_batch_keys) *whole_batch_keys = std::move(all);
+            return out;
+        }
+    }
     size_t lo = 0;
     std::set<std::string> keys;
     auto close = [&](size_t hi) {
@@ -171,7 +184,7 @@ std::vector<corev1::Pod> split_wide_pod(const corev1::Pod &pod) {
 // the fit mask is the same in every group), and the pick made by the device from the combined mask (ksched_pick).  On the first
 // device of a multi-device snapshot: such pods are rare, and every device holds the whole snapshot.
 void eval_wide_pod(Snapshot &snap, const corev1::Pod &pod, size_t i, uint32_t pick, const std::vector<uint32_t> *samples, uint32_t attempts,
-                   BatchValidity &out, bool want_masks) {
+                   BatchValidity &out, bool want_masks, const std::function<void()> *samples_ready = nullptr) {
     const uint32_t W = out.W;
     std::vector<uint64_t> feas(W, ~0ull), fit(W, 0ull), f(W), ft(W);
     DeviceEvaluator &dev = snap.device();
@@ -189,6 +202,7 @@ void eval_wide_pod(Snapshot &snap, const corev1::Pod &pod, size_t i, uint32_t pi
         std::copy(feas.begin(), feas.end(), out.feasible.begin() + (std::ptrdiff_t)(i * W));
         std::copy(fit.begin(), fit.end(), out.fit.begin() + (std::ptrdiff_t)(i * W));
     }
+    if (pick && samples_ready) (*samples_ready)();
     if (pick)
         dev.check(ksched_pick(dev.handle(), 1, feas.data(), &req_mem, (pick & KSCHED_PICK_SAMPLED) ? samples->data() + i * attempts : nullptr, attempts,
                               pick | (out.flags & (KSCHED_FIT | KSCHED_SEL | KSCHED_TAINT)), out.binding.data() + i),
@@ -197,10 +211,20 @@ void eval_wide_pod(Snapshot &snap, const corev1::Pod &pod, size_t i, uint32_t pi
 
 // One device call for pods [lo, hi) of the batch, written into rows [lo, hi) of `out`.
 void eval_range(Snapshot &snap, const std::vector<const corev1::Pod *> &pods, size_t lo, size_t hi, uint32_t pick,
-                const std::vector<uint32_t> *samples, uint32_t attempts, BatchValidity &out, bool want_masks) {
-    const std::vector<const corev1::Pod *> part(pods.begin() + (std::ptrdiff_t)lo, pods.begin() + (std::ptrdiff_t)hi);
-    PodColumns pc = snap.encode_pods(part);
+                const std::vector<uint32_t> *samples, uint32_t attempts, BatchValidity &out, bool want_masks,
+                const std::set<std::string> *known_keys = nullptr, const std::function<void()> *samples_ready = nullptr) {
+    PhaseClock clock("eval_range");
+    const bool whole = lo == 0 && hi == pods.size();
+    const std::vector<const corev1::Pod *> part = whole ? std::vector<const corev1::Pod *>() : std::vector<const corev1::Pod *>(pods.begin() + (std::ptrdiff_t)lo, pods.begin() + (std::ptrdiff_t)hi);
+    PodColumns pc = snap.encode_pods(whole ? pods : part, whole ? known_keys : nullptr);
+    clock.lap("encode_pods");
+    if (out.req_cpu_nanos.size() == out.p) {
+        std::copy(pc.req_cpu_nanos.begin(), pc.req_cpu_nanos.end(), out.req_cpu_nanos.begin() + (std::ptrdiff_t)lo);
+        std::copy(pc.req_mem_nanos.begin(), pc.req_mem_nanos.end(), out.req_mem_nanos.begin() + (std::ptrdiff_t)lo);
+    }
     const uint32_t flags = out.flags | (want_masks ? KSCHED_WANT_FIT_MASK : 0u) | pick;
+    if (samples_ready) (*samples_ready)();  // (the draws are read from here on)
+    clock.lap("waiting for the draws");
     if (ShardedContext *sh = snap.sharded()) {
         // several devices (or KSCHED_SHARDED): the range's rows are cut over them, each device evaluates its rows against its
         // replica of the snapshot, the bindings meet in one RCCL all-gather (sharded.hpp); masks land in this range's rows directly
@@ -216,12 +240,13 @@ void eval_range(Snapshot &snap, const std::vector<const corev1::Pod *> &pods, si
                           flags, want_masks ? out.feasible.data() + lo * out.W : nullptr,
                           want_masks ? out.fit.data() + lo * out.W : nullptr, pick ? out.binding.data() + lo : nullptr),
               "ksched_eval");
+    clock.lap("ksched_eval (copies in, device, bindings out)");
 }
 
 }  // namespace
 
 BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, bool taints, uint32_t pick_flags,
-                                        const std::vector<uint32_t> *samples, uint32_t attempts, bool want_masks) {
+                                        const std::vector<uint32_t> *samples, uint32_t attempts, bool want_masks, const std::function<void()> *samples_ready) {
     if (!ctx.snapshot) ctx.refresh_snapshot();
     Snapshot &snap = *ctx.snapshot;
     if (taints && snap.has_taints()) snap.enable_taints();  // extension E2 is opt-in: interning happens (and can fail) only here
@@ -242,9 +267,20 @@ BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &
         throw EncodeError("check_node_validity_batch: samples must hold p * attempts indices");
     // (key_ranges: consecutive pod ranges within the device's budget of label columns per call; a pod with more keys than that is
     // evaluated group by group and ANDed -- no input the reference schedules is refused)
-    for (const KeyRange &r : key_ranges(pods)) {
-        if (r.wide) eval_wide_pod(snap, *pods[r.lo], r.lo, pick, samples, attempts, out, want_masks);
-        else eval_range(snap, pods, r.lo, r.hi, pick, samples, attempts, out, want_masks);
+    PhaseClock clock("check_node_validity_batch");
+    std::optional<std::set<std::string>> whole_keys;  // set when the batch is ONE range whose keys the plan has collected already
+    const std::vector<KeyRange> ranges = key_ranges(pods, &whole_keys);
+    clock.lap("key_ranges");
+    out.req_cpu_nanos.assign(out.p, 0);
+    out.req_mem_nanos.assign(out.p, 0);
+    out.exact_requests = true;
+    for (const KeyRange &r : ranges) {
+        if (r.wide) {
+            out.exact_requests = false;  // (its rows come from the pod's key groups; a caller that needs the sums parses that pod itself)
+            eval_wide_pod(snap, *pods[r.lo], r.lo, pick, samples, attempts, out, want_masks, samples_ready);
+        } else {
+            eval_range(snap, pods, r.lo, r.hi, pick, samples, attempts, out, want_masks, whole_keys ? &*whole_keys : nullptr, samples_ready);
+        }
     }
     return out;
 }

@@ -19,6 +19,7 @@
 // ctx.snapshot in one ksched_eval.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <optional>
 #include <vector>
 
@@ -49,6 +50,10 @@ struct BatchValidity {
     uint32_t flags = 0;
     std::vector<uint64_t> feasible, fit;  // [p][W]
     std::vector<int32_t> binding;         // [p] when a pick was requested, canonical node index or -1
+    // [p] the pods' exact request sums in nano-units as the encoder computed them (empty for rows a wide pod's key groups produced: those
+    // hold 0 and `exact_requests` is false): lets the caller update the snapshot with the batch's bindings without parsing the pods again
+    std::vector<__int128> req_cpu_nanos, req_mem_nanos;
+    bool exact_requests = false;
 
     bool is_valid(uint32_t pod, uint32_t node) const { return (feasible[(size_t)pod * W + (node >> 6)] >> (node & 63u)) & 1ull; }
     // check_node_validity's result for the pair, rebuilt in the reference's order (fit first)
@@ -60,9 +65,11 @@ struct BatchValidity {
 // `samples`, [p][attempts] canonical node indices) or KSCHED_PICK_BESTFIT; `taints` adds extension E2.
 // want_masks = false (with a pick): bindings only -- `feasible` / `fit` stay empty, no mask kernel runs and nothing but the bindings
 // comes back from the device (the reference's reconcile needs the chosen node, not the matrix: src/main.rs:53-66).
+// `samples_ready`: called (once or more) right before the first device call that reads `samples` -- a caller that is still filling the
+// draws on another thread while the batch is planned and encoded waits for that thread there (scheduler.cpp).
 BatchValidity check_node_validity_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, bool taints = false,
                                         uint32_t pick_flags = 0, const std::vector<uint32_t> *samples = nullptr,
-                                        uint32_t attempts = 0, bool want_masks = true);
+                                        uint32_t attempts = 0, bool want_masks = true, const std::function<void()> *samples_ready = nullptr);
 
 // How check_node_validity_batch cuts a batch into device evaluations (no device involved: the host-side plan alone, what the CPU tests
 // check).  The device takes KSCHED_MAX_KEYS label columns per call and the reference has no limit on selector keys

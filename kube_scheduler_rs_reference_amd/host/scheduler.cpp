@@ -1,12 +1,16 @@
 #include "scheduler.hpp"
 
+#include "pool.hpp"
+
 #include <chrono>
+#include <exception>
 #include <cstdio>
 #include <cstdlib>
 
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <tuple>
 
 namespace ksched_host {
 
@@ -63,16 +67,51 @@ BatchSelection select_nodes_for_pods(const std::vector<const corev1::Pod *> &pod
     if (want_rejected) out.rejected.resize(p);
     // the draws, in the reference's order: pod by pod, attempt by attempt, over the store's own ordering;
     // converted to canonical column indices for the device (an empty store gives "no draw" = index n)
+    PhaseClock clock("select");
     std::vector<uint32_t> samples((size_t)p * ATTEMPTS, n);
-    for (uint32_t i = 0; i < p; ++i)
-        for (uint32_t t = 0; t < ATTEMPTS; ++t) {
-            const std::optional<size_t> idx = chooser.choose(ctx.node_store.size());
-            if (idx) samples[(size_t)i * ATTEMPTS + t] = snap.canonical_index((uint32_t)*idx);
+    auto draw = [&] {
+        const size_t store = ctx.node_store.size();
+        for (uint32_t i = 0; i < p; ++i)
+            for (uint32_t t = 0; t < ATTEMPTS; ++t) {
+                const std::optional<size_t> idx = chooser.choose(store);
+                if (idx) samples[(size_t)i * ATTEMPTS + t] = snap.canonical_index((uint32_t)*idx);
+            }
+    };
+    // A large batch draws on a thread of its own while this one plans and encodes the batch (the draws are a serial walk -- one
+    // generator, the reference's order -- of 2 ms per 100 000 pods; the device call is the first reader).  Joined on every path out.
+    std::thread drawer;
+    std::exception_ptr draw_error;
+    struct Join {
+        std::thread &t;
+        ~Join() {
+            if (t.joinable()) t.join();
         }
-    out.samples = samples;
-    if (n == 0 || p == 0) return out;
+    } join_guard{drawer};
+    const std::function<void()> samples_ready = [&] {
+        if (drawer.joinable()) drawer.join();
+        if (draw_error) std::rethrow_exception(draw_error);
+    };
+    if (p >= 4096 && n != 0) {
+        drawer = std::thread([&] {
+            try {
+                draw();
+            } catch (...) {
+                draw_error = std::current_exception();
+            }
+        });
+    } else {
+        draw();
+    }
+    clock.lap("draws (a large batch: on their own thread from here)");
+    if (n == 0 || p == 0) {
+        out.samples = samples;
+        return out;
+    }
     // (the masks only when the caller wants the rejected draws' reasons: a batch's bindings alone need no mask kernel and no mask copy)
-    out.validity = predicates::check_node_validity_batch(pods, ctx, /*taints=*/false, KSCHED_PICK_SAMPLED, &samples, ATTEMPTS, /*want_masks=*/want_rejected);
+    out.validity = predicates::check_node_validity_batch(pods, ctx, /*taints=*/false, KSCHED_PICK_SAMPLED, &samples, ATTEMPTS, /*want_masks=*/want_rejected, &samples_ready);
+    samples_ready();
+    out.samples = samples;
+    clock.lap("check_node_validity_batch");
     for (uint32_t i = 0; i < p; ++i) {
         const int32_t b = out.validity.binding[i];
         if (b >= 0) out.node_store_index[i] = (int32_t)snap.store_index((uint32_t)b);
@@ -223,51 +262,101 @@ ReconcileOutcome reconcile(const corev1::Pod &pod, Context &ctx, NodeChooser &ch
 
 std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Pod *> &pods, Context &ctx, NodeChooser &chooser,
                                               BindingSink &sink, unsigned post_concurrency) {
+    PhaseClock clock("reconcile_batch");
     std::vector<ReconcileOutcome> out(pods.size());
     std::vector<const corev1::Pod *> pending;
     std::vector<size_t> where;
+    pending.reserve(pods.size());
+    where.reserve(pods.size());
     for (size_t i = 0; i < pods.size(); ++i) {
         if (is_pod_bound(*pods[i])) continue;  // Ok(await_change) without touching the evaluator
         pending.push_back(pods[i]);
         where.push_back(i);
     }
+    clock.lap("outcome slots + the pending pods");
     const bool timing = std::getenv("KSCHED_HOST_TIMING") != nullptr;  // (tools/host_loop.py: where a batch's host time goes, to stderr)
     const auto t0 = std::chrono::steady_clock::now();
-    const BatchSelection sel = select_nodes_for_pods(pending, ctx, chooser);
-    warn_rejected(pending, ctx, sel);  // src/main.rs:62, for the whole batch (one ksched_explain call; skipped when nobody listens)
+    BatchSelection sel = select_nodes_for_pods(pending, ctx, chooser);
     const auto t1 = std::chrono::steady_clock::now();
     std::vector<const corev1::Node *> chosen(pending.size(), nullptr);
     for (size_t j = 0; j < pending.size(); ++j)
         if (sel.node_store_index[j] >= 0) chosen[j] = &ctx.node_store[(size_t)sel.node_store_index[j]];
-    const std::vector<ReconcileOutcome> posted = post_bindings(pending, chosen, sink, post_concurrency);  // src/main.rs:94-108, overlapped
-    std::vector<std::pair<const corev1::Pod *, const std::string *>> landed;  // (pod, the node it was bound to), for the snapshot update
-    for (size_t j = 0; j < pending.size(); ++j) {
-        out[where[j]] = posted[j];
-        if (out[where[j]].ok && out[where[j]].bound_to) landed.emplace_back(pending[j], &*out[where[j]].bound_to);  // (`out` is not resized any more)
+    // The bindings count against their nodes for the NEXT batch (the reference gets that from re-LISTing on every evaluation,
+    // src/predicates.rs:34-38; here the snapshot is patched in one device update).  Everything of that update that only READS the
+    // snapshot -- the pods' keys, what the bookkeeping holds for them, the per-node sums -- is worked out WHILE THE POSTS ARE IN FLIGHT
+    // (they run on their own thread; the reference's are network round trips), for every pod that was given a node, from the node index
+    // the device returned and the request sums the encoder made (no name lookup, no second parse).  It is committed afterwards, and only
+    // if every one of those POSTs landed; otherwise it is dropped and the ones that did land are observed the plain way.
+    std::shared_ptr<Snapshot::StagedUpdate> staged;
+    std::vector<ReconcileOutcome> posted;
+    {
+        std::exception_ptr post_error;
+        std::thread poster([&] {
+            try {
+                posted = post_bindings(pending, chosen, sink, post_concurrency);  // src/main.rs:94-108, overlapped
+            } catch (...) {
+                post_error = std::current_exception();
+            }
+        });
+        try {
+            if (ctx.snapshot && sel.validity.exact_requests && sel.validity.binding.size() == pending.size()) {
+                std::vector<Snapshot::Bound> all;
+                all.reserve(pending.size());
+                for (size_t j = 0; j < pending.size(); ++j)
+                    if (chosen[j] && pending[j]->metadata.namespace_)  // (a pod without a namespace is never POSTed: bind())
+                        all.push_back({pending[j], (uint32_t)sel.validity.binding[j], sel.validity.req_cpu_nanos[j], sel.validity.req_mem_nanos[j]});
+                if (!all.empty()) staged = ctx.snapshot->stage_bound(all);
+            }
+        } catch (const EncodeError &) {
+            staged.reset();  // (decided after the POSTs, on the plain path)
+        } catch (...) {
+            poster.join();
+            throw;
+        }
+        poster.join();
+        if (post_error) std::rethrow_exception(post_error);
     }
     const auto t2 = std::chrono::steady_clock::now();
+    std::vector<std::pair<const corev1::Pod *, const std::string *>> landed;  // (pod, the node it was bound to), for the snapshot update
+    size_t expected = 0;
+    for (size_t j = 0; j < pending.size(); ++j) {
+        out[where[j]] = std::move(posted[j]);
+        if (chosen[j] && pending[j]->metadata.namespace_) ++expected;
+        if (out[where[j]].ok && out[where[j]].bound_to) landed.emplace_back(pending[j], &*out[where[j]].bound_to);  // (`out` is not resized any more)
+    }
     // The whole batch was evaluated against ONE snapshot (the reference's racing reconciles all see the same API-server state).
-    // The bindings it created then count against their nodes for the NEXT batch -- the reference gets that from re-LISTing on
-    // every evaluation (src/predicates.rs:34-38); here the snapshot is patched in one device update.
     if (ctx.snapshot && !landed.empty()) {
-        // (observe_bound, the tracked form: when the watch later echoes these bindings as MODIFIED events they change nothing)
+        // (the tracked form: when the watch later echoes these bindings as MODIFIED events they change nothing)
         // The bindings EXIST by now: whatever happens to the snapshot update, the caller gets `out` (an exception here would make
         // a batching caller lose the outcomes, or worse reconcile -- and POST -- the batch again).  A device failure leaves the
         // snapshot marked stale (it uploads everything before the next evaluation); a bookkeeping failure (int64 overflow of
         // `available`) drops the snapshot, so that the next batch starts from fresh LISTs.
         try {
-            ctx.snapshot->observe_bound(landed);
+            if (staged && landed.size() == expected) (void)ctx.snapshot->commit_staged(*staged);
+            else ctx.snapshot->observe_bound(landed);
         } catch (const EncodeError &) {
             if (!ctx.snapshot->device_stale()) ctx.snapshot.reset();
         }
     }
+    const auto t3 = std::chrono::steady_clock::now();
+    // src/main.rs:62, for the whole batch (one ksched_explain call; skipped when nobody listens).  Behind the POSTs and outside the
+    // evaluation's span: the line is a log line -- a failure to produce it (the explain call, an encode error of the re-encoded pods)
+    // degrades to one warning and never costs the batch its bindings.
+    try {
+        warn_rejected(pending, ctx, sel);
+    } catch (const std::exception &e) {
+        if (ctx.warn) ctx.warn(std::string("the rejected candidates of this batch could not be listed: ") + e.what());
+    }
     warn_failed(pods, out, ctx);
     if (timing) {
-        const auto t3 = std::chrono::steady_clock::now();
+        const auto t4 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "reconcile_batch %zu pods: draws + encode + device %.2f ms, bindings (POST) %.2f ms, snapshot update %.2f ms\n", pending.size(), ms(t0, t1),
-                     ms(t1, t2), ms(t2, t3));
+        std::fprintf(stderr, "reconcile_batch %zu pods: draws + encode + device %.2f ms, bindings (POST) with the snapshot update staged beside them %.2f ms, snapshot update committed %.2f ms, WARN lines %.2f ms\n",
+                     pending.size(), ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
     }
+    // (100 000 outcomes' strings, the draws, the staged update's keys: freeing them takes 4 ms of a C3-size batch's 21 -- not on the caller's thread)
+    Reaper::instance().discard_later(std::make_tuple(std::move(sel), std::move(posted), std::move(staged), std::move(chosen), std::move(landed), std::move(pending), std::move(where)));
+    clock.lap("everything up to the return");
     return out;
 }
 
