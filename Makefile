@@ -6,6 +6,8 @@
 #   make host       -> kube_scheduler_rs_reference_amd/libksched_host.so    g++, links libksched_hip.so; + tests/cpp/host_tests
 #   make oracle     -> oracle/liboracle.so                                  gcc, test infrastructure only
 #   make tools      -> tools/pmc_calib                                      hipcc: calibration kernels for the HBM counters
+#   make test-lib   -> tests/cpp/hooks/libksched_hip.so                     the SAME object code + tests/cpp/test_hooks.cpp: the only build in which
+#                      $KSCHED_TEST_HOOKS=1 switches on the RCCL stand-in, fault injection and the k-replica shard (the shipped library has none of it)
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 CC      ?= gcc
@@ -31,8 +33,11 @@ INDEX_TEST := tests/cpp/index_tests
 
 PMC_CALIB := tools/pmc_calib
 
-.PHONY: all lib host oracle tools clean
-all: lib host oracle tools
+LIB_OBJ  := $(CSRC)/ksched_api.o
+LIB_HIP_TEST := tests/cpp/hooks/libksched_hip.so
+
+.PHONY: all lib host oracle tools clean test-lib
+all: lib test-lib host oracle tools
 
 # kernels of KNOWN byte counts for calibrating the HBM counters (bench.py --live-traffic, tools/gpu_round.sh pmc)
 tools: $(PMC_CALIB)
@@ -40,10 +45,18 @@ $(PMC_CALIB): tools/pmc_calib.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ tools/pmc_calib.hip
 
 lib: $(LIB_HIP)
-$(LIB_HIP): $(CSRC)/ksched_api.hip $(wildcard $(CSRC)/*.hpp) include/ksched.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ksched_api.hip
+# the kernels are compiled ONCE; the shipped library and the test build are two links of the same object
+$(LIB_OBJ): $(CSRC)/ksched_api.hip $(wildcard $(CSRC)/*.hpp) include/ksched.h
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/ksched_api.hip
+$(LIB_HIP): $(LIB_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(LIB_OBJ)
+test-lib: $(LIB_HIP_TEST)
+$(LIB_HIP_TEST): $(LIB_OBJ) tests/cpp/test_hooks.cpp
+	mkdir -p tests/cpp/hooks
+	$(CXX) -O2 -std=c++17 -fPIC -c -o tests/cpp/hooks/test_hooks.o tests/cpp/test_hooks.cpp
+	$(HIPCC) --offload-arch=$(ARCH) -shared -Wl,-soname,libksched_hip.so -o $@ $(LIB_OBJ) tests/cpp/hooks/test_hooks.o
 
-host: $(LIB_HOST) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL) $(FAKE_RCCL)
+host: $(LIB_HOST) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL) $(FAKE_RCCL) $(LIB_HIP_TEST)
 # TEST-ONLY stand-in for librccl (n ranks on one GPU; loaded only with KSCHED_TEST_HOOKS=1 + KSCHED_RCCL_LIB, see csrc/comm_rccl.hpp)
 $(FAKE_RCCL): tests/cpp/fake_rccl.cpp
 	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -shared -o $@ tests/cpp/fake_rccl.cpp -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lrt -lpthread
@@ -65,4 +78,4 @@ $(LIB_ORA): oracle/oracle.c oracle/oracle.h
 	$(CC) $(CFLAGS) -shared -o $@ oracle/oracle.c
 
 clean:
-	rm -f $(LIB_HIP) $(LIB_HOST) $(LIB_ORA) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL) $(FAKE_RCCL) $(PMC_CALIB)
+	rm -f $(LIB_OBJ) $(LIB_HIP_TEST) tests/cpp/hooks/test_hooks.o $(LIB_HIP) $(LIB_HOST) $(LIB_ORA) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL) $(FAKE_RCCL) $(PMC_CALIB)

@@ -379,6 +379,12 @@ def main():
     ap.add_argument("--no-others", action="store_true",
                     help="N = 1, default workload: skip config.other_workloads (C4s, C5s measured in the same process, a few hundred ms) "
                          "and config.in_place")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="leave this many of the 256 compute units out of every fused mask launch (KSCHED_OPT_GRID_CUS = 256 - K).  For the first run on a real "
+                         "multi-GPU node: RCCL's all-gather kernels run beside a mask kernel whose blocks own every CU's LDS; `--gpus 8` against `--gpus 8 --reserve-cus 8` "
+                         "is the A/B (VERDICT r5 item 6b).  0 = the whole chip (default)")
+    ap.add_argument("--round-order", type=int, default=0, choices=[0, 1, 2],
+                    help="KSCHED_OPT_ROUND_ORDER of the graded loop's evaluator: 0 interleaved wave-major (default), 1 blocked (rounds 1 - 5), 2 interleaved chunk-major")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="N = 1: skip config.end_to_end (host arrays -> bindings / mask, and objects -> reconcile_batch through the C++ host mirror: ~25 s)")
     ap.add_argument("--live-traffic", choices=["auto", "on", "off"], default="auto",
@@ -516,6 +522,10 @@ def main():
             ev.set_option(L.OPT_FUSED_PICK, args.fused_pick)
             if args.debug:
                 ev.set_option(L.OPT_DEBUG, args.debug)
+            if args.reserve_cus:
+                ev.set_option(L.OPT_GRID_CUS, 256 - args.reserve_cus)
+            if args.round_order:
+                ev.set_option(L.OPT_ROUND_ORDER, args.round_order)
             ev.set_nodes(**c.node_columns())
             self.ev = ev
             t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
@@ -1041,6 +1051,10 @@ def main():
             "untimed_steps_before_timed_region": args.warmup + ramp_steps, "ms_per_step": step_s * 1e3, "timed_region_split": region_split,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": desc, "pods_per_gpu": P_gpu, "pods_total": P_total, "nodes": N,
+                       "workload_note": ("the same per-GPU workload at every N (weak scaling): the driver derives scaling efficiency from the per-N values, which a workload that "
+                                         "changed with N would corrupt -- BASELINE.json's 8-GPU configuration, configs[3] = 1M pods x 10k nodes split N ways, is measured in the same "
+                                         "run as config.configs3_strong" if world > 1 else None),
+                       "grid_cus": (256 - args.reserve_cus) if args.reserve_cus else 256, "round_order": args.round_order,
                        **({"one_gpu_stand_in": "TEST HOOK: the %d ranks share ONE GPU and gather through the RCCL stand-in; a check of the N > 1 code, not a scaling figure" % world}
                           if one_gpu else {}),
                        "predicates": "+".join(flag_names), "pick": pick, "mask_written": not args.no_mask,

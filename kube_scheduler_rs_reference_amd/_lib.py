@@ -163,6 +163,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    # (the TEST build -- tests/cpp/hooks/libksched_hip.so, reached through $KSCHED_LIB -- exports two more functions; the shipped library does not)
+    if hasattr(lib, "ksched_test_hooks_linked"):
+        lib.ksched_test_hooks_linked.restype = C.c_int
+        lib.ksched_test_hooks_linked.argtypes = []
     if lib.ksched_abi_version() != ABI_VERSION:
         raise ImportError(f"ABI mismatch: library {lib.ksched_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

@@ -7,9 +7,10 @@
 // librccl.so.1) the same library instance is reused instead of a second copy being mapped next to it.  The header is
 // only used for its types and prototypes.
 //
-// Test hook: with BOTH $KSCHED_TEST_HOOKS=1 and $KSCHED_RCCL_LIB=<path> that library is loaded instead -- tests/cpp/fake_rccl.cpp,
-// which lets one GPU stand for n ranks so that the multi-device host's exchange runs with n > 1 on a one-GPU box.  $KSCHED_RCCL_LIB
-// without the hook switch is an error, never a silent substitute.
+// Test hook, in the TEST build of the library only (tests/cpp/hooks/libksched_hip.so = the same object code + tests/cpp/test_hooks.cpp, which
+// defines ksched_test_hooks_enabled): with $KSCHED_TEST_HOOKS=1 and $KSCHED_RCCL_LIB=<path> that library is loaded instead of RCCL --
+// tests/cpp/fake_rccl.cpp, which lets one GPU stand for n ranks so that the multi-device host's exchange runs with n > 1 on a one-GPU box.
+// The shipped library does not define the symbol: the weak reference below is null there and $KSCHED_RCCL_LIB is never read.
 #pragma once
 #include <dlfcn.h>
 #include <stdlib.h>
@@ -19,7 +20,12 @@
 #include <mutex>
 #include <string>
 
+extern "C" __attribute__((weak)) int ksched_test_hooks_enabled(void);  // tests/cpp/test_hooks.cpp (the test build) or null (the shipped library)
+extern "C" __attribute__((weak)) const char *ksched_test_rccl_lib(int *refused);  // the same: the stand-in's path, read from the environment THERE
+
 namespace ksched {
+
+inline bool test_hooks_on() { return ksched_test_hooks_enabled != nullptr && ksched_test_hooks_enabled() != 0; }
 
 struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
@@ -41,15 +47,16 @@ inline RcclApi &rccl_api() {
     static std::once_flag once;
     std::call_once(once, [] {
         void *h = nullptr;
-        if (const char *over = getenv("KSCHED_RCCL_LIB")) {
-            const char *hooks = getenv("KSCHED_TEST_HOOKS");
-            if (!hooks || std::string(hooks) != "1") {
-                api.error = "KSCHED_RCCL_LIB is set but KSCHED_TEST_HOOKS=1 is not: refusing a substitute for RCCL";
-                return;
-            }
+        int refused = 0;
+        const char *over = ksched_test_rccl_lib != nullptr ? ksched_test_rccl_lib(&refused) : nullptr;  // (the shipped library has no such function)
+        if (refused) {
+            api.error = "a substitute for RCCL is named in the environment but the test hooks are not switched on: refusing a substitute for RCCL";
+            return;
+        }
+        if (over) {
             h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
             if (!h) {
-                api.error = std::string("cannot load $KSCHED_RCCL_LIB: ") + dlerror();
+                api.error = std::string("cannot load the RCCL stand-in: ") + dlerror();
                 return;
             }
             api.substitute = over;

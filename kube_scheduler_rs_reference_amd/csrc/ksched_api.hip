@@ -1202,6 +1202,10 @@ int ksched_set_option(ksched_ctx *c, int option, int64_t value) try {
             c->opt_mask_probe = (uint32_t)value;
             return KSCHED_OK;
         case KSCHED_OPT_FAULT:  // low byte: 0 off, 1 std::bad_alloc, 2 std::runtime_error; bits 8..: fault points to pass first
+            if (ksched_test_hooks_enabled == nullptr) {  // the shipped library: no fault injection (tests/cpp/test_hooks.cpp is not linked in)
+                c->last_error = "KSCHED_OPT_FAULT exists in the test build of the library only";
+                return KSCHED_E_UNSUPPORTED;
+            }
             if (value < 0 || (value & 0xFF) > 2 || value > 0xFFFFFF) return KSCHED_E_INVAL;
             c->fault_kind = (uint32_t)(value & 0xFF);
             c->fault_skip = (uint32_t)(value >> 8);
@@ -1439,6 +1443,7 @@ struct ksched_pipe {
     std::vector<hipEvent_t> mask_done, pick_done;
     std::vector<hipStream_t> slot_stream;  // the stream that carries the slot's mask kernel (alternate mode: also its pick)
     std::vector<hipStream_t> pick_stream;  // the stream that carried the slot's latest pick (ksched_pipe_slot_stream)
+    std::vector<uint8_t> last_split;       // the slot's latest submit ran in the split mode (its mask kernel and its pick on different streams)
 };
 
 int ksched_pipe_create(ksched_ctx *c, uint32_t depth, ksched_pipe **out) try {
@@ -1454,6 +1459,7 @@ int ksched_pipe_create(ksched_ctx *c, uint32_t depth, ksched_pipe **out) try {
               hipStreamCreateWithFlags(&q->s_pick, hipStreamNonBlocking) == hipSuccess;
     q->slot_stream.assign(depth, nullptr);
     q->pick_stream.assign(depth, nullptr);
+    q->last_split.assign(depth, 0);
     for (uint32_t i = 0; ok && i < 2 * depth; ++i) {
         hipEvent_t e;
         ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -1529,8 +1535,9 @@ int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t 
     const bool pick_reads_mask = c->opt_pick_from_mask || ((pick & KSCHED_PICK_BESTFIT) && !bf_rows_expected(c));
     if (c->opt_pipe_mode >= 1 && !pick_reads_mask) {
         // alternate: the whole evaluation of the slot on ONE of the pipe's streams (one launch when the pick rides in the mask
-        // kernel), stream = slot mod k.  While depth is a multiple of k a slot always comes back to the same stream, so the reuse
-        // of its buffers is ordered by the stream itself; otherwise the slot's new stream first waits for its previous use.
+        // kernel), stream = slot mod k.  A slot comes back to the same stream as long as the mode stays what it is, so the reuse of
+        // its buffers is ordered by the stream itself; when the slot's previous use ran elsewhere -- another k, or the split mode,
+        // whose mask kernel sits on the mask stream un-ordered against anything -- its new stream first waits for that use.
         const uint32_t k = std::max(2u, (uint32_t)c->opt_pipe_mode), which = slot % k;
         while (which >= 2u && q->extra.size() < (size_t)which - 1u) {
             hipStream_t ns = nullptr;
@@ -1538,7 +1545,9 @@ int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t 
             q->extra.push_back(ns);
         }
         hipStream_t st = which == 0u ? q->s_mask : which == 1u ? q->s_pick : q->extra[which - 2u];
-        if (q->pick_stream[slot] && q->pick_stream[slot] != st) HIPCHK(c, hipStreamWaitEvent(st, q->pick_done[slot], 0));
+        if (q->pick_stream[slot] && (q->pick_stream[slot] != st || q->last_split[slot])) HIPCHK(c, hipStreamWaitEvent(st, q->pick_done[slot], 0));
+        if (q->last_split[slot] && q->slot_stream[slot] != st) HIPCHK(c, hipStreamWaitEvent(st, q->mask_done[slot], 0));  // (the split mode records it after every mask kernel)
+        q->last_split[slot] = 0;
         q->slot_stream[slot] = st;
         q->pick_stream[slot] = st;
         rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, samples, attempts, flags, mask, nullptr, binding, mask_pitch_words, st);
@@ -1554,10 +1563,11 @@ int ksched_pipe_submit(ksched_pipe *q, uint32_t slot, uint32_t p, const int64_t 
     q->slot_stream[slot] = sm;
     q->pick_stream[slot] = q->s_pick;
     if (pick_reads_mask) HIPCHK(c, hipStreamWaitEvent(sm, q->pick_done[slot], 0));  // the slot's mask may be overwritten once its pick has run
+    q->last_split[slot] = 1;
     rc = eval_on_device(c, p, pcpu, pmem, psel, ptol, nullptr, 0, flags & ~pick, mask, nullptr, nullptr, mask_pitch_words, sm);
     if (rc) return rc;
+    HIPCHK(c, hipEventRecord(q->mask_done[slot], sm));  // (always: a later submit of this slot in the alternate mode orders itself behind this mask kernel)
     if (pick_reads_mask) {
-        HIPCHK(c, hipEventRecord(q->mask_done[slot], sm));
         HIPCHK(c, hipStreamWaitEvent(q->s_pick, q->mask_done[slot], 0));
         if (p > 0) {
             if (c->n == 0) HIPCHK(c, hipMemsetAsync(binding, 0xFF, (size_t)p * sizeof(int32_t), q->s_pick));

@@ -248,6 +248,7 @@ class PipelinedScheduler:
         self._pick_stream = pipe.stream(1) if pipe is not None else None
         self._alternate = alternate
         self._streams2 = (pipe.stream(0), pipe.stream(1)) if alternate else None  # alternate: slot k lives on stream k % 2
+        self._stream2_handles = tuple(int(s_.cuda_stream) for s_ in self._streams2) if alternate else None
         # single-stream form with the ABI communicator: the gather runs on a side stream behind an event, like torch's async_op
         self._side = torch.cuda.Stream(device=device) if (comm is not None and pipe is None) else None
         self._ready = [torch.cuda.Event() for _ in range(depth)] if self._side is not None else None  # reused: no event creation per step
@@ -305,12 +306,13 @@ class PipelinedScheduler:
         out = self.binding_buffer(k, g)
         if self.n_local > 0:
             run(k * self.gather_every + g if self.pipe is not None else k, out)
-            if self._alternate and not self._used[k]:
+            if self._alternate:
                 # The slot's all-gather is pre-bound to stream (k mod 2) and relies on the pick having gone onto that very stream.
                 # ksched_pipe_submit falls back to its split mode when the pick reads the mask (KSCHED_OPT_PICK_FROM_MASK, a best-fit
-                # pick without the bitmap index): the pick is then on the pick stream whatever the slot.  Ask the pipe once per slot.
-                used = self.pipe.slot_stream(k)
-                if used is None or used.cuda_stream != self._streams2[k & 1].cuda_stream:
+                # pick without the bitmap index) and deals slots over more streams when KSCHED_OPT_PIPE_MODE > 2: the pick is then
+                # somewhere else.  Asked after EVERY submit (one C call; the option can change between two steps: ADVICE r5).
+                used = self.pipe.slot_stream_handle(k)
+                if used != self._stream2_handles[k & 1]:
                     raise RuntimeError("PipelinedScheduler(alternate=True): the pipe ran this request in its split mode (the pick reads the mask), so the "
                                        "slot's all-gather would not be ordered behind its pick; use alternate=False for this request")
             self._used[k] = True

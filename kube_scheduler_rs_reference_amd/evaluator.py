@@ -438,6 +438,10 @@ class Pipe:
         h = self._lib.ksched_pipe_slot_stream(self._h, slot)
         return torch.cuda.ExternalStream(int(h), device=self.ev.device) if h else None
 
+    def slot_stream_handle(self, slot: int) -> int:
+        """ksched_pipe_slot_stream as the raw hipStream_t (0 before the slot's first submit): the cheap form for a per-step check."""
+        return int(self._lib.ksched_pipe_slot_stream(self._h, slot) or 0)
+
     def submit(self, slot: int, req_cpu_milli, req_mem_bytes, sel_val_ids, tolerations, samples, flags: int, mask, binding):
         """torch CUDA tensors (see Evaluator.eval_device); `mask` is a [p, W] (possibly pitched) view, `binding` int32 [p]."""
         p, W = int(req_cpu_milli.shape[0]), self.ev.W

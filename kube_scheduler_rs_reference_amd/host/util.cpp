@@ -6,6 +6,8 @@
 #include "encoder.hpp"
 #include "sharded.hpp"
 
+extern "C" __attribute__((weak)) int ksched_test_hooks_enabled(void);  // defined by the TEST build of libksched_hip.so only (tests/cpp/test_hooks.cpp)
+
 namespace ksched_host {
 
 std::vector<corev1::Pod> StaticPodLister::list_pods_on_node(const std::string &node_name) {
@@ -50,10 +52,10 @@ void Context::refresh_snapshot() {
         std::vector<int> devs_env = devices.empty() ? devices_from_env(std::getenv("KSCHED_DEVICES"), device) : devices;
         const char *force = std::getenv("KSCHED_SHARDED");
         const bool sharded = force && *force && *force != '0';
-        // test hook (with $KSCHED_TEST_HOOKS=1 only; the exchange then needs the stand-in of $KSCHED_RCCL_LIB): KSCHED_SHARDED=k, k >= 2,
-        // with ONE device = k evaluators on that device, so that a one-GPU box runs the mirror through a k-way row shard
-        const char *hooks = std::getenv("KSCHED_TEST_HOOKS");
-        if (sharded && hooks && std::string(hooks) == "1" && devs_env.size() == 1) {
+        // test hook (only when the evaluator library underneath is its TEST build -- it alone defines ksched_test_hooks_enabled -- and
+        // $KSCHED_TEST_HOOKS=1; the exchange then needs the stand-in of $KSCHED_RCCL_LIB): KSCHED_SHARDED=k, k >= 2, with ONE device =
+        // k evaluators on that device, so that a one-GPU box runs the mirror through a k-way row shard
+        if (sharded && ksched_test_hooks_enabled != nullptr && ksched_test_hooks_enabled() && devs_env.size() == 1) {
             const long k = std::strtol(force, nullptr, 10);
             if (k >= 2 && k <= 64) devs_env.assign((size_t)k, devs_env[0]);
         }

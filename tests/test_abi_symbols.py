@@ -110,3 +110,25 @@ def test_product_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oracle.h" not in src and "liboracle" not in src, f
+
+
+def test_the_shipped_library_carries_no_test_hooks(built):
+    """The hooks the tests use (an RCCL stand-in named by $KSCHED_RCCL_LIB, fault injection, k replicas of one device) live in tests/cpp/test_hooks.cpp,
+    which is linked into tests/cpp/hooks/libksched_hip.so ONLY: the shipped library neither defines the hook functions nor contains the variable's
+    name, so no environment can redirect it."""
+    import subprocess
+    shipped = os.path.join(ROOT, "kube_scheduler_rs_reference_amd", "libksched_hip.so")
+    test_build = os.path.join(ROOT, "tests", "cpp", "hooks", "libksched_hip.so")
+    assert os.path.exists(shipped) and os.path.exists(test_build)
+
+    def defined(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    ds, dt = defined(shipped), defined(test_build)
+    hooks = {"ksched_test_hooks_enabled", "ksched_test_hooks_linked", "ksched_test_rccl_lib"}
+    assert not (hooks & ds), hooks & ds
+    assert hooks <= dt
+    assert {s_ for s_ in ds if s_.startswith("ksched_")} == {s_ for s_ in dt if s_.startswith("ksched_")} - hooks  # otherwise the same library
+    text = open(shipped, "rb").read()
+    assert b"KSCHED_RCCL_LIB" not in text and b"KSCHED_TEST_HOOKS" not in text
+    assert b"KSCHED_RCCL_LIB" in open(test_build, "rb").read()

@@ -142,6 +142,7 @@ def test_multi_gpu_path_in_a_one_rank_group(built):
 
 
 FAKE_RCCL = os.path.join(ROOT, "tests", "cpp", "libfake_rccl.so")
+TEST_LIB = os.path.join(ROOT, "tests", "cpp", "hooks", "libksched_hip.so")  # the test build of the evaluator library: the only one with the hooks (tests/cpp/test_hooks.cpp)
 
 
 def test_two_ranks_on_one_gpu_run_the_n_greater_one_code_end_to_end(built):
@@ -152,7 +153,7 @@ def test_two_ranks_on_one_gpu_run_the_n_greater_one_code_end_to_end(built):
     not a scaling figure and the line says so."""
     assert os.path.exists(FAKE_RCCL), "make host"
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(KSCHED_TEST_HOOKS="1", KSCHED_RCCL_LIB=FAKE_RCCL, KSCHED_BENCH_ONE_GPU="1")
+    env.update(KSCHED_TEST_HOOKS="1", KSCHED_LIB=TEST_LIB, KSCHED_RCCL_LIB=FAKE_RCCL, KSCHED_BENCH_ONE_GPU="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--ramp-ms", "5", "--kernel-samples", "8",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -185,7 +186,7 @@ def test_a_rank_whose_gathered_table_differs_fails_the_bench(built):
     wrong word in rank 0's part of the table, both ranks' own rows are still right -- the per-shard sums compared across ranks are what notices, and the
     run exits non-zero."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(KSCHED_TEST_HOOKS="1", KSCHED_RCCL_LIB=FAKE_RCCL, KSCHED_BENCH_ONE_GPU="1", FAKE_RCCL_CORRUPT_RANK="1")
+    env.update(KSCHED_TEST_HOOKS="1", KSCHED_LIB=TEST_LIB, KSCHED_RCCL_LIB=FAKE_RCCL, KSCHED_BENCH_ONE_GPU="1", FAKE_RCCL_CORRUPT_RANK="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--ramp-ms", "5", "--kernel-samples", "8",
                         "--no-cpu-baseline", "--no-strong-leg", "--repeats", "0"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode != 0, "a table that differs between the ranks must fail the run"

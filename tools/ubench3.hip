@@ -30,6 +30,8 @@ __device__ __forceinline__ void st16(uint64_t *p, u32x4 f) {
     if (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(f) : "memory");
     else if (POL == 2) __builtin_nontemporal_store(f, reinterpret_cast<u32x4_a8 *>(p));
     else if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(f) : "memory");
+    else if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(f) : "memory");  // the shipped policy (round 5)
+    else if (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(f) : "memory");
     else *reinterpret_cast<u32x4_a8 *>(p) = f;
 }
 
@@ -38,7 +40,8 @@ struct Args {
 };
 
 // TW words per (pod, tile) segment; LPR = TW / 2 lanes per pod row; a wave instruction writes 64 / LPR pod rows
-template <int TW, int POL>
+// ORD: 0 = every wave owns a contiguous pod range (rounds 1 - 5), 1 = the launch's rounds of 64 pods dealt over its chunks * 16 waves, wave-major (round 6's default)
+template <int TW, int POL, int ORD = 0>
 __global__ __launch_bounds__(1024) void st_tiles(uint64_t *__restrict__ out, const Args a) {
     extern __shared__ uint8_t smem[];
     const uint32_t b = blockIdx.x;
@@ -56,9 +59,17 @@ __global__ __launch_bounds__(1024) void st_tiles(uint64_t *__restrict__ out, con
     const uint32_t c_lo = chunk * a.unit_q + min(chunk, a.unit_rem);
     const uint32_t c_n = a.unit_q + (chunk < a.unit_rem ? 1u : 0u);
     const uint32_t u_lo = c_lo + (wave * c_n) / 16u, u_hi = c_lo + ((wave + 1u) * c_n) / 16u;
-    for (uint32_t pod0 = u_lo * 8u; pod0 < u_hi * 8u; pod0 += RPI) {
-        const uint32_t pod = pod0 + sub;
-        if (pod < a.P && w0 < a.pitch) st16<POL>(out + (size_t)pod * a.pitch + w0, u32x4{pod, lane, w0, 7u});
+    if (ORD == 0) {
+        for (uint32_t pod0 = u_lo * 8u; pod0 < u_hi * 8u; pod0 += RPI) {
+            const uint32_t pod = pod0 + sub;
+            if (pod < a.P && w0 < a.pitch) st16<POL>(out + (size_t)pod * a.pitch + w0, u32x4{pod, lane, w0, 7u});
+        }
+    } else {
+        for (uint32_t r = wave * a.chunks + chunk; r * 64u < a.P; r += a.chunks * 16u)
+            for (uint32_t pod0 = r * 64u; pod0 < r * 64u + 64u; pod0 += RPI) {
+                const uint32_t pod = pod0 + sub;
+                if (pod < a.P && w0 < a.pitch) st16<POL>(out + (size_t)pod * a.pitch + w0, u32x4{pod, lane, w0, 7u});
+            }
     }
 }
 
@@ -90,7 +101,7 @@ float time_us(L launch, int reps = 24) {
     return tot * 1000.f / reps;
 }
 
-template <int TW, int POL>
+template <int TW, int POL, int ORD = 0>
 void run_tiles(const char *name, uint64_t *out, uint32_t P, uint32_t W) {
     Args a{};
     a.P = P;
@@ -103,7 +114,7 @@ void run_tiles(const char *name, uint64_t *out, uint32_t P, uint32_t W) {
     a.unit_rem = a.units % a.chunks;
     const uint32_t total = a.chunks * a.tiles;
     a.run = (total + 7u) / 8u;
-    auto kern = st_tiles<TW, POL>;
+    auto kern = st_tiles<TW, POL, ORD>;
     const uint32_t lds = 100 * 1024;
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const float us = time_us([&](hipEvent_t s, hipEvent_t e) {
@@ -112,7 +123,7 @@ void run_tiles(const char *name, uint64_t *out, uint32_t P, uint32_t W) {
         else hipLaunchKernelGGL(kern, dim3(a.run * 8u), dim3(1024), lds, 0, o, a);
     });
     const double bytes = (double)P * W * 8;
-    printf("  %-34s %7.2f us  %7.1f GB/s  (blocks %u = %u chunks x %u tiles)\n", name, us, bytes / us * 1e-3, total, a.chunks, a.tiles);
+    printf("  %-40s %7.2f us  %7.1f GB/s  (blocks %u = %u chunks x %u tiles)\n", name, us, bytes / us * 1e-3, total, a.chunks, a.tiles);
 }
 
 template <int POL>
@@ -124,7 +135,7 @@ void run_flat(const char *name, uint64_t *out, uint32_t P, uint32_t W) {
         if (s) hipExtLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, s, e, 0, o, words);
         else hipLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, o, words);
     });
-    printf("  %-34s %7.2f us  %7.1f GB/s  (pitched bytes %.1f MB)\n", name, us, (double)P * W * 8 / us * 1e-3, words * 8e-6);
+    printf("  %-40s %7.2f us  %7.1f GB/s  (pitched bytes %.1f MB)\n", name, us, (double)P * W * 8 / us * 1e-3, words * 8e-6);
 }
 
 int main() {
@@ -149,6 +160,16 @@ int main() {
         run_tiles<16, 1>("tile 16 words sc1", out, P, W);
         run_tiles<16, 2>("tile 16 words nt", out, P, W);
         run_tiles<16, 3>("tile 16 words sc0 sc1", out, P, W);
+        // round 6: the shipped policy `sc0 sc1 nt` and `sc1 nt` for both segment sizes, and the interleaved round order
+        run_tiles<8, 4>("tile 8 words (64 B) sc0 sc1 nt", out, P, W);
+        run_tiles<8, 5>("tile 8 words (64 B) sc1 nt", out, P, W);
+        run_tiles<16, 4>("tile 16 words sc0 sc1 nt", out, P, W);
+        run_tiles<16, 5>("tile 16 words sc1 nt", out, P, W);
+        run_tiles<8, 4, 1>("tile 8 w (64 B) sc0 sc1 nt, interleaved", out, P, W);
+        run_tiles<16, 4, 1>("tile 16 w sc0 sc1 nt, interleaved", out, P, W);
+        run_tiles<16, 1, 1>("tile 16 w sc1, interleaved", out, P, W);
+        run_tiles<16, 0, 1>("tile 16 w plain, interleaved", out, P, W);
+        run_tiles<32, 4, 1>("tile 32 w sc0 sc1 nt, interleaved", out, P, W);
         run_tiles<32, 0>("tile 32 words plain", out, P, W);
         run_tiles<32, 1>("tile 32 words sc1", out, P, W);
         run_tiles<64, 0>("tile 64 words plain", out, P, W);
