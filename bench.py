@@ -1055,6 +1055,9 @@ def main():
                                          "changed with N would corrupt -- BASELINE.json's 8-GPU configuration, configs[3] = 1M pods x 10k nodes split N ways, is measured in the same "
                                          "run as config.configs3_strong" if world > 1 else None),
                        "grid_cus": (256 - args.reserve_cus) if args.reserve_cus else 256, "round_order": args.round_order,
+                       "mask_allocation": (None if args.no_mask else ("packed torch tensors" if args.packed else
+                                           "ksched_mask_alloc(KSCHED_MASK_ALLOC_AUTO): probe-and-keep for masks >= 128 MiB (config.other_workloads' C4s / C5s), plain hipMalloc below (this workload's "
+                                           f"{loop.mask_bytes / 2**20:.0f} MiB masks)" if loop.mask_bytes < (128 << 20) else "ksched_mask_alloc(KSCHED_MASK_ALLOC_AUTO): probe-and-keep (masks >= 128 MiB)")),
                        **({"one_gpu_stand_in": "TEST HOOK: the %d ranks share ONE GPU and gather through the RCCL stand-in; a check of the N > 1 code, not a scaling figure" % world}
                           if one_gpu else {}),
                        "predicates": "+".join(flag_names), "pick": pick, "mask_written": not args.no_mask,

@@ -34,6 +34,10 @@ cp("pytest_gpu.log", "pytest_gpu.log")
 cp("smoke.log", "smoke.log")
 cp("host_costs.txt", "host_costs_snapshot_calls.txt")
 cp("fuzz.txt", "fuzz.txt")
+cp("host_loop_C3.txt", "host_loop_C3_size_batch.txt")
+cp("host_loop_small.txt", "host_loop_5k_and_20k_pods.txt")
+cp("spread.json", "C3_spread_over_fresh_processes.json")
+cp("box.txt", "box.txt")
 cp("stream_probe.txt", "stream_probe.txt")
 if os.path.exists(os.path.join(src, "pmc_traffic.json")):
     shutil.copy(os.path.join(src, "pmc_traffic.json"), os.path.join(dst, "pmc_traffic.json"))  # what bench.py reports as roofline.traffic

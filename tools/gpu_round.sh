@@ -149,6 +149,34 @@ if has host; then
   stamp "host-side cost of the snapshot calls"
   timeout 300 python tools/host_costs.py > $OUT/host_costs.txt 2>&1; cat $OUT/host_costs.txt
 fi
+if has hostloop; then
+  stamp "objects -> reconcile_batch through the C++ host mirror (C3-size batch and the round-3 sizes), phases of the last repeat"
+  KSCHED_HOST_TIMING=2 timeout 600 python tools/host_loop.py --sizes 100000x5000 --modes batch --reps 5 > $OUT/host_loop_C3.txt 2>&1; cat $OUT/host_loop_C3.txt | cut -c1-260
+  timeout 600 python tools/host_loop.py --sizes 5000x500,20000x2000 --reps 3 > $OUT/host_loop_small.txt 2>&1; grep -v "phase\|reconcile_batch" $OUT/host_loop_small.txt | cut -c1-260
+fi
+if has spread; then
+  stamp "the default line in ${SPREAD_N:-5} fresh processes (VERDICT r5 item 1: C3 per-step spread)"
+  for i in $(seq 1 ${SPREAD_N:-5}); do
+    timeout 600 python bench.py --no-cpu-baseline --live-traffic off --no-others --repeats 1 2>/dev/null | tail -1 > $OUT/spread_$i.json
+  done
+  python - <<PY
+import json
+v = [json.load(open("$OUT/spread_%d.json" % i)) for i in range(1, ${SPREAD_N:-5} + 1)]
+st = [d["ms_per_step"] * 1e3 for d in v]; ke = [d["roofline"]["avg_kernel_us"] for d in v]
+print("C3 step us in fresh processes: " + " ".join("%.2f" % x for x in st) + "  -> spread (max - min) / min = %.1f %%" % ((max(st) - min(st)) / min(st) * 100))
+print("C3 mask kernel us:             " + " ".join("%.2f" % x for x in ke) + "  -> spread %.1f %%" % ((max(ke) - min(ke)) / min(ke) * 100))
+json.dump({"step_us": st, "kernel_us": ke, "step_spread_frac": (max(st) - min(st)) / min(st), "kernel_spread_frac": (max(ke) - min(ke)) / min(ke)}, open("$OUT/spread.json", "w"))
+PY
+  for i in 1 2 3; do timeout 600 python bench.py --workload C5s --no-cpu-baseline --live-traffic off --steps 300 --repeats 1 2>/dev/null | tail -1 > $OUT/spread_C5s_$i.json; done
+  python - <<PY
+import json
+v = [json.load(open("$OUT/spread_C5s_%d.json" % i)) for i in (1, 2, 3)]
+print("C5 shard in 3 fresh processes (masks from ksched_mask_alloc: probe-and-keep): mask kernel us " + " ".join("%.1f" % d["roofline"]["avg_kernel_us"] for d in v) + " | step us " + " ".join("%.1f" % (d["ms_per_step"] * 1e3) for d in v))
+PY
+fi
+if has box; then
+  bash tools/box_fingerprint.sh > $OUT/box.txt 2>&1; grep -i "unique\|nproc" $OUT/box.txt
+fi
 if has fuzz; then
   stamp "randomised differential parity against the oracle (${FUZZ_S:-60} s, seed ${FUZZ_SEED:-20260923})"
   timeout $(( ${FUZZ_S:-60} + 60 )) python tools/fuzz_parity.py ${FUZZ_S:-60} ${FUZZ_SEED:-20260923} > $OUT/fuzz.txt 2>&1; tail -3 $OUT/fuzz.txt
