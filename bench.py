@@ -66,7 +66,7 @@ WORKLOADS = {
     "C5s": ("C5", 125_000, 50_000, ("FIT", "SEL", "TAINT"), "bestfit",
             "C5 shard: 125k pods x 50k nodes per GPU, fit + sel + taints, best-fit pick (configs[4] = 8 shards)"),
     "C3x4": ("C3", 400_000, 5_000, ("FIT", "SEL"), "sampled",
-             "four C3 batches a caller has queued, passed as ONE call (400k pods x 5k nodes): the tile index is staged once per block for all of them, but the pick no longer hides in the fill and runs as its own launch"),
+             "four C3 batches a caller has queued, passed as ONE call (400k pods x 5k nodes): the tile index is staged once per block for all of them; the tile-test pick rides in the launch (up to 524 288 pods per call)"),
 }
 
 

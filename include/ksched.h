@@ -308,20 +308,19 @@ uint32_t ksched_mask_pitch(uint32_t n_nodes);
  * ksched_mask_free waits for the device before it unmaps; ksched_destroy frees what the caller left. */
 #define KSCHED_MASK_ALLOC_AUTO 0u
 #define KSCHED_MASK_ALLOC_PLAIN 1u      /* hipMalloc */
-#define KSCHED_MASK_ALLOC_VMM 2u        /* hipMemCreate in one piece at the recommended granularity, VA aligned to 2 MiB */
-#define KSCHED_MASK_ALLOC_VMM_1G 3u     /* the same, VA aligned to 1 GiB */
-#define KSCHED_MASK_ALLOC_VMM_MIN 4u    /* the same at the minimum granularity, default VA alignment */
-#define KSCHED_MASK_ALLOC_CONTIGUOUS 5u /* hipExtMallocWithFlags(hipDeviceMallocContiguous) */
-#define KSCHED_MASK_ALLOC_UNCACHED 6u   /* hipExtMallocWithFlags(hipDeviceMallocUncached) */
-#define KSCHED_MASK_ALLOC_POOL 7u       /* hipMallocFromPoolAsync, a pool that never releases */
+#define KSCHED_MASK_ALLOC_PROBE 11u     /* probe-and-keep: KSCHED_OPT_MASK_PROBE hipMalloc candidates alive at once; the fused mask kernel is timed into each
+                                         * (fit only, zero requests, the current snapshot); the fastest is kept, the others are freed */
+/* Measurement paths (tools/alloc_probe.py re-measures the choice with them; none selects the fast placement, profiles/r06_mask_alloc.md).  They go
+ * through HIP's virtual-memory API, which on ROCm 7.0 showed STALE READS on a mapping's first use right after memory-pool activity in the same
+ * process (same file, section 3): not for production masks -- AUTO and PROBE never use them. */
+#define KSCHED_MASK_ALLOC_VMM 2u        /* hipMemCreate in one piece at the recommended granularity + hipMemAddressReserve + hipMemMap */
+#define KSCHED_MASK_ALLOC_VMM_MIN 4u    /* the same at the minimum granularity */
+#define KSCHED_MASK_ALLOC_CONTIGUOUS 5u /* hipExtMallocWithFlags(hipDeviceMallocContiguous): one physical range */
 #define KSCHED_MASK_ALLOC_SCATTER_2M 8u  /* physical pieces of 2 MiB created one by one (a quarter more than needed), shuffled, mapped at consecutive addresses */
 #define KSCHED_MASK_ALLOC_SCATTER_16M 9u /* the same with pieces of 16 MiB */
-#define KSCHED_MASK_ALLOC_SCATTER_64K 10u /* the same with pieces of 64 KiB (large masks: tens of thousands of mappings) */
-#define KSCHED_MASK_ALLOC_PROBE 11u /* probe-and-keep: KSCHED_OPT_MASK_PROBE candidates over several of the paths above, all alive at once; the fused
-                                     * mask kernel is timed into each (fit only, zero requests, the current snapshot); the fastest is kept */
-#define KSCHED_MASK_ALLOC_LAST 11u
+#define KSCHED_MASK_ALLOC_LAST 11u      /* (3, 6, 7, 10 -- 1 GiB-aligned VMM, uncached, a memory pool, 64 KiB pieces -- were measured in round 6 and removed) */
 /* AUTO = PROBE for masks of at least KSCHED_MASK_PROBE_MIN_BYTES when the snapshot has its bitmap index, PLAIN otherwise: no allocation path selects
- * the fast placement (profiles/r06_mask_alloc.md), and below that size a buffer's own rate does not stand out of the run-to-run noise */
+ * the fast placement, and below that size a buffer's own rate does not stand out of the run-to-run noise */
 #define KSCHED_MASK_PROBE_MIN_BYTES 0x8000000u /* 128 MiB */
 int ksched_mask_alloc(ksched_ctx *ctx, uint32_t p, uint32_t how, uint64_t **out_mask, uint32_t *out_pitch_words);
 int ksched_mask_free(ksched_ctx *ctx, uint64_t *mask);

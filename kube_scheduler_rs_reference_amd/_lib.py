@@ -64,16 +64,13 @@ KERNEL_FUSED = 3
 MASK_ALLOC_AUTO = 0
 MASK_ALLOC_PLAIN = 1
 MASK_ALLOC_VMM = 2
-MASK_ALLOC_VMM_1G = 3
 MASK_ALLOC_VMM_MIN = 4
 MASK_ALLOC_CONTIGUOUS = 5
-MASK_ALLOC_UNCACHED = 6
-MASK_ALLOC_POOL = 7
 MASK_ALLOC_SCATTER_2M = 8
 MASK_ALLOC_SCATTER_16M = 9
-MASK_ALLOC_SCATTER_64K = 10
 MASK_ALLOC_PROBE = 11
 MASK_ALLOC_LAST = 11
+MASK_ALLOC_NAMES = {0: "auto", 1: "plain", 2: "vmm", 4: "vmm-min", 5: "contiguous", 8: "scatter-2m", 9: "scatter-16m", 11: "probe"}
 MASK_PROBE_MIN_BYTES = 128 << 20
 MASK_ALLOC_NAMES = {0: "auto", 1: "plain", 2: "vmm", 3: "vmm-1g", 4: "vmm-min", 5: "contiguous", 6: "uncached", 7: "pool", 8: "scatter-2m", 9: "scatter-16m", 10: "scatter-64k", 11: "probe"}
 

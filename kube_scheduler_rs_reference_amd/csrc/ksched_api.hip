@@ -807,15 +807,27 @@ int eval_on_device(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int64_t
     // a step is one kernel); otherwise it is its own launch, first (nothing waits on a mask kernel), and a bindings-only
     // request launches no mask kernel at all.  KSCHED_OPT_PICK_FROM_MASK restores the mask-reading pick (a cross-check).
     const bool select_direct = pick_s && !c->opt_pick_from_mask;
-    // A riding pick is nearly free while a launch is short -- its work hides in the fill, where nothing can store yet -- and costs twice
-    // the stand-alone kernel once a launch is bound by its rounds (400 k pods x 5 k nodes: +6.5 us per 100 k pods riding, +3.4 us as its
-    // own launch; the returning atomics queue behind the store stream, the tests share the LDS with phase 2): in the default mode it
-    // rides when a wave has at most five rounds (C3: 2, the C4 shard: 5).
+    // Does a riding pick pay?  Two forms (kernels_fused.hpp PICK): TILE TESTS -- every tile-block of a pod range tests the draws that fall into
+    // its tile from the rows it holds -- and WAVES OF THE FILL, which run select_one_pod while the tile is staged.
+    //  * Waves of the fill only hide in the fill: they ride when a wave has at most five rounds (C3: 2, the C4 shard: 5; beyond that they cost
+    //    twice the stand-alone kernel, round 3's measurement, re-measured in round 6: 400 k x 5 k 67.1 us riding against 66.1).
+    //  * Tile tests re-read a pod's operands and draws once per tile; the tile-blocks of a pod range sit on one XCD, so tiles - 1 of those reads
+    //    come from that XCD's L2 -- as long as the XCD's share of the batch's operands and draws (68 B per pod / 8 XCDs) stays in its 4 MiB.
+    //    Round 6 (session r7a, interleaved round order, step us riding / own launch): 100 k x 5 k  17.6 / 22.6;  400 k x 5 k  53.4 / 65.9;
+    //    250 k x 10 k  64.8 / 75.0;  500 k x 10 k  123.3 / 142.8;  but 800 k x 5 k  143.4 / 125.3, 1 M x 10 k  322.0 / 288.6, 1.6 M x 5 k  281.8 / 241.6.
+    //    (Rounds 3 - 5 had the tile tests stop riding at five rounds per wave too: with every wave on its own contiguous pod range the blocks of
+    //    a pod range drifted apart much earlier.)  They ride up to 524 288 pods per call.
+    const bool tile_form = c->opt_fused_pick == 3 || (c->opt_fused_pick == 1 && can_fused && c->idx.lay.tiles >= 2u && c->idx.lay.tiles <= 12u &&
+                                                      fused_tile_pick_applicable(c->idx, flags, attempts, psel != nullptr));
     bool ride_pays = true;
     if (c->opt_fused_pick == 1 && can_fused) {
-        const uint32_t tiles = std::max(1u, c->idx.lay.tiles), cus = c->opt_grid_cus ? c->opt_grid_cus : 256u;
-        const uint32_t chunks = std::max(1u, std::min(cus / tiles, (p + 255u) / 256u));
-        ride_pays = (uint64_t)p <= (uint64_t)chunks * 5u * 64u * kFusedWaves;
+        if (tile_form) {
+            ride_pays = p <= (1u << 19);
+        } else {
+            const uint32_t tiles = std::max(1u, c->idx.lay.tiles), cus = c->opt_grid_cus ? c->opt_grid_cus : 256u;
+            const uint32_t chunks = std::max(1u, std::min(cus / tiles, (p + 255u) / 256u));
+            ride_pays = (uint64_t)p <= (uint64_t)chunks * 5u * 64u * kFusedWaves;
+        }
     }
     const bool pick_rides = select_direct && want_mask && c->opt_fused_pick && kern == KSCHED_KERNEL_FUSED && can_fused && ride_pays &&
                             fused_pick_applicable(c->idx, flags, (flags & KSCHED_WANT_FIT_MASK) && out_fit, p);
@@ -1799,37 +1811,10 @@ hipError_t mask_alloc_path(ksched_ctx *c, size_t bytes, uint32_t how, MaskAlloca
     switch (how) {
         case KSCHED_MASK_ALLOC_PLAIN: return hipMalloc(&a.ptr, bytes);
         case KSCHED_MASK_ALLOC_VMM: return mask_alloc_vmm(c->device, bytes, 2u << 20, true, &a);
-        case KSCHED_MASK_ALLOC_VMM_1G: return mask_alloc_vmm(c->device, bytes, 1u << 30, true, &a);
         case KSCHED_MASK_ALLOC_VMM_MIN: return mask_alloc_vmm(c->device, bytes, 0, false, &a);
         case KSCHED_MASK_ALLOC_SCATTER_2M: return mask_alloc_scattered(c->device, bytes, 2u << 20, 25, &a);
         case KSCHED_MASK_ALLOC_SCATTER_16M: return mask_alloc_scattered(c->device, bytes, 16u << 20, 25, &a);
-        case KSCHED_MASK_ALLOC_SCATTER_64K: return mask_alloc_scattered(c->device, bytes, 64u << 10, 25, &a);
         case KSCHED_MASK_ALLOC_CONTIGUOUS: return hipExtMallocWithFlags(&a.ptr, bytes, hipDeviceMallocContiguous);
-        case KSCHED_MASK_ALLOC_UNCACHED: return hipExtMallocWithFlags(&a.ptr, bytes, hipDeviceMallocUncached);
-        case KSCHED_MASK_ALLOC_POOL: {
-            MaskRegistry &reg = mask_registry();
-            std::lock_guard<std::mutex> rl(reg.mu);
-            hipMemPool_t pool = nullptr;
-            for (auto &pp : reg.pools)
-                if (pp.first == c->device) pool = pp.second;
-            hipError_t e = hipSuccess;
-            if (!pool) {
-                hipMemPoolProps props{};
-                props.allocType = hipMemAllocationTypePinned;
-                props.location.type = hipMemLocationTypeDevice;
-                props.location.id = c->device;
-                e = hipMemPoolCreate(&pool, &props);
-                if (e != hipSuccess) return e;
-                uint64_t never = ~0ull;
-                e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &never);
-                reg.pools.emplace_back(c->device, pool);
-                if (e != hipSuccess) return e;
-            }
-            e = hipMallocFromPoolAsync(&a.ptr, bytes, pool, nullptr);
-            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-            a.pooled = true;
-            return e;
-        }
         default: return hipErrorInvalidValue;
     }
 }
@@ -1840,7 +1825,9 @@ hipError_t mask_alloc_path(ksched_ctx *c, size_t bytes, uint32_t how, MaskAlloca
 // (a freed buffer's pages come straight back), the fused mask kernel timed into each (fit only, zero requests: every pair feasible
 // or not by the node's sign, the same 128-byte segments at the same addresses as any other instantiation), the fastest kept.
 int mask_alloc_probe(ksched_ctx *c, uint32_t p, uint32_t pitch, size_t bytes, MaskAllocation &best) {
-    static const uint32_t paths[] = {KSCHED_MASK_ALLOC_VMM_MIN, KSCHED_MASK_ALLOC_PLAIN, KSCHED_MASK_ALLOC_SCATTER_16M, KSCHED_MASK_ALLOC_VMM};
+    // (hipMalloc only: the virtual-memory paths gave the same ladder of rates and showed stale reads on a mapping's first use after memory-pool
+    // activity in the process -- profiles/r06_mask_alloc.md section 3; candidates kept alive side by side land on different physical blocks anyway)
+    static const uint32_t paths[] = {KSCHED_MASK_ALLOC_PLAIN, KSCHED_MASK_ALLOC_PLAIN, KSCHED_MASK_ALLOC_PLAIN, KSCHED_MASK_ALLOC_PLAIN};
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     const uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(c->opt_mask_probe, free_b / 4 / std::max<size_t>(bytes, 1)));
@@ -1920,7 +1907,11 @@ int mask_alloc_probe(ksched_ctx *c, uint32_t p, uint32_t pitch, size_t bytes, Ma
 int ksched_mask_alloc(ksched_ctx *c, uint32_t p, uint32_t how, uint64_t **out_mask, uint32_t *out_pitch_words) try {
     if (!c || !out_mask) return KSCHED_E_INVAL;
     *out_mask = nullptr;
-    if (how > KSCHED_MASK_ALLOC_LAST) return KSCHED_E_INVAL;
+    switch (how) {  // (3, 6, 7, 10: paths measured in round 6 and removed)
+        case KSCHED_MASK_ALLOC_AUTO: case KSCHED_MASK_ALLOC_PLAIN: case KSCHED_MASK_ALLOC_PROBE: case KSCHED_MASK_ALLOC_VMM: case KSCHED_MASK_ALLOC_VMM_MIN:
+        case KSCHED_MASK_ALLOC_CONTIGUOUS: case KSCHED_MASK_ALLOC_SCATTER_2M: case KSCHED_MASK_ALLOC_SCATTER_16M: break;
+        default: return KSCHED_E_INVAL;
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->have_nodes) {
         c->last_error = "ksched_mask_alloc before ksched_set_nodes: the row pitch follows the node count";

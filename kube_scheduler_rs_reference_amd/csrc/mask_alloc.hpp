@@ -27,7 +27,6 @@ struct MaskAllocation {
     bool vmm = false;
     std::vector<hipMemGenericAllocationHandle_t> pieces;  // the scattered form: one handle per piece, mapped at consecutive addresses
     size_t piece_bytes = 0;
-    bool pooled = false;                       // pool form (the device's pool below)
     const void *owner = nullptr;               // the ctx that allocated it (ksched_destroy frees what its caller left)
 };
 
@@ -35,7 +34,6 @@ struct MaskAllocation {
 struct MaskRegistry {
     std::mutex mu;
     std::vector<MaskAllocation> live;
-    std::vector<std::pair<int, hipMemPool_t>> pools;  // one per device, release threshold = never
 };
 inline MaskRegistry &mask_registry() {
     static MaskRegistry r;
@@ -180,10 +178,6 @@ inline hipError_t mask_release(MaskAllocation &a) {
         hipError_t e3 = hipMemRelease(a.handle);
         if (e == hipSuccess) e = e2;
         if (e == hipSuccess) e = e3;
-    } else if (a.pooled) {
-        e = hipFreeAsync(a.ptr, nullptr);
-        hipError_t e2 = hipStreamSynchronize(nullptr);
-        if (e == hipSuccess) e = e2;
     } else {
         e = hipFree(a.ptr);
     }

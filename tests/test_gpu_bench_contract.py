@@ -46,8 +46,8 @@ def test_default_line_contract(built):
     for wl in ("C4s", "C5s"):
         o = c["other_workloads"][wl]
         assert "error" not in o and o["value"] > 1e12 and 0.2 < o["mask_kernel_frac"] < 1.0 and o["pick_alone_us_per_step"] > 0, wl
-    q = c["other_workloads"]["C3x4"]  # four queued batches passed as one call (the mask kernel's fill is paid once, the pick no longer hides in it)
-    assert "error" not in q and q["us_per_100k_pods"] > 0 and q["pick_in_mask_launch"] is False, q
+    q = c["other_workloads"]["C3x4"]  # four queued batches passed as one call (the mask kernel's fill is paid once; round 6: the tile-test pick rides here too)
+    assert "error" not in q and q["us_per_100k_pods"] > 0 and q["pick_in_mask_launch"] is True, q
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_kernel_us"] * 1e-6) / 1e9) < 1e-3 * r["achieved"]
     assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-9 and r["frac"] >= 0.38, "north_star: >= 40 % of the HBM roofline (0.40-0.42 measured with rotated outputs; 5 % slack for the box)"
     assert r["min_kernel_us"] <= r["median_kernel_us"] <= r["max_kernel_us"]

@@ -167,13 +167,13 @@ def test_riding_pick_on_device_buffers_repeated_steps(evaluator):
     ev.forget_stream(s2)
 
 
-def test_a_long_launch_keeps_its_pick_separate_by_default(evaluator):
-    """The pick rides while a launch is short (its work hides in the fill); once a wave has more than five rounds the default is the
-    stand-alone kernel again (the returning atomics and the tests cost a round-bound launch twice what the separate launch costs).  Both
-    forms, and the forced tile form at this size, == oracle."""
+def test_how_long_a_launch_keeps_its_pick(evaluator):
+    """The tile-test pick rides in the mask launch up to 524 288 pods per call (as long as an XCD's share of the batch's operands and draws stays in its
+    L2, the tile-blocks of a pod range re-read them from there: session r7a, 400k x 5k 53.4 us riding against 65.9 us with the pick as its own launch,
+    800k x 5k 143.4 against 125.3); beyond that the default is the stand-alone kernel.  Every form at both sizes == oracle."""
     import torch
     ev = evaluator
-    c = synth.make_config("C3", P=280_000)  # 5 tiles -> 51 chunks x 5 120 pods = 261 120: one step beyond
+    c = synth.make_config("C3", P=540_000)  # one step beyond the limit
     ev.set_nodes(**c.node_columns())
     dev = torch.device("cuda", 0)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
@@ -190,11 +190,12 @@ def test_a_long_launch_keeps_its_pick_separate_by_default(evaluator):
             assert ev.last_pick == want, (mode, ev.last_pick)
             assert np.array_equal(out.cpu().numpy(), bind), mode
         ev.set_option(_lib.OPT_FUSED_PICK, 1)
-        small = 250_000  # (inside the limit: rides)
-        ev.eval_device(d_cpu[:small].contiguous(), d_mem[:small].contiguous(), d_sel[:, :small].contiguous(), None, d_smp[:small].contiguous(),
-                       FIT | SEL | PICK_SAMPLED, out_feasible=ev.alloc_mask(small, pitched=True), out_binding=out[:small])
-        torch.cuda.synchronize()
-        assert ev.last_pick == "fused-tile" and np.array_equal(out[:small].cpu().numpy(), bind[:small])
+        for small in (524_288, 400_000):  # (inside the limit: rides)
+            out.fill_(-7)
+            ev.eval_device(d_cpu[:small].contiguous(), d_mem[:small].contiguous(), d_sel[:, :small].contiguous(), None, d_smp[:small].contiguous(),
+                           FIT | SEL | PICK_SAMPLED, out_feasible=ev.alloc_mask(small, pitched=True), out_binding=out[:small])
+            torch.cuda.synchronize()
+            assert ev.last_pick == "fused-tile" and np.array_equal(out[:small].cpu().numpy(), bind[:small]), small
     finally:
         ev.set_option(_lib.OPT_FUSED_PICK, 1)
 

@@ -26,12 +26,11 @@ def _oracle(c, pc, flags):
     return capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, None, pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], None, pc["samples"], flags)
 
 
-PATHS = [_lib.MASK_ALLOC_AUTO, _lib.MASK_ALLOC_PLAIN, _lib.MASK_ALLOC_VMM, _lib.MASK_ALLOC_VMM_1G, _lib.MASK_ALLOC_VMM_MIN, _lib.MASK_ALLOC_CONTIGUOUS,
-         _lib.MASK_ALLOC_POOL, _lib.MASK_ALLOC_SCATTER_2M, _lib.MASK_ALLOC_SCATTER_16M, _lib.MASK_ALLOC_PROBE]
+PRODUCT_PATHS = [_lib.MASK_ALLOC_AUTO, _lib.MASK_ALLOC_PLAIN, _lib.MASK_ALLOC_PROBE]
+MEASUREMENT_PATHS = [_lib.MASK_ALLOC_VMM, _lib.MASK_ALLOC_VMM_MIN, _lib.MASK_ALLOC_CONTIGUOUS, _lib.MASK_ALLOC_SCATTER_2M, _lib.MASK_ALLOC_SCATTER_16M]
 
 
-@pytest.mark.parametrize("how", PATHS, ids=lambda h: _lib.MASK_ALLOC_NAMES[h])
-def test_every_allocation_path_holds_the_same_mask(built, how):
+def _same_mask_through(how):
     import torch
     c, pc = _case()
     flags = FIT | SEL | PICK_SAMPLED
@@ -58,6 +57,27 @@ def test_every_allocation_path_holds_the_same_mask(built, how):
         elif how != _lib.MASK_ALLOC_AUTO:
             assert rep.size == 0
         del mask  # (ksched_mask_free through the tensor's owner; the evaluator is still open)
+
+
+@pytest.mark.parametrize("how", PRODUCT_PATHS, ids=lambda h: _lib.MASK_ALLOC_NAMES[h])
+def test_the_product_paths_hold_the_same_mask(built, how):
+    """AUTO, PLAIN and PROBE (hipMalloc underneath, all three): what every mask of the GPU suite and of bench.py comes from."""
+    _same_mask_through(how)
+
+
+@pytest.mark.parametrize("how", MEASUREMENT_PATHS, ids=lambda h: _lib.MASK_ALLOC_NAMES[h])
+def test_a_measurement_path_holds_the_same_mask_in_a_process_of_its_own(built, how):
+    """The paths tools/alloc_probe.py measures (HIP's virtual-memory API, one contiguous physical range, scattered pieces): same words, same
+    bindings -- each in a fresh process, because on ROCm 7.0 a virtual-memory mapping made right after a contiguous allocation was freed in the same
+    process returned STALE shader reads on its first use (the data in memory -- read back by the DMA engine -- was right; deterministic in one
+    allocation order, absent in others: profiles/r06_mask_alloc.md section 3).  That is why AUTO and PROBE keep to hipMalloc."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"import tests.test_gpu_mask_alloc as t; t._same_mask_through({how}); print('path ok')"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "path ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
 def test_the_probe_keeps_one_buffer_and_frees_the_rest(built):
@@ -103,6 +123,8 @@ def test_error_behaviour_of_the_two_entry_points(built):
         c, _ = _case(P=8, N=130)
         ev.set_nodes(**c.node_columns())
         assert lib.ksched_mask_alloc(ev._h, 10, _lib.MASK_ALLOC_LAST + 1, C.byref(ptr), C.byref(pitch)) == _lib.E_INVAL
+        for removed in (3, 6, 7, 10):  # paths measured in round 6 and removed (a memory pool among them: profiles/r06_mask_alloc.md section 3)
+            assert lib.ksched_mask_alloc(ev._h, 10, removed, C.byref(ptr), C.byref(pitch)) == _lib.E_INVAL and not ptr.value
         assert lib.ksched_mask_alloc(ev._h, 10, _lib.MASK_ALLOC_PLAIN, None, None) == _lib.E_INVAL
         assert lib.ksched_mask_alloc(None, 10, _lib.MASK_ALLOC_PLAIN, C.byref(ptr), None) == _lib.E_INVAL
         # p = 0 is a valid (empty) mask; the pitch pointer is optional

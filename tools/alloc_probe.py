@@ -2,7 +2,7 @@
 """Which allocation path gives the mask kernel its fast rate, and which hardware counter separates the two rates?
 (the finding it follows up: profiles/r05_bimodal_by_allocation.md.)
 
-    python tools/alloc_probe.py <workload=C5s> survey [k=4] [hows=1,2,3,4,5,7] [n=24]
+    python tools/alloc_probe.py <workload=C5s> survey [k=4] [hows=1,2,4,5,8,9,11] [n=24]
         k mask buffers (sets of R buffers where the workload rotates) per allocation path of ksched_mask_alloc, each timed with HIP events on the
         mask kernel; a fragmenting pattern of spacer allocations runs between the paths so that the plain path sees used memory.
     python tools/alloc_probe.py <workload> pmc [k=6] [hows=1,2] [n=16]
@@ -26,7 +26,7 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "survey"
 kw = dict(a.split("=", 1) for a in sys.argv[3:] if "=" in a)
 K = int(kw.get("k", 4))
 N = int(kw.get("n", 24))
-hows = [int(h) for h in kw.get("hows", "1,2,3,4,5,7").split(",")]
+hows = [int(h) for h in kw.get("hows", "1,2,4,5,8,9,11").split(",")]
 frag = int(kw.get("frag", 1))
 dev = torch.device("cuda:0")
 rig = bench.SingleRig(torch, L, synth, Evaluator, dev, name, debug=int(kw.get("debug", "0"), 0))
