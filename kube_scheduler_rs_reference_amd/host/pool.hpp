@@ -13,11 +13,14 @@
 #include <exception>
 #include <functional>
 #include <memory>
+#include <new>
 #include <type_traits>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 namespace ksched_host {
 
@@ -82,12 +85,19 @@ public:
             ++generation_;
         }
         cv_.notify_all();
-        for (auto &t : threads_) t.join();
+        if (pid_ == ::getpid())
+            for (auto &t : threads_) t.join();
+        else
+            new (&threads_) std::vector<std::thread>();  // (a forked child: nothing to join)
     }
 
 private:
     WorkerPool() = default;
     void ensure(uint32_t workers) {
+        if (pid_ != ::getpid()) {  // a forked child inherits the object but none of the threads: start over (the old handles are abandoned, never joined)
+            new (&threads_) std::vector<std::thread>();
+            pid_ = ::getpid();
+        }
         while (threads_.size() < workers) threads_.emplace_back([this] { loop(); });
     }
     void loop() {
@@ -127,6 +137,7 @@ private:
     uint32_t parts_ = 0, next_part_ = 0, pending_ = 0;
     uint64_t generation_ = 0;
     bool stop_ = false;
+    pid_t pid_ = ::getpid();
     static thread_local bool in_region_;
 };
 inline thread_local bool WorkerPool::in_region_ = false;
