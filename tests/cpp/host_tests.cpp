@@ -24,6 +24,7 @@
 #include "../../kube_scheduler_rs_reference_amd/host/sharded.hpp"
 #include <dlfcn.h>
 #include "../../kube_scheduler_rs_reference_amd/host/scheduler.hpp"
+#include "../../kube_scheduler_rs_reference_amd/host/pool.hpp"
 #include "../../kube_scheduler_rs_reference_amd/host/util.hpp"
 
 using namespace ksched_host;
@@ -445,6 +446,79 @@ static void cpu_tests() {
         const auto before = a.columns().avail_cpu_milli;
         CHECK_THROWS(a.observe_bound(again));
         CHECK(a.columns().avail_cpu_milli == before && a.counted_pods() == b.counted_pods());
+    });
+    run("snapshot builder: stage_bound + commit_staged == observe_bound (the two halves reconcile_batch runs beside and behind its POSTs)", [] {
+        std::vector<corev1::Node> nodes;
+        for (int i = 0; i < 40; ++i) nodes.push_back(node_with("n" + std::to_string(100 + i), "64", "256Gi"));
+        Snapshot a(Snapshot::kEncodeOnly), b(Snapshot::kEncodeOnly);
+        a.rebuild(nodes, nullptr);
+        b.rebuild(nodes, nullptr);
+        const size_t P = 5000;
+        std::vector<corev1::Pod> pods;
+        std::vector<std::string> names;
+        for (size_t i = 0; i < P; ++i) {
+            const std::string cpu = std::to_string(1 + i % 7) + "m", mem = std::to_string(1 + i % 5) + "Mi";
+            pods.push_back(pod_with("p" + std::to_string(i % 4900), {container(cpu.c_str(), mem.c_str())}, nullptr));  // (the last hundred repeat earlier keys: moves)
+            names.push_back("n" + std::to_string(100 + i % 40));
+        }
+        std::vector<const corev1::Pod *> pp;
+        for (const auto &p : pods) pp.push_back(&p);
+        const PodColumns pc = a.encode_pods(pp);  // the exact request sums, as the evaluation leaves them
+        std::vector<Snapshot::Bound> bound;
+        std::vector<std::pair<const corev1::Pod *, const std::string *>> by_name;
+        for (size_t i = 0; i < P; ++i) {
+            bound.push_back({&pods[i], (uint32_t)a.index_of(names[i]), pc.req_cpu_nanos[i], pc.req_mem_nanos[i]});
+            by_name.emplace_back(&pods[i], &names[i]);
+        }
+        const auto before_cpu = a.columns().avail_cpu_milli;
+        const uint64_t gen = a.generation();
+        auto staged = a.stage_bound(bound);
+        CHECK(a.columns().avail_cpu_milli == before_cpu && a.generation() == gen && a.counted_pods() == 0);  // staging changes nothing
+        const size_t ca = a.commit_staged(*staged), cb = b.observe_bound(by_name);
+        CHECK(ca == cb && ca == P);
+        CHECK(a.columns().avail_cpu_milli == b.columns().avail_cpu_milli && a.columns().avail_mem_bytes == b.columns().avail_mem_bytes);
+        CHECK(a.counted_pods() == b.counted_pods() && a.counted_pods() == 4900);
+        CHECK_THROWS(a.commit_staged(*staged));  // an update is committed once
+        // ... and the same events again leave `available` where it is: the 4 800 single bindings change nothing, the hundred keys bound twice
+        // move to their first node and back (two changes each)
+        CHECK(a.observe_bound(bound) == 200 && a.columns().avail_cpu_milli == b.columns().avail_cpu_milli && a.columns().avail_mem_bytes == b.columns().avail_mem_bytes);
+        // an update staged against a snapshot that has changed since is refused, and changes nothing
+        auto stale = a.stage_bound({{&pods[0], 3u, pc.req_cpu_nanos[0], pc.req_mem_nanos[0]}});
+        corev1::Pod late = pod_with("late", {container("5m", "1Mi")}, nullptr);
+        late.spec->node_name = "n101";
+        CHECK(a.observe_pod(Snapshot::PodEvent::Applied, late));
+        const auto cpu_now = a.columns().avail_cpu_milli;
+        CHECK_THROWS(a.commit_staged(*stale));
+        CHECK(a.columns().avail_cpu_milli == cpu_now);
+        // a node index outside the snapshot = "no node": the pod is not counted (and an earlier count of it is dropped)
+        CHECK(a.observe_bound(std::vector<Snapshot::Bound>{{&pods[1], 4000000u, pc.req_cpu_nanos[1], pc.req_mem_nanos[1]}}) == 1);
+        CHECK(a.counted_pods() == 4900);  // p1 out, "late" in
+    });
+    run("worker pool: parts cover the range once, the lowest part's exception comes back, a nested region runs on the calling thread", [] {
+        WorkerPool &pool = WorkerPool::instance();
+        std::vector<uint8_t> hit(100000, 0);
+        std::atomic<int> parts_seen{0};
+        pool.run(hit.size(), 7, [&](size_t lo, size_t hi, uint32_t) {
+            ++parts_seen;
+            for (size_t i = lo; i < hi; ++i) ++hit[i];
+        });
+        CHECK(parts_seen == 7 && std::count(hit.begin(), hit.end(), (uint8_t)1) == (long)hit.size());
+        bool threw = false;
+        try {
+            pool.run(1000, 5, [&](size_t, size_t, uint32_t part) {
+                if (part == 3 || part == 1) throw EncodeError("part " + std::to_string(part));
+            });
+        } catch (const EncodeError &e) {
+            threw = std::string(e.what()) == "part 1";
+        }
+        CHECK(threw);
+        std::atomic<int> inner{0};
+        pool.run(8, 4, [&](size_t lo, size_t hi, uint32_t) {
+            for (size_t i = lo; i < hi; ++i) pool.run(10, 3, [&](size_t a_, size_t b_, uint32_t) { inner += (int)(b_ - a_); });  // (no deadlock: runs inline)
+        });
+        CHECK(inner == 80);
+        pool.run(0, 4, [&](size_t lo, size_t hi, uint32_t) { CHECK(lo == 0 && hi == 0); });
+        CHECK(WorkerPool::parts_for(100, 1024) == 1 && WorkerPool::parts_for(1 << 20, 1024, 4) <= 4);
     });
     run("snapshot builder: a rebuild that throws leaves the snapshot as it was (commit at the end)", [] {
         // 5 nodes with taints enabled; then a rebuild of 2 nodes carrying 65 distinct taints: "more than 64" -- thrown BEFORE anything is
