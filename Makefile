@@ -53,7 +53,7 @@ $(LIB_HIP): $(LIB_OBJ)
 test-lib: $(LIB_HIP_TEST)
 $(LIB_HIP_TEST): $(LIB_OBJ) tests/cpp/test_hooks.cpp
 	mkdir -p tests/cpp/hooks
-	$(CXX) -O2 -std=c++17 -fPIC -c -o tests/cpp/hooks/test_hooks.o tests/cpp/test_hooks.cpp
+	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c -o tests/cpp/hooks/test_hooks.o tests/cpp/test_hooks.cpp
 	$(HIPCC) --offload-arch=$(ARCH) -shared -Wl,-soname,libksched_hip.so -o $@ $(LIB_OBJ) tests/cpp/hooks/test_hooks.o
 
 host: $(LIB_HOST) $(HOST_TEST) $(INDEX_TEST) $(OBJ_TOOL) $(FAKE_RCCL) $(LIB_HIP_TEST)

@@ -310,9 +310,10 @@ uint32_t ksched_mask_pitch(uint32_t n_nodes);
 #define KSCHED_MASK_ALLOC_PLAIN 1u      /* hipMalloc */
 #define KSCHED_MASK_ALLOC_PROBE 11u     /* probe-and-keep: KSCHED_OPT_MASK_PROBE hipMalloc candidates alive at once; the fused mask kernel is timed into each
                                          * (fit only, zero requests, the current snapshot); the fastest is kept, the others are freed */
-/* Measurement paths (tools/alloc_probe.py re-measures the choice with them; none selects the fast placement, profiles/r06_mask_alloc.md).  They go
- * through HIP's virtual-memory API, which on ROCm 7.0 showed STALE READS on a mapping's first use right after memory-pool activity in the same
- * process (same file, section 3): not for production masks -- AUTO and PROBE never use them. */
+/* Measurement paths: implemented in the TEST build of the library only (tests/cpp/hooks/libksched_hip.so = the shipped object code +
+ * tests/cpp/test_hooks.cpp); the shipped library answers KSCHED_E_UNSUPPORTED.  tools/alloc_probe.py re-measures the choice with them; none
+ * selects the fast placement, and HIP's virtual-memory API showed STALE READS on a mapping's first use right after a contiguous allocation was
+ * freed in the same process (profiles/r06_mask_alloc.md section 3): AUTO and PROBE never use them. */
 #define KSCHED_MASK_ALLOC_VMM 2u        /* hipMemCreate in one piece at the recommended granularity + hipMemAddressReserve + hipMemMap */
 #define KSCHED_MASK_ALLOC_VMM_MIN 4u    /* the same at the minimum granularity */
 #define KSCHED_MASK_ALLOC_CONTIGUOUS 5u /* hipExtMallocWithFlags(hipDeviceMallocContiguous): one physical range */

@@ -1800,23 +1800,21 @@ int ksched_eval_begin(ksched_ctx *c, uint32_t p, const int64_t *pcpu, const int6
 
 // ---- mask buffers owned by the library (mask_alloc.hpp; profiles/r06_mask_alloc.md) ---------------------------------------------
 namespace {
-// one buffer through one allocation path (never AUTO / PROBE)
-hipError_t mask_alloc_path(ksched_ctx *c, size_t bytes, uint32_t how, MaskAllocation &a) {
+// one buffer through one allocation path (never AUTO / PROBE).  *unsupported: a measurement path asked of the shipped library.
+hipError_t mask_alloc_path(ksched_ctx *c, size_t bytes, uint32_t how, MaskAllocation &a, bool *unsupported = nullptr) {
     a = MaskAllocation();
     a.bytes = bytes;
     a.device = c->device;
     a.owner = c;
     a.how = how;
-    a.mapped = bytes;
-    switch (how) {
-        case KSCHED_MASK_ALLOC_PLAIN: return hipMalloc(&a.ptr, bytes);
-        case KSCHED_MASK_ALLOC_VMM: return mask_alloc_vmm(c->device, bytes, 2u << 20, true, &a);
-        case KSCHED_MASK_ALLOC_VMM_MIN: return mask_alloc_vmm(c->device, bytes, 0, false, &a);
-        case KSCHED_MASK_ALLOC_SCATTER_2M: return mask_alloc_scattered(c->device, bytes, 2u << 20, 25, &a);
-        case KSCHED_MASK_ALLOC_SCATTER_16M: return mask_alloc_scattered(c->device, bytes, 16u << 20, 25, &a);
-        case KSCHED_MASK_ALLOC_CONTIGUOUS: return hipExtMallocWithFlags(&a.ptr, bytes, hipDeviceMallocContiguous);
-        default: return hipErrorInvalidValue;
+    if (how == KSCHED_MASK_ALLOC_PLAIN) return hipMalloc(&a.ptr, bytes);
+    // VMM, VMM_MIN, CONTIGUOUS, SCATTER_*: tests/cpp/test_hooks.cpp, linked into the test build only (mask_alloc.hpp)
+    if (ksched_test_mask_alloc == nullptr) {
+        if (unsupported) *unsupported = true;
+        return hipErrorNotSupported;
     }
+    const int rc = ksched_test_mask_alloc(c->device, bytes, how, &a.ptr, &a.test_token);
+    return rc == 0 ? hipSuccess : rc > 0 ? (hipError_t)rc : hipErrorInvalidValue;
 }
 
 // Probe-and-keep (KSCHED_MASK_ALLOC_PROBE).  The rate of the mask kernel into a buffer is a property of the buffer's physical placement
@@ -1827,7 +1825,7 @@ hipError_t mask_alloc_path(ksched_ctx *c, size_t bytes, uint32_t how, MaskAlloca
 int mask_alloc_probe(ksched_ctx *c, uint32_t p, uint32_t pitch, size_t bytes, MaskAllocation &best) {
     // (hipMalloc only: the virtual-memory paths gave the same ladder of rates and showed stale reads on a mapping's first use after memory-pool
     // activity in the process -- profiles/r06_mask_alloc.md section 3; candidates kept alive side by side land on different physical blocks anyway)
-    static const uint32_t paths[] = {KSCHED_MASK_ALLOC_PLAIN, KSCHED_MASK_ALLOC_PLAIN, KSCHED_MASK_ALLOC_PLAIN, KSCHED_MASK_ALLOC_PLAIN};
+    static const uint32_t paths[] = {KSCHED_MASK_ALLOC_PLAIN, KSCHED_MASK_ALLOC_PLAIN, KSCHED_MASK_ALLOC_PLAIN, KSCHED_MASK_ALLOC_PLAIN};  // (hipMalloc and nothing else)
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     const uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(c->opt_mask_probe, free_b / 4 / std::max<size_t>(bytes, 1)));
@@ -1931,7 +1929,12 @@ int ksched_mask_alloc(ksched_ctx *c, uint32_t p, uint32_t how, uint64_t **out_ma
         const int rc = mask_alloc_probe(c, p, pitch, bytes, a);
         if (rc) return rc;
     } else {
-        const hipError_t e = mask_alloc_path(c, bytes, eff, a);
+        bool unsupported = false;
+        const hipError_t e = mask_alloc_path(c, bytes, eff, a, &unsupported);
+        if (unsupported) {
+            c->last_error = "ksched_mask_alloc: this allocation path is a measurement path of the test build of the library (tests/cpp/hooks); the shipped library allocates with hipMalloc only";
+            return KSCHED_E_UNSUPPORTED;
+        }
         if (e != hipSuccess || !a.ptr) {
             c->last_error = std::string("ksched_mask_alloc: ") + hipGetErrorString(e);
             (void)hipGetLastError();

@@ -125,10 +125,14 @@ def test_the_shipped_library_carries_no_test_hooks(built):
         out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
         return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
     ds, dt = defined(shipped), defined(test_build)
-    hooks = {"ksched_test_hooks_enabled", "ksched_test_hooks_linked", "ksched_test_rccl_lib"}
+    hooks = {"ksched_test_hooks_enabled", "ksched_test_hooks_linked", "ksched_test_rccl_lib", "ksched_test_mask_alloc", "ksched_test_mask_release"}
     assert not (hooks & ds), hooks & ds
     assert hooks <= dt
     assert {s_ for s_ in ds if s_.startswith("ksched_")} == {s_ for s_ in dt if s_.startswith("ksched_")} - hooks  # otherwise the same library
     text = open(shipped, "rb").read()
     assert b"KSCHED_RCCL_LIB" not in text and b"KSCHED_TEST_HOOKS" not in text
     assert b"KSCHED_RCCL_LIB" in open(test_build, "rb").read()
+    # ... nor HIP's virtual-memory API (the measurement paths of ksched_mask_alloc: test build only)
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", shipped], capture_output=True, text=True, check=True).stdout
+    assert "hipMemCreate" not in undefined and "hipMemMap" not in undefined and "hipMemAddressReserve" not in undefined
+    assert "hipMemCreate" in subprocess.run(["nm", "-D", "--undefined-only", test_build], capture_output=True, text=True, check=True).stdout

@@ -6,6 +6,7 @@ a buffer the evaluator writes the SAME words into (== the oracle), the pitch it 
 path keeps exactly one candidate and reports what it measured, and the error behaviour of the two entry points.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -65,19 +66,28 @@ def test_the_product_paths_hold_the_same_mask(built, how):
     _same_mask_through(how)
 
 
+TEST_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cpp", "hooks", "libksched_hip.so")
+
+
 @pytest.mark.parametrize("how", MEASUREMENT_PATHS, ids=lambda h: _lib.MASK_ALLOC_NAMES[h])
-def test_a_measurement_path_holds_the_same_mask_in_a_process_of_its_own(built, how):
-    """The paths tools/alloc_probe.py measures (HIP's virtual-memory API, one contiguous physical range, scattered pieces): same words, same
-    bindings -- each in a fresh process, because on ROCm 7.0 a virtual-memory mapping made right after a contiguous allocation was freed in the same
-    process returned STALE shader reads on its first use (the data in memory -- read back by the DMA engine -- was right; deterministic in one
-    allocation order, absent in others: profiles/r06_mask_alloc.md section 3).  That is why AUTO and PROBE keep to hipMalloc."""
-    import os
+def test_a_measurement_path_holds_the_same_mask_in_the_test_build(built, how):
+    """The paths tools/alloc_probe.py measures (HIP's virtual-memory API, one contiguous physical range, scattered pieces) exist in the TEST build of
+    the library only (tests/cpp/test_hooks.cpp): same words, same bindings -- each in a fresh process that loads that build ($KSCHED_LIB), also because
+    on ROCm 7.0 a virtual-memory mapping made right after a contiguous allocation was freed in the same process returned STALE shader reads on its
+    first use (the data in memory -- read back by the DMA engine -- was right; profiles/r06_mask_alloc.md section 3).  The shipped library answers
+    KSCHED_E_UNSUPPORTED for all of them."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = f"import tests.test_gpu_mask_alloc as t; t._same_mask_through({how}); print('path ok')"
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, KSCHED_LIB=TEST_LIB))
     assert r.returncode == 0 and "path ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    with Evaluator(0) as ev:  # the shipped library (this process)
+        c, _ = _case(P=8, N=130)
+        ev.set_nodes(**c.node_columns())
+        with pytest.raises(KschedError) as ei:
+            ev.alloc_mask(10, how=how)
+        assert ei.value.code == _lib.E_UNSUPPORTED and "test build" in str(ei.value)
 
 
 def test_the_probe_keeps_one_buffer_and_frees_the_rest(built):
@@ -134,7 +144,8 @@ def test_error_behaviour_of_the_two_entry_points(built):
         assert b"ksched_mask_free" in lib.ksched_last_error(ev._h)
         assert lib.ksched_mask_free(ev._h, None) == _lib.OK  # like free(NULL)
         assert lib.ksched_mask_free(ev._h, C.c_void_p(0x1000)) == _lib.E_INVAL  # not ours
-        assert lib.ksched_mask_alloc(ev._h, 10, _lib.MASK_ALLOC_VMM, C.byref(ptr), C.byref(pitch)) == _lib.OK
+        assert lib.ksched_mask_alloc(ev._h, 10, _lib.MASK_ALLOC_VMM, C.byref(ptr), C.byref(pitch)) == _lib.E_UNSUPPORTED and not ptr.value  # (a measurement path: test build only)
+        assert lib.ksched_mask_alloc(ev._h, 10, _lib.MASK_ALLOC_PLAIN, C.byref(ptr), C.byref(pitch)) == _lib.OK
         assert pitch.value == lib.ksched_mask_pitch(130) == 16
         # left to ksched_destroy (the `with` block): no leak report, no crash
     with Evaluator(0) as ev2:  # a second context does not see the first one's buffers

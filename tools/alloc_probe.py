@@ -1,5 +1,7 @@
 #!/usr/bin/env python
 """Which allocation path gives the mask kernel its fast rate, and which hardware counter separates the two rates?
+NEEDS THE TEST BUILD of the library for every path but 1 (plain) and 11 (probe): KSCHED_LIB=tests/cpp/hooks/libksched_hip.so (the measurement paths
+live in tests/cpp/test_hooks.cpp; the shipped library answers KSCHED_E_UNSUPPORTED).
 (the finding it follows up: profiles/r05_bimodal_by_allocation.md.)
 
     python tools/alloc_probe.py <workload=C5s> survey [k=4] [hows=1,2,4,5,8,9,11] [n=24]

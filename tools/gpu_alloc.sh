@@ -3,6 +3,7 @@
 TAG=${1:-alloc}; shift
 STEPS=${@:-"list survey pmc"}
 REPO=$PWD; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+export KSCHED_LIB=$REPO/tests/cpp/hooks/libksched_hip.so  # the measurement allocation paths exist in the test build of the library only
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 stamp() { echo "[$(date +%H:%M:%S)] $*"; }
 if has list; then
