@@ -529,6 +529,8 @@ std::shared_ptr<Snapshot::StagedUpdate> Snapshot::stage_impl(const std::vector<O
     return out;
 }
 
+bool Snapshot::staged_is_current(const StagedUpdate &S) const { return !S.committed && S.generation == generation_; }
+
 size_t Snapshot::commit_staged(StagedUpdate &S) {
     if (S.committed) throw EncodeError("commit_staged: this update has been committed already");
     if (S.generation != generation_) throw EncodeError("commit_staged: the snapshot has changed since the update was staged");

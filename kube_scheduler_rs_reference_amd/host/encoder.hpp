@@ -247,6 +247,7 @@ public:
     struct StagedUpdate;
     std::shared_ptr<StagedUpdate> stage_bound(const std::vector<Bound> &bound);
     size_t commit_staged(StagedUpdate &staged);
+    bool staged_is_current(const StagedUpdate &staged) const;  // the snapshot has not changed since `staged` was made (commit_staged would not refuse it for that)
 
 private:
     std::shared_ptr<StagedUpdate> stage_impl(const std::vector<Observed> &events);

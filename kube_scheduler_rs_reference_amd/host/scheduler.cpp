@@ -332,7 +332,8 @@ std::vector<ReconcileOutcome> reconcile_batch(const std::vector<const corev1::Po
         // snapshot marked stale (it uploads everything before the next evaluation); a bookkeeping failure (int64 overflow of
         // `available`) drops the snapshot, so that the next batch starts from fresh LISTs.
         try {
-            if (staged && landed.size() == expected) (void)ctx.snapshot->commit_staged(*staged);
+            // (a snapshot that changed while the POSTs ran -- a watch event applied by another caller -- takes the plain path too)
+            if (staged && landed.size() == expected && ctx.snapshot->staged_is_current(*staged)) (void)ctx.snapshot->commit_staged(*staged);
             else ctx.snapshot->observe_bound(landed);
         } catch (const EncodeError &) {
             if (!ctx.snapshot->device_stale()) ctx.snapshot.reset();
