@@ -1185,6 +1185,16 @@ inline hipError_t run_fused(const IndexedSnapshot &s, uint32_t p, const int64_t 
     // (other streams) find free ones and fill while this one stores; 0 = the whole chip
     const uint32_t cus = grid_cus ? std::min(256u, grid_cus) : 256u;
     a.chunks = std::max(1u, std::min((cus * blocks_per_cu) / l.tiles, want));
+    // Interleaved orders, launches of TWO rounds per wave (C3: 1 563 rounds over 51 x 16 waves): the launch lasts as long as its two-round waves, and
+    // at the largest resident chunk count one wave in twelve has only one -- the smallest chunk count that still needs no third round (49: 784 waves x 2
+    // rounds) fills fewer blocks for the same two rounds: step 18.05 -> 17.6 us (sweep of 44 .. 51 chunks, session r7i: 18.43 18.25 17.94 17.91 17.77
+    // 17.6 17.8 18.05).  Longer launches are bound by their stores, not by the quantisation, and want every compute unit (session r7k, even / largest
+    // chunk count: 150 k pods 23.5 / 23.3 us, 300 k 43.3 / 40.0, 400 k 55.7 / 52.4); one-round launches keep the finer cut (a riding pick's pods spread wider).
+    if (round_order != 1 && !(debug & 0x80000000u)) {  // (debug bit 31: the largest resident chunk count, the A/B of this rule)
+        const uint32_t streams = a.chunks * kFusedWaves;
+        const uint32_t per_wave = (rounds + streams - 1u) / streams;
+        if (per_wave == 2u) a.chunks = std::max(1u, std::min(a.chunks, (rounds + 2u * kFusedWaves - 1u) / (2u * kFusedWaves)));
+    }
     a.unit_q = a.units / a.chunks;
     a.unit_rem = a.units % a.chunks;
     // KSCHED_OPT_ROUND_ORDER: 0 = interleaved, wave-major (default); 1 = blocked; 2 = interleaved, chunk-major

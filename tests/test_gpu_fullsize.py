@@ -248,6 +248,45 @@ def test_round_orders_write_the_same_words(evaluator, name, P):
         assert np.array_equal(out[0][1].cpu().numpy(), o_bind)
 
 
+@pytest.mark.parametrize("name,P", [("C3", 100_000), ("C3", 52_225), ("C3", 104_448), ("C3", 60_001), ("C4s", 40_000), ("C3", 19_999)])
+def test_chunk_count_rule_writes_the_same_words(evaluator, name, P):
+    """Round 6, `run_fused`: a launch whose waves take exactly two rounds each uses the SMALLEST chunk count that still needs no third round
+    (C3: 49 chunks instead of the 51 that fit) -- fewer blocks filled for the same two rounds.  KSCHED_OPT_DEBUG bit 31 switches the rule off
+    (the largest resident chunk count: the A/B of `profiles/r06_r7i_r7k_chunk_count.txt`).  Sizes on both sides of the rule's edges (one round
+    per wave <-> two <-> three at C3: 816 streams of 64 pods), with the pick riding: every word and binding identical with and without the rule,
+    and == the oracle on the smaller ones (the full size is compared with the oracle by the tests above, which run the rule)."""
+    import torch
+    from kube_scheduler_rs_reference_amd import _lib
+    cfg, _, N, preds, pick = CASES[name]
+    c = synth.make_config(cfg, P=P, N=N)
+    ev = evaluator
+    dev = torch.device("cuda", ev.device)
+    ev.set_nodes(**c.node_columns())
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)  # noqa: E731
+    d_cpu, d_mem, d_sel, d_smp = t(c.req_cpu, np.int64), t(c.req_mem, np.int64), t(c.pod_sel, np.int32), t(c.samples, np.int32)
+    flags = preds | pick
+    ev.set_kernel("auto")
+    out = []
+    try:
+        for dbg in (0, 0x80000000):
+            ev.set_option(_lib.OPT_DEBUG, dbg)
+            feas = ev.alloc_mask(P, pitched=True)
+            bind = torch.full((P,), -7, dtype=torch.int32, device=dev)
+            ev.eval_device(d_cpu, d_mem, d_sel, None, d_smp, flags, out_feasible=feas, out_binding=bind)
+            torch.cuda.synchronize()
+            assert ev.last_kernel == "fused" and ev.last_pick == "fused-tile", (ev.last_kernel, ev.last_pick)
+            out.append((feas, bind))
+    finally:
+        ev.set_option(_lib.OPT_DEBUG, 0)
+    assert torch.equal(out[0][0], out[1][0]), "the mask differs with the chunk-count rule on / off"
+    assert torch.equal(out[0][1], out[1][1]), "the bindings differ with the chunk-count rule on / off"
+    if P <= 60_001:
+        o_feas, _, o_bind = capi.eval_encoded(c.avail_cpu, c.avail_mem, c.node_labels, None, c.req_cpu, c.req_mem, np.ascontiguousarray(c.pod_sel), None,
+                                              np.ascontiguousarray(c.samples), flags)
+        assert np.array_equal(out[0][0].contiguous().cpu().numpy().view(np.uint64), o_feas)
+        assert np.array_equal(out[0][1].cpu().numpy(), o_bind)
+
+
 def test_mask_larger_than_4_gib(evaluator):
     """One evaluation whose mask does not fit 32-bit byte offsets: 700k pods x 50k nodes (C5's predicates, pitched rows of 784 words)
     = 4.39 GB of feasible mask, more than half of BASELINE.json's configs[4] on ONE GPU.  Every word and every binding == the oracle
