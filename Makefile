@@ -6,6 +6,8 @@
 #   make host       -> kube_scheduler_rs_reference_amd/libksched_host.so    g++, links libksched_hip.so; + tests/cpp/host_tests
 #   make oracle     -> oracle/liboracle.so                                  gcc, test infrastructure only
 #   make tools      -> tools/pmc_calib                                      hipcc: calibration kernels for the HBM counters
+#   make sanitize   -> build/san/host_tests_{asan,tsan}                     the host mirror + its C++ tests under AddressSanitizer + UBSan, and under ThreadSanitizer
+#                      (CPU sanitizers over HOST code only; `tools/sanitize.sh` runs them: the CPU half here, the device half on a GPU box)
 #   make test-lib   -> tests/cpp/hooks/libksched_hip.so                     the SAME object code + tests/cpp/test_hooks.cpp: the only build in which
 #                      $KSCHED_TEST_HOOKS=1 switches on the RCCL stand-in, fault injection and the k-replica shard (the shipped library has none of it)
 HIPCC   ?= /opt/rocm/bin/hipcc
@@ -36,7 +38,7 @@ PMC_CALIB := tools/pmc_calib
 LIB_OBJ  := $(CSRC)/ksched_api.o
 LIB_HIP_TEST := tests/cpp/hooks/libksched_hip.so
 
-.PHONY: all lib host oracle tools clean test-lib
+.PHONY: all lib host oracle tools clean test-lib sanitize
 all: lib test-lib host oracle tools
 
 # kernels of KNOWN byte counts for calibrating the HBM counters (bench.py --live-traffic, tools/gpu_round.sh pmc)
@@ -72,6 +74,30 @@ $(HOST_TEST): tests/cpp/host_tests.cpp $(LIB_HOST) $(HOST_HDRS)
 # objects JSON -> host encoder -> device, printed for the Python parity tests (tests/test_gpu_objects.py)
 $(OBJ_TOOL): tests/cpp/objects_eval.cpp tests/cpp/json_min.hpp $(LIB_HOST) $(HOST_HDRS)
 	$(CXX) $(CXXFLAGS) -o $@ tests/cpp/objects_eval.cpp -L$(PKG) -lksched_host -lksched_hip -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lpthread
+
+# Host-side sanitizer builds (g++; the evaluator library they link is the ordinary test build: device code is not instrumented)
+SAN_DIR  := build/san
+SAN_SRCS := tests/cpp/host_tests.cpp $(HOST_SRCS)
+SAN_FLAGS := -O1 -g -std=c++17 -fPIC -Wall -Wextra -Iinclude -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -fno-omit-frame-pointer
+SAN_LINK := -Ltests/cpp/hooks -lksched_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../../tests/cpp/hooks' -Wl,-rpath,/opt/rocm/lib -lpthread -ldl
+SAN_OBJ_SRCS := tests/cpp/objects_eval.cpp $(HOST_SRCS)
+sanitize: $(SAN_DIR)/host_tests_asan $(SAN_DIR)/host_tests_tsan $(SAN_DIR)/objects_eval_asan $(SAN_DIR)/objects_eval_tsan
+$(SAN_DIR)/asan/%.o: %.cpp $(HOST_HDRS)
+	mkdir -p $(dir $@)
+	$(CXX) $(SAN_FLAGS) -fsanitize=address,undefined -c -o $@ $<
+$(SAN_DIR)/tsan/%.o: %.cpp $(HOST_HDRS)
+	mkdir -p $(dir $@)
+	$(CXX) $(SAN_FLAGS) -fsanitize=thread -c -o $@ $<
+$(SAN_DIR)/asan/tests/cpp/objects_eval.o $(SAN_DIR)/tsan/tests/cpp/objects_eval.o: tests/cpp/json_min.hpp
+# the objects -> reconcile_batch -> POST sink -> snapshot loop at any size (tools/host_loop.py with OBJECTS_EVAL_BIN): the threaded path at production batch sizes
+$(SAN_DIR)/objects_eval_asan: $(SAN_OBJ_SRCS:%.cpp=$(SAN_DIR)/asan/%.o) $(LIB_HIP_TEST)
+	$(CXX) -fsanitize=address,undefined -o $@ $(SAN_OBJ_SRCS:%.cpp=$(SAN_DIR)/asan/%.o) $(SAN_LINK)
+$(SAN_DIR)/objects_eval_tsan: $(SAN_OBJ_SRCS:%.cpp=$(SAN_DIR)/tsan/%.o) $(LIB_HIP_TEST)
+	$(CXX) -fsanitize=thread -o $@ $(SAN_OBJ_SRCS:%.cpp=$(SAN_DIR)/tsan/%.o) $(SAN_LINK)
+$(SAN_DIR)/host_tests_asan: $(SAN_SRCS:%.cpp=$(SAN_DIR)/asan/%.o) $(LIB_HIP_TEST)
+	$(CXX) -fsanitize=address,undefined -o $@ $(SAN_SRCS:%.cpp=$(SAN_DIR)/asan/%.o) $(SAN_LINK)
+$(SAN_DIR)/host_tests_tsan: $(SAN_SRCS:%.cpp=$(SAN_DIR)/tsan/%.o) $(LIB_HIP_TEST)
+	$(CXX) -fsanitize=thread -o $@ $(SAN_SRCS:%.cpp=$(SAN_DIR)/tsan/%.o) $(SAN_LINK)
 
 oracle: $(LIB_ORA)
 $(LIB_ORA): oracle/oracle.c oracle/oracle.h

@@ -12,7 +12,7 @@ import argparse, json, os, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kube_scheduler_rs_reference_amd import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOOL = os.path.join(ROOT, "tests", "cpp", "objects_eval")
+TOOL = os.environ.get("OBJECTS_EVAL_BIN") or os.path.join(ROOT, "tests", "cpp", "objects_eval")  # (OBJECTS_EVAL_BIN: a sanitizer build, tools/sanitize.sh)
 
 
 def objects_file(P, N):
@@ -30,6 +30,8 @@ def run(mode, path, reps=1, post_concurrency=1, warn=False, timeout=900):
     t0 = time.perf_counter()
     r = subprocess.run([TOOL, mode, path, "4242", "0", str(post_concurrency)], capture_output=True, text=True, env=env, timeout=timeout)
     wall = time.perf_counter() - t0
+    if "Sanitizer" in r.stderr or "runtime error:" in r.stderr:  # a sanitizer build (OBJECTS_EVAL_BIN): its reports are the point
+        sys.stdout.write(r.stderr)
     if r.returncode:
         raise RuntimeError(f"objects_eval {mode} failed: {r.stderr[-400:]}")
     # (RCCL prints a five-line version banner to stdout when a communicator is created -- KSCHED_SHARDED=1 --, in the middle of the tool's JSON)
