@@ -28,6 +28,8 @@ while time.time() < t_end:
     r = np.random.default_rng(cs)
     N = int(r.choice([1, 2, 63, 64, 65, 300, 1023, 1024, 1025, 2500, 4097, 6000]))
     P = int(r.choice([1, 7, 64, 65, 500, 1500, 3000]))
+    if r.random() < 0.05:  # now and then a batch long enough for two or more rounds per wave of a whole-chip launch (run_fused's chunk-count rule, the riding pick's longer forms)
+        P = int(r.choice([12_000, 20_011, 40_000, 52_225]))
     K = int(r.choice([0, 1, 3, 8, 9, 12]))
     cards = [int(r.choice([1, 2, 5, 40, 300, N, 4 * N + 7])) for _ in range(K)]
     scale = int(r.choice([10, 1000, 1 << 20]))
