@@ -175,7 +175,9 @@ class Evaluator:
 
     # -- evaluation, host buffers ------------------------------------------------------------------
     def eval(self, req_cpu_milli, req_mem_bytes, sel_val_ids=None, tolerations=None, samples=None, flags: int = L.FIT,
-             want_mask: bool = True) -> EvalResult:
+             want_mask: bool = True, out: "EvalResult | None" = None) -> EvalResult:
+        """`out`: an EvalResult of an earlier call with the same shapes whose arrays are written again instead of fresh ones -- a caller that evaluates batch
+        after batch keeps its result buffers (a fresh 63 MB numpy array is first touched BY the copy: 6 ms per C3 mask instead of 1.4)."""
         cpu = _np(req_cpu_milli, np.int64, "req_cpu_milli")
         mem = _np(req_mem_bytes, np.int64, "req_mem_bytes")
         p = cpu.shape[0]
@@ -191,12 +193,17 @@ class Evaluator:
             attempts = smp.shape[1]
         W = self.W
         res = EvalResult()
+
+        def buf(prev, shape, dtype):
+            if prev is not None and prev.shape == shape and prev.dtype == dtype and prev.flags.c_contiguous and prev.flags.writeable:
+                return prev
+            return np.empty(shape, dtype=dtype)
         if want_mask:
-            res.feasible = np.empty((p, W), dtype=np.uint64)
+            res.feasible = buf(out.feasible if out is not None else None, (p, W), np.uint64)
         if flags & L.WANT_FIT_MASK:
-            res.fit = np.empty((p, W), dtype=np.uint64)
+            res.fit = buf(out.fit if out is not None else None, (p, W), np.uint64)
         if flags & (L.PICK_SAMPLED | L.PICK_BESTFIT):
-            res.binding = np.empty((p,), dtype=np.int32)
+            res.binding = buf(out.binding if out is not None else None, (p,), np.int32)
         rc = self._lib.ksched_eval(self._h, p, _ptr(cpu), _ptr(mem), _ptr(sel), _ptr(tol), _ptr(smp), attempts, flags,
                                    _ptr(res.feasible), _ptr(res.fit), _ptr(res.binding))
         self._check(rc, "ksched_eval")

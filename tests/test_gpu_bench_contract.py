@@ -70,6 +70,8 @@ def test_default_line_contract(built):
     hb, hm, ob = e["host_arrays_to_bindings"], e["host_arrays_to_mask"], e["objects"]
     assert 0 < hb["ms_per_batch"] < hm["ms_per_batch"] and hb["calls"] >= 20 and abs(hb["evals_per_s"] - 5e8 / (hb["ms_per_batch"] * 1e-3)) < 1e-6 * hb["evals_per_s"]
     assert hb["evals_per_s"] < d["value"], "the PCIe-inclusive rate is never the metric"
+    # the mask copied back: into result arrays kept from call to call (the figure), and into a fresh array per call (first touched by the copy) beside it
+    assert hm["output"].startswith("result arrays kept") and hm["fresh_output_ms_per_batch"] > hm["ms_per_batch"] > 63.2 / 64.0, hm  # (63.2 MB cannot cross a 64 GB/s link in under a millisecond)
     assert "error" not in ob and ob["batches"] == 5 and 0 < ob["best_ms_per_batch"] <= ob["median_ms_per_batch"] and 20_000 < ob["pods_bound"] < 80_000
     assert ob["best_ms_per_batch"] < 40.0, "objects -> bindings -> snapshot for a C3-size batch: 47 ms in round 3, 15 - 21 ms on the 256-thread boxes of round 6"
     sp = ob["median_split"]

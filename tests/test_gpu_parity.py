@@ -139,6 +139,29 @@ def test_selector_semantics_encoded(evaluator):
     ev.set_kernel("auto")
 
 
+@pytest.mark.gpu
+def test_result_arrays_kept_from_call_to_call(evaluator):
+    """`Evaluator.eval(..., out=previous)`: the host-buffer entry point writes the caller's own result arrays again (bench.py `end_to_end.host_arrays_to_mask`);
+    same arrays, new contents == the oracle; a shape that no longer fits gets fresh arrays."""
+    ev = evaluator
+    c1 = synth.make_cluster(P=700, N=900, n_keys=6, n_taints=0, seed=41)
+    ev.set_nodes(**c1.node_columns())
+    flags = FIT | SEL | PICK_SAMPLED | WANT_FIT_MASK
+    pc = c1.pod_columns()
+    r1 = ev.eval(pc["req_cpu_milli"], pc["req_mem_bytes"], pc["sel_val_ids"], None, pc["samples"], flags)
+    first = r1.feasible.copy()
+    c2 = synth.make_cluster(P=700, N=900, n_keys=6, n_taints=0, seed=42)
+    pc2 = c2.pod_columns()  # other pods against the same snapshot
+    r2 = ev.eval(pc2["req_cpu_milli"], pc2["req_mem_bytes"], pc2["sel_val_ids"], None, pc2["samples"], flags, out=r1)
+    assert r2.feasible is r1.feasible and r2.fit is r1.fit and r2.binding is r1.binding
+    feas, fit, bind = capi.eval_encoded(c1.avail_cpu, c1.avail_mem, c1.node_labels, None, c2.req_cpu, c2.req_mem, c2.pod_sel, None, c2.samples, flags)
+    assert np.array_equal(r2.feasible, feas) and np.array_equal(r2.fit, fit) and np.array_equal(r2.binding, bind)
+    assert not np.array_equal(first, r2.feasible)
+    r3 = ev.eval(pc2["req_cpu_milli"][:100], pc2["req_mem_bytes"][:100], np.ascontiguousarray(pc2["sel_val_ids"][:, :100]), None, pc2["samples"][:100], flags, out=r2)
+    assert r3.feasible is not r2.feasible and r3.feasible.shape == (100, ev.W) and np.array_equal(r3.feasible, feas[:100]) and np.array_equal(r3.binding, bind[:100])
+
+
+
 def test_many_keys_multi_pass(evaluator):
     """More label keys than one pass of the direct kernel handles (8): 19 keys."""
     rng = np.random.default_rng(5)

@@ -17,6 +17,9 @@ rng = np.random.default_rng(seed)
 ev = Evaluator(0)
 # the multi-device sequence with n > 1 needs the TEST-ONLY librccl stand-in (one GPU stands for n ranks): replicas + one clique per n, made on first use
 HOOKS = os.environ.get("KSCHED_TEST_HOOKS") == "1" and bool(os.environ.get("KSCHED_RCCL_LIB"))
+if HOOKS and not hasattr(L.load(), "ksched_test_hooks_linked"):  # the stand-in is loadable by the TEST build of the library only (KSCHED_LIB=tests/cpp/hooks/libksched_hip.so)
+    print("fuzz: KSCHED_TEST_HOOKS is set but the loaded library is the shipped one (no hooks): the n > 1 multi-device cases are left out; set KSCHED_LIB=tests/cpp/hooks/libksched_hip.so", flush=True)
+    HOOKS = False
 replicas, cliques = [], {}
 t_end = time.time() + budget
 cases = fails = 0
