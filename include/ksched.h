@@ -230,6 +230,8 @@ uint32_t ksched_num_keys(const ksched_ctx *ctx);
  *   out_fit       : [p][W] or NULL; requires KSCHED_WANT_FIT_MASK
  *   out_binding   : [p] or NULL; requires one of the KSCHED_PICK_* flags; -1 = no node
  * Predicates not selected in `flags` are treated as true.
+ * The output arrays may be ordinary pageable memory (the copies run at the link's rate into it: 63 MB of mask in 1.2 ms on an MI355X box); keep them from
+ * call to call -- a freshly allocated array is first touched BY the copy, which then takes four times as long (bench.py end_to_end.host_arrays_to_mask).
  */
 int ksched_eval(ksched_ctx *ctx, uint32_t p, const int64_t *req_cpu_milli, const int64_t *req_mem_bytes,
                 const uint32_t *sel_val_ids, const uint64_t *tolerations, const uint32_t *samples,
