@@ -2,6 +2,7 @@
 # Host-side sanitizer runs of the C++ mirror's tests (make sanitize builds build/san/host_tests_{asan,tsan}): AddressSanitizer + UBSan, and ThreadSanitizer,
 # over HOST code only -- the worker pool, the staged snapshot update beside the POSTs, the draws' thread, the reaper, PodBatcher / run_batches, the sharded
 # context.  Device code is not instrumented (GPU sanitizers are not available on this pool).
+# (on a GPU box through gpurun: build/san/ is listed in .gpurunignore -- comment that line out for the session, or the binaries do not travel)
 # usage: bash tools/sanitize.sh <outdir> [modes...]      modes: cpu (no GPU needed) gpu sharded comm sharded_rccl gpu3 (= gpu through a three-way shard over the RCCL
 #                                                        stand-in), loop (tools/host_loop.py through build/san/objects_eval_*: a 20 000 x 2 000 and a C3-size
 #                                                        100 000 x 5 000 batch, objects -> reconcile_batch -> POST sink -> staged snapshot update, batch + sequential);
