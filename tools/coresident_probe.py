@@ -64,3 +64,22 @@ two2 = timed(lambda: (mask_only(sa), pick_only(sb)), steps)
 ok = bool(torch.equal(bind, ref))
 print(f"lib {os.environ.get('KSCHED_LIB', 'default')}: mask only {m:.1f} us | pick only {p:.1f} us | one stream {seq:.1f} us | two streams (pick enqueued first) {two:.1f} us | "
       f"two streams (mask first) {two2:.1f} us | bindings unchanged: {ok}")
+
+# Per-CALL form (what a fork / join inside ksched_eval_device would be): every step is synchronised, so nothing of step i + 1 overlaps step i;
+# the mask kernel kept to fewer compute units (KSCHED_OPT_GRID_CUS) leaves the pick's one-wave blocks room beside it.
+if os.environ.get("PROBE_PER_CALL", "1") == "1":
+    def timed_sync(fn, k):
+        for _ in range(3):
+            fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn(); torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k * 1e6
+    base = timed_sync(lambda: (mask_only(sa), pick_only(sa)), steps)
+    print(f"per call (synchronised every step): one stream {base:.1f} us")
+    for cus in (0, 236, 226, 216, 196):
+        ev.set_option(L.OPT_GRID_CUS, cus)
+        m1 = timed_sync(lambda: mask_only(sa), steps)
+        t2 = timed_sync(lambda: (mask_only(sa), pick_only(sb)), steps)
+        print(f"  mask kernel on {cus or 256} CUs: mask alone {m1:.1f} us | mask + pick on two streams {t2:.1f} us ({t2 - base:+.1f} vs one stream) | bindings unchanged: {bool(torch.equal(bind, ref))}")
+    ev.set_option(L.OPT_GRID_CUS, 0)
