@@ -56,9 +56,18 @@
 //                        linger in the caches leave them to the operands and the tile index: C3 20.1 -> 18.4 us per step, the C4 shard 42.5 -> 38.1,
 //                        the C5 shard 220 -> 196 (sessions r5g, r5h: profiles/r05_r5h_store_policy.txt; 4 and 5 within noise of each other except at
 //                        the C5 shard, where 5 is 2 - 3 % ahead); in place nothing changes (19.9 - 20.5 us either way).
+//                        6 = MIXED (shipped since the end of round 6): policy 5, except that ONE of a round's eight pod-row steps (KSCHED_STORE_ALT, default: the last)
+//                        is stored write-through WITHOUT the nt hint (sc1).  One such store in eight is enough: the C5 shard's mask kernel 140 - 151 us -> 137 - 138 us
+//                        in every one of twelve fresh processes (the spread over allocations that round 5 found and round 6 could only probe around is gone with it),
+//                        its step 197 - 209 -> 193 us; the C4 shard 37.2 -> 36.9 us, C3 unchanged (17.4 us, steadier).  More of them loses again (every other step:
+//                        = policy 5; three in four: C3 + 0.9 us, the C5 shard + 10 us), and the odd store has to be write-through and temporal (sc1 or sc0 sc1; plain
+//                        write-back + 1.5 us at the C5 shard, nt alone nothing): sessions r8g - r8i, profiles/r06_r8g_r8i_mixed_store_policy.txt.
 //   KSCHED_FUSED_THREADS threads per block (waves x 64)
 #ifndef KSCHED_STORE_POLICY
-#define KSCHED_STORE_POLICY 5
+#define KSCHED_STORE_POLICY 6
+#endif
+#ifndef KSCHED_STORE_ALT  // policy 6: which pod-row step of a round (0 .. 7) is stored without the nt hint
+#define KSCHED_STORE_ALT(it) ((it) == 7u)
 #endif
 #ifndef KSCHED_FUSED_THREADS
 #define KSCHED_FUSED_THREADS 1024
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst + o), "v"(f) : "memory");
 #elif KSCHED_STORE_POLICY == 4
         asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(dst + o), "v"(f) : "memory");
-#elif KSCHED_STORE_POLICY == 5
+#elif KSCHED_STORE_POLICY == 5 || KSCHED_STORE_POLICY == 6
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(dst + o), "v"(f) : "memory");
 #else
         *reinterpret_cast<u32x4_a8 *>(dst + o) = f;
@@ -474,8 +483,11 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
     // lane's constant 32-bit byte offset: no per-lane address arithmetic at all (it was a 64-bit multiply-add per store).
     const uint32_t lane_off = (sub * a.pitch + w0) * 8u;  // of pod `sub` within a step
     const uint32_t step_bytes = a.pitch * 64u;            // 8 pod rows
-    auto store_rel = [&](uint64_t base, uint32_t voff, const u32x4 f) {
-#if KSCHED_STORE_POLICY == 2
+    auto store_rel = [&](uint64_t base, uint32_t voff, const u32x4 f, bool alt = false) {
+#if KSCHED_STORE_POLICY == 6  // the two write-through forms mixed: `alt` = this pod-row step goes without the nt hint (file header)
+        if (alt) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(f), "s"(base) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt\n\ts_nop 1" ::"v"(voff), "v"(f), "s"(base) : "memory");
+#elif KSCHED_STORE_POLICY == 2
         asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(f), "s"(base) : "memory");
 #elif KSCHED_STORE_POLICY == 3
         asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(f), "s"(base) : "memory");
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
         if (SEL) f = ((f & R.l0) & R.l1) & (R.l2 & R.l3);
         if (SEL && extra) f = ((f & R.x0) & R.x1) & (R.x2 & R.x3);
         if (TAINT) f = ((f & R.t0) & R.t1) & (R.t2 & R.t3);
-        store_rel(rb_feas + step, lane_off, f);  // out_feas is never null here (the API supplies a scratch mask when the caller gives none)
+        store_rel(rb_feas + step, lane_off, f, KSCHED_STORE_ALT(it));  // out_feas is never null here (the API supplies a scratch mask when the caller gives none)
     };
 
     // Checked form of one pod-row: end-of-range / partial-tile predicates and the overflow walks
