@@ -61,7 +61,7 @@
 //                        in every one of twelve fresh processes (the spread over allocations that round 5 found and round 6 could only probe around is gone with it),
 //                        its step 197 - 209 -> 193 us; the C4 shard 37.2 -> 36.9 us, C3 unchanged (17.4 us, steadier).  More of them loses again (every other step:
 //                        = policy 5; three in four: C3 + 0.9 us, the C5 shard + 10 us), and the odd store has to be write-through and temporal (sc1 or sc0 sc1; plain
-//                        write-back + 1.5 us at the C5 shard, nt alone nothing): sessions r8g - r8i, profiles/r06_r8g_r8i_mixed_store_policy.txt.
+//                        write-back + 1.5 us at the C5 shard, nt alone nothing): sessions r8g - r8j, profiles/r06_r8g_r8j_mixed_store_policy.txt.
 //   KSCHED_FUSED_THREADS threads per block (waves x 64)
 #ifndef KSCHED_STORE_POLICY
 #define KSCHED_STORE_POLICY 6
