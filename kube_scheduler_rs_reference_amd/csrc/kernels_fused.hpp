@@ -938,7 +938,7 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
                     load_rows(FIT ? (uint32_t)(fit_o + nx * 128u)[0] : 0u, FIT ? (uint32_t)(fit_o + nx * 128u)[8] : 0u, (lab_o + nx * 16u)[0],
                               TAINT ? (trow_o + nx * 8u)[0] : make_uint2(0u, 0u), A);
                     f = apply_lists(f, lr_now, prev_bound);
-                    store_rel(rb_feas + step, lane_off, f);
+                    store_rel(rb_feas + step, lane_off, f, KSCHED_STORE_ALT(it));
                 }
             } else if (fast && prev_nu == 8u) {
                 // STEP pod rows per step; the records of the next step are fetched while this step's rows are combined.
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(kFusedThreads) KSCHED_FUSED_WPE_ATTR void k_eval_fu
                         __builtin_amdgcn_sched_barrier(0);
                         load_extra(rec_lx(it), A);
                         f = ((f & A.x0) & A.x1) & (A.x2 & A.x3);
-                        store_rel(rb_feas + step, lane_off, f);
+                        store_rel(rb_feas + step, lane_off, f, KSCHED_STORE_ALT(it));
                     }
                 } else {
 #pragma unroll
